@@ -1,0 +1,80 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+May be imported from `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg, and nowhere else.  The product package
+(`bevformer_tensorrt_amd`) never imports this module; it fails loudly when its
+HIP library is missing instead of falling back to anything here.
+
+`liboracle.so` is plain C (gcc, OpenMP) built by `make -C oracle`
+(`__graft_entry__.build()` does that).  Numpy in, numpy out.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith("_ref.c")]
+    stale = (not os.path.exists(so)) or any(
+        os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _msda_dims(value, shapes, ref, off, logit):
+    bs, nk, heads, C = value.shape
+    L = shapes.shape[0]
+    nq = off.shape[1]
+    ppg = ref.shape[-1] // 2
+    P = logit.shape[-1] // L
+    assert off.shape[-1] == L * P * 2 and int((shapes[:, 0] * shapes[:, 1]).sum()) == nk
+    return [ctypes.c_int(int(x)) for x in (bs, nk, heads, C, L, nq, P, ppg)]
+
+
+def msda_f32(value, shapes, ref, off, logit):
+    """fp32 MSDA (msda_ref.c:oracle_msda_f32).  Accepts any float dtype; upcasts
+    to fp32 exactly like the eager path does for fp16 inputs
+    (det2trt/models/functions/multi_scale_deformable_attn.py:96-101)."""
+    value, ref, off, logit = (_c(x, np.float32) for x in (value, ref, off, logit))
+    shapes = _c(shapes, np.int32)
+    out = np.empty(off.shape[:3] + (value.shape[-1],), np.float32)
+    lib().oracle_msda_f32(_p(value), _p(shapes), _p(ref), _p(off), _p(logit), _p(out),
+                          *_msda_dims(value, shapes, ref, off, logit))
+    return out
+
+
+def msda_s8(value, s_v, shapes, ref, off, s_o, logit, s_w, s_out, u8_weights=False):
+    """int8 MSDA; `u8_weights=False`: <float> flavour (kernel.cu:848-955),
+    True: <__half2> flavour (kernel.cu:957-1104)."""
+    value, off, logit = (_c(x, np.int8) for x in (value, off, logit))
+    ref = _c(ref, np.float32)
+    shapes = _c(shapes, np.int32)
+    out = np.empty(off.shape[:3] + (value.shape[-1],), np.int8)
+    fn = lib().oracle_msda_s8_u8w if u8_weights else lib().oracle_msda_s8
+    f = ctypes.c_float
+    fn(_p(value), f(s_v), _p(shapes), _p(ref), _p(off), f(s_o), _p(logit), f(s_w),
+       _p(out), f(s_out), *_msda_dims(value, shapes, ref, off, logit))
+    return out

@@ -1,0 +1,32 @@
+"""Pin the CPU oracle against golden vectors produced by the reference's own
+Python code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+MSDA_CASES = ["sca_like", "tsa_like", "tiny_sca", "edges", "odd_lp"]
+
+
+@pytest.mark.parametrize("case", MSDA_CASES)
+def test_msda_oracle_matches_reference_fp32(oracle_mod, case):
+    g = golden("msda_" + case)
+    out = oracle_mod.msda_f32(g["value"], g["shapes"], g["ref"], g["off"], g["logit"])
+    # reference test tolerance is mean-abs 1e-5 (test_multi_scale_deformable_attn.py:139-141);
+    # we hold the oracle to an element-wise bound
+    np.testing.assert_allclose(out, g["out_fp32"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", MSDA_CASES)
+def test_msda_oracle_vs_reference_fp16_eager(oracle_mod, case):
+    """The reference's fp16 eager path does its pre-processing (locations, softmax)
+    in half before upcasting (functions/multi_scale_deformable_attn.py:58-101); the
+    oracle computes in fp32 from the same fp16-rounded inputs.  They agree within
+    the reference's own fp16 tolerance (mean abs err <= 0.01,
+    test_multi_scale_deformable_attn.py:142-144)."""
+    g = golden("msda_" + case)
+    h = lambda a: a.astype(np.float16)
+    out = oracle_mod.msda_f32(h(g["value"]), g["shapes"], h(g["ref"]), h(g["off"]),
+                              h(g["logit"]))
+    err = np.abs(out - g["out_fp16_eager"].astype(np.float32))
+    assert err.mean() <= 0.01
