@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the BEVFormer-base sampling hot path on MI355X.
+
+A "step" is ONE FRAME's pass over the hot path at the BEVFormer-base shapes
+(SURVEY.md section 8 shape table; configs/bevformer/bevformer_base.py), bs=1, fp16,
+synthetic inputs drawn like the reference's op tests (seed 0; value/offsets/logits
+~N(0,1), reference points ~U[0,1); test_multi_scale_deformable_attn.py:25-33):
+
+    rotate(prev_bev [256,200,200])                                   x1  (when built)
+    6 encoder layers x [ TSA MSDA (2, 40000 keys, 40000 q, 1 lvl x 4 pts)
+                       + SCA MSDA (6 cams, 30825 keys, 40000 q, 4 lvl x 8 pts) ]
+    6 decoder layers x   MSDA (1, 40000 keys, 900 q, 1 lvl x 4 pts)
+
+Inputs are resident in HBM before the timed region.  N>1: the 6 cameras of the
+SCA call are sharded over the ranks and the per-camera BEV features
+[cams, 40000, 256] are exchanged with one RCCL all-gather per encoder layer
+(BASELINE.json config 4); TSA/decoder are replicated.  That is strong scaling:
+the job is still one frame.
+
+Prints ONE JSON line (rank 0) -- see the task contract -- including
+  roofline     : achieved algorithmic GB/s of the dominant kernel (base SCA MSDA,
+                 590.1 MB/launch fp16) from HIP events around every
+                 launch in the timed region, vs the 8 TB/s HBM peak;
+  cpu_baseline : the torch port of the reference's PyTorch CPU path
+                 (oracle/torch_ref.py) timed on this host, N=1 rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BASE = dict(
+    sca=dict(bs=6, levels=[[116, 200], [58, 100], [29, 50], [15, 25]], nq=40000, P=8, ppg=4),
+    tsa=dict(bs=2, levels=[[200, 200]], nq=40000, P=4, ppg=1),
+    dec=dict(bs=1, levels=[[200, 200]], nq=900, P=4, ppg=1),
+    enc_layers=6, dec_layers=6, heads=8, C=32, bev=(200, 200), embed=256,
+)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def msda_inputs(cfg, dtype, device, gen, cams=None):
+    heads, C = BASE["heads"], BASE["C"]
+    L = len(cfg["levels"])
+    nk = sum(h * w for h, w in cfg["levels"])
+    bs = cfg["bs"] if cams is None else len(cams)
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    value = mk(cfg["bs"], nk, heads, C)
+    ref = torch.rand(cfg["bs"], cfg["nq"], 1, 2 * cfg["ppg"], generator=gen)
+    off = mk(cfg["bs"], cfg["nq"], heads, L * cfg["P"] * 2)
+    logit = mk(cfg["bs"], cfg["nq"], heads, L * cfg["P"])
+    if cams is not None:  # camera shard: same global tensors, local slice
+        idx = torch.tensor(cams, dtype=torch.long)
+        value, ref, off, logit = (t[idx] if len(cams) else t[:0] for t in (value, ref, off, logit))
+    shapes = torch.tensor(cfg["levels"], dtype=torch.int32)
+    return [value.to(dtype).to(device), shapes.to(device), ref.to(dtype).to(device),
+            off.to(dtype).to(device), logit.to(dtype).to(device)], bs
+
+
+def msda_bytes(cfg, esize, bs=None):
+    heads, C = BASE["heads"], BASE["C"]
+    L = len(cfg["levels"])
+    nk = sum(h * w for h, w in cfg["levels"])
+    bs = cfg["bs"] if bs is None else bs
+    n = bs * (nk * heads * C + cfg["nq"] * 2 * cfg["ppg"] + cfg["nq"] * heads * L * cfg["P"] * 3 +
+              cfg["nq"] * heads * C)
+    return n * esize + 8 * L
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Reference PyTorch CPU path (port), fp32, on a bounded sample: one base TSA
+    call + one base decoder call + a query-slice of the base SCA call, scaled to a
+    frame (6 x each).  Returns frames/s."""
+    from oracle import torch_ref
+    gen = torch.Generator().manual_seed(0)
+    t_frame = 0.0
+    parts = []
+    for name, cfg, frac in (("tsa", BASE["tsa"], 1.0), ("dec", BASE["dec"], 1.0),
+                            ("sca", BASE["sca"], 0.125)):
+        c = dict(cfg)
+        c["nq"] = max(1, int(cfg["nq"] * frac))
+        args, _ = msda_inputs(c, torch.float32, "cpu", gen)
+        args[1] = args[1].long()
+        torch_ref.msda(*args)  # warm-up
+        t0 = time.perf_counter()
+        torch_ref.msda(*args)
+        dt = (time.perf_counter() - t0) / frac
+        parts.append(f"{name}:{dt:.3f}s")
+        t_frame += dt * (BASE["enc_layers"] if name != "dec" else BASE["dec_layers"])
+    return 1.0 / t_frame, " ".join(parts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.camera_shard import camera_shards, gather_camera_features
+
+    dtype = torch.float16 if args.dtype == "fp16" else torch.float32
+    esize = 2 if dtype == torch.float16 else 4
+    gen = torch.Generator().manual_seed(0)
+    my_cams = camera_shards(BASE["sca"]["bs"], world)[rank]
+    sca, sca_bs = msda_inputs(BASE["sca"], dtype, dev, gen, cams=my_cams)
+    tsa, _ = msda_inputs(BASE["tsa"], dtype, dev, gen)
+    dec, _ = msda_inputs(BASE["dec"], dtype, dev, gen)
+    extra = []
+    rot = None
+    if hasattr(bev, "rotate"):
+        prev_bev = torch.randn(BASE["embed"], *BASE["bev"], generator=gen).to(dtype).to(dev)
+        angle = torch.tensor(1.5, device=dev)
+        center = torch.tensor([100.0, 100.0], device=dev)
+        rot = (prev_bev, angle, center)
+        extra.append("rotate")
+
+    nq, embed = BASE["sca"]["nq"], BASE["embed"]
+    sca_out = torch.empty((max(sca_bs, 1), nq, BASE["heads"], BASE["C"]), dtype=dtype, device=dev)
+    gathered = None
+    sca_events = []
+
+    def step(record):
+        if rot is not None:
+            bev.rotate(*rot)
+        for _ in range(BASE["enc_layers"]):
+            bev.multi_scale_deformable_attn(*tsa)
+            if sca_bs:
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                out = bev.multi_scale_deformable_attn(*sca)
+                if record:
+                    e1.record()
+                    sca_events.append((e0, e1))
+            else:
+                out = sca_out[:0]
+            if world > 1:
+                gather_camera_features(out.view(out.shape[0], nq, embed), BASE["sca"]["bs"], dist)
+        for _ in range(BASE["dec_layers"]):
+            bev.multi_scale_deformable_attn(*dec)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = args.steps / elapsed
+
+    roofline = None
+    if sca_events:
+        ms = [a.elapsed_time(b) for a, b in sca_events]
+        avg_ms = sum(ms) / len(ms)
+        byt = msda_bytes(BASE["sca"], esize, bs=sca_bs)
+        achieved = byt / (avg_ms * 1e-3) / 1e9
+        roofline = {"kernel": "msda_quad_kernel (base SCA call)", "bound": "hbm",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "launches": len(ms)}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            v, sample = cpu_baseline()
+            cpu = {"value": round(v, 5), "unit": "frames/s", "cores": torch.get_num_threads(),
+                   "kind": "port",
+                   "sample": "reference PyTorch CPU MSDA path (oracle/torch_ref.py), fp32, base "
+                             "TSA + decoder calls in full and 1/8 of the SCA queries, scaled to "
+                             "6+6+6 calls per frame; per-call " + sample}
+        line = {
+            "metric": "frames/sec BEVFormer-base bs=1 fp16 sampling hot path (synthetic)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16" if dtype == torch.float16 else "f32", "data": "synthetic",
+            "config": {"workload": "BEVFormer-base hot path per frame: "
+                                   + "+".join(extra + ["6x(TSA+SCA) MSDA", "6x decoder MSDA"]),
+                       "shapes": "SCA(6,30825,40000,4x8) TSA(2,40000,40000,1x4) dec(1,40000,900,1x4)",
+                       "parallelism": f"cameras/{world}" if world > 1 else "single"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

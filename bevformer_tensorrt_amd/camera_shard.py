@@ -1,0 +1,50 @@
+"""Camera sharding of the SCA sampler across GPUs (new design --
+the reference is single-GPU).  One process per GPU; rank g owns cameras
+{c : c mod G == g}; after the per-camera MSDA each rank holds [cams_local, nq, embed]
+and ONE all-gather per encoder layer (RCCL over xGMI, backend "nccl") rebuilds
+[n_cams, nq, embed] on every rank for the replicated masked camera sum + output_proj
+(det2trt/models/modules/spatial_cross_attention.py:270-273).
+
+xGMI is point-to-point, so the exchange is a single large all_gather_into_tensor per
+layer (20.5 MB per camera at base fp16) rather than many small ones.
+"""
+import torch
+
+_BUFFERS = {}
+
+
+def camera_shards(n_cams, world):
+    """List (indexed by rank) of the camera ids each rank owns."""
+    return [[c for c in range(n_cams) if c % world == r] for r in range(world)]
+
+
+def _buffers(key, max_local, world, tail, dtype, device):
+    hit = _BUFFERS.get(key)
+    if hit is None:
+        send = torch.zeros((max_local,) + tail, dtype=dtype, device=device)
+        recv = torch.empty((world, max_local) + tail, dtype=dtype, device=device)
+        hit = (send, recv)
+        _BUFFERS[key] = hit
+    return hit
+
+
+def gather_camera_features(local, n_cams, dist, group=None):
+    """all-gather per-camera features.
+
+    local: [cams_local, ...] for this rank's cameras (camera_shards order).
+    Returns [n_cams, ...] in global camera order on every rank.  Uneven shards
+    (e.g. 6 cameras on 4 or 8 ranks) are padded to ceil(n_cams / world) slots.
+    """
+    world = dist.get_world_size(group)
+    max_local = -(-n_cams // world)
+    tail = tuple(local.shape[1:])
+    key = (max_local, world, tail, local.dtype, str(local.device))
+    send, recv = _buffers(key, max_local, world, tail, local.dtype, local.device)
+    if local.shape[0] == max_local and local.is_contiguous():
+        src = local
+    else:
+        send[: local.shape[0]].copy_(local)
+        src = send
+    dist.all_gather_into_tensor(recv.view(-1), src.view(-1), group=group)
+    # recv[r, i] is camera r + world*i  ->  camera-major order
+    return recv.transpose(0, 1).reshape((max_local * world,) + tail)[:n_cams]

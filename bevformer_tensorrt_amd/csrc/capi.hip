@@ -1,0 +1,38 @@
+// Library identification + name -> entry-point table (stands in for TensorRT's
+// plugin-creator registry: REGISTER_TENSORRT_PLUGIN,
+// TensorRT/plugin/multi_scale_deformable_attn/multiScaleDeformableAttnPlugin.cpp:345-346).
+#include <string.h>
+
+#include "common.h"
+
+extern "C" const char *bevops_version(void) { return "bevops-hip 0.1 (gfx950)"; }
+
+extern "C" const char *bevops_status_string(int status) {
+  switch (status) {
+    case BEVOPS_SUCCESS: return "success";
+    case BEVOPS_FAILURE: return "failure (kernel launch error)";
+    case BEVOPS_BAD_PARAM: return "bad parameter";
+    case BEVOPS_NOT_SUPPORTED: return "dtype/shape combination not supported";
+    case BEVOPS_NOT_INITIALIZED: return "not initialized";
+    default: return "unknown status";
+  }
+}
+
+namespace {
+struct Entry {
+  const char *name;
+  void *fn;
+};
+const Entry kTable[] = {
+    {"bevops_msda_forward", (void *)&bevops_msda_forward},
+    {"MultiScaleDeformableAttnTRT", (void *)&bevops_msda_forward},
+    {"MultiScaleDeformableAttnTRT2", (void *)&bevops_msda_forward},
+};
+}  // namespace
+
+extern "C" void *bevops_query(const char *name) {
+  if (!name) return nullptr;
+  for (const Entry &e : kTable)
+    if (strcmp(e.name, name) == 0) return e.fn;
+  return nullptr;
+}

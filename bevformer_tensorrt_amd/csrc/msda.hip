@@ -1,0 +1,419 @@
+// Multi-scale deformable attention forward for MI355X (gfx950).
+//
+// Replaces ms_deformable_im2col_cuda{,_h2,_int8} + MultiScaleDeformableAttnPlugin::enqueue
+// of the reference (TensorRT/plugin/multi_scale_deformable_attn/
+// multiScaleDeformableAttnKernel.cu:611-1218, ...Plugin.cpp:71-140).  Numerical
+// contract: SURVEY.md Appendix A.1/A.2 (fused softmax over L*P logits, location
+// = ref*(W,H) + offset - 0.5, 4-tap bilinear with per-corner bounds, sum/S).
+//
+// Design (not the reference's one-thread-per-output-scalar):
+//   * one QUAD of lanes (4 lanes) owns one (batch, query, head) item; a lane holds
+//     C/4 = 8 channels, so one tap is 4 x 16 B (fp16) contiguous = one 64 B segment
+//     of the [bs, nk, heads, C] value map; a wave covers 16 items.
+//   * the L*P points of an item are SPLIT over the quad: each lane loads 1/4 of the
+//     logits/offsets (perfectly coalesced 16 B/lane across the wave), does the
+//     softmax-exp / location / bounds / corner-weight math for its own points only,
+//     and hands (4 corner weights, 4 corner byte-offsets) to its three neighbours
+//     with DPP quad broadcasts -- no LDS, no redundant exp.  softmax max/sum are
+//     quad DPP reductions.
+//   * taps go through a buffer descriptor (32-bit offsets, wave-uniform SRD from
+//     kernargs), fp32 accumulate (v_fma_mix_f32 on packed halves).
+//   * items whose every point of the whole wave is out of range leave early
+//     (cameras that do not see a BEV pillar).
+//   * blockIdx is remapped so each XCD walks a contiguous item range (L2 locality
+//     for neighbouring BEV queries).
+#include "common.h"
+
+namespace bevops {
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kBlock = 256;
+
+struct MsdaDims {
+  int bs, nk, heads, C, L, nq, P, ppg;
+};
+
+// ---------------------------------------------------------------------------
+// element loaders: N consecutive T -> float
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void load_f(const float *p, float (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = p[0];
+  } else if constexpr (N == 2) {
+    const float2 v = *reinterpret_cast<const float2 *>(p);
+    d[0] = v.x; d[1] = v.y;
+  } else {
+    static_assert(N % 4 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[i];
+      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void load_f(const __half *p, float (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = __half2float(p[0]);
+  } else if constexpr (N == 2) {
+    const unsigned v = *reinterpret_cast<const unsigned *>(p);
+    d[0] = h2f_lo(v); d[1] = h2f_hi(v);
+  } else if constexpr (N == 4) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    d[0] = h2f_lo(v.x); d[1] = h2f_hi(v.x); d[2] = h2f_lo(v.y); d[3] = h2f_hi(v.y);
+  } else {
+    static_assert(N % 8 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+      d[8 * i] = h2f_lo(v.x); d[8 * i + 1] = h2f_hi(v.x);
+      d[8 * i + 2] = h2f_lo(v.y); d[8 * i + 3] = h2f_hi(v.y);
+      d[8 * i + 4] = h2f_lo(v.z); d[8 * i + 5] = h2f_hi(v.z);
+      d[8 * i + 6] = h2f_lo(v.w); d[8 * i + 7] = h2f_hi(v.w);
+    }
+  }
+}
+__device__ __forceinline__ float2 load_ref(const float *p) {
+  return *reinterpret_cast<const float2 *>(p);
+}
+__device__ __forceinline__ float2 load_ref(const __half *p) {
+  const unsigned v = *reinterpret_cast<const unsigned *>(p);
+  return make_float2(h2f_lo(v), h2f_hi(v));
+}
+
+// one 8-channel tap: acc[c] += w * value[c]
+__device__ __forceinline__ void tap8(const __half *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                     float w, float (&acc)[8]) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+  acc[0] = fmaf(w, h2f_lo(r.x), acc[0]); acc[1] = fmaf(w, h2f_hi(r.x), acc[1]);
+  acc[2] = fmaf(w, h2f_lo(r.y), acc[2]); acc[3] = fmaf(w, h2f_hi(r.y), acc[3]);
+  acc[4] = fmaf(w, h2f_lo(r.z), acc[4]); acc[5] = fmaf(w, h2f_hi(r.z), acc[5]);
+  acc[6] = fmaf(w, h2f_lo(r.w), acc[6]); acc[7] = fmaf(w, h2f_hi(r.w), acc[7]);
+}
+__device__ __forceinline__ void tap8(const float *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                     float w, float (&acc)[8]) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u), 0, 0);
+  acc[0] = fmaf(w, __uint_as_float(a.x), acc[0]); acc[1] = fmaf(w, __uint_as_float(a.y), acc[1]);
+  acc[2] = fmaf(w, __uint_as_float(a.z), acc[2]); acc[3] = fmaf(w, __uint_as_float(a.w), acc[3]);
+  acc[4] = fmaf(w, __uint_as_float(b.x), acc[4]); acc[5] = fmaf(w, __uint_as_float(b.y), acc[5]);
+  acc[6] = fmaf(w, __uint_as_float(b.z), acc[6]); acc[7] = fmaf(w, __uint_as_float(b.w), acc[7]);
+}
+__device__ __forceinline__ void store8(__half *p, const float (&a)[8]) {
+  uint4 v;
+  v.x = pack_h2(a[0], a[1]); v.y = pack_h2(a[2], a[3]);
+  v.z = pack_h2(a[4], a[5]); v.w = pack_h2(a[6], a[7]);
+  *reinterpret_cast<uint4 *>(p) = v;
+}
+__device__ __forceinline__ void store8(float *p, const float (&a)[8]) {
+  reinterpret_cast<float4 *>(p)[0] = make_float4(a[0], a[1], a[2], a[3]);
+  reinterpret_cast<float4 *>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
+}
+
+// location arithmetic kept un-fused so that it rounds exactly like the
+// reference's fp32 kernel (mul, add, sub as separate roundings).
+__device__ __forceinline__ float loc_im(float ref, float size, float off) {
+#pragma clang fp contract(off)
+  const float t = ref * size;
+  const float u = t + off;
+  return u - 0.5f;
+}
+
+// ---------------------------------------------------------------------------
+// quad kernel: C == 32, (L*P) % 4 == 0.  PPL = points owned per lane = L*P/4.
+// CH = how many of its own points a lane prepares per pass (register pressure
+// knob: state is 8 VGPR per prepared point).
+// ---------------------------------------------------------------------------
+template <typename T, int PPL, int CH>
+__global__ __launch_bounds__(kBlock) void msda_quad_kernel(
+    const T *__restrict__ value, unsigned value_bytes, const int32_t *__restrict__ shapes,
+    const T *__restrict__ ref, const T *__restrict__ off, const T *__restrict__ logit,
+    T *__restrict__ out, MsdaDims d, unsigned n_item) {
+  static_assert(PPL % CH == 0, "CH must divide PPL");
+  constexpr int V = 8;  // channels per lane
+  __shared__ int4 lvl[kMaxLevels];  // {H, W, first pixel of the level, -}
+  if (threadIdx.x == 0) {
+    int start = 0;
+    for (int l = 0; l < d.L; ++l) {
+      const int H = shapes[2 * l], W = shapes[2 * l + 1];
+      lvl[l] = make_int4(H, W, start, 0);
+      start += H * W;
+    }
+  }
+  __syncthreads();
+
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned item = vb * (kBlock / 4) + (threadIdx.x >> 2);
+  if (item >= n_item) return;  // whole quads leave together
+  const unsigned sub = threadIdx.x & 3u;
+  const unsigned bq = item / (unsigned)d.heads;
+  const unsigned h = item - bq * (unsigned)d.heads;
+  const unsigned b = bq / (unsigned)d.nq;
+  constexpr int LP = 4 * PPL;
+  const unsigned row_bytes = (unsigned)d.heads * 32u * (unsigned)sizeof(T);  // one pixel, all heads
+  const unsigned lane_base =
+      ((b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V) * (unsigned)sizeof(T);
+
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value), 0, value_bytes, 0x00020000);
+
+  // ---- own logits -> softmax numerators ----
+  float e[PPL];
+  load_f<PPL>(logit + (size_t)item * LP + sub * PPL, e);
+  float m = e[0];
+#pragma unroll
+  for (int k = 1; k < PPL; ++k) m = fmaxf(m, e[k]);
+  m = quad_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    e[k] = __expf(e[k] - m);
+    s += e[k];
+  }
+  s = quad_sum(s);
+
+  float offs[2 * PPL];
+  load_f<2 * PPL>(off + ((size_t)item * LP + sub * PPL) * 2, offs);
+  const T *refp = ref + (size_t)bq * (unsigned)d.ppg * 2u;
+
+  // running (level, point-in-level, point-in-group) of this lane's next own point
+  int j0 = (int)sub * PPL;
+  int l = j0 / d.P;
+  int p = j0 - l * d.P;
+  int g = p % d.ppg;
+
+  float acc[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) acc[c] = 0.f;
+
+#pragma unroll
+  for (int pass = 0; pass < PPL / CH; ++pass) {
+    float ow[CH][4];
+    unsigned oo[CH][4];
+    bool any_valid = false;
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k = pass * CH + kk;
+      const int4 t = lvl[l];
+      const int H = t.x, W = t.y;
+      const float2 r = load_ref(refp + 2 * g);
+      const float x = loc_im(r.x, (float)W, offs[2 * k]);
+      const float y = loc_im(r.y, (float)H, offs[2 * k + 1]);
+      const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
+      any_valid |= valid;
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const float hx = 1.f - lx, hy = 1.f - ly;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const bool x0ok = valid && x0 >= 0, x1ok = valid && x0 + 1 <= W - 1;
+      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1;
+      const float wt = e[k];
+      ow[kk][0] = (y0ok && x0ok) ? wt * (hy * hx) : 0.f;
+      ow[kk][1] = (y0ok && x1ok) ? wt * (hy * lx) : 0.f;
+      ow[kk][2] = (y1ok && x0ok) ? wt * (ly * hx) : 0.f;
+      ow[kk][3] = (y1ok && x1ok) ? wt * (ly * lx) : 0.f;
+      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x0 + 1, 0), W - 1);
+      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+      const unsigned r0 = (unsigned)(t.z + y0c * W), r1 = (unsigned)(t.z + y1c * W);
+      oo[kk][0] = (r0 + (unsigned)x0c) * row_bytes;
+      oo[kk][1] = (r0 + (unsigned)x1c) * row_bytes;
+      oo[kk][2] = (r1 + (unsigned)x0c) * row_bytes;
+      oo[kk][3] = (r1 + (unsigned)x1c) * row_bytes;
+      // advance (l, p, g)
+      ++p; ++g;
+      if (g == d.ppg) g = 0;
+      if (p == d.P) { p = 0; g = 0; ++l; }
+    }
+    // cameras that do not see this pillar: nothing in the whole wave to gather
+    if (!__any(any_valid)) continue;
+
+#define BEVOPS_MSDA_SRC(S)                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < CH; ++kk) {                         \
+      const float w0 = quad_bcast<S>(ow[kk][0]), w1 = quad_bcast<S>(ow[kk][1]); \
+      const float w2 = quad_bcast<S>(ow[kk][2]), w3 = quad_bcast<S>(ow[kk][3]); \
+      const unsigned o0 = quad_bcast<S>(oo[kk][0]) + lane_base;                 \
+      const unsigned o1 = quad_bcast<S>(oo[kk][1]) + lane_base;                 \
+      const unsigned o2 = quad_bcast<S>(oo[kk][2]) + lane_base;                 \
+      const unsigned o3 = quad_bcast<S>(oo[kk][3]) + lane_base;                 \
+      tap8(value, rs, o0, w0, acc);                                             \
+      tap8(value, rs, o1, w1, acc);                                             \
+      tap8(value, rs, o2, w2, acc);                                             \
+      tap8(value, rs, o3, w3, acc);                                             \
+    }
+    BEVOPS_MSDA_SRC(0)
+    BEVOPS_MSDA_SRC(1)
+    BEVOPS_MSDA_SRC(2)
+    BEVOPS_MSDA_SRC(3)
+#undef BEVOPS_MSDA_SRC
+  }
+
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int c = 0; c < V; ++c) acc[c] *= inv;
+  store8(out + (size_t)item * 32u + sub * V, acc);
+}
+
+// ---------------------------------------------------------------------------
+// generic kernel: any heads / C / L / P / ppg, 64-bit addressing.  One thread per
+// output element (item, channel); the slow, always-correct path for shapes the
+// quad kernel does not cover.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half_rn(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void msda_generic_kernel(
+    const T *__restrict__ value, const int32_t *__restrict__ shapes, const T *__restrict__ ref,
+    const T *__restrict__ off, const T *__restrict__ logit, T *__restrict__ out, MsdaDims d,
+    size_t n_out) {
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n_out) return;
+  const int c = (int)(idx % d.C);
+  const size_t item = idx / d.C;
+  const int h = (int)(item % d.heads);
+  const size_t bq = item / d.heads;
+  const size_t b = bq / d.nq;
+  const int LP = d.L * d.P;
+  const T *lg = logit + item * LP;
+  const T *of = off + item * LP * 2;
+  const T *rp = ref + bq * d.ppg * 2;
+  const size_t step = (size_t)d.heads * d.C;
+  const T *vp = value + (b * d.nk * d.heads + h) * (size_t)d.C + c;
+  float m = -INFINITY;
+  for (int j = 0; j < LP; ++j) m = fmaxf(m, to_f(lg[j]));
+  float acc = 0.f, s = 0.f;
+  int j = 0;
+  for (int l = 0; l < d.L; ++l) {
+    const int H = shapes[2 * l], W = shapes[2 * l + 1];
+    for (int p = 0; p < d.P; ++p, ++j) {
+      const int g = p % d.ppg;
+      const float x = loc_im(to_f(rp[2 * g]), (float)W, to_f(of[2 * j]));
+      const float y = loc_im(to_f(rp[2 * g + 1]), (float)H, to_f(of[2 * j + 1]));
+      const float wt = __expf(to_f(lg[j]) - m);
+      s += wt;
+      if (y > -1.f && x > -1.f && y < (float)H && x < (float)W) {
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (y0 >= 0 && x0 >= 0) v1 = to_f(vp[((size_t)y0 * W + x0) * step]);
+        if (y0 >= 0 && x0 + 1 <= W - 1) v2 = to_f(vp[((size_t)y0 * W + x0 + 1) * step]);
+        if (y0 + 1 <= H - 1 && x0 >= 0) v3 = to_f(vp[((size_t)(y0 + 1) * W + x0) * step]);
+        if (y0 + 1 <= H - 1 && x0 + 1 <= W - 1)
+          v4 = to_f(vp[((size_t)(y0 + 1) * W + x0 + 1) * step]);
+        acc += wt * (hy * hx * v1 + hy * lx * v2 + ly * hx * v3 + ly * lx * v4);
+      }
+    }
+    vp += (size_t)H * W * step;
+  }
+  out[idx] = from_f<T>(acc / s);
+}
+
+thread_local int g_variant = 0;
+
+template <typename T, int PPL, int CH>
+int launch_quad(const T *value, const int32_t *shapes, const T *ref, const T *off, const T *logit,
+                T *out, const MsdaDims &d, hipStream_t st) {
+  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
+  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C * sizeof(T);
+  const unsigned grid = (unsigned)((n_item + kBlock / 4 - 1) / (kBlock / 4));
+  hipLaunchKernelGGL((msda_quad_kernel<T, PPL, CH>), dim3(grid), dim3(kBlock), 0, st, value,
+                     (unsigned)vbytes, shapes, ref, off, logit, out, d, (unsigned)n_item);
+  return launch_status();
+}
+
+template <typename T>
+int msda_float(const T *value, const int32_t *shapes, const T *ref, const T *off, const T *logit,
+               T *out, const MsdaDims &d, hipStream_t st) {
+  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
+  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C * sizeof(T);
+  const int LP = d.L * d.P;
+  const bool quad_ok = d.C == 32 && LP % 4 == 0 && d.L <= kMaxLevels &&
+                       vbytes < 0xFFFFFF00ull && n_item < 0x7FFFFFFFull &&
+                       n_item * 32 * sizeof(T) < 0xFFFFFFFFFFull && aligned16(value) &&
+                       aligned16(off) && aligned16(logit) && aligned16(out) && aligned16(ref) &&
+                       g_variant != 99;
+  if (quad_ok) {
+    const int v = g_variant;
+    switch (LP / 4) {
+      case 1: return launch_quad<T, 1, 1>(value, shapes, ref, off, logit, out, d, st);
+      case 2: return launch_quad<T, 2, 2>(value, shapes, ref, off, logit, out, d, st);
+      case 4:
+        if (v == 2) return launch_quad<T, 4, 2>(value, shapes, ref, off, logit, out, d, st);
+        return launch_quad<T, 4, 4>(value, shapes, ref, off, logit, out, d, st);
+      case 8:
+        if (v == 1) return launch_quad<T, 8, 8>(value, shapes, ref, off, logit, out, d, st);
+        if (v == 2) return launch_quad<T, 8, 2>(value, shapes, ref, off, logit, out, d, st);
+        return launch_quad<T, 8, 4>(value, shapes, ref, off, logit, out, d, st);
+      case 16:
+        if (v == 2) return launch_quad<T, 16, 2>(value, shapes, ref, off, logit, out, d, st);
+        return launch_quad<T, 16, 4>(value, shapes, ref, off, logit, out, d, st);
+      default: break;
+    }
+  }
+  const size_t n_out = n_item * d.C;
+  const size_t grid = (n_out + kBlock - 1) / kBlock;
+  if (grid > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL((msda_generic_kernel<T>), dim3((unsigned)grid), dim3(kBlock), 0, st, value,
+                     shapes, ref, off, logit, out, d, n_out);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace bevops
+
+using namespace bevops;
+
+extern "C" int bevops_msda_set_variant(int variant) {
+  const int prev = g_variant;
+  g_variant = variant;
+  return prev;
+}
+
+extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
+                                   const int32_t *spatial_shapes_host,
+                                   const void *reference_points, int ref_dtype,
+                                   const void *sampling_offsets, const void *attention_weights,
+                                   void *output, int bs, int nk, int heads, int channels,
+                                   int num_levels, int num_query, int num_point,
+                                   int points_per_group, float scale_value, float scale_offset,
+                                   float scale_weight, float scale_out, void *stream) {
+  if (!value || !spatial_shapes || !reference_points || !sampling_offsets || !attention_weights ||
+      !output)
+    return BEVOPS_BAD_PARAM;
+  if (bs <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0 || points_per_group <= 0)
+    return BEVOPS_BAD_PARAM;
+  if (spatial_shapes_host) {
+    long total = 0;
+    for (int l = 0; l < num_levels; ++l) {
+      const long H = spatial_shapes_host[2 * l], W = spatial_shapes_host[2 * l + 1];
+      if (H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
+      total += H * W;
+    }
+    if (total != nk) return BEVOPS_BAD_PARAM;
+  }
+  const MsdaDims d{bs, nk, heads, channels, num_levels, num_query, num_point, points_per_group};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BEVOPS_F32:
+      if (ref_dtype != BEVOPS_F32) return BEVOPS_NOT_SUPPORTED;
+      return msda_float<float>((const float *)value, spatial_shapes, (const float *)reference_points,
+                               (const float *)sampling_offsets, (const float *)attention_weights,
+                               (float *)output, d, st);
+    case BEVOPS_F16:
+      if (ref_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+      return msda_float<__half>((const __half *)value, spatial_shapes,
+                                (const __half *)reference_points, (const __half *)sampling_offsets,
+                                (const __half *)attention_weights, (__half *)output, d, st);
+    default:
+      (void)scale_value; (void)scale_offset; (void)scale_weight; (void)scale_out;
+      return BEVOPS_NOT_SUPPORTED;
+  }
+}

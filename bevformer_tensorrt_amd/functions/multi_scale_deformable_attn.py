@@ -1,0 +1,106 @@
+"""multi_scale_deformable_attn / multi_scale_deformable_attn2 -- drop-in for
+det2trt/models/functions/multi_scale_deformable_attn.py:150-217.
+
+The reference's eager `forward()` materialises sampling locations and a softmax
+and then calls mmcv's CUDA extension (:58-115); its TensorRT engine runs the fused
+plugin instead.  Here both are one fused HIP kernel (csrc/msda.hip) reached
+through `bevops_msda_forward`.  fp16 inputs are upcast inside the kernel (fp32
+location/softmax/accumulate), output returned in the input dtype like :123.
+"""
+import torch
+
+from ..utils import lib as _lib
+
+_SHAPE_CACHE = {}
+
+
+def _shapes_i32(shapes, device):
+    """int32 device copy (+ host copy when free) of value_spatial_shapes."""
+    if shapes.device.type == "cpu":
+        key = ("cpu", tuple(shapes.flatten().tolist()), str(device))
+        hit = _SHAPE_CACHE.get(key)
+        if hit is None:
+            host = shapes.to(torch.int32).contiguous()
+            hit = (host.to(device), host)
+            _SHAPE_CACHE[key] = hit
+        return hit
+    if shapes.dtype == torch.int32 and shapes.is_contiguous():
+        return shapes, None
+    key = (shapes.data_ptr(), shapes._version, shapes.dtype, tuple(shapes.shape))
+    hit = _SHAPE_CACHE.get(key)
+    if hit is None:
+        if len(_SHAPE_CACHE) > 64:
+            _SHAPE_CACHE.clear()
+        hit = (shapes.to(torch.int32).contiguous(), None)
+        _SHAPE_CACHE[key] = hit
+    return hit
+
+
+def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights,
+          scales=(1.0, 1.0, 1.0, 1.0), out=None):
+    assert value.is_cuda, "multi_scale_deformable_attn: value must be on the GPU"
+    if value.dim() != 4:
+        raise ValueError(f"value must be [bs, num_keys, heads, channels], got {tuple(value.shape)}")
+    handle = _lib.load_library()
+    bs, nk, heads, ch = value.shape
+    L = value_spatial_shapes.shape[0]
+    nq = sampling_offsets.shape[1]
+    ppg = reference_points.shape[-1] // 2
+    P = attention_weights.numel() // (bs * nq * heads * L)
+    if sampling_offsets.numel() != bs * nq * heads * L * P * 2:
+        raise ValueError("sampling_offsets / attention_weights shapes disagree")
+    if reference_points.numel() != bs * nq * ppg * 2:
+        raise ValueError("reference_points must be [bs, num_query, 1, 2*points_per_group]")
+    dt = _lib.torch_dtype_code(value)
+    for name, t in (("sampling_offsets", sampling_offsets), ("attention_weights", attention_weights)):
+        if t.dtype != value.dtype:
+            raise TypeError(f"{name} dtype {t.dtype} != value dtype {value.dtype}")
+    rdt = _lib.torch_dtype_code(reference_points)
+    value, reference_points, sampling_offsets, attention_weights = (
+        t.contiguous() for t in (value, reference_points, sampling_offsets, attention_weights))
+    shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, value.device)
+    if out is None:
+        out = torch.empty((bs, nq, heads, ch), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        st = handle.bevops_msda_forward(
+            dt, value.data_ptr(), shapes_dev.data_ptr(),
+            shapes_host.data_ptr() if shapes_host is not None else None,
+            reference_points.data_ptr(), rdt, sampling_offsets.data_ptr(),
+            attention_weights.data_ptr(), out.data_ptr(), bs, nk, heads, ch, L, nq, P, ppg,
+            float(scales[0]), float(scales[1]), float(scales[2]), float(scales[3]),
+            _lib.current_stream_ptr(value.device))
+    _lib.check(st, "bevops_msda_forward")
+    return out
+
+
+def multi_scale_deformable_attn(value, value_spatial_shapes, reference_points, sampling_offsets,
+                                attention_weights):
+    """Multi-scale deformable attention (plugin MultiScaleDeformableAttnTRT: fp32, fp16).
+
+    Args (as det2trt/models/functions/multi_scale_deformable_attn.py:153-174):
+        value: (bs, num_keys, num_heads, embed_dims // num_heads)
+        value_spatial_shapes: (num_levels, 2), last dim (h, w)
+        reference_points: (bs, num_queries, 1, 2 * points_per_group), normalised
+        sampling_offsets: (bs, num_queries, num_heads, num_levels * num_points * 2), (x, y) pixels
+        attention_weights: (bs, num_queries, num_heads, num_levels * num_points), pre-softmax
+    Returns: (bs, num_queries, num_heads, embed_dims // num_heads)
+    """
+    return _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights)
+
+
+def multi_scale_deformable_attn2(value, value_spatial_shapes, reference_points, sampling_offsets,
+                                 attention_weights):
+    """Same op under the reference's `half2` plugin name (MultiScaleDeformableAttnTRT2,
+    :184-217).  On MI355X both names run the same 16-byte-vectorised kernel."""
+    return _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights)
+
+
+def multi_scale_deformable_attn_int8(value, value_spatial_shapes, reference_points,
+                                     sampling_offsets, attention_weights, scale_value,
+                                     scale_offset, scale_weight, scale_out):
+    """INT8 flavour.  In the reference the int8 tensors and their per-tensor scales come
+    from TensorRT (PluginTensorDesc::scale, multiScaleDeformableAttnPlugin.cpp:75-77);
+    here the caller passes int8 tensors + scales explicitly.  reference_points stay
+    fp32 (signed x127 weights) or fp16 (unsigned x255 weights)."""
+    return _msda(value, value_spatial_shapes, reference_points, sampling_offsets,
+                 attention_weights, (scale_value, scale_offset, scale_weight, scale_out))

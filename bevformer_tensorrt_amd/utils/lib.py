@@ -1,0 +1,75 @@
+"""ctypes loader for libbevops_hip.so (the C ABI in include/bevops.h).
+
+Mirrors the reference's load hook -- `ctypes.CDLL(os.path.realpath(
+"TensorRT/lib/libtensorrt_ops.so"))` at import (det2trt/models/utils/register.py:72-75)
+-- except that the path is package-relative and a missing library is a hard error
+with the build command, never a silent fallback.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in step with include/bevops.h (tests check this)
+SIGNATURES = {
+    "bevops_version": (ctypes.c_char_p, []),
+    "bevops_status_string": (ctypes.c_char_p, [c_int]),
+    "bevops_query": (c_void_p, [ctypes.c_char_p]),
+    "bevops_msda_set_variant": (c_int, [c_int]),
+    "bevops_msda_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
+                            [c_float] * 4 + [c_void_p]),
+}
+
+F32, F16, I8 = 0, 1, 2
+
+
+def lib_path():
+    return os.environ.get("BEVOPS_LIB", os.path.join(_PKG, "libbevops_hip.so"))
+
+
+def load_library():
+    """Load (once) and return the ctypes handle.  `import torch` first so that the
+    HIP runtime torch ships (same SONAME libamdhip64.so.7) is the one both sides use."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build the HIP kernels first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C bevformer_tensorrt_amd/csrc`). There is no fallback path.")
+    import torch  # noqa: F401
+    handle = ctypes.CDLL(os.path.realpath(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    _LIB = handle
+    return handle
+
+
+class BevopsError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        msg = load_library().bevops_status_string(status).decode()
+        raise BevopsError(f"{what}: {msg} (status {status})")
+
+
+def torch_dtype_code(t):
+    import torch
+    code = {torch.float32: F32, torch.float16: F16, torch.int8: I8}.get(t.dtype)
+    if code is None:
+        raise TypeError(f"unsupported dtype {t.dtype}; expected float32, float16 or int8")
+    return code
+
+
+def current_stream_ptr(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,103 @@
+/*
+ * bevops.h -- C ABI of libbevops_hip.so: MI355X (gfx950) HIP kernels for the
+ * BEVFormer / BEVDet sampling hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces the device side of
+ * one TensorRT plugin of the reference (DerryHub/BEVFormer_tensorrt), i.e. what
+ * `IPluginV2DynamicExt::enqueue(inputDesc, outputDesc, inputs, outputs,
+ * workspace, stream)` did there; the tensor descriptors are flattened into
+ * plain ints/floats.  The reference interface each function replaces is cited
+ * as file:line relative to the reference tree.
+ *
+ * Conventions (restating the reference's, TensorRT/common/helper.h:19-25 and
+ * SURVEY.md section 8b):
+ *   - return value: bevops_status_t (0 = success).  Never aborts, exits or
+ *     throws across the ABI; launch errors are returned, not printed.
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library
+ *     allocates nothing and keeps no mutable global state.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream).  No host synchronisation inside.
+ *   - tensors are dense, row-major ("kLINEAR"), 16-byte aligned.
+ *   - dtype enums: BEVOPS_F32 / BEVOPS_F16 / BEVOPS_I8.  INT8 tensors carry a
+ *     per-tensor scale (real = int8 * scale), as TensorRT's
+ *     PluginTensorDesc::scale did.
+ */
+#ifndef BEVOPS_H_
+#define BEVOPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  BEVOPS_SUCCESS = 0,         /* STATUS_SUCCESS          helper.h:20 */
+  BEVOPS_FAILURE = 1,         /* STATUS_FAILURE          helper.h:21 */
+  BEVOPS_BAD_PARAM = 2,       /* STATUS_BAD_PARAM        helper.h:22 */
+  BEVOPS_NOT_SUPPORTED = 3,   /* STATUS_NOT_SUPPORTED    helper.h:23 */
+  BEVOPS_NOT_INITIALIZED = 4  /* STATUS_NOT_INITIALIZED  helper.h:24 */
+} bevops_status_t;
+
+typedef enum { BEVOPS_F32 = 0, BEVOPS_F16 = 1, BEVOPS_I8 = 2 } bevops_dtype_t;
+
+/* interpolation / padding enums: functions/grid_sampler.py:134-136,
+ * gridSamplerKernel.h:9-12 */
+typedef enum { BEVOPS_BILINEAR = 0, BEVOPS_NEAREST = 1, BEVOPS_BICUBIC = 2 } bevops_interp_t;
+typedef enum { BEVOPS_PAD_ZEROS = 0, BEVOPS_PAD_BORDER = 1, BEVOPS_PAD_REFLECTION = 2 } bevops_pad_t;
+
+/* Library identification. */
+const char *bevops_version(void);
+/* Human-readable text for a status code (static storage). */
+const char *bevops_status_string(int status);
+/* Address of an entry point by plugin/op name, or NULL.  Accepts the ABI symbol
+ * ("bevops_msda_forward") and the reference's plugin type names
+ * ("MultiScaleDeformableAttnTRT", "MultiScaleDeformableAttnTRT2", "RotateTRT",
+ * ...; multiScaleDeformableAttnPlugin.cpp:17-18 etc.), standing in for
+ * TensorRT's plugin-creator registry (REGISTER_TENSORRT_PLUGIN,
+ * multiScaleDeformableAttnPlugin.cpp:345-346). */
+void *bevops_query(const char *name);
+
+/* ------------------------------------------------------------------------
+ * Multi-scale deformable attention, fused softmax + sampling + weighted sum.
+ * Replaces MultiScaleDeformableAttnPlugin::enqueue
+ *   (TensorRT/plugin/multi_scale_deformable_attn/multiScaleDeformableAttnPlugin.cpp:71-140)
+ * and the launchers ms_deformable_im2col_cuda{,_h2,_int8}
+ *   (multiScaleDeformableAttnKernel.h:12-38, multiScaleDeformableAttnKernel.cu:1106-1218).
+ *
+ *   value            [bs, nk, heads, channels]       dtype
+ *   spatial_shapes   [num_levels, 2] int32 (h, w)    device
+ *   spatial_shapes_host  same values on the host, or NULL (enables the
+ *                    host-side shape check nk == sum h*w; never required)
+ *   reference_points [bs, num_query, 1, 2*points_per_group]  ref_dtype (F32|F16);
+ *                    must equal dtype for F32/F16 values, either for I8
+ *                    (supportsFormatCombination, ...Plugin.cpp:148-189)
+ *   sampling_offsets [bs, num_query, heads, num_levels*num_point*2]  dtype
+ *   attention_weights[bs, num_query, heads, num_levels*num_point]    dtype, PRE-softmax
+ *   output           [bs, num_query, heads, channels] dtype
+ *   scale_*          INT8 per-tensor scales (ignored otherwise)
+ * INT8 requires channels % 4 == 0 and num_point % 4 == 0 (...Plugin.cpp:151-156),
+ * else BEVOPS_NOT_SUPPORTED.  With I8 values, ref_dtype F32 selects the signed
+ * x127 weight flavour (kernel.cu:848-955), F16 the unsigned x255 flavour
+ * (kernel.cu:957-1104).
+ * ------------------------------------------------------------------------ */
+int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
+                        const int32_t *spatial_shapes_host, const void *reference_points,
+                        int ref_dtype, const void *sampling_offsets,
+                        const void *attention_weights, void *output, int bs, int nk,
+                        int heads, int channels, int num_levels, int num_query,
+                        int num_point, int points_per_group, float scale_value,
+                        float scale_offset, float scale_weight, float scale_out,
+                        void *stream);
+
+/* Tuning hook: selects an internal MSDA kernel variant for subsequent calls from
+ * this thread (0 = automatic).  Results are identical across variants; exists so
+ * bench/tuning scripts can A/B them in one process.  Returns the previous value. */
+int bevops_msda_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVOPS_H_ */

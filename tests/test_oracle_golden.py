@@ -30,3 +30,14 @@ def test_msda_oracle_vs_reference_fp16_eager(oracle_mod, case):
                               h(g["logit"]))
     err = np.abs(out - g["out_fp16_eager"].astype(np.float32))
     assert err.mean() <= 0.01
+
+
+@pytest.mark.parametrize("case", MSDA_CASES)
+def test_torch_port_matches_reference(case):
+    """oracle/torch_ref.py (the CPU-baseline port) against the reference's output."""
+    import torch
+    from oracle import torch_ref
+    g = golden("msda_" + case)
+    t = lambda k: torch.from_numpy(g[k])
+    out = torch_ref.msda(t("value"), t("shapes").long(), t("ref"), t("off"), t("logit"))
+    np.testing.assert_allclose(out.numpy(), g["out_fp32"], rtol=1e-5, atol=2e-6)
