@@ -27,6 +27,15 @@ const Entry kTable[] = {
     {"bevops_msda_forward", (void *)&bevops_msda_forward},
     {"MultiScaleDeformableAttnTRT", (void *)&bevops_msda_forward},
     {"MultiScaleDeformableAttnTRT2", (void *)&bevops_msda_forward},
+    {"bevops_rotate_forward", (void *)&bevops_rotate_forward},
+    {"RotateTRT", (void *)&bevops_rotate_forward},
+    {"RotateTRT2", (void *)&bevops_rotate_forward},
+    {"bevops_grid_sampler_2d_forward", (void *)&bevops_grid_sampler_2d_forward},
+    {"GridSampler2DTRT", (void *)&bevops_grid_sampler_2d_forward},
+    {"GridSampler2DTRT2", (void *)&bevops_grid_sampler_2d_forward},
+    {"bevops_grid_sampler_3d_forward", (void *)&bevops_grid_sampler_3d_forward},
+    {"GridSampler3DTRT", (void *)&bevops_grid_sampler_3d_forward},
+    {"GridSampler3DTRT2", (void *)&bevops_grid_sampler_3d_forward},
 };
 }  // namespace
 

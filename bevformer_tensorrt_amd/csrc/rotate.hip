@@ -1,0 +1,148 @@
+// rotate: prev_bev [C,H,W] rotated by `angle` degrees about `center`, zeros padding,
+// align_corners=False, bilinear or nearest.  Replaces RotatePlugin::enqueue
+// (TensorRT/plugin/rotate/rotatePlugin.cpp:75-116) and rotate<T>/rotate_h2/rotate_int8
+// (rotateKernel.cu:128-748); arithmetic = the PyTorch path functions/rotate.py:12-80.
+//
+// MI355X mapping: the reference runs H*W threads, each looping over all C planes
+// (40 000 threads for the 200x200 BEV = 2.4 waves per CU).  Here the grid is
+// (pixel tiles) x (channel chunks): every thread resolves the affine source
+// footprint once and moves CPT channel planes, so the 256-channel BEV launches
+// ~5 000 workgroups; loads/stores are coalesced along W inside each plane.
+#include "sampler.h"
+
+namespace bevops {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kCPT = 8;  // channel planes per thread
+
+template <typename A> __device__ __forceinline__ float scalar_at(const void *p, int i);
+template <> __device__ __forceinline__ float scalar_at<float>(const void *p, int i) {
+  return static_cast<const float *>(p)[i];
+}
+template <> __device__ __forceinline__ float scalar_at<__half>(const void *p, int i) {
+  return __half2float(static_cast<const __half *>(p)[i]);
+}
+
+template <typename T, typename A>
+__global__ __launch_bounds__(kBlock) void rotate_kernel(const T *__restrict__ img,
+                                                        const void *__restrict__ angle,
+                                                        const void *__restrict__ center,
+                                                        T *__restrict__ out, int C, int H, int W,
+                                                        int interp, float s_in, float s_out) {
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int w = pix % W, h = pix / W;
+  float gx, gy;
+  {
+#pragma clang fp contract(off)
+    // functions/rotate.py:15-28
+    const float cx = scalar_at<A>(center, 0) - (float)(W * 0.5);
+    const float cy = scalar_at<A>(center, 1) - (float)(H * 0.5);
+    const float ang = -scalar_at<A>(angle, 0) * 3.14159265358979323846f / 180.f;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    const float t02 = -cx * cs - cy * sn + cx;
+    const float t12 = cx * sn - cy * cs + cy;
+    // rescaled_theta = 2 * theta^T / (W, H)   (:44-46);  grid = base_grid @ rescaled_theta (:48)
+    const float ax = 2 * cs / W, bx = 2 * sn / W, cx2 = 2 * t02 / W;
+    const float ay = 2 * -sn / H, by = 2 * cs / H, cy2 = 2 * t12 / H;
+    const float x = (float)(-W * 0.5 + 0.5) + (float)w, y = (float)(-H * 0.5 + 0.5) + (float)h;
+    gx = (x * ax + y * bx) + cx2;
+    gy = (x * ay + y * by) + cy2;
+  }
+  const float ix = gs_source_index(gx, W, BEVOPS_PAD_ZEROS, false);
+  const float iy = gs_source_index(gy, H, BEVOPS_PAD_ZEROS, false);
+  const int c0 = blockIdx.y * kCPT;
+  const int c1 = min(c0 + kCPT, C);
+  const T *ip = img + (size_t)c0 * HW;
+  T *op = out + (size_t)c0 * HW + pix;
+  constexpr bool kInt8 = sizeof(T) == 1;
+  if (interp == BEVOPS_NEAREST) {
+    const int o = footprint_nearest(ix, iy, H, W);
+    const float os = kInt8 ? s_in / s_out : 1.f;
+    for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
+      if (o >= 0) {
+        if constexpr (kInt8) st<T>(op, ld<T>(ip + o), os);
+        else *op = ip[o];  // pure copy: bit-exact for fp16/fp32
+      } else {
+        st<T>(op, 0.f, 1.f);
+      }
+    }
+  } else {
+    Footprint2D<4> f;
+    footprint_bilinear(ix, iy, H, W, f);
+    if constexpr (kInt8) {
+      // rotateKernel.cu:463-540: int8 area weights x127, int32 dot, requantise
+      int wq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wq[k] = q127_rne(f.w[k]);
+      const float os = (1.f / 127.f) * s_in / s_out;
+      for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (f.off[k] >= 0) t += (int)ip[f.off[k]] * wq[k];
+        *op = t2int8((float)t * os);
+      }
+    } else {
+      for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
+        float o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (f.off[k] >= 0) {
+#pragma clang fp contract(off)
+            o += ld<T>(ip + f.off[k]) * f.w[k];
+          }
+        st<T>(op, o, 1.f);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(const void *img, const void *angle, const void *center, int angle_dtype, void *out,
+           int C, int H, int W, int interp, float s_in, float s_out, hipStream_t st) {
+  const dim3 grid((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)((C + kCPT - 1) / kCPT));
+  if (angle_dtype == BEVOPS_F32)
+    hipLaunchKernelGGL((rotate_kernel<T, float>), grid, dim3(kBlock), 0, st, (const T *)img, angle,
+                       center, (T *)out, C, H, W, interp, s_in, s_out);
+  else
+    hipLaunchKernelGGL((rotate_kernel<T, __half>), grid, dim3(kBlock), 0, st, (const T *)img, angle,
+                       center, (T *)out, C, H, W, interp, s_in, s_out);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace bevops
+
+using namespace bevops;
+
+extern "C" int bevops_rotate_forward(int dtype, const void *img, const void *angle,
+                                     const void *center, int angle_dtype, void *output,
+                                     int channels, int height, int width, int interpolation,
+                                     float scale_in, float scale_out, void *stream) {
+  if (!img || !angle || !center || !output) return BEVOPS_BAD_PARAM;
+  if (channels <= 0 || height <= 0 || width <= 0) return BEVOPS_BAD_PARAM;
+  if (interpolation != BEVOPS_BILINEAR && interpolation != BEVOPS_NEAREST) return BEVOPS_BAD_PARAM;
+  if (angle_dtype != BEVOPS_F32 && angle_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if ((long)height * width > 0x7FFFFFFFL || (long)channels > 65535L * kCPT)
+    return BEVOPS_NOT_SUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BEVOPS_F32:
+      if (angle_dtype != BEVOPS_F32) return BEVOPS_NOT_SUPPORTED;  // rotatePlugin.cpp:152-155
+      return launch<float>(img, angle, center, angle_dtype, output, channels, height, width,
+                           interpolation, 1.f, 1.f, st);
+    case BEVOPS_F16:
+      return launch<__half>(img, angle, center, angle_dtype, output, channels, height, width,
+                            interpolation, 1.f, 1.f, st);
+    case BEVOPS_I8:
+      if (!(scale_in > 0.f) || !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
+      return launch<int8_t>(img, angle, center, angle_dtype, output, channels, height, width,
+                            interpolation, scale_in, scale_out, st);
+    default:
+      return BEVOPS_NOT_SUPPORTED;
+  }
+}

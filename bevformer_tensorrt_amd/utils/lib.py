@@ -22,6 +22,12 @@ SIGNATURES = {
     "bevops_msda_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                             [c_float] * 4 + [c_void_p]),
+    "bevops_rotate_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "bevops_grid_sampler_2d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                                       [c_float] * 3 + [c_void_p]),
+    "bevops_grid_sampler_3d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +
+                                       [c_void_p]),
 }
 
 F32, F16, I8 = 0, 1, 2

@@ -97,6 +97,42 @@ int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_sha
  * bench/tuning scripts can A/B them in one process.  Returns the previous value. */
 int bevops_msda_set_variant(int variant);
 
+
+/* ------------------------------------------------------------------------
+ * rotate: img [channels, height, width] rotated by *angle degrees (counter-clockwise)
+ * about *center (x, y in pixels); zeros padding, align_corners = false.
+ * Replaces RotatePlugin::enqueue (TensorRT/plugin/rotate/rotatePlugin.cpp:75-116) and
+ * rotate<T> / rotate_h2 / rotate_int8 (rotateKernel.h:14-26, rotateKernel.cu:708-748).
+ *   angle  : 1 element, center : 2 elements, DEVICE memory, angle_dtype F32|F16
+ *            (F32 images need F32 angle/center, rotatePlugin.cpp:125-156)
+ *   interpolation : BEVOPS_BILINEAR | BEVOPS_NEAREST
+ *   I8 : dense [C,H,W] int8 (the reference used kCHW4), real = int8 * scale_in;
+ *        output requantised with scale_out.
+ * ------------------------------------------------------------------------ */
+int bevops_rotate_forward(int dtype, const void *img, const void *angle, const void *center,
+                          int angle_dtype, void *output, int channels, int height, int width,
+                          int interpolation, float scale_in, float scale_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * grid_sampler, 2-D: input [N,C,H_in,W_in], grid [N,2,H_out,W_out] channel-first
+ * (x, y) in [-10, 10] units, output [N,C,H_out,W_out]; all of dtype.
+ * Replaces GridSamplerPlugin::enqueue (TensorRT/plugin/grid_sampler/gridSamplerPlugin.cpp:110-156),
+ * grid_sample<T> and grid_sample_int8 (gridSamplerKernel.h:14-26, gridSamplerKernel.cu:1933-2043).
+ *   interpolation : bilinear | nearest | bicubic;  padding : zeros | border | reflection
+ *   I8 : bilinear / nearest only here; grid is int8 with scale_grid.
+ * 3-D: input [N,C,D,H,W], grid [N,3,D_out,H_out,W_out] (x, y, z); F32 / F16;
+ *      bilinear (trilinear) | nearest.
+ * ------------------------------------------------------------------------ */
+int bevops_grid_sampler_2d_forward(int dtype, const void *input, const void *grid, void *output,
+                                   int N, int C, int H_in, int W_in, int H_out, int W_out,
+                                   int interpolation, int padding, int align_corners,
+                                   float scale_in, float scale_grid, float scale_out,
+                                   void *stream);
+int bevops_grid_sampler_3d_forward(int dtype, const void *input, const void *grid, void *output,
+                                   int N, int C, int D_in, int H_in, int W_in, int D_out,
+                                   int H_out, int W_out, int interpolation, int padding,
+                                   int align_corners, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

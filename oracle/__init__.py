@@ -78,3 +78,55 @@ def msda_s8(value, s_v, shapes, ref, off, s_o, logit, s_w, s_out, u8_weights=Fal
     fn(_p(value), f(s_v), _p(shapes), _p(ref), _p(off), f(s_o), _p(logit), f(s_w),
        _p(out), f(s_out), *_msda_dims(value, shapes, ref, off, logit))
     return out
+
+
+def grid_sampler(inp, grid, interp, pad, align):
+    """sampler_ref.c: oracle_grid_sampler_2d / _3d (fp32).  grid is channel-first in
+    [-10, 10] units like the reference op (functions/grid_sampler.py:140-236)."""
+    inp, grid = _c(inp, np.float32), _c(grid, np.float32)
+    i = ctypes.c_int
+    if grid.ndim == 4:
+        N, C, H, W = inp.shape
+        Ho, Wo = grid.shape[2:]
+        out = np.empty((N, C, Ho, Wo), np.float32)
+        lib().oracle_grid_sampler_2d(_p(inp), _p(grid), _p(out), i(N), i(C), i(H), i(W), i(Ho),
+                                     i(Wo), i(interp), i(pad), i(int(align)))
+    else:
+        N, C, D, H, W = inp.shape
+        Do, Ho, Wo = grid.shape[2:]
+        out = np.empty((N, C, Do, Ho, Wo), np.float32)
+        lib().oracle_grid_sampler_3d(_p(inp), _p(grid), _p(out), i(N), i(C), i(D), i(H), i(W),
+                                     i(Do), i(Ho), i(Wo), i(interp), i(pad), i(int(align)))
+    return out
+
+
+def rotate(img, angle, center, interp):
+    """sampler_ref.c: oracle_rotate (functions/rotate.py:12-80).  interp 0=bilinear 1=nearest."""
+    img = _c(img, np.float32)
+    C, H, W = img.shape
+    out = np.empty_like(img)
+    f, i = ctypes.c_float, ctypes.c_int
+    lib().oracle_rotate(_p(img), f(float(angle)), f(float(center[0])), f(float(center[1])),
+                        _p(out), i(C), i(H), i(W), i(interp))
+    return out
+
+
+def grid_sampler_s8(inp, grid, interp, pad, align, s_in, s_grid, s_out):
+    inp, grid = _c(inp, np.int8), _c(grid, np.int8)
+    N, C, H, W = inp.shape
+    Ho, Wo = grid.shape[2:]
+    out = np.empty((N, C, Ho, Wo), np.int8)
+    i, f = ctypes.c_int, ctypes.c_float
+    lib().oracle_grid_sampler_2d_s8(_p(inp), _p(grid), _p(out), i(N), i(C), i(H), i(W), i(Ho), i(Wo),
+                                    i(interp), i(pad), i(int(align)), f(s_in), f(s_grid), f(s_out))
+    return out
+
+
+def rotate_s8(img, angle, center, interp, s_in, s_out):
+    img = _c(img, np.int8)
+    C, H, W = img.shape
+    out = np.empty_like(img)
+    f, i = ctypes.c_float, ctypes.c_int
+    lib().oracle_rotate_s8(_p(img), f(float(angle)), f(float(center[0])), f(float(center[1])),
+                           _p(out), i(C), i(H), i(W), i(interp), f(s_in), f(s_out))
+    return out

@@ -41,3 +41,43 @@ def test_torch_port_matches_reference(case):
     t = lambda k: torch.from_numpy(g[k])
     out = torch_ref.msda(t("value"), t("shapes").long(), t("ref"), t("off"), t("logit"))
     np.testing.assert_allclose(out.numpy(), g["out_fp32"], rtol=1e-5, atol=2e-6)
+
+
+MODES = ("bilinear", "nearest", "bicubic")
+PADS = ("zeros", "border", "reflection")
+
+
+@pytest.mark.parametrize("mode", range(3))
+@pytest.mark.parametrize("pad", range(3))
+@pytest.mark.parametrize("align", [False, True])
+def test_grid_sampler_2d_oracle(oracle_mod, mode, pad, align):
+    g = golden("grid_sampler_2d")
+    out = oracle_mod.grid_sampler(g["input"], g["grid"], mode, pad, align)
+    want = g[f"{MODES[mode]}_{PADS[pad]}_{int(align)}"]
+    if mode == 1:
+        # nearest: identical pixels except possible .5 ties (reference test allows 0.1 mean)
+        assert (out != want).mean() <= 1e-3
+    else:
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", range(2))
+@pytest.mark.parametrize("pad", range(3))
+@pytest.mark.parametrize("align", [False, True])
+def test_grid_sampler_3d_oracle(oracle_mod, mode, pad, align):
+    g = golden("grid_sampler_3d")
+    out = oracle_mod.grid_sampler(g["input"], g["grid"], mode, pad, align)
+    want = g[f"{MODES[mode]}_{PADS[pad]}_{int(align)}"]
+    if mode == 1:
+        assert (out != want).mean() <= 1e-3
+    else:
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["sq_small", "rect", "offcenter", "bev_like"])
+def test_rotate_oracle(oracle_mod, case):
+    g = golden("rotate_" + case)
+    ob = oracle_mod.rotate(g["img"], g["angle"], g["center"], 0)
+    np.testing.assert_allclose(ob, g["bilinear"], rtol=1e-4, atol=1e-4)  # test_rotate.py fp32 1e-4
+    on = oracle_mod.rotate(g["img"], g["angle"], g["center"], 1)
+    assert (on != g["nearest"]).mean() <= 2e-3

@@ -1,0 +1,233 @@
+"""GPU parity tests: rotate and grid_sampler HIP kernels vs the CPU oracle and the
+golden vectors the reference's Python functions produced.
+Tolerances (reference tests in brackets, mean-abs):
+  fp32 bilinear/bicubic: element-wise 1e-5 (+1e-5 rel)       [grid_sampler 1e-5, rotate 1e-4]
+  fp32 nearest: identical except <=0.1% of pixels (.5 ties)    [0.1 mean]
+  fp16: element-wise 1e-2 vs fp32 evaluation of the fp16-rounded inputs [0.05 .. 0.6 mean]
+  int8: |err| <= 1 LSB, <=1% of elements off by one            [0.1 .. 0.5 mean]
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+MODES = ("bilinear", "nearest", "bicubic")
+PADS = ("zeros", "border", "reflection")
+
+
+@pytest.fixture(scope="module")
+def bev():
+    import bevformer_tensorrt_amd as b
+    from bevformer_tensorrt_amd.utils import load_library
+    load_library()
+    return b
+
+
+def ref_grid(N, Ho, Wo, lo=-15.0, hi=15.0, seed=0, jitter=0.0):
+    """test_grid_sampler.py:22-37: linspace(-15, 15) meshgrid (50% out of range)."""
+    gy, gx = torch.meshgrid(torch.linspace(lo, hi, Ho), torch.linspace(lo, hi, Wo), indexing="ij")
+    grid = torch.stack([gx, gy], 0)[None].repeat(N, 1, 1, 1)
+    if jitter:
+        grid = grid + torch.randn(grid.shape, generator=torch.Generator().manual_seed(seed)) * jitter
+    return grid
+
+
+def close_nearest(out, want, frac=1e-3):
+    return float((out != want).mean()) <= frac
+
+
+# ------------------------------------------------------------------ grid_sampler 2-D
+@pytest.mark.parametrize("mode", range(3))
+@pytest.mark.parametrize("pad", range(3))
+@pytest.mark.parametrize("align", [False, True])
+def test_grid_sampler_2d_golden(bev, mode, pad, align):
+    g = golden("grid_sampler_2d")
+    out = bev.grid_sampler(torch.from_numpy(g["input"]).cuda(), torch.from_numpy(g["grid"]).cuda(),
+                           MODES[mode], PADS[pad], align).cpu().numpy()
+    want = g[f"{MODES[mode]}_{PADS[pad]}_{int(align)}"]
+    if mode == 1:
+        assert close_nearest(out, want)
+    else:
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", range(3))
+@pytest.mark.parametrize("pad", range(3))
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_grid_sampler_2d_reference_shape(bev, oracle_mod, mode, pad, align, dtype):
+    """reference test shape [8,32,100,100] (test_grid_sampler.py:5-7), output 301x301."""
+    g = torch.Generator().manual_seed(0)
+    inp = torch.randn(8, 32, 100, 100, generator=g).to(dtype)
+    grid = ref_grid(8, 301, 301, jitter=0.3).to(dtype)
+    out = bev.grid_sampler(inp.cuda(), grid.cuda(), MODES[mode], PADS[pad], align).float().cpu().numpy()
+    want = oracle_mod.grid_sampler(inp.float().numpy(), grid.float().numpy(), mode, pad, align)
+    if dtype == torch.float32:
+        if mode == 1:
+            assert close_nearest(out, want)
+        else:
+            np.testing.assert_allclose(out, want, rtol=1e-5, atol=2e-5)
+    else:
+        if mode == 1:
+            assert close_nearest(out, want)
+        else:
+            assert np.abs(out - want).max() <= 1e-2 * max(1.0, np.abs(want).max() / 4)
+
+
+def test_grid_sampler_2d_full_reference_size(bev, oracle_mod):
+    """The full reference test size: grid [8,2,1001,1001] (test_grid_sampler.py:22-37)."""
+    g = torch.Generator().manual_seed(0)
+    inp = torch.randn(8, 32, 100, 100, generator=g)
+    grid = ref_grid(8, 1001, 1001)
+    out = bev.grid_sampler(inp.cuda(), grid.cuda(), "bilinear", "zeros", False)
+    torch.cuda.synchronize()
+    want = oracle_mod.grid_sampler(inp.numpy(), grid.numpy(), 0, 0, False)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    # identity grid property at full size: align_corners=True, grid = pixel centres -> copy
+    gy, gx = torch.meshgrid(torch.linspace(-10, 10, 100), torch.linspace(-10, 10, 100), indexing="ij")
+    ident = torch.stack([gx, gy], 0)[None].repeat(8, 1, 1, 1)
+    out = bev.grid_sampler(inp.cuda(), ident.cuda(), "bilinear", "zeros", True).cpu()
+    assert (out - inp).abs().max().item() <= 2e-5
+    out = bev.grid_sampler(inp.cuda(), ident.cuda(), "nearest", "border", True).cpu()
+    assert torch.equal(out, inp)
+
+
+@pytest.mark.parametrize("mode", range(2))
+@pytest.mark.parametrize("pad", range(3))
+@pytest.mark.parametrize("align", [False, True])
+def test_grid_sampler_3d_golden(bev, mode, pad, align):
+    g = golden("grid_sampler_3d")
+    out = bev.grid_sampler(torch.from_numpy(g["input"]).cuda(), torch.from_numpy(g["grid"]).cuda(),
+                           MODES[mode], PADS[pad], align).cpu().numpy()
+    want = g[f"{MODES[mode]}_{PADS[pad]}_{int(align)}"]
+    if mode == 1:
+        assert close_nearest(out, want)
+    else:
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", range(2))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_grid_sampler_3d_reference_shape(bev, oracle_mod, mode, dtype):
+    """[8,32,10,10,10] -> grid [8,3,31,31,31] (test_grid_sampler.py:9-11 uses 101^3)."""
+    g = torch.Generator().manual_seed(0)
+    inp = torch.randn(8, 32, 10, 10, 10, generator=g).to(dtype)
+    lin = torch.linspace(-14, 14, 31)
+    gz, gy, gx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    grid = (torch.stack([gx, gy, gz], 0)[None].repeat(8, 1, 1, 1, 1)
+            + torch.randn(8, 3, 31, 31, 31, generator=g) * 0.3).to(dtype)
+    for pad in range(3):
+        out = bev.grid_sampler(inp.cuda(), grid.cuda(), MODES[mode], PADS[pad], False).float().cpu().numpy()
+        want = oracle_mod.grid_sampler(inp.float().numpy(), grid.float().numpy(), mode, pad, False)
+        if mode == 1:
+            assert close_nearest(out, want)
+        elif dtype == torch.float32:
+            np.testing.assert_allclose(out, want, rtol=1e-5, atol=2e-5)
+        else:
+            assert np.abs(out - want).max() <= 1e-2
+
+
+def test_grid_sampler_bicubic_3d_not_supported(bev):
+    from bevformer_tensorrt_amd.utils.lib import BevopsError
+    with pytest.raises(BevopsError):
+        bev.grid_sampler(torch.zeros(1, 1, 2, 2, 2).cuda(), torch.zeros(1, 3, 2, 2, 2).cuda(),
+                         "bicubic", "zeros", False)
+
+
+@pytest.mark.parametrize("mode", range(2))
+@pytest.mark.parametrize("pad", range(3))
+def test_grid_sampler_int8(bev, oracle_mod, mode, pad):
+    g = torch.Generator().manual_seed(0)
+    inp = torch.randint(-127, 128, (4, 16, 40, 50), generator=g, dtype=torch.int8)
+    s_grid = 15.0 / 127
+    grid = torch.round(ref_grid(4, 77, 91, jitter=0.5) / s_grid).clamp(-127, 127).to(torch.int8)
+    s_in, s_out = 0.031, 0.027
+    out = bev.grid_sampler_int8(inp.cuda(), grid.cuda(), MODES[mode], PADS[pad], False, s_in, s_grid,
+                                s_out).cpu().numpy().astype(np.int32)
+    want = oracle_mod.grid_sampler_s8(inp.numpy(), grid.numpy(), mode, pad, False, s_in, s_grid,
+                                      s_out).astype(np.int32)
+    d = np.abs(out - want)
+    assert d.max() <= 1 and (d > 0).mean() <= 0.01
+    # and the int8 result tracks the fp32 op within the quantisation error
+    f = oracle_mod.grid_sampler(inp.numpy().astype(np.float32) * s_in,
+                                grid.numpy().astype(np.float32) * s_grid, mode, pad, False)
+    assert np.abs(np.clip(f / s_out, -128, 127) - out).mean() <= 1.0
+
+
+# ------------------------------------------------------------------ rotate
+@pytest.mark.parametrize("case", ["sq_small", "rect", "offcenter", "bev_like"])
+def test_rotate_golden(bev, case):
+    g = golden("rotate_" + case)
+    img = torch.from_numpy(g["img"]).cuda()
+    ang = torch.tensor(float(g["angle"])).cuda()
+    ctr = torch.from_numpy(g["center"]).cuda()
+    ob = bev.rotate(img, ang, ctr, "bilinear").cpu().numpy()
+    np.testing.assert_allclose(ob, g["bilinear"], rtol=1e-4, atol=1e-4)
+    on = bev.rotate(img, ang, ctr, "nearest").cpu().numpy()
+    assert close_nearest(on, g["nearest"], 2e-3)
+
+
+@pytest.mark.parametrize("shape", [(256, 50, 50), (256, 150, 150), (256, 200, 200)],
+                         ids=["tiny", "small", "base"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+def test_rotate_model_shapes(bev, oracle_mod, shape, dtype, interp):
+    """prev_bev [256, bev_h, bev_w], centre = rotate_center [100,100]
+    (det2trt/models/modules/transformer.py:26,298-302), small ego-motion angle."""
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(*shape, generator=g).to(dtype)
+    for angle in (1.7, -38.25):
+        center = (100.0, 100.0)
+        out = bev.rotate(img.cuda(), torch.tensor(angle), torch.tensor(center), interp).float().cpu().numpy()
+        want = oracle_mod.rotate(img.float().numpy(), angle, center, 0 if interp == "bilinear" else 1)
+        if interp == "nearest":
+            assert close_nearest(out, want, 2e-3)   # pure copies: bit-exact off the .5 ties
+        elif dtype == torch.float32:
+            np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4)
+        else:
+            assert np.abs(out - want).max() <= 1e-2
+
+
+def test_rotate_reference_test_shape(bev, oracle_mod):
+    """test_rotate.py:6-9,21-25: img randn[256,512,512], angle randn*360, centre [500,500]."""
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(256, 512, 512, generator=g)
+    angle = float(torch.randn(1, generator=g)) * 360
+    out = bev.rotate(img.cuda(), torch.tensor(angle).cuda(), torch.tensor([500.0, 500.0]).cuda(),
+                     "bilinear").cpu().numpy()
+    want = oracle_mod.rotate(img.numpy(), angle, (500.0, 500.0), 0)
+    # source coordinates reach ~1e3 px here, so fp32 sin/cos ulps show up at ~1e-4 px
+    assert np.abs(out - want).mean() <= 1e-4           # the reference's own criterion
+    assert np.abs(out - want).max() <= 5e-3
+
+
+def test_rotate_properties_full_base_size(bev):
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(256, 200, 200, generator=g).half().cuda()
+    ctr = torch.tensor([100.0, 100.0]).cuda()
+    # angle 0 about the image centre is the identity for both modes
+    for interp in ("nearest", "bilinear"):
+        assert torch.equal(bev.rotate(img, torch.tensor(0.0).cuda(), ctr, interp), img)
+    # 90 + 270 degrees (nearest, centre) returns the original image
+    r = bev.rotate(bev.rotate(img, torch.tensor(90.0).cuda(), ctr, "nearest"),
+                   torch.tensor(270.0).cuda(), ctr, "nearest")
+    assert (r != img).float().mean().item() <= 2e-2  # border row/column may fall outside
+    # rotate2 is the same op
+    a = torch.tensor(12.5).cuda()
+    assert torch.equal(bev.rotate(img, a, ctr), bev.rotate2(img, a, ctr))
+
+
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+def test_rotate_int8(bev, oracle_mod, interp):
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(-127, 128, (64, 50, 50), generator=g, dtype=torch.int8)
+    s_in, s_out = 0.02, 0.025
+    out = bev.rotate_int8(img.cuda(), torch.tensor(17.0), torch.tensor([25.0, 25.0]), s_in, s_out,
+                          interp).cpu().numpy().astype(np.int32)
+    want = oracle_mod.rotate_s8(img.numpy(), 17.0, (25.0, 25.0), 0 if interp == "bilinear" else 1,
+                                s_in, s_out).astype(np.int32)
+    d = np.abs(out - want)
+    assert d.max() <= 1 and (d > 0).mean() <= 0.01
