@@ -36,6 +36,9 @@ const Entry kTable[] = {
     {"bevops_grid_sampler_3d_forward", (void *)&bevops_grid_sampler_3d_forward},
     {"GridSampler3DTRT", (void *)&bevops_grid_sampler_3d_forward},
     {"GridSampler3DTRT2", (void *)&bevops_grid_sampler_3d_forward},
+    {"bevops_bev_pool_v2_forward", (void *)&bevops_bev_pool_v2_forward},
+    {"BEVPoolV2TRT", (void *)&bevops_bev_pool_v2_forward},
+    {"BEVPoolV2TRT2", (void *)&bevops_bev_pool_v2_forward},
 };
 }  // namespace
 

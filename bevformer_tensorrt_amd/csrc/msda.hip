@@ -315,6 +315,307 @@ __global__ __launch_bounds__(kBlock) void msda_generic_kernel(
   out[idx] = from_f<T>(acc / s);
 }
 
+
+// ---------------------------------------------------------------------------
+// INT8 flavours.  Same quad structure; a lane holds 8 int8
+// channels (8-byte taps).  The owner lane quantises the 4 bilinear area weights of a
+// point into one packed dword and the softmax weight into an int, so a point costs 6
+// DPP broadcasts; the consumer transposes the 4 corner dwords with v_perm_b32 and
+// reduces them with v_dot4_i32_i8.
+//   U8W = false : reference <float> flavour  (kernel.cu:848-955, 290-358): signed x127
+//                 weights, T2int8 = clamp + round-half-away, S = sum of QUANTISED weights
+//   U8W = true  : reference <__half2> flavour (kernel.cu:957-1104, 360-460): unsigned x255
+//                 weights, RNE rounding, S = sum of UN-quantised weights; gfx950 has no
+//                 mixed-sign dot4, so v*a (a in 0..255) = dot4(v, a^0x80) + 128*dot4(v, 1).
+//                 Intermediate math is fp32 here (the reference uses half2).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int t2i8_away(float a) {  // kernel.cu:44-55
+  a = fminf(fmaxf(a, -128.f), 127.f);
+  return (int)(a + (a > 0.f ? 0.5f : -0.5f));
+}
+__device__ __forceinline__ int t2i8_rne(float a) {  // kernel.cu:57-62
+  return (int)fminf(fmaxf(rintf(a), -128.f), 127.f);
+}
+__device__ __forceinline__ unsigned u16_rne(float a) {  // __half2ushort_rn
+  return (unsigned)fminf(fmaxf(rintf(a), 0.f), 65535.f);
+}
+template <int N>
+__device__ __forceinline__ void load_i8(const int8_t *p, float (&d)[N]) {
+  int8_t raw[N];
+  if constexpr (N == 16) *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(p);
+  else if constexpr (N == 8) *reinterpret_cast<uint2 *>(raw) = *reinterpret_cast<const uint2 *>(p);
+  else if constexpr (N == 4) *reinterpret_cast<unsigned *>(raw) = *reinterpret_cast<const unsigned *>(p);
+  else if constexpr (N == 2) *reinterpret_cast<unsigned short *>(raw) = *reinterpret_cast<const unsigned short *>(p);
+  else if constexpr (N == 1) raw[0] = p[0];
+  else {
+    static_assert(N % 16 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 16; ++i)
+      reinterpret_cast<uint4 *>(raw)[i] = reinterpret_cast<const uint4 *>(p)[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = (float)raw[i];
+}
+// 4x4 byte transpose: r[k] = 4 channels of corner k  ->  o[c] = channel c of corners 0..3
+__device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned r2, unsigned r3,
+                                             unsigned (&o)[4]) {
+  const unsigned a = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+  const unsigned b = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+  const unsigned c = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+  const unsigned d = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(d, b, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+}
+
+template <typename RefT, int PPL, int CH, bool U8W>
+__global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
+    const int8_t *__restrict__ value, unsigned value_bytes, const int32_t *__restrict__ shapes,
+    const RefT *__restrict__ ref, const int8_t *__restrict__ off, const int8_t *__restrict__ logit,
+    int8_t *__restrict__ out, MsdaDims d, unsigned n_item, float s_v, float s_o, float s_w,
+    float s_out) {
+  static_assert(PPL % CH == 0, "CH must divide PPL");
+  constexpr int V = 8;
+  __shared__ int4 lvl[kMaxLevels];
+  if (threadIdx.x == 0) {
+    int start = 0;
+    for (int l = 0; l < d.L; ++l) {
+      const int H = shapes[2 * l], W = shapes[2 * l + 1];
+      lvl[l] = make_int4(H, W, start, 0);
+      start += H * W;
+    }
+  }
+  __syncthreads();
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned item = vb * (kBlock / 4) + (threadIdx.x >> 2);
+  if (item >= n_item) return;
+  const unsigned sub = threadIdx.x & 3u;
+  const unsigned bq = item / (unsigned)d.heads;
+  const unsigned h = item - bq * (unsigned)d.heads;
+  const unsigned b = bq / (unsigned)d.nq;
+  constexpr int LP = 4 * PPL;
+  const unsigned row_bytes = (unsigned)d.heads * 32u;
+  const unsigned lane_base = (b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(value), 0, value_bytes, 0x00020000);
+
+  float e[PPL];
+  load_i8<PPL>(logit + (size_t)item * LP + sub * PPL, e);
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    e[k] *= s_w;
+    m = fmaxf(m, e[k]);
+  }
+  m = quad_max(m);
+  float s = 0.f;
+  int wq[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    if constexpr (U8W) {
+      const float w255 = __expf(e[k] - m) * 255.f;
+      s += w255;
+      wq[k] = (int)u16_rne(w255);
+    } else {
+      wq[k] = t2i8_away(__expf(e[k] - m) * 127.f);
+      s += (float)wq[k];
+    }
+  }
+  s = quad_sum(s);
+
+  float offs[2 * PPL];
+  load_i8<2 * PPL>(off + ((size_t)item * LP + sub * PPL) * 2, offs);
+  const RefT *refp = ref + (size_t)bq * (unsigned)d.ppg * 2u;
+  int j0 = (int)sub * PPL;
+  int l = j0 / d.P;
+  int p = j0 - l * d.P;
+  int g = p % d.ppg;
+
+  int acc[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) acc[c] = 0;
+
+#pragma unroll
+  for (int pass = 0; pass < PPL / CH; ++pass) {
+    unsigned oaw[CH], oo[CH][4];
+    int owq[CH];
+    bool any_valid = false;
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k = pass * CH + kk;
+      const int4 t = lvl[l];
+      const int H = t.x, W = t.y;
+      const float2 r = load_ref(refp + 2 * g);
+      float x, y;
+      {
+#pragma clang fp contract(off)
+        if constexpr (U8W) {  // kernel.cu:1040-1056: ref*size + (off*scale - 0.5)
+          x = r.x * (float)W + (offs[2 * k] * s_o - 0.5f);
+          y = r.y * (float)H + (offs[2 * k + 1] * s_o - 0.5f);
+        } else {  // kernel.cu:905-917
+          x = (r.x * (float)W + offs[2 * k] * s_o) - 0.5f;
+          y = (r.y * (float)H + offs[2 * k + 1] * s_o) - 0.5f;
+        }
+      }
+      const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
+      any_valid |= valid;
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const float hx = 1.f - lx, hy = 1.f - ly;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1;
+      unsigned a0, a1, a2, a3;
+      if constexpr (U8W) {
+        a0 = u16_rne(hy * hx * 255.f); a1 = u16_rne(hy * lx * 255.f);
+        a2 = u16_rne(ly * hx * 255.f); a3 = u16_rne(ly * lx * 255.f);
+      } else {
+#pragma clang fp contract(off)
+        const float sa = 1 / 127.f;
+        a0 = (unsigned)t2i8_away((hy * hx) / sa); a1 = (unsigned)t2i8_away((hy * lx) / sa);
+        a2 = (unsigned)t2i8_away((ly * hx) / sa); a3 = (unsigned)t2i8_away((ly * lx) / sa);
+      }
+      a0 = (y0ok && x0ok) ? a0 : 0u; a1 = (y0ok && x1ok) ? a1 : 0u;
+      a2 = (y1ok && x0ok) ? a2 : 0u; a3 = (y1ok && x1ok) ? a3 : 0u;
+      oaw[kk] = (a0 & 255u) | ((a1 & 255u) << 8) | ((a2 & 255u) << 16) | ((a3 & 255u) << 24);
+      owq[kk] = valid ? wq[k] : 0;
+      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x0 + 1, 0), W - 1);
+      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+      const unsigned r0 = (unsigned)(t.z + y0c * W), r1 = (unsigned)(t.z + y1c * W);
+      oo[kk][0] = (r0 + (unsigned)x0c) * row_bytes;
+      oo[kk][1] = (r0 + (unsigned)x1c) * row_bytes;
+      oo[kk][2] = (r1 + (unsigned)x0c) * row_bytes;
+      oo[kk][3] = (r1 + (unsigned)x1c) * row_bytes;
+      ++p; ++g;
+      if (g == d.ppg) g = 0;
+      if (p == d.P) { p = 0; g = 0; ++l; }
+    }
+    if (!__any(any_valid)) continue;
+
+#define BEVOPS_MSDA_I8_SRC(S)                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < CH; ++kk) {                                        \
+      const unsigned aw = quad_bcast<S>(oaw[kk]);                                              \
+      const int wgt = (int)quad_bcast<S>((unsigned)owq[kk]);                                   \
+      u32x2 tp[4];                                                                             \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) tp[q] = __builtin_amdgcn_raw_buffer_load_b64( \
+          rs, (int)(quad_bcast<S>(oo[kk][q]) + lane_base), 0, 0);                              \
+      _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                       \
+        unsigned tr[4];                                                                        \
+        transpose4x4(hf ? tp[0].y : tp[0].x, hf ? tp[1].y : tp[1].x, hf ? tp[2].y : tp[2].x,   \
+                     hf ? tp[3].y : tp[3].x, tr);                                              \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                        \
+          int tsum, smp;                                                                       \
+          if constexpr (U8W) {                                                                 \
+            tsum = __builtin_amdgcn_sdot4((int)tr[c], (int)(aw ^ 0x80808080u), 0, false) +     \
+                   (__builtin_amdgcn_sdot4((int)tr[c], 0x01010101, 0, false) << 7);            \
+            smp = t2i8_rne((float)tsum * (1.0f / 255.f));                                      \
+          } else {                                                                             \
+            tsum = __builtin_amdgcn_sdot4((int)tr[c], (int)aw, 0, false);                      \
+            smp = t2i8_away((float)tsum * (1 / 127.f));                                        \
+          }                                                                                    \
+          acc[hf * 4 + c] += smp * wgt;                                                        \
+        }                                                                                      \
+      }                                                                                        \
+    }
+    BEVOPS_MSDA_I8_SRC(0)
+    BEVOPS_MSDA_I8_SRC(1)
+    BEVOPS_MSDA_I8_SRC(2)
+    BEVOPS_MSDA_I8_SRC(3)
+#undef BEVOPS_MSDA_I8_SRC
+  }
+
+  int8_t res[V];
+  {
+#pragma clang fp contract(off)
+    const float scale_o = s_v * (1.0f / s_out);
+    const float f = scale_o * (1.0f / s);
+#pragma unroll
+    for (int c = 0; c < V; ++c)
+      res[c] = (int8_t)(U8W ? t2i8_rne((float)acc[c] * f) : t2i8_away((float)acc[c] * f));
+  }
+  *reinterpret_cast<uint2 *>(out + (size_t)item * 32u + sub * V) = *reinterpret_cast<const uint2 *>(res);
+}
+
+// generic int8: one thread per output element, any shape (reference needs C%4==0, P%4==0)
+template <typename RefT, bool U8W>
+__global__ __launch_bounds__(kBlock) void msda_generic_int8_kernel(
+    const int8_t *__restrict__ value, const int32_t *__restrict__ shapes,
+    const RefT *__restrict__ ref, const int8_t *__restrict__ off, const int8_t *__restrict__ logit,
+    int8_t *__restrict__ out, MsdaDims d, size_t n_out, float s_v, float s_o, float s_w,
+    float s_out) {
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n_out) return;
+  const int c = (int)(idx % d.C);
+  const size_t item = idx / d.C;
+  const int h = (int)(item % d.heads);
+  const size_t bq = item / d.heads;
+  const size_t b = bq / d.nq;
+  const int LP = d.L * d.P;
+  const int8_t *lg = logit + item * LP;
+  const int8_t *of = off + item * LP * 2;
+  const RefT *rp = ref + bq * d.ppg * 2;
+  const size_t step = (size_t)d.heads * d.C;
+  const int8_t *vp = value + (b * d.nk * d.heads + h) * (size_t)d.C + c;
+  float m = -INFINITY;
+  for (int j = 0; j < LP; ++j) m = fmaxf(m, (float)lg[j] * s_w);
+  int acc = 0;
+  float s = 0.f;
+  int j = 0;
+  for (int l = 0; l < d.L; ++l) {
+    const int H = shapes[2 * l], W = shapes[2 * l + 1];
+    for (int p = 0; p < d.P; ++p, ++j) {
+      const int g = p % d.ppg;
+      const float2 r = load_ref(rp + 2 * g);
+      float x, y;
+      int wq;
+      {
+#pragma clang fp contract(off)
+        if constexpr (U8W) {
+          x = r.x * (float)W + ((float)of[2 * j] * s_o - 0.5f);
+          y = r.y * (float)H + ((float)of[2 * j + 1] * s_o - 0.5f);
+          const float w255 = __expf((float)lg[j] * s_w - m) * 255.f;
+          s += w255;
+          wq = (int)u16_rne(w255);
+        } else {
+          x = (r.x * (float)W + (float)of[2 * j] * s_o) - 0.5f;
+          y = (r.y * (float)H + (float)of[2 * j + 1] * s_o) - 0.5f;
+          wq = t2i8_away(__expf((float)lg[j] * s_w - m) * 127.f);
+          s += (float)wq;
+        }
+      }
+      if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
+      const float xf = floorf(x), yf = floorf(y);
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+      int v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+      if (y0 >= 0 && x0 >= 0) v1 = vp[((size_t)y0 * W + x0) * step];
+      if (y0 >= 0 && x0 + 1 <= W - 1) v2 = vp[((size_t)y0 * W + x0 + 1) * step];
+      if (y0 + 1 <= H - 1 && x0 >= 0) v3 = vp[((size_t)(y0 + 1) * W + x0) * step];
+      if (y0 + 1 <= H - 1 && x0 + 1 <= W - 1) v4 = vp[((size_t)(y0 + 1) * W + x0 + 1) * step];
+      int smp;
+      if constexpr (U8W) {
+        const int t = v1 * (int)u16_rne(hy * hx * 255.f) + v2 * (int)u16_rne(hy * lx * 255.f) +
+                      v3 * (int)u16_rne(ly * hx * 255.f) + v4 * (int)u16_rne(ly * lx * 255.f);
+        smp = t2i8_rne((float)t * (1.0f / 255.f));
+      } else {
+#pragma clang fp contract(off)
+        const float sa = 1 / 127.f;
+        const int t = v1 * t2i8_away((hy * hx) / sa) + v2 * t2i8_away((hy * lx) / sa) +
+                      v3 * t2i8_away((ly * hx) / sa) + v4 * t2i8_away((ly * lx) / sa);
+        smp = t2i8_away((float)t * sa);
+      }
+      acc += smp * wq;
+    }
+    vp += (size_t)H * W * step;
+  }
+  {
+#pragma clang fp contract(off)
+    const float f = (s_v * (1.0f / s_out)) * (1.0f / s);
+    out[idx] = (int8_t)(U8W ? t2i8_rne((float)acc * f) : t2i8_away((float)acc * f));
+  }
+}
+
 thread_local int g_variant = 0;
 
 template <typename T, int PPL, int CH>
@@ -365,6 +666,47 @@ int msda_float(const T *value, const int32_t *shapes, const T *ref, const T *off
   return launch_status();
 }
 
+template <typename RefT, bool U8W, int PPL, int CH>
+int launch_quad_i8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
+                   const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o,
+                   float s_w, float s_out, hipStream_t st) {
+  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
+  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
+  const unsigned grid = (unsigned)((n_item + kBlock / 4 - 1) / (kBlock / 4));
+  hipLaunchKernelGGL((msda_quad_int8_kernel<RefT, PPL, CH, U8W>), dim3(grid), dim3(kBlock), 0, st,
+                     value, (unsigned)vbytes, shapes, ref, off, logit, out, d, (unsigned)n_item, s_v,
+                     s_o, s_w, s_out);
+  return launch_status();
+}
+
+template <typename RefT, bool U8W>
+int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
+              const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o, float s_w,
+              float s_out, hipStream_t st) {
+  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
+  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
+  const int LP = d.L * d.P;
+  const bool quad_ok = d.C == 32 && LP % 4 == 0 && d.L <= kMaxLevels && vbytes < 0xFFFFFF00ull &&
+                       n_item < 0x7FFFFFFFull && aligned16(value) && aligned16(off) &&
+                       aligned16(logit) && aligned16(out) && aligned16(ref) && g_variant != 99;
+  if (quad_ok) {
+    switch (LP / 4) {
+      case 1: return launch_quad_i8<RefT, U8W, 1, 1>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
+      case 2: return launch_quad_i8<RefT, U8W, 2, 2>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
+      case 4: return launch_quad_i8<RefT, U8W, 4, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
+      case 8: return launch_quad_i8<RefT, U8W, 8, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
+      case 16: return launch_quad_i8<RefT, U8W, 16, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
+      default: break;
+    }
+  }
+  const size_t n_out = n_item * d.C;
+  const size_t grid = (n_out + kBlock - 1) / kBlock;
+  if (grid > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL((msda_generic_int8_kernel<RefT, U8W>), dim3((unsigned)grid), dim3(kBlock), 0,
+                     st, value, shapes, ref, off, logit, out, d, n_out, s_v, s_o, s_w, s_out);
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace bevops
 
@@ -412,8 +754,26 @@ extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *
       return msda_float<__half>((const __half *)value, spatial_shapes,
                                 (const __half *)reference_points, (const __half *)sampling_offsets,
                                 (const __half *)attention_weights, (__half *)output, d, st);
+    case BEVOPS_I8:
+      // supportsFormatCombination (multiScaleDeformableAttnPlugin.cpp:151-156)
+      if (channels % 4 != 0 || num_point % 4 != 0) return BEVOPS_NOT_SUPPORTED;
+      if (!(scale_value > 0.f) || !(scale_offset > 0.f) || !(scale_weight > 0.f) ||
+          !(scale_out > 0.f))
+        return BEVOPS_BAD_PARAM;
+      if (ref_dtype == BEVOPS_F32)
+        return msda_int8<float, false>((const int8_t *)value, spatial_shapes,
+                                       (const float *)reference_points,
+                                       (const int8_t *)sampling_offsets,
+                                       (const int8_t *)attention_weights, (int8_t *)output, d,
+                                       scale_value, scale_offset, scale_weight, scale_out, st);
+      if (ref_dtype == BEVOPS_F16)
+        return msda_int8<__half, true>((const int8_t *)value, spatial_shapes,
+                                       (const __half *)reference_points,
+                                       (const int8_t *)sampling_offsets,
+                                       (const int8_t *)attention_weights, (int8_t *)output, d,
+                                       scale_value, scale_offset, scale_weight, scale_out, st);
+      return BEVOPS_NOT_SUPPORTED;
     default:
-      (void)scale_value; (void)scale_offset; (void)scale_weight; (void)scale_out;
       return BEVOPS_NOT_SUPPORTED;
   }
 }

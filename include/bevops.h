@@ -133,6 +133,25 @@ int bevops_grid_sampler_3d_forward(int dtype, const void *input, const void *gri
                                    int H_out, int W_out, int interpolation, int padding,
                                    int align_corners, void *stream);
 
+/* ------------------------------------------------------------------------
+ * bev_pool_v2 (BEVDet pillar pooling):
+ *   out[ranks_bev[s_k], :] = sum_{i < len_k} depth.flat[ranks_depth[s_k+i]] * feat.flat[ranks_feat[s_k+i], :]
+ * all other output cells are zero.  Replaces BEVPoolPlugin::enqueue
+ * (TensorRT/plugin/bev_pool_v2/bevPoolPlugin.cpp:68-109) and bev_pool_v2 / _h2 / _int8
+ * (bevPoolKernel.h:13-31, bevPoolKernel.cu:151-190).
+ *   depth  [N,D,H,W] dtype, feat [N,H,W,channels] dtype, ranks_* [n_points] int32,
+ *   interval_starts / interval_lengths [n_intervals] int32,
+ *   output [1, out_height, out_width, channels] dtype (fully written: cleared on `stream`).
+ *   I8: out = T2int8(acc * scale_depth * scale_feat / scale_out), int32 accumulation.
+ * ------------------------------------------------------------------------ */
+int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
+                               const int32_t *ranks_depth, const int32_t *ranks_feat,
+                               const int32_t *ranks_bev, const int32_t *interval_starts,
+                               const int32_t *interval_lengths, void *output, int channels,
+                               int n_intervals, int out_height, int out_width,
+                               float scale_depth, float scale_feat, float scale_out,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

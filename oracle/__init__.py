@@ -130,3 +130,25 @@ def rotate_s8(img, angle, center, interp, s_in, s_out):
     lib().oracle_rotate_s8(_p(img), f(float(angle)), f(float(center[0])), f(float(center[1])),
                            _p(out), i(C), i(H), i(W), i(interp), f(s_in), f(s_out))
     return out
+
+
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                interval_lengths, out_height, out_width, scale_io=None):
+    """bev_pool_ref.c.  depth [N,D,H,W], feat [N,H,W,C] -> [1,out_h,out_w,C].
+    int8 when scale_io (= s_depth*s_feat/s_out) is given."""
+    r = [_c(x, np.int32) for x in (ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                                   interval_lengths)]
+    c = feat.shape[-1]
+    n_out = out_height * out_width * c
+    i = ctypes.c_int
+    if scale_io is None:
+        depth, feat = _c(depth, np.float32), _c(feat, np.float32)
+        out = np.empty((1, out_height, out_width, c), np.float32)
+        lib().oracle_bev_pool_v2_f32(_p(depth), _p(feat), *[_p(x) for x in r], _p(out), i(c),
+                                     i(len(r[3])), ctypes.c_long(n_out))
+    else:
+        depth, feat = _c(depth, np.int8), _c(feat, np.int8)
+        out = np.empty((1, out_height, out_width, c), np.int8)
+        lib().oracle_bev_pool_v2_s8(_p(depth), _p(feat), *[_p(x) for x in r], _p(out), i(c),
+                                    i(len(r[3])), ctypes.c_long(n_out), ctypes.c_float(scale_io))
+    return out

@@ -176,3 +176,24 @@ if __name__ == "__main__":
     make_msda()
     make_rotate()
     make_grid_sampler()
+    make_bev_pool()
+
+
+def make_bev_pool():
+    """Run the reference test's own input generator `bev_pool_prepare()` (hard-coded
+    NuScenes calibration, det2trt/models/utils/test_trt_ops/test_bev_pool_v2.py:16-...) on
+    the CPU and keep the index tensors it produces + the oracle-independent expected
+    output computed by torch.index_add_ (semantics of third_party/bev_mmdet3d/ops/
+    bev_pool_v2/src/bev_pool_cuda.cu:22-46)."""
+    src = open(os.path.join(REF, "det2trt/models/utils/test_trt_ops/test_bev_pool_v2.py")).read()
+    src = src.split("class ")[0]                      # generator functions only
+    src = src.replace("from .base_test_case import BaseTestCase", "")
+    src = src.replace('device="cuda"', 'device="cpu"').replace(".cuda()", "")
+    ns = {}
+    exec(compile(src, "ref_test_bev_pool_v2", "exec"), ns)
+    out = ns["bev_pool_prepare"]()
+    names = ["ranks_bev", "ranks_depth", "ranks_feat", "interval_starts", "interval_lengths"]  # :247
+    arrs = {n: t.cpu().numpy().astype(np.int32) for n, t in zip(names, out)}
+    for n, a in arrs.items():
+        print("bev_pool", n, a.shape, a.min(), a.max())
+    np.savez_compressed(os.path.join(OUT, "bev_pool_ref_ranks.npz"), **arrs)

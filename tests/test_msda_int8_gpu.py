@@ -1,0 +1,92 @@
+"""GPU parity for the INT8 MSDA flavours.
+  * vs the C oracle of the same integer arithmetic (oracle/msda_ref.c): |diff| <= 1 LSB on
+    at most 1% of the outputs (exp() ulps can flip a rounding), everything else bit-equal;
+  * vs the fp32 op on the de-quantised tensors: mean abs error <= 0.01 -- the reference's
+    own criterion with min-max calibration (test_multi_scale_deformable_attn.py:145-149).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "tiny_sca": (6, [[15, 25]], 2500, 8, 4),
+    "tiny_tsa": (2, [[50, 50]], 2500, 4, 1),
+    "base_sca_q2k": (6, [[116, 200], [58, 100], [29, 50], [15, 25]], 2000, 8, 4),
+    "base_dec": (1, [[200, 200]], 900, 4, 1),
+    "generic_c12": (2, [[9, 11], [4, 5]], 70, 4, 2),
+}
+
+
+@pytest.fixture(scope="module")
+def bev():
+    import bevformer_tensorrt_amd as b
+    return b
+
+
+def quantize(x):
+    s = float(x.abs().max()) / 127.0   # min-max calibration (test_trt_ops/utils.py:18-51)
+    return torch.clamp(torch.round(x / s), -127, 127).to(torch.int8), s
+
+
+def make(shape, heads=8, C=32, seed=0):
+    bs, levels, nq, P, ppg = shape
+    g = torch.Generator().manual_seed(seed)
+    L = len(levels)
+    nk = sum(h * w for h, w in levels)
+    value = torch.randn(bs, nk, heads, C, generator=g)
+    ref = torch.rand(bs, nq, 1, 2 * ppg, generator=g)
+    off = torch.randn(bs, nq, heads, L * P * 2, generator=g)
+    logit = torch.randn(bs, nq, heads, L * P, generator=g)
+    sh = torch.tensor(levels, dtype=torch.int32)
+    return value, sh, ref, off, logit
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("ref_dtype", [torch.float32, torch.float16], ids=["s8w_f32ref", "u8w_f16ref"])
+def test_int8_vs_oracle_and_fp32(bev, oracle_mod, name, ref_dtype):
+    heads, C = (3, 12) if name == "generic_c12" else (8, 32)
+    value, sh, ref, off, logit = make(SHAPES[name], heads, C)
+    qv, s_v = quantize(value)
+    qo, s_o = quantize(off)
+    qw, s_w = quantize(logit)
+    ref_in = ref.to(ref_dtype)
+    want32 = oracle_mod.msda_f32(value.numpy(), sh.numpy(), ref.numpy(), off.numpy(), logit.numpy())
+    s_out = float(np.abs(want32).max()) / 127.0
+    out = bev.multi_scale_deformable_attn_int8(qv.cuda(), sh.cuda(), ref_in.cuda(), qo.cuda(),
+                                               qw.cuda(), s_v, s_o, s_w, s_out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.int32)
+    want = oracle_mod.msda_s8(qv.numpy(), s_v, sh.numpy(), ref_in.float().numpy(), qo.numpy(), s_o,
+                              qw.numpy(), s_w, s_out,
+                              u8_weights=(ref_dtype == torch.float16)).astype(np.int32)
+    d = np.abs(got - want)
+    assert d.max() <= 1, d.max()
+    assert (d > 0).mean() <= 0.01, (d > 0).mean()
+    assert np.abs(got * s_out - want32).mean() <= 0.01
+
+
+def test_int8_quad_matches_generic_kernel(bev):
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    value, sh, ref, off, logit = make(SHAPES["base_sca_q2k"])
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    args = (qv.cuda(), sh.cuda(), ref.cuda(), qo.cuda(), qw.cuda(), s_v, s_o, s_w, 0.01)
+    a = bev.multi_scale_deformable_attn_int8(*args)
+    try:
+        lib.bevops_msda_set_variant(99)
+        b = bev.multi_scale_deformable_attn_int8(*args)
+    finally:
+        lib.bevops_msda_set_variant(0)
+    d = (a.int() - b.int()).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 0.01
+
+
+def test_int8_requires_p_multiple_of_4(bev):
+    from bevformer_tensorrt_amd.utils.lib import BevopsError
+    value, sh, ref, off, logit = make((1, [[4, 4]], 8, 2, 1))
+    q = lambda t: quantize(t)[0].cuda()
+    with pytest.raises(BevopsError):   # multiScaleDeformableAttnPlugin.cpp:151-156
+        bev.multi_scale_deformable_attn_int8(q(value), sh.cuda(), ref.cuda(), q(off), q(logit),
+                                             0.1, 0.1, 0.1, 0.1)
