@@ -111,10 +111,12 @@ extern "C" int bevops_bev_pool_v2_forward(int dtype, const void *depth, const vo
                                           int channels, int n_intervals, int out_height,
                                           int out_width, float scale_depth, float scale_feat,
                                           float scale_out, void *stream) {
-  if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
-      !interval_lengths || !output)
+  if (!output || channels <= 0 || n_intervals < 0 || out_height <= 0 || out_width <= 0)
     return BEVOPS_BAD_PARAM;
-  if (channels <= 0 || n_intervals < 0 || out_height <= 0 || out_width <= 0) return BEVOPS_BAD_PARAM;
+  if (n_intervals > 0 && (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
+                          !interval_starts || !interval_lengths))
+    return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16 && dtype != BEVOPS_I8) return BEVOPS_NOT_SUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t esize = dtype == BEVOPS_F32 ? 4 : dtype == BEVOPS_F16 ? 2 : 1;
   const size_t n_out = (size_t)out_height * out_width * channels;

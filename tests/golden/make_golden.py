@@ -177,6 +177,7 @@ if __name__ == "__main__":
     make_rotate()
     make_grid_sampler()
     make_bev_pool()
+    make_geometry()
 
 
 def make_bev_pool():
@@ -197,3 +198,65 @@ def make_bev_pool():
     for n, a in arrs.items():
         print("bev_pool", n, a.shape, a.min(), a.max())
     np.savez_compressed(os.path.join(OUT, "bev_pool_ref_ranks.npz"), **arrs)
+
+
+def _extract_functions(path, names, min_line=0):
+    """exec only the named (static)methods of a reference module whose top-level imports
+    (mmcv, ...) cannot be satisfied here.  `min_line` selects the class (the *TRTP wrappers
+    come after the *TRT ones in the file)."""
+    import ast
+    import textwrap
+    src = open(os.path.join(REF, path)).read()
+    ns = {"torch": torch, "np": np}
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.lineno >= min_line:
+            seg = textwrap.dedent(ast.get_source_segment(src, node))
+            print("  ref function", node.name, "at", path, node.lineno)
+            exec(compile(seg, path, "exec"), ns)
+    return ns
+
+
+def make_geometry():
+    """Reference index/grid generation executed on CPU: encoder.py:170-259 (static /
+    self-light methods) and the shift arithmetic of transformer.py:262-294."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from bevformer_tensorrt_amd.geometry import synthetic_lidar2img
+    enc = _extract_functions("det2trt/models/modules/encoder.py",
+                             ["get_reference_points_3d", "point_sampling_trt"], min_line=165)
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+    class _Self:
+        num_points_in_pillar = 4
+
+    res = {}
+    for tag, (bh, bw, img) in {"tiny": (50, 50, (480, 800)), "small40": (40, 40, (736, 1280))}.items():
+        ref_3d = enc["get_reference_points_3d"](bh, bw, pc_range[5] - pc_range[2], 4, bs=1,
+                                                device="cpu", dtype=torch.float)
+        l2i = synthetic_lidar2img(img)
+        cam, mask = enc["point_sampling_trt"](_Self(), ref_3d, pc_range, l2i, img)
+        res[f"{tag}_ref3d"] = ref_3d.numpy()
+        res[f"{tag}_lidar2img"] = l2i.numpy()
+        res[f"{tag}_cam"] = cam.numpy()
+        res[f"{tag}_mask"] = mask.numpy()
+        res[f"{tag}_meta"] = np.array([bh, bw, img[0], img[1]], np.int32)
+    # shift arithmetic: lift the statements of get_bev_features_trt (transformer.py:262-294)
+    src = open(os.path.join(REF, "det2trt/models/modules/transformer.py")).read().split("\n")
+    start = next(i for i, l in enumerate(src) if "delta_x = can_bus[0:1]" in l and i > 250)
+    end = next(i for i, l in enumerate(src) if "shift = torch.cat([shift_x, shift_y])" in l and i > start)
+    import textwrap
+    body = textwrap.dedent("\n".join(src[start:end + 1]))
+    can = torch.tensor([[0.8, -0.3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.31, 1.7],
+                        [-1.2, 0.05, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -2.9, -0.4],
+                        [0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0]])
+    shifts = []
+    for c in can:
+        class _S:
+            use_shift = True
+        ns = {"torch": torch, "np": np, "can_bus": c, "grid_length": [0.512, 0.512], "bev_h": 200,
+              "bev_w": 200, "self": _S()}
+        exec(body, ns)
+        shifts.append(ns["shift"].numpy())
+    res["can_bus"] = can.numpy()
+    res["shift"] = np.stack(shifts)
+    np.savez_compressed(os.path.join(OUT, "geometry.npz"), **res)
+    print("geometry", {k: v.shape for k, v in res.items()})

@@ -209,8 +209,10 @@ def test_rotate_properties_full_base_size(bev):
     img = torch.randn(256, 200, 200, generator=g).half().cuda()
     ctr = torch.tensor([100.0, 100.0]).cuda()
     # angle 0 about the image centre is the identity for both modes
-    for interp in ("nearest", "bilinear"):
-        assert torch.equal(bev.rotate(img, torch.tensor(0.0).cuda(), ctr, interp), img)
+    assert torch.equal(bev.rotate(img, torch.tensor(0.0).cuda(), ctr, "nearest"), img)
+    # (bilinear: the affine grid of functions/rotate.py is only integer to ~1e-5 px)
+    ident = bev.rotate(img, torch.tensor(0.0).cuda(), ctr, "bilinear")
+    assert (ident.float() - img.float()).abs().max().item() <= 4e-3
     # 90 + 270 degrees (nearest, centre) returns the original image
     r = bev.rotate(bev.rotate(img, torch.tensor(90.0).cuda(), ctr, "nearest"),
                    torch.tensor(270.0).cuda(), ctr, "nearest")
