@@ -39,6 +39,10 @@ const Entry kTable[] = {
     {"bevops_bev_pool_v2_forward", (void *)&bevops_bev_pool_v2_forward},
     {"BEVPoolV2TRT", (void *)&bevops_bev_pool_v2_forward},
     {"BEVPoolV2TRT2", (void *)&bevops_bev_pool_v2_forward},
+    {"bevops_mdconv_forward", (void *)&bevops_mdconv_forward},
+    {"bevops_mdconv_workspace_size", (void *)&bevops_mdconv_workspace_size},
+    {"ModulatedDeformableConv2dTRT", (void *)&bevops_mdconv_forward},
+    {"ModulatedDeformableConv2dTRT2", (void *)&bevops_mdconv_forward},
 };
 }  // namespace
 

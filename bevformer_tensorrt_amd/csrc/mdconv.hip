@@ -1,0 +1,416 @@
+// Modulated deformable convolution (DCNv2) forward for MI355X (gfx950).
+// Replaces ModulatedDeformableConv2dPlugin::enqueue / getWorkspaceSize
+// (TensorRT/plugin/modulated_deformable_conv2d/modulatedDeformableConv2dPlugin.cpp:73-197)
+// and ModulatedDeformConvForwardCUDAKernel<T> (modulatedDeformableConv2dKernel.cu:695-978).
+// Numerical contract: SURVEY.md Appendix A.5.
+//
+// The reference runs, per image and per group, a channel-planar im2col (one thread per
+// (c_in, pixel), nine scattered 2-byte gathers each) followed by one cuBLAS GEMM, with a
+// per-image column buffer.  MI355X-first restructuring:
+//   1. x is re-laid out once to channels-last (NHWC) so that a bilinear corner is ONE
+//      contiguous 16-byte load of 8 channels per lane (64..512 B per pixel across lanes);
+//   2. weights are re-packed to [Cout][tap][Cin/g] so both GEMM operands are K-contiguous
+//      with K ordered (tap, c_in): the sampling footprint (4 corner indices + weights*mask)
+//      of a (pixel, tap) is computed once and reused across all input channels;
+//   3. ONE batched GEMM over all images of the call (N = B*Ho*Wo columns) on the matrix
+//      cores: 128x128x32 tiles, v_mfma_f32_32x32x16_f16, fp32 accumulate, bias fused in
+//      the epilogue which scatters straight into NCHW.  (fp32 I/O uses an fp32 FMA tile
+//      kernel -- exact fp32, parity path.)
+// Workspace (caller-owned, bevops_mdconv_workspace_size): NHWC copy + packed weights +
+// columns [G][N][K*K*Cin/g].
+#include "common.h"
+
+namespace bevops {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvDims {
+  int B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo;
+};
+
+template <typename T> __device__ __forceinline__ float tof(T v);
+template <> __device__ __forceinline__ float tof<float>(float v) { return v; }
+template <> __device__ __forceinline__ float tof<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T fromf(float v);
+template <> __device__ __forceinline__ float fromf<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half fromf<__half>(float v) { return __float2half_rn(v); }
+
+// ---- 1. NCHW -> NHWC ------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T *__restrict__ in,
+                                                           T *__restrict__ out, int C, int HW) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const T *ib = in + (size_t)b * C * HW;
+  T *ob = out + (size_t)b * C * HW;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int c = c0 + ty + r, p = p0 + tx;
+    if (c < C && p < HW) tile[ty + r][tx] = ib[(size_t)c * HW + p];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int p = p0 + ty + r, c = c0 + tx;
+    if (c < C && p < HW) ob[(size_t)p * C + c] = tile[tx][ty + r];
+  }
+}
+
+// ---- 2. weight [Cout][Cin/g][KK] -> [Cout][KK][Cin/g] ------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void repack_weight_kernel(const T *__restrict__ w,
+                                                            T *__restrict__ wt, int Cout,
+                                                            int cin_g, int KK) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)Cout * cin_g * KK;
+  if (i >= total) return;
+  const int ci = (int)(i % cin_g);
+  const int t = (int)((i / cin_g) % KK);
+  const size_t co = i / ((size_t)cin_g * KK);
+  wt[i] = w[(co * cin_g + ci) * KK + t];
+}
+
+// ---- 3. deformable + modulated im2col on NHWC --------------------------------------
+// thread = (global pixel n, tap, channel vector); columns [G][N][KK][cin_g]
+template <typename T, int V>
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const T *__restrict__ xt,
+                                                          const T *__restrict__ offset,
+                                                          const T *__restrict__ mask,
+                                                          T *__restrict__ col, ConvDims d) {
+  const int vec_per_pix = d.Cin / V;
+  const int KK = d.Kh * d.Kw;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int cv = (int)(idx % vec_per_pix);
+  const size_t r = idx / vec_per_pix;
+  const int t = (int)(r % KK);
+  const size_t n = r / KK;
+  const int HoWo = d.Ho * d.Wo;
+  const size_t N = (size_t)d.B * HoWo;
+  if (n >= N) return;
+  const int b = (int)(n / HoWo);
+  const int pix = (int)(n - (size_t)b * HoWo);
+  const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
+  const int c = cv * V;
+  const int dg = c / (d.Cin / d.DG);
+  const int i = t / d.Kw, j = t - i * d.Kw;
+  // offset [B][DG][2*KK][Ho][Wo] (h then w), mask [B][DG][KK][Ho][Wo]  (kernel.cu:283-300)
+  const size_t obase = (((size_t)b * d.DG + dg) * 2 * KK) * HoWo + pix;
+  const float off_h = tof(offset[obase + (size_t)(2 * t) * HoWo]);
+  const float off_w = tof(offset[obase + (size_t)(2 * t + 1) * HoWo]);
+  const float m = tof(mask[(((size_t)b * d.DG + dg) * KK + t) * HoWo + pix]);
+  float h_im, w_im;
+  {
+#pragma clang fp contract(off)
+    h_im = (float)(ho * d.sh - d.ph + i * d.dh) + off_h;
+    w_im = (float)(wo * d.sw - d.pw + j * d.dw) + off_w;
+  }
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W) {
+#pragma clang fp contract(off)
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h0 = (int)hf, w0 = (int)wf;
+    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const float wt[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+    const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 <= d.W - 1,
+                        h0 + 1 <= d.H - 1 && w0 >= 0, h0 + 1 <= d.H - 1 && w0 + 1 <= d.W - 1};
+    const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
+    const T *xb = xt + (size_t)b * d.H * d.W * d.Cin + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!ok[q]) continue;
+      const T *p = xb + ((size_t)hs[q] * d.W + ws[q]) * d.Cin;
+      if constexpr (sizeof(T) == 2 && V == 8) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        acc[0] += wt[q] * h2f_lo(v.x); acc[1] += wt[q] * h2f_hi(v.x);
+        acc[2] += wt[q] * h2f_lo(v.y); acc[3] += wt[q] * h2f_hi(v.y);
+        acc[4] += wt[q] * h2f_lo(v.z); acc[5] += wt[q] * h2f_hi(v.z);
+        acc[6] += wt[q] * h2f_lo(v.w); acc[7] += wt[q] * h2f_hi(v.w);
+      } else if constexpr (sizeof(T) == 4 && V == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        acc[0] += wt[q] * v.x; acc[1] += wt[q] * v.y; acc[2] += wt[q] * v.z; acc[3] += wt[q] * v.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += wt[q] * tof(p[k]);
+      }
+    }
+  }
+  const int cin_g = d.Cin / d.G;
+  const int g = c / cin_g, cg = c - g * cin_g;
+  T *o = col + (((size_t)g * N + n) * KK + t) * cin_g + cg;
+  if constexpr (sizeof(T) == 2 && V == 8) {
+    uint4 v;
+    v.x = pack_h2(acc[0] * m, acc[1] * m); v.y = pack_h2(acc[2] * m, acc[3] * m);
+    v.z = pack_h2(acc[4] * m, acc[5] * m); v.w = pack_h2(acc[6] * m, acc[7] * m);
+    *reinterpret_cast<uint4 *>(o) = v;
+  } else if constexpr (sizeof(T) == 4 && V == 4) {
+    *reinterpret_cast<float4 *>(o) = make_float4(acc[0] * m, acc[1] * m, acc[2] * m, acc[3] * m);
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = fromf<T>(acc[k] * m);
+  }
+}
+
+// ---- 4a. fp16 GEMM on the matrix cores:  C[m][n] = sum_k A[m][k] * B[n][k] ------------
+// A = packed weights of one group [M][K], B = columns [N][K]; epilogue adds bias and
+// scatters to NCHW.  128x128x32 tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16.
+constexpr int kBM = 128, kBN = 128, kBK = 32, kLd = kBK + 8;  // +8 halves: conflict-free b128 reads
+
+struct GemmEpi {
+  int HoWo, Cout, co0;  // out[(n / HoWo) * Cout + co0 + m][n % HoWo]
+};
+
+__device__ __forceinline__ uint4 ld16_guard(const __half *p, bool ok) {
+  return ok ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_f16_kernel(const __half *__restrict__ A,
+                                                          const __half *__restrict__ Bm,
+                                                          const __half *__restrict__ bias,
+                                                          __half *__restrict__ out, int M, int N,
+                                                          int K, GemmEpi e) {
+  __shared__ __attribute__((aligned(16))) __half As[kBM][kLd];
+  __shared__ __attribute__((aligned(16))) __half Bs[kBN][kLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  // global->LDS mapping: 128 rows x 4 chunks of 16 B; thread handles chunks tid and tid+256
+  const int r0 = tid >> 2, kc = (tid & 3) * 8;
+  const int r1 = r0 + 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + kBK - 1) / kBK;
+  uint4 ra0, ra1, rb0, rb1;
+  auto gload = [&](int kt) {
+    const int k = kt * kBK + kc;
+    const bool kok = k < K;  // K % 8 == 0 is guaranteed by the launcher
+    ra0 = ld16_guard(A + (size_t)(m0 + r0) * K + k, kok && m0 + r0 < M);
+    ra1 = ld16_guard(A + (size_t)(m0 + r1) * K + k, kok && m0 + r1 < M);
+    rb0 = ld16_guard(Bm + (size_t)(n0 + r0) * K + k, kok && n0 + r0 < N);
+    rb1 = ld16_guard(Bm + (size_t)(n0 + r1) * K + k, kok && n0 + r1 < N);
+  };
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    *reinterpret_cast<uint4 *>(&As[r0][kc]) = ra0;
+    *reinterpret_cast<uint4 *>(&As[r1][kc]) = ra1;
+    *reinterpret_cast<uint4 *>(&Bs[r0][kc]) = rb0;
+    *reinterpret_cast<uint4 *>(&Bs[r1][kc]) = rb1;
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 16 + (lane >> 5) * 8;
+      f16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const f16x8 *>(&As[wm * 64 + i * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const f16x8 *>(&Bs[wn * 64 + j * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    const int b = n / e.HoWo, pix = n - b * e.HoWo;
+    __half *ob = out + ((size_t)b * e.Cout + e.co0) * e.HoWo + pix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) {
+          float v = acc[i][j][r];
+          if (bias) v += __half2float(bias[e.co0 + m]);
+          ob[(size_t)m * e.HoWo] = __float2half_rn(v);
+        }
+      }
+  }
+}
+
+// ---- 4b. fp32 GEMM (exact fp32 FMA tiles; parity path) -------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A,
+                                                          const float *__restrict__ Bm,
+                                                          const float *__restrict__ bias,
+                                                          float *__restrict__ out, int M, int N,
+                                                          int K, GemmEpi e) {
+  constexpr int T = 64, BK = 16;
+  __shared__ float As[BK][T + 4], Bs[BK][T + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;  // 64 rows x 4 chunks of 4 floats
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + lk + q;
+      av[q] = (m0 + lr < M && k < K) ? A[(size_t)(m0 + lr) * K + k] : 0.f;
+      bv[q] = (n0 + lr < N && k < K) ? Bm[(size_t)(n0 + lr) * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      As[lk + q][lr] = av[q];
+      Bs[lk + q][lr] = bv[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK; ++k) {
+      const float4 a = *reinterpret_cast<const float4 *>(&As[k][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
+      const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + tx * 4 + j;
+    if (n >= N) continue;
+    const int b = n / e.HoWo, pix = n - b * e.HoWo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ty * 4 + i;
+      if (m < M)
+        out[((size_t)b * e.Cout + e.co0 + m) * e.HoWo + pix] = acc[i][j] + (bias ? bias[e.co0 + m] : 0.f);
+    }
+  }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+bool make_dims(ConvDims &d, int B, int Cin, int H, int W, int Cout, int Kh, int Kw, int sh, int sw,
+               int ph, int pw, int dh, int dw, int G, int DG) {
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Kh <= 0 || Kw <= 0 || sh <= 0 ||
+      sw <= 0 || ph < 0 || pw < 0 || dh <= 0 || dw <= 0 || G <= 0 || DG <= 0)
+    return false;
+  if (Cin % G || Cout % G || Cin % DG) return false;
+  const int Ho = (H + 2 * ph - (dh * (Kh - 1) + 1)) / sh + 1;
+  const int Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) return false;
+  d = ConvDims{B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo};
+  return true;
+}
+
+struct WsLayout {
+  size_t xt, wt, col, total;
+};
+WsLayout ws_layout(const ConvDims &d, size_t es) {
+  WsLayout w;
+  w.xt = 0;
+  w.wt = align256((size_t)d.B * d.Cin * d.H * d.W * es);
+  w.col = w.wt + align256((size_t)d.Cout * (d.Cin / d.G) * d.Kh * d.Kw * es);
+  w.total = w.col + align256((size_t)d.B * d.Ho * d.Wo * d.Cin * d.Kh * d.Kw * es);
+  return w;
+}
+
+template <typename T>
+int run(const void *input, const void *offset, const void *mask, const void *weight,
+        const void *bias, void *output, void *workspace, const ConvDims &d, hipStream_t st) {
+  const WsLayout w = ws_layout(d, sizeof(T));
+  char *ws = static_cast<char *>(workspace);
+  T *xt = reinterpret_cast<T *>(ws + w.xt);
+  T *wt = reinterpret_cast<T *>(ws + w.wt);
+  T *col = reinterpret_cast<T *>(ws + w.col);
+  const int HW = d.H * d.W, KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
+  const size_t N = (size_t)d.B * d.Ho * d.Wo;
+  if (N > 0x7FFFFFFFull || (size_t)d.B * d.Cin * HW > 0x7FFFFFFF00ull) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
+                     0, st, (const T *)input, xt, d.Cin, HW);
+  const size_t wtot = (size_t)d.Cout * cin_g * KK;
+  hipLaunchKernelGGL((repack_weight_kernel<T>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
+                     (const T *)weight, wt, d.Cout, cin_g, KK);
+  constexpr int VMAX = sizeof(T) == 2 ? 8 : 4;
+  const bool vec = cin_g % VMAX == 0 && (d.Cin / d.DG) % VMAX == 0;
+  {
+    const int V = vec ? VMAX : 1;
+    const size_t threads = N * KK * (d.Cin / V);
+    const size_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+    if (vec)
+      hipLaunchKernelGGL((im2col_nhwc_kernel<T, VMAX>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
+                         (const T *)offset, (const T *)mask, col, d);
+    else
+      hipLaunchKernelGGL((im2col_nhwc_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
+                         (const T *)offset, (const T *)mask, col, d);
+  }
+  const int Kg = KK * cin_g;
+  for (int g = 0; g < d.G; ++g) {
+    const GemmEpi e{d.Ho * d.Wo, d.Cout, g * cout_g};
+    const T *Ag = wt + (size_t)g * cout_g * Kg;
+    const T *Bg = col + (size_t)g * N * Kg;
+    if constexpr (sizeof(T) == 2) {
+      if (Kg % 8 == 0) {
+        hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3((unsigned)((N + kBN - 1) / kBN), (cout_g + kBM - 1) / kBM),
+                           dim3(256), 0, st, (const __half *)Ag, (const __half *)Bg, (const __half *)bias,
+                           (__half *)output, cout_g, (int)N, Kg, e);
+        continue;
+      }
+      return BEVOPS_NOT_SUPPORTED;  // fp16 needs (Cin/groups * Kh * Kw) % 8 == 0
+    } else {
+      hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)((N + 63) / 64), (cout_g + 63) / 64), dim3(256),
+                         0, st, (const float *)Ag, (const float *)Bg, (const float *)bias, (float *)output,
+                         cout_g, (int)N, Kg, e);
+    }
+  }
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace bevops
+
+using namespace bevops;
+
+extern "C" size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout,
+                                               int Kh, int Kw, int stride_h, int stride_w,
+                                               int pad_h, int pad_w, int dil_h, int dil_w,
+                                               int groups, int deform_groups) {
+  ConvDims d;
+  if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                 groups, deform_groups))
+    return 0;
+  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16) return 0;
+  return ws_layout(d, dtype == BEVOPS_F32 ? 4 : 2).total;
+}
+
+extern "C" int bevops_mdconv_forward(int dtype, const void *input, const void *offset,
+                                     const void *mask, const void *weight, const void *bias,
+                                     void *output, void *workspace, size_t workspace_bytes, int B,
+                                     int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
+                                     int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                     int groups, int deform_groups, void *stream) {
+  if (!input || !offset || !mask || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
+  ConvDims d;
+  if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                 groups, deform_groups))
+    return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (workspace_bytes < ws_layout(d, dtype == BEVOPS_F32 ? 4 : 2).total) return BEVOPS_BAD_PARAM;
+  if (!aligned16(workspace)) return BEVOPS_BAD_PARAM;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == BEVOPS_F32)
+    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st);
+  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st);
+}

@@ -1,0 +1,56 @@
+"""modulated_deformable_conv2d / modulated_deformable_conv2d2 -- drop-in for
+det2trt/models/functions/modulated_deformable_conv2d.py:205-291 (DCNv2 forward)."""
+import torch
+from torch.nn.modules.utils import _pair
+
+from ..utils import lib as _lib
+
+
+def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups):
+    assert input.is_cuda, "modulated_deformable_conv2d: input must be on the GPU"
+    if input.dim() != 4:
+        raise ValueError(f"Expected 4D tensor as input, got {input.dim()}D tensor instead.")
+    handle = _lib.load_library()
+    # dtype follows `offset`, as the reference does (:73-75)
+    input = input.type_as(offset).contiguous()
+    weight = weight.type_as(input).contiguous()
+    mask = mask.type_as(input).contiguous()
+    offset = offset.contiguous()
+    if bias is not None:
+        bias = bias.type_as(input).contiguous()
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, Cin, H, W = input.shape
+    Cout, _, Kh, Kw = weight.shape
+    Ho = (H + 2 * ph - (dh * (Kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) // sw + 1
+    if tuple(offset.shape) != (B, deform_groups * 2 * Kh * Kw, Ho, Wo):
+        raise ValueError(f"offset shape {tuple(offset.shape)} != {(B, deform_groups * 2 * Kh * Kw, Ho, Wo)}")
+    if tuple(mask.shape) != (B, deform_groups * Kh * Kw, Ho, Wo):
+        raise ValueError(f"mask shape {tuple(mask.shape)} != {(B, deform_groups * Kh * Kw, Ho, Wo)}")
+    dt = _lib.torch_dtype_code(input)
+    dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
+    ws_bytes = handle.bevops_mdconv_workspace_size(dt, *dims)
+    if ws_bytes == 0:
+        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+    out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device)
+    with torch.cuda.device(input.device):
+        st = handle.bevops_mdconv_forward(
+            dt, input.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), ws.data_ptr(), ws_bytes,
+            *dims, _lib.current_stream_ptr(input.device))
+    _lib.check(st, "bevops_mdconv_forward")
+    return out
+
+
+def modulated_deformable_conv2d(input, offset, mask, weight, bias=None, stride=1, padding=0,
+                                dilation=1, groups=1, deform_groups=1):
+    """DCNv2 forward (plugin ModulatedDeformableConv2dTRT: fp32, fp16).  input [B,Cin,H,W],
+    offset [B, dg*2*K*K, Ho, Wo], mask [B, dg*K*K, Ho, Wo], weight [Cout, Cin/groups, K, K]."""
+    return _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups)
+
+
+def modulated_deformable_conv2d2(input, offset, mask, weight, bias=None, stride=1, padding=0,
+                                 dilation=1, groups=1, deform_groups=1):
+    """Same op under the half2 plugin name ModulatedDeformableConv2dTRT2."""
+    return _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups)

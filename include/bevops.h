@@ -152,6 +152,29 @@ int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
                                float scale_depth, float scale_feat, float scale_out,
                                void *stream);
 
+/* ------------------------------------------------------------------------
+ * Modulated deformable convolution (DCNv2) forward.
+ * Replaces ModulatedDeformableConv2dPlugin::enqueue / getWorkspaceSize
+ * (TensorRT/plugin/modulated_deformable_conv2d/modulatedDeformableConv2dPlugin.cpp:73-197)
+ * and ModulatedDeformConvForwardCUDAKernel<T> (modulatedDeformableConv2dKernel.h:11-30,
+ * modulatedDeformableConv2dKernel.cu:695-978).
+ *   input  [B,Cin,H,W], offset [B, deform_groups*2*Kh*Kw, Ho, Wo] (per tap: h then w),
+ *   mask   [B, deform_groups*Kh*Kw, Ho, Wo], weight [Cout, Cin/groups, Kh, Kw],
+ *   bias   [Cout] or NULL, output [B,Cout,Ho,Wo];  Ho/Wo from the usual conv formula.
+ *   workspace: caller-owned scratch of at least bevops_mdconv_workspace_size(...) bytes
+ *   (mirrors getWorkspaceSize; 0 = unsupported arguments), 16-byte aligned.
+ * F32 and F16 (F16 needs (Cin/groups*Kh*Kw) % 8 == 0); INT8 is not built yet
+ * (BEVOPS_NOT_SUPPORTED).
+ * ------------------------------------------------------------------------ */
+size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout, int Kh,
+                                    int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                                    int dil_h, int dil_w, int groups, int deform_groups);
+int bevops_mdconv_forward(int dtype, const void *input, const void *offset, const void *mask,
+                          const void *weight, const void *bias, void *output, void *workspace,
+                          size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
+                          int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                          int dil_w, int groups, int deform_groups, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,22 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts
         lib().oracle_bev_pool_v2_s8(_p(depth), _p(feat), *[_p(x) for x in r], _p(out), i(c),
                                     i(len(r[3])), ctypes.c_long(n_out), ctypes.c_float(scale_io))
     return out
+
+
+def mdconv(x, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups):
+    """mdconv_ref.c: DCNv2 forward (fp32).  stride/padding/dilation are (h, w) pairs."""
+    x, offset, mask, weight = (_c(a, np.float32) for a in (x, offset, mask, weight))
+    B, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (Kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (Kw - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (B, deform_groups * 2 * Kh * Kw, Ho, Wo), offset.shape
+    assert mask.shape == (B, deform_groups * Kh * Kw, Ho, Wo), mask.shape
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    b = _c(bias, np.float32) if bias is not None else None
+    i = ctypes.c_int
+    lib().oracle_mdconv_f32(_p(x), _p(offset), _p(mask), _p(weight), _p(b) if b is not None else None,
+                            _p(out), i(B), i(Cin), i(H), i(W), i(Cout), i(Kh), i(Kw), i(stride[0]),
+                            i(stride[1]), i(padding[0]), i(padding[1]), i(dilation[0]), i(dilation[1]),
+                            i(groups), i(deform_groups))
+    return out

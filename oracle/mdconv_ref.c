@@ -1,0 +1,82 @@
+/*
+ * oracle/mdconv_ref.c -- TEST INFRASTRUCTURE ONLY.
+ * Modulated deformable convolution (DCNv2) forward, restating
+ *   TensorRT/plugin/modulated_deformable_conv2d/modulatedDeformableConv2dKernel.cu
+ *     :85-116   dmcn_im2col_bilinear (per-corner bounds)
+ *     :259-318  modulated_deformable_im2col_gpu_kernel (offset layout [dg, 2*K*K, Ho, Wo],
+ *               h before w; mask layout [dg, K*K, Ho, Wo]; gate -1 < h_im < H, -1 < w_im < W)
+ *     :695-760  per (batch, group) GEMM  out = W_g[Cout/g, Cin/g*K*K] . col_g  (+ bias :550-567)
+ * and the op signature det2trt/models/functions/modulated_deformable_conv2d.py:40-110.
+ * The reference's PyTorch path calls mmcv-full 1.5.0 `_ext.modulated_deform_conv_forward`
+ * (un-vendored CUDA, absent here; same algorithm as the plugin kernel above).
+ * PARITY UNPINNED by a runnable reference: pinned instead by construction properties in
+ * tests (zero offsets + unit mask == torch conv2d; integer offsets == shifted conv; the
+ * mask is linear), see tests/test_mdconv_cpu.py.
+ *
+ * input [B,Cin,H,W], offset [B, dg*2*Kh*Kw, Ho, Wo], mask [B, dg*Kh*Kw, Ho, Wo],
+ * weight [Cout, Cin/g, Kh, Kw], bias [Cout] or NULL, out [B,Cout,Ho,Wo].  fp32, double
+ * accumulation is NOT used (fp32 like the kernel) but the k-order is (ci, i, j) ascending.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+static inline float bilinear(const float *in, int H, int W, float h, float w) {
+  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = in[h_low * W + w_low];
+  if (h_low >= 0 && w_high <= W - 1) v2 = in[h_low * W + w_high];
+  if (h_high <= H - 1 && w_low >= 0) v3 = in[h_high * W + w_low];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = in[h_high * W + w_high];
+  const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+void oracle_mdconv_f32(const float *input, const float *offset, const float *mask,
+                       const float *weight, const float *bias, float *out, int B, int Cin, int H,
+                       int W, int Cout, int Kh, int Kw, int stride_h, int stride_w, int pad_h,
+                       int pad_w, int dil_h, int dil_w, int groups, int dg) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (Kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (Kw - 1) + 1)) / stride_w + 1;
+  const int KK = Kh * Kw, cin_g = Cin / groups, cout_g = Cout / groups, cpdg = Cin / dg;
+  const long n = (long)Ho * Wo;
+  for (int b = 0; b < B; ++b) {
+    /* columns [Cin*KK][n] for this image (:259-318) */
+    float *col = (float *)malloc(sizeof(float) * (size_t)Cin * KK * n);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < Cin; ++c)
+      for (int ho = 0; ho < Ho; ++ho)
+        for (int wo = 0; wo < Wo; ++wo) {
+          const int g = c / cpdg;
+          const float *im = input + ((long)b * Cin + c) * H * W;
+          const float *op = offset + ((long)b * dg + g) * 2 * KK * n;
+          const float *mp = mask + ((long)b * dg + g) * KK * n;
+          const int h_in = ho * stride_h - pad_h, w_in = wo * stride_w - pad_w;
+          for (int i = 0; i < Kh; ++i)
+            for (int j = 0; j < Kw; ++j) {
+              const int t = i * Kw + j;
+              const float off_h = op[(long)(2 * t) * n + ho * Wo + wo];
+              const float off_w = op[(long)(2 * t + 1) * n + ho * Wo + wo];
+              const float m = mp[(long)t * n + ho * Wo + wo];
+              const float h_im = h_in + i * dil_h + off_h, w_im = w_in + j * dil_w + off_w;
+              float val = 0;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = bilinear(im, H, W, h_im, w_im);
+              col[((long)c * KK + t) * n + ho * Wo + wo] = val * m;
+            }
+        }
+    /* out[b, g] = W_g . col_g + bias (:735-760) */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int co = 0; co < Cout; ++co)
+      for (long p = 0; p < n; ++p) {
+        const int g = co / cout_g;
+        const float *wrow = weight + (long)co * cin_g * KK;
+        const float *cg = col + (long)g * cin_g * KK * n;
+        float acc = 0;
+        for (int k = 0; k < cin_g * KK; ++k) acc += wrow[k] * cg[(long)k * n + p];
+        out[((long)b * Cout + co) * n + p] = acc + (bias ? bias[co] : 0.f);
+      }
+    free(col);
+  }
+}
