@@ -6,7 +6,9 @@ A "step" is ONE FRAME's pass over the hot path at the BEVFormer-base shapes
 synthetic inputs drawn like the reference's op tests (seed 0; value/offsets/logits
 ~N(0,1), reference points ~U[0,1); test_multi_scale_deformable_attn.py:25-33):
 
-    rotate(prev_bev [256,200,200])                                   x1  (when built)
+    ResNet-101-DCN backbone's 26 DCNv2 convolutions (modulated_deformable_conv2d):
+        23 x (6 cams, 256 -> 256 ch, 58x100) + 3 x (6 cams, 512 -> 512 ch, 29x50), 3x3
+    rotate(prev_bev [256,200,200])                                   x1
     6 encoder layers x [ TSA MSDA (2, 40000 keys, 40000 q, 1 lvl x 4 pts)
                        + SCA MSDA (6 cams, 30825 keys, 40000 q, 4 lvl x 8 pts) ]
     6 decoder layers x   MSDA (1, 40000 keys, 900 q, 1 lvl x 4 pts)
@@ -40,6 +42,8 @@ BASE = dict(
     tsa=dict(bs=2, levels=[[200, 200]], nq=40000, P=4, ppg=1),
     dec=dict(bs=1, levels=[[200, 200]], nq=900, P=4, ppg=1),
     enc_layers=6, dec_layers=6, heads=8, C=32, bev=(200, 200), embed=256,
+    # R101-DCN stages 3/4 at 928x1600 (configs/bevformer/bevformer_base.py:42-64): (count, C, H, W)
+    dcn=[(23, 256, 58, 100), (3, 512, 29, 50)],
 )
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -127,14 +131,20 @@ def main():
     sca, sca_bs = msda_inputs(BASE["sca"], dtype, dev, gen, cams=my_cams)
     tsa, _ = msda_inputs(BASE["tsa"], dtype, dev, gen)
     dec, _ = msda_inputs(BASE["dec"], dtype, dev, gen)
-    extra = []
-    rot = None
-    if hasattr(bev, "rotate"):
-        prev_bev = torch.randn(BASE["embed"], *BASE["bev"], generator=gen).to(dtype).to(dev)
-        angle = torch.tensor(1.5, device=dev)
-        center = torch.tensor([100.0, 100.0], device=dev)
-        rot = (prev_bev, angle, center)
-        extra.append("rotate")
+    extra = ["26x DCNv2", "rotate"]
+    prev_bev = torch.randn(BASE["embed"], *BASE["bev"], generator=gen).to(dtype).to(dev)
+    rot = (prev_bev, torch.tensor(1.5, device=dev), torch.tensor([100.0, 100.0], device=dev))
+    dcn = []
+    ncam = max(len(my_cams), 0)
+    for count, C, H, W in BASE["dcn"]:
+        if ncam == 0:
+            continue
+        x = torch.randn(ncam, C, H, W, generator=gen).to(dtype).to(dev)
+        off = torch.randn(ncam, 18, H, W, generator=gen).to(dtype).to(dev)
+        mask = torch.rand(ncam, 9, H, W, generator=gen).to(dtype).to(dev)
+        w = (torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5).to(dtype).to(dev)
+        b = torch.randn(C, generator=gen).to(dtype).to(dev)
+        dcn.append((count, (x, off, mask, w, b, 1, 1, 1, 1, 1)))
 
     nq, embed = BASE["sca"]["nq"], BASE["embed"]
     sca_out = torch.empty((max(sca_bs, 1), nq, BASE["heads"], BASE["C"]), dtype=dtype, device=dev)
@@ -142,8 +152,10 @@ def main():
     sca_events = []
 
     def step(record):
-        if rot is not None:
-            bev.rotate(*rot)
+        for count, a in dcn:
+            for _ in range(count):
+                bev.modulated_deformable_conv2d(*a)
+        bev.rotate(*rot)
         for _ in range(BASE["enc_layers"]):
             bev.multi_scale_deformable_attn(*tsa)
             if sca_bs:
@@ -183,6 +195,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
 
+    def pmc_traffic():
+        """HBM/fabric bytes per SCA launch from the committed rocprofv3 PMC passes
+        (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
+        correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM")."""
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel.json")))[-1]
+            for k, v in json.load(open(f)).items():
+                if "msda" in k and "grid=7680000" in k and "FETCH_SIZE_KiB_avg" in v:
+                    return int((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+        return None, None
+
     roofline = None
     if sca_events:
         ms = [a.elapsed_time(b) for a, b in sca_events]
@@ -191,9 +217,11 @@ def main():
         achieved = byt / (avg_ms * 1e-3) / 1e9
         roofline = {"kernel": "msda_quad_kernel (base SCA call)", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
                     "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches": len(ms)}
+        if sca_bs == BASE["sca"]["bs"]:
+            roofline["traffic"], roofline["traffic_src"] = pmc_traffic()
 
     if rank == 0:
         cpu = None
