@@ -22,104 +22,10 @@
 //     (cameras that do not see a BEV pillar).
 //   * blockIdx is remapped so each XCD walks a contiguous item range (L2 locality
 //     for neighbouring BEV queries).
-#include "common.h"
+#include "msda_common.h"
 
 namespace bevops {
 namespace {
-
-constexpr int kMaxLevels = 16;
-constexpr int kBlock = 256;
-
-struct MsdaDims {
-  int bs, nk, heads, C, L, nq, P, ppg;
-};
-
-// ---------------------------------------------------------------------------
-// element loaders: N consecutive T -> float
-// ---------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void load_f(const float *p, float (&d)[N]) {
-  if constexpr (N == 1) {
-    d[0] = p[0];
-  } else if constexpr (N == 2) {
-    const float2 v = *reinterpret_cast<const float2 *>(p);
-    d[0] = v.x; d[1] = v.y;
-  } else {
-    static_assert(N % 4 == 0, "N");
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
-      const float4 v = reinterpret_cast<const float4 *>(p)[i];
-      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
-    }
-  }
-}
-template <int N>
-__device__ __forceinline__ void load_f(const __half *p, float (&d)[N]) {
-  if constexpr (N == 1) {
-    d[0] = __half2float(p[0]);
-  } else if constexpr (N == 2) {
-    const unsigned v = *reinterpret_cast<const unsigned *>(p);
-    d[0] = h2f_lo(v); d[1] = h2f_hi(v);
-  } else if constexpr (N == 4) {
-    const uint2 v = *reinterpret_cast<const uint2 *>(p);
-    d[0] = h2f_lo(v.x); d[1] = h2f_hi(v.x); d[2] = h2f_lo(v.y); d[3] = h2f_hi(v.y);
-  } else {
-    static_assert(N % 8 == 0, "N");
-#pragma unroll
-    for (int i = 0; i < N / 8; ++i) {
-      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-      d[8 * i] = h2f_lo(v.x); d[8 * i + 1] = h2f_hi(v.x);
-      d[8 * i + 2] = h2f_lo(v.y); d[8 * i + 3] = h2f_hi(v.y);
-      d[8 * i + 4] = h2f_lo(v.z); d[8 * i + 5] = h2f_hi(v.z);
-      d[8 * i + 6] = h2f_lo(v.w); d[8 * i + 7] = h2f_hi(v.w);
-    }
-  }
-}
-__device__ __forceinline__ float2 load_ref(const float *p) {
-  return *reinterpret_cast<const float2 *>(p);
-}
-__device__ __forceinline__ float2 load_ref(const __half *p) {
-  const unsigned v = *reinterpret_cast<const unsigned *>(p);
-  return make_float2(h2f_lo(v), h2f_hi(v));
-}
-
-// one 8-channel tap: acc[c] += w * value[c]
-__device__ __forceinline__ void tap8(const __half *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                     float w, float (&acc)[8]) {
-  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
-  acc[0] = fmaf(w, h2f_lo(r.x), acc[0]); acc[1] = fmaf(w, h2f_hi(r.x), acc[1]);
-  acc[2] = fmaf(w, h2f_lo(r.y), acc[2]); acc[3] = fmaf(w, h2f_hi(r.y), acc[3]);
-  acc[4] = fmaf(w, h2f_lo(r.z), acc[4]); acc[5] = fmaf(w, h2f_hi(r.z), acc[5]);
-  acc[6] = fmaf(w, h2f_lo(r.w), acc[6]); acc[7] = fmaf(w, h2f_hi(r.w), acc[7]);
-}
-__device__ __forceinline__ void tap8(const float *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                     float w, float (&acc)[8]) {
-  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
-  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u), 0, 0);
-  acc[0] = fmaf(w, __uint_as_float(a.x), acc[0]); acc[1] = fmaf(w, __uint_as_float(a.y), acc[1]);
-  acc[2] = fmaf(w, __uint_as_float(a.z), acc[2]); acc[3] = fmaf(w, __uint_as_float(a.w), acc[3]);
-  acc[4] = fmaf(w, __uint_as_float(b.x), acc[4]); acc[5] = fmaf(w, __uint_as_float(b.y), acc[5]);
-  acc[6] = fmaf(w, __uint_as_float(b.z), acc[6]); acc[7] = fmaf(w, __uint_as_float(b.w), acc[7]);
-}
-__device__ __forceinline__ void store8(__half *p, const float (&a)[8]) {
-  uint4 v;
-  v.x = pack_h2(a[0], a[1]); v.y = pack_h2(a[2], a[3]);
-  v.z = pack_h2(a[4], a[5]); v.w = pack_h2(a[6], a[7]);
-  *reinterpret_cast<uint4 *>(p) = v;
-}
-__device__ __forceinline__ void store8(float *p, const float (&a)[8]) {
-  reinterpret_cast<float4 *>(p)[0] = make_float4(a[0], a[1], a[2], a[3]);
-  reinterpret_cast<float4 *>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
-}
-
-// location arithmetic kept un-fused so that it rounds exactly like the
-// reference's fp32 kernel (mul, add, sub as separate roundings).
-__device__ __forceinline__ float loc_im(float ref, float size, float off) {
-#pragma clang fp contract(off)
-  const float t = ref * size;
-  const float u = t + off;
-  return u - 0.5f;
-}
 
 // ---------------------------------------------------------------------------
 // quad kernel: C == 32, (L*P) % 4 == 0.  PPL = points owned per lane = L*P/4.
@@ -718,6 +624,15 @@ extern "C" int bevops_msda_set_variant(int variant) {
   return prev;
 }
 
+extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
+                                             int num_levels, int num_query, int num_point) {
+  if (dtype != BEVOPS_F16 || bs <= 0 || nk <= 0 || heads <= 0 || num_levels <= 0 ||
+      num_query <= 0 || num_point <= 0)
+    return 0;
+  if ((num_levels * num_point) % 4 != 0) return 0;
+  return msda_hm_workspace_bytes(bs, nk, heads, channels, num_levels);
+}
+
 extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
                                    const int32_t *spatial_shapes_host,
                                    const void *reference_points, int ref_dtype,
@@ -726,6 +641,22 @@ extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *
                                    int num_levels, int num_query, int num_point,
                                    int points_per_group, float scale_value, float scale_offset,
                                    float scale_weight, float scale_out, void *stream) {
+  return bevops_msda_forward_ws(dtype, value, spatial_shapes, spatial_shapes_host,
+                                reference_points, ref_dtype, sampling_offsets, attention_weights,
+                                output, bs, nk, heads, channels, num_levels, num_query, num_point,
+                                points_per_group, scale_value, scale_offset, scale_weight,
+                                scale_out, nullptr, 0, stream);
+}
+
+extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,
+                                      const int32_t *spatial_shapes_host,
+                                      const void *reference_points, int ref_dtype,
+                                      const void *sampling_offsets, const void *attention_weights,
+                                      void *output, int bs, int nk, int heads, int channels,
+                                      int num_levels, int num_query, int num_point,
+                                      int points_per_group, float scale_value, float scale_offset,
+                                      float scale_weight, float scale_out, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
   if (!value || !spatial_shapes || !reference_points || !sampling_offsets || !attention_weights ||
       !output)
     return BEVOPS_BAD_PARAM;
@@ -751,6 +682,21 @@ extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *
                                (float *)output, d, st);
     case BEVOPS_F16:
       if (ref_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+      // head-major path (msda_hm.hip) when the caller lends a workspace and the call is big
+      // enough to amortise the re-layout; variants 10 (never) / 11 (no LDS staging) / 12 (force)
+      if (workspace && g_variant != 10 && g_variant != 99 && g_variant != 1 && g_variant != 2) {
+        const double samples = (double)bs * num_query * heads * num_levels * num_point;
+        const double pixels = (double)bs * nk * heads;
+        if (g_variant == 11 || g_variant == 12 || g_variant == 13 || samples >= 4.0 * pixels) {
+          const int rc = msda_hm_forward_f16(
+              (const __half *)value, spatial_shapes, spatial_shapes_host,
+              (const __half *)reference_points, (const __half *)sampling_offsets,
+              (const __half *)attention_weights, (__half *)output, bs, nk, heads, channels,
+              num_levels, num_query, num_point, points_per_group, workspace, workspace_bytes,
+              g_variant, st);
+          if (rc != BEVOPS_NOT_SUPPORTED) return rc;
+        }
+      }
       return msda_float<__half>((const __half *)value, spatial_shapes,
                                 (const __half *)reference_points, (const __half *)sampling_offsets,
                                 (const __half *)attention_weights, (__half *)output, d, st);

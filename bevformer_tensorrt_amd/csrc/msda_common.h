@@ -1,0 +1,113 @@
+// Shared pieces of the MSDA kernels (msda.hip: quad / generic / int8 kernels on the
+// reference layout; msda_hm.hip: head-major re-layout path).
+#pragma once
+#include "common.h"
+
+namespace bevops {
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kBlock = 256;
+
+struct MsdaDims {
+  int bs, nk, heads, C, L, nq, P, ppg;
+};
+
+// ---------------------------------------------------------------------------
+// element loaders: N consecutive T -> float
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void load_f(const float *p, float (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = p[0];
+  } else if constexpr (N == 2) {
+    const float2 v = *reinterpret_cast<const float2 *>(p);
+    d[0] = v.x; d[1] = v.y;
+  } else {
+    static_assert(N % 4 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[i];
+      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void load_f(const __half *p, float (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = __half2float(p[0]);
+  } else if constexpr (N == 2) {
+    const unsigned v = *reinterpret_cast<const unsigned *>(p);
+    d[0] = h2f_lo(v); d[1] = h2f_hi(v);
+  } else if constexpr (N == 4) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    d[0] = h2f_lo(v.x); d[1] = h2f_hi(v.x); d[2] = h2f_lo(v.y); d[3] = h2f_hi(v.y);
+  } else {
+    static_assert(N % 8 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+      d[8 * i] = h2f_lo(v.x); d[8 * i + 1] = h2f_hi(v.x);
+      d[8 * i + 2] = h2f_lo(v.y); d[8 * i + 3] = h2f_hi(v.y);
+      d[8 * i + 4] = h2f_lo(v.z); d[8 * i + 5] = h2f_hi(v.z);
+      d[8 * i + 6] = h2f_lo(v.w); d[8 * i + 7] = h2f_hi(v.w);
+    }
+  }
+}
+__device__ __forceinline__ float2 load_ref(const float *p) {
+  return *reinterpret_cast<const float2 *>(p);
+}
+__device__ __forceinline__ float2 load_ref(const __half *p) {
+  const unsigned v = *reinterpret_cast<const unsigned *>(p);
+  return make_float2(h2f_lo(v), h2f_hi(v));
+}
+
+// one 8-channel tap: acc[c] += w * value[c]
+__device__ __forceinline__ void tap8(const __half *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                     float w, float (&acc)[8]) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+  acc[0] = fmaf(w, h2f_lo(r.x), acc[0]); acc[1] = fmaf(w, h2f_hi(r.x), acc[1]);
+  acc[2] = fmaf(w, h2f_lo(r.y), acc[2]); acc[3] = fmaf(w, h2f_hi(r.y), acc[3]);
+  acc[4] = fmaf(w, h2f_lo(r.z), acc[4]); acc[5] = fmaf(w, h2f_hi(r.z), acc[5]);
+  acc[6] = fmaf(w, h2f_lo(r.w), acc[6]); acc[7] = fmaf(w, h2f_hi(r.w), acc[7]);
+}
+__device__ __forceinline__ void tap8(const float *, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                     float w, float (&acc)[8]) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u), 0, 0);
+  acc[0] = fmaf(w, __uint_as_float(a.x), acc[0]); acc[1] = fmaf(w, __uint_as_float(a.y), acc[1]);
+  acc[2] = fmaf(w, __uint_as_float(a.z), acc[2]); acc[3] = fmaf(w, __uint_as_float(a.w), acc[3]);
+  acc[4] = fmaf(w, __uint_as_float(b.x), acc[4]); acc[5] = fmaf(w, __uint_as_float(b.y), acc[5]);
+  acc[6] = fmaf(w, __uint_as_float(b.z), acc[6]); acc[7] = fmaf(w, __uint_as_float(b.w), acc[7]);
+}
+__device__ __forceinline__ void store8(__half *p, const float (&a)[8]) {
+  uint4 v;
+  v.x = pack_h2(a[0], a[1]); v.y = pack_h2(a[2], a[3]);
+  v.z = pack_h2(a[4], a[5]); v.w = pack_h2(a[6], a[7]);
+  *reinterpret_cast<uint4 *>(p) = v;
+}
+__device__ __forceinline__ void store8(float *p, const float (&a)[8]) {
+  reinterpret_cast<float4 *>(p)[0] = make_float4(a[0], a[1], a[2], a[3]);
+  reinterpret_cast<float4 *>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
+}
+
+// location arithmetic kept un-fused so that it rounds exactly like the
+// reference's fp32 kernel (mul, add, sub as separate roundings).
+__device__ __forceinline__ float loc_im(float ref, float size, float off) {
+#pragma clang fp contract(off)
+  const float t = ref * size;
+  const float u = t + off;
+  return u - 0.5f;
+}
+
+
+}  // namespace
+
+// msda_hm.hip -- fp16 head-major path.  Returns BEVOPS_NOT_SUPPORTED when the shape is
+// outside its domain (caller falls back to the quad kernel).
+size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L);
+int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_t *shapes_host,
+                        const __half *ref, const __half *off, const __half *logit, __half *out,
+                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
+                        void *workspace, size_t workspace_bytes, int variant, hipStream_t st);
+}  // namespace bevops

@@ -1,0 +1,331 @@
+// MSDA fp16, head-major path ("hm"): built on what profiles/r01 showed --
+//   * a bilinear tap costs one 128-byte cache LINE whatever it uses (~2.4 clk/line/CU from
+//     L2, 4-5x more beyond the XCD's 4 MiB L2), and on the reference layout
+//     [bs, nk, heads, 32] the two x-corners of a sample are 512 B apart (2 lines) while a
+//     camera's maps (15.8 MB at base) thrash the L2: 10 GB of fabric traffic per SCA call
+//     for 0.59 GB of algorithmic bytes.
+// So:
+//   1. repack kernel: value -> VH [bs][heads][nkp][32] (head-major, level starts padded to
+//      even pixels): the two x-corners of a sample become 128 contiguous bytes -- ONE line
+//      when the pixel index is even, two half-lines otherwise (3 lines per sample on
+//      average instead of 4);
+//   2. work is ordered (batch, head)-major and blocks are XCD-remapped, so at any time an
+//      XCD gathers from one or two (camera, head) planes (1.97 MB at base) -> L2-resident;
+//   3. an OCTET of lanes owns one (b, q, h) item: lanes 0-3 take the x0 corner, lanes 4-7
+//      the x1 corner (8 channels each), so one buffer_load_dwordx4 per bilinear ROW fetches
+//      the 128-byte pair; the two quads of an octet run the quad algorithm of msda.hip
+//      (points split 4 ways, DPP broadcasts) on their own corner and are summed at the end
+//      with one DPP row_shl:4 per channel;
+//   4. (STAGE) the trailing pyramid levels that fit (<= ~150 KiB per (camera, head), e.g.
+//      29x50 + 15x25 at base) are copied once per block into LDS and their taps served by
+//      ds_read_b128 (~3x the L2-resident tap rate), leaving the L1/TA path to the big levels.
+#include "msda_common.h"
+
+namespace bevops {
+namespace {
+
+constexpr int kPixBytes = 64;       // 32 ch x fp16
+constexpr int kTabBytes = 256;      // level table at the front of dynamic LDS
+constexpr int kStageBudget = 150 * 1024;
+
+__host__ __device__ inline int hm_nkp(int nk, int L) { return (nk + L + 2) & ~1; }
+
+// level table entry: {H, W, first pixel in VH (even), first pixel in the source}
+__device__ __forceinline__ void build_levels(const int32_t *shapes, int L, int4 *tab) {
+  int src = 0, dst = 0;
+  for (int l = 0; l < L; ++l) {
+    const int H = shapes[2 * l], W = shapes[2 * l + 1];
+    tab[l] = make_int4(H, W, dst, src);
+    src += H * W;
+    dst += (H * W + 1) & ~1;
+  }
+  if (L < kMaxLevels) tab[L] = make_int4(0, 0, dst, src);  // end sentinel
+}
+
+// ---- 1. repack: [bs, nk, heads, 32] -> [bs, heads, nkp, 32]; pads written as zero -------
+__global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__restrict__ value,
+                                                             const int32_t *__restrict__ shapes,
+                                                             __half *__restrict__ vh, int bs,
+                                                             int nk, int heads, int L, int nkp) {
+  __shared__ int4 tab[kMaxLevels + 1];
+  if (threadIdx.x == 0) build_levels(shapes, L, tab);
+  __syncthreads();
+  // thread = (b, dst pixel p, head h, 16-byte chunk c): h, c fastest -> 512 B source rows
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(idx & 3);
+  const int h = (int)((idx >> 2) % heads);
+  const size_t r = (idx >> 2) / heads;
+  const int p = (int)(r % nkp);
+  const size_t b = r / nkp;
+  if (b >= (size_t)bs) return;
+  int src = -1;
+  for (int l = 0; l < L; ++l) {
+    const int4 t = tab[l];
+    const int rel = p - t.z;
+    if (rel >= 0 && rel < t.x * t.y) src = t.w + rel;
+  }
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (src >= 0)
+    v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + src) * heads + h) * 32 + c * 8);
+  *reinterpret_cast<uint4 *>(vh + (((size_t)b * heads + h) * nkp + p) * 32 + c * 8) = v;
+}
+
+// N dwords (= N (x, y) half pairs) starting at p
+template <int N>
+__device__ __forceinline__ void load_raw(const __half *p, unsigned (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = *reinterpret_cast<const unsigned *>(p);
+  } else if constexpr (N == 2) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    d[0] = v.x; d[1] = v.y;
+  } else {
+    static_assert(N % 4 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+  }
+}
+
+__device__ __forceinline__ void fma8(const u32x4 r, float w, float (&acc)[8]) {
+  acc[0] = fmaf(w, h2f_lo(r.x), acc[0]); acc[1] = fmaf(w, h2f_hi(r.x), acc[1]);
+  acc[2] = fmaf(w, h2f_lo(r.y), acc[2]); acc[3] = fmaf(w, h2f_hi(r.y), acc[3]);
+  acc[4] = fmaf(w, h2f_lo(r.z), acc[4]); acc[5] = fmaf(w, h2f_hi(r.z), acc[5]);
+  acc[6] = fmaf(w, h2f_lo(r.w), acc[6]); acc[7] = fmaf(w, h2f_hi(r.w), acc[7]);
+}
+__device__ __forceinline__ float row_shl4(float v) {  // lane i <- lane i+4 (within a 16-lane row)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));
+}
+
+// ---- 2. main kernel ------------------------------------------------------------------
+// PPL = points per quad lane (L*P/4), CH = own points prepared per pass, STAGE = serve the
+// levels >= stage_level from LDS.  Block = (batch*head, query chunk).
+template <int PPL, int CH, bool STAGE, int THREADS>
+__global__ __launch_bounds__(THREADS) void msda_hm_kernel(
+    const __half *__restrict__ vh, unsigned vh_bytes, const int32_t *__restrict__ shapes,
+    const __half *__restrict__ ref, const __half *__restrict__ off,
+    const __half *__restrict__ logit, __half *__restrict__ out, MsdaDims d, int nkp, int chunk,
+    int nchunk, int stage_level) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int4 *lvl = reinterpret_cast<int4 *>(smem);
+  if (threadIdx.x == 0) build_levels(shapes, d.L, lvl);
+  __syncthreads();
+
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bh = vb / (unsigned)nchunk, ck = vb - bh * (unsigned)nchunk;
+  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  const unsigned plane = bh * (unsigned)nkp * kPixBytes;  // byte offset of this (b, h) plane
+  int stage_pix0 = 0x7fffffff;                            // first staged pixel (VH index)
+  const int stage_j0 = stage_level * d.P;                 // first point index served from LDS
+  if constexpr (STAGE) {
+    stage_pix0 = lvl[stage_level].z;
+    const unsigned nbytes = (unsigned)(nkp - stage_pix0) * kPixBytes;
+    const char *src = reinterpret_cast<const char *>(vh) + plane + (unsigned)stage_pix0 * kPixBytes;
+    for (unsigned i = threadIdx.x * 16u; i < nbytes; i += THREADS * 16u)
+      *reinterpret_cast<uint4 *>(smem + kTabBytes + i) = *reinterpret_cast<const uint4 *>(src + i);
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(vh), 0, vh_bytes, 0x00020000);
+
+  constexpr int LP = 4 * PPL;
+  constexpr int IPP = THREADS / 8;  // items per pass
+  const unsigned lane8 = threadIdx.x & 7u;
+  const unsigned sub = lane8 & 3u;   // channel group AND owner index inside the quad
+  const unsigned side = lane8 >> 2;  // 0: x0 corner, 1: x1 corner
+  const unsigned q_end = min((ck + 1u) * (unsigned)chunk, (unsigned)d.nq);
+
+  for (unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3); q < q_end; q += IPP) {
+    const size_t item = ((size_t)b * d.nq + q) * d.heads + h;
+    float e[PPL];
+    load_f<PPL>(logit + item * LP + sub * PPL, e);
+    float m = e[0];
+#pragma unroll
+    for (int k = 1; k < PPL; ++k) m = fmaxf(m, e[k]);
+    m = quad_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      e[k] = __expf(e[k] - m);
+      s += e[k];
+    }
+    s = quad_sum(s);
+    // this lane's 2*PPL offsets stay packed (one dword = the (x, y) pair of a point)
+    unsigned offraw[PPL];
+    load_raw<PPL>(off + (item * LP + sub * PPL) * 2, offraw);
+    const __half *refp = ref + ((size_t)b * d.nq + q) * (unsigned)d.ppg * 2u;
+
+    int j0 = (int)sub * PPL;
+    int l = j0 / d.P;
+    int p = j0 - l * d.P;
+    int g = p % d.ppg;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+
+#pragma unroll
+    for (int pass = 0; pass < PPL / CH; ++pass) {
+      __builtin_amdgcn_sched_barrier(0);  // do not hoist later passes' point math up here
+      float ow[CH][2];     // attention x bilinear weight of (row0, row1) on MY x-corner
+      unsigned oo[CH][2];  // pixel index (row0, row1) of MY x-corner in the (b,h) plane
+      bool any_valid = false;
+#pragma unroll
+      for (int kk = 0; kk < CH; ++kk) {
+        const int k = pass * CH + kk;
+        const int4 t = lvl[l];
+        const int H = t.x, W = t.y;
+        const float2 r = load_ref(refp + 2 * g);
+        const float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
+        const float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
+        const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
+        any_valid |= valid;
+        const float xf = floorf(x), yf = floorf(y);
+        const float lx = x - xf, ly = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        // The octet reads pixels (xb, xb+1) of a row as one 128-byte pair: xb = x0 clamped
+        // into [0, W-2], so the pair stays inside the row at the borders.  Each side takes
+        // the weight of whichever true corner (x0 or x0+1) its column c coincides with.
+        const int xb = min(max(x0, 0), max(W - 2, 0));
+        const int c = xb + (int)side;
+        const bool c_ok = valid && c <= W - 1;  // only false for side 1 of a 1-pixel-wide map
+        const float wx = (c_ok && c == x0) ? (1.f - lx) : ((c_ok && c == x0 + 1) ? lx : 0.f);
+        const float wxe = wx * e[k];
+        ow[kk][0] = (y0 >= 0) ? (1.f - ly) * wxe : 0.f;
+        ow[kk][1] = (y0 + 1 <= H - 1) ? ly * wxe : 0.f;
+        const int cc = min(c, W - 1);
+        const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+        oo[kk][0] = (unsigned)(t.z + y0c * W + cc);
+        oo[kk][1] = (unsigned)(t.z + y1c * W + cc);
+        ++p; ++g;
+        if (g == d.ppg) g = 0;
+        if (p == d.P) { p = 0; g = 0; ++l; }
+      }
+      if (!__any(any_valid)) continue;
+
+#define BEVOPS_HM_SRC(S)                                                                     \
+      _Pragma("unroll") for (int kk = 0; kk < CH; ++kk) {                                    \
+        const float w0 = quad_bcast<S>(ow[kk][0]), w1 = quad_bcast<S>(ow[kk][1]);            \
+        const unsigned p0 = quad_bcast<S>(oo[kk][0]), p1 = quad_bcast<S>(oo[kk][1]);         \
+        u32x4 r0, r1;                                                                        \
+        if (STAGE && (S * PPL + pass * CH + kk) >= stage_j0) { /* wave-uniform */            \
+          r0 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p0 - stage_pix0) * kPixBytes + sub * 16u); \
+          r1 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p1 - stage_pix0) * kPixBytes + sub * 16u); \
+        } else {                                                                             \
+          r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p0 * kPixBytes + sub * 16u), 0, 0); \
+          r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p1 * kPixBytes + sub * 16u), 0, 0); \
+        }                                                                                    \
+        fma8(r0, w0, acc);                                                                   \
+        fma8(r1, w1, acc);                                                                   \
+      }                                                                                      \
+      /* keep at most CH points (2*CH loads) in flight per lane: the scheduler otherwise */  \
+      /* hoists all 8*CH loads of the pass and spills under the 128-VGPR budget */           \
+      __builtin_amdgcn_sched_barrier(0);
+      BEVOPS_HM_SRC(0)
+      BEVOPS_HM_SRC(1)
+      BEVOPS_HM_SRC(2)
+      BEVOPS_HM_SRC(3)
+#undef BEVOPS_HM_SRC
+    }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = (acc[c] + row_shl4(acc[c])) * inv;
+    if (side == 0) {
+      uint4 v;
+      v.x = pack_h2(acc[0], acc[1]); v.y = pack_h2(acc[2], acc[3]);
+      v.z = pack_h2(acc[4], acc[5]); v.w = pack_h2(acc[6], acc[7]);
+      *reinterpret_cast<uint4 *>(out + item * 32u + sub * 8u) = v;
+    }
+  }
+}
+
+template <int PPL, int CH>
+int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __half *ref,
+              const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp,
+              int stage_level, size_t stage_bytes, bool threads512, hipStream_t st) {
+  const bool stage = stage_level < d.L && stage_bytes > 0;
+  if (stage) {
+    const int chunk = 1024;
+    const int nchunk = (d.nq + chunk - 1) / chunk;
+    const size_t lds = kTabBytes + stage_bytes;
+    auto go = [&](auto kern, int T) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return (int)BEVOPS_FAILURE;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(T), lds, st, vh,
+                         (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk,
+                         stage_level);
+      return launch_status();
+    };
+    // one block per CU (the staged pyramid tail fills the LDS): 16 waves at <=128 VGPR, or
+    // 8 waves with the full register file (variant 13)
+    if (threads512) return go(msda_hm_kernel<PPL, CH, true, 512>, 512);
+    return go(msda_hm_kernel<PPL, CH, true, 1024>, 1024);
+  } else {
+    constexpr int T = 256;
+    const int chunk = 128;
+    const int nchunk = (d.nq + chunk - 1) / chunk;
+    hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
+                       dim3(T), kTabBytes, st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d,
+                       nkp, chunk, nchunk, d.L);
+  }
+  return launch_status();
+}
+
+}  // namespace
+
+size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L) {
+  if (C != 32 || L > kMaxLevels - 1) return 0;
+  const size_t bytes = (size_t)bs * heads * hm_nkp(nk, L) * kPixBytes;
+  return bytes < 0xFFFFFF00ull ? bytes : 0;
+}
+
+int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_t *shapes_host,
+                        const __half *ref, const __half *off, const __half *logit, __half *out,
+                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
+                        void *workspace, size_t workspace_bytes, int variant, hipStream_t st) {
+  const size_t need = msda_hm_workspace_bytes(bs, nk, heads, C, L);
+  const int LP = L * P;
+  if (need == 0 || !workspace || workspace_bytes < need || LP % 4 != 0 || !aligned16(workspace))
+    return BEVOPS_NOT_SUPPORTED;
+  const int nkp = hm_nkp(nk, L);
+  __half *vh = static_cast<__half *>(workspace);
+  {
+    const size_t threads = (size_t)bs * nkp * heads * 4;
+    hipLaunchKernelGGL(msda_hm_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                       value, shapes, vh, bs, nk, heads, L, nkp);
+  }
+  // LDS staging needs the shapes on the host: stage the longest tail of levels that fits
+  int stage_level = L;
+  size_t stage_bytes = 0;
+  if (shapes_host && variant != 11) {
+    int dst = 0;
+    int starts[kMaxLevels + 1];
+    for (int l = 0; l < L; ++l) {
+      starts[l] = dst;
+      dst += (shapes_host[2 * l] * shapes_host[2 * l + 1] + 1) & ~1;
+    }
+    for (int l = 0; l < L; ++l) {
+      const size_t bytes = (size_t)(nkp - starts[l]) * kPixBytes;
+      if (bytes <= (size_t)kStageBudget) {
+        stage_level = l;
+        stage_bytes = bytes;
+        break;
+      }
+    }
+    // staging one whole plane per 1024-query block only pays when a plane has many queries
+    if (nq < 2048) { stage_level = L; stage_bytes = 0; }
+  }
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg};
+  const bool t512 = variant == 13;
+  switch (LP / 4) {
+    case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    case 2: return launch_hm<2, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    case 4: return launch_hm<4, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    case 8: return launch_hm<8, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    case 16: return launch_hm<16, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    default: return BEVOPS_NOT_SUPPORTED;
+  }
+}
+
+}  // namespace bevops

@@ -12,6 +12,32 @@ import torch
 from ..utils import lib as _lib
 
 _SHAPE_CACHE = {}
+_HOST_SHAPES = {}
+_WORKSPACES = {}
+
+
+def _host_shapes(shapes_dev):
+    """Host copy of a device-resident value_spatial_shapes (enables LDS staging of the small
+    pyramid levels).  One blocking .cpu() per distinct tensor, then cached."""
+    key = (shapes_dev.data_ptr(), shapes_dev._version, tuple(shapes_dev.shape))
+    hit = _HOST_SHAPES.get(key)
+    if hit is None:
+        if len(_HOST_SHAPES) > 64:
+            _HOST_SHAPES.clear()
+        hit = shapes_dev.to("cpu", torch.int32).contiguous()
+        _HOST_SHAPES[key] = hit
+    return hit
+
+
+def _workspace(nbytes, device, stream_ptr):
+    """Scratch for the head-major re-layout, one buffer per (device, stream): calls on one
+    stream are ordered, so reuse is safe; other streams get their own."""
+    key = (str(device), stream_ptr)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
 
 
 def _shapes_i32(shapes, device):
@@ -62,14 +88,21 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
     if out is None:
         out = torch.empty((bs, nq, heads, ch), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        st = handle.bevops_msda_forward(
+        stream = _lib.current_stream_ptr(value.device)
+        ws_bytes = handle.bevops_msda_workspace_size(dt, bs, nk, heads, ch, L, nq, P)
+        ws = None
+        if ws_bytes:
+            ws = _workspace(ws_bytes, value.device, stream)
+            if shapes_host is None:
+                shapes_host = _host_shapes(shapes_dev)
+        st = handle.bevops_msda_forward_ws(
             dt, value.data_ptr(), shapes_dev.data_ptr(),
             shapes_host.data_ptr() if shapes_host is not None else None,
             reference_points.data_ptr(), rdt, sampling_offsets.data_ptr(),
             attention_weights.data_ptr(), out.data_ptr(), bs, nk, heads, ch, L, nq, P, ppg,
             float(scales[0]), float(scales[1]), float(scales[2]), float(scales[3]),
-            _lib.current_stream_ptr(value.device))
-    _lib.check(st, "bevops_msda_forward")
+            ws.data_ptr() if ws is not None else None, ws_bytes if ws is not None else 0, stream)
+    _lib.check(st, "bevops_msda_forward_ws")
     return out
 
 

@@ -92,6 +92,23 @@ int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_sha
                         float scale_offset, float scale_weight, float scale_out,
                         void *stream);
 
+/* Same op with a caller-owned scratch buffer (TensorRT's `workspace` argument of enqueue):
+ * lets the library re-lay `value` out head-major ([bs][heads][keys][32]) so that the two
+ * x-corners of a sample share one cache line and each XCD's L2 holds the (camera, head)
+ * plane it gathers from.  bevops_msda_workspace_size returns the bytes required (0 = the
+ * path does not apply: non-fp16, channels != 32, ...); a NULL / too small workspace simply
+ * selects the layout-preserving kernels, results are identical within fp32 rounding. */
+size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
+                                  int num_levels, int num_query, int num_point);
+int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,
+                           const int32_t *spatial_shapes_host, const void *reference_points,
+                           int ref_dtype, const void *sampling_offsets,
+                           const void *attention_weights, void *output, int bs, int nk,
+                           int heads, int channels, int num_levels, int num_query,
+                           int num_point, int points_per_group, float scale_value,
+                           float scale_offset, float scale_weight, float scale_out,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* Tuning hook: selects an internal MSDA kernel variant for subsequent calls from
  * this thread (0 = automatic).  Results are identical across variants; exists so
  * bench/tuning scripts can A/B them in one process.  Returns the previous value. */

@@ -1,0 +1,93 @@
+"""GPU parity for the head-major fp16 MSDA path (msda_hm.hip): re-layout + octet pairing
++ optional LDS staging.  Same tolerances as tests/test_msda_gpu.py (fp16: 1e-2 element-wise
+vs the fp32 oracle on fp16-rounded inputs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {"layout_preserving": 10, "hm_no_staging": 11, "hm_staged_1024": 12, "hm_staged_512": 13}
+
+SHAPES = {
+    # (bs, levels, nq, P, ppg)
+    "tiny_sca": (6, [[15, 25]], 2500, 8, 4),
+    "tiny_tsa": (2, [[50, 50]], 2500, 4, 1),
+    "small_sca": (6, [[23, 40]], 22500, 8, 4),
+    "base_sca_q4k": (6, [[116, 200], [58, 100], [29, 50], [15, 25]], 4000, 8, 4),
+    "odd_widths": (3, [[7, 9], [5, 3], [3, 1], [1, 1]], 2100, 4, 2),     # odd W, 1-pixel-wide maps
+    "ragged_nq": (2, [[12, 17], [6, 9]], 2049, 2, 1),
+    "lp16": (2, [[10, 12], [5, 6]], 300, 8, 2),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bevformer_tensorrt_amd as b
+    from bevformer_tensorrt_amd.utils import load_library
+    return b, load_library()
+
+
+def gen(shape, seed=0, ref_lo=-0.1, ref_hi=1.1, off_std=1.5):
+    bs, levels, nq, P, ppg = shape
+    heads, C = 8, 32
+    g = torch.Generator().manual_seed(seed)
+    L = len(levels)
+    nk = sum(h * w for h, w in levels)
+    value = torch.randn(bs, nk, heads, C, generator=g)
+    ref = torch.rand(bs, nq, 1, 2 * ppg, generator=g) * (ref_hi - ref_lo) + ref_lo
+    off = torch.randn(bs, nq, heads, L * P * 2, generator=g) * off_std
+    logit = torch.randn(bs, nq, heads, L * P, generator=g)
+    sh = torch.tensor(levels, dtype=torch.int32)
+    return [value.half().cuda(), sh.cuda(), ref.half().cuda(), off.half().cuda(), logit.half().cuda()]
+
+
+def run(ctx, args, variant):
+    bev, lib = ctx
+    lib.bevops_msda_set_variant(variant)
+    try:
+        out = bev.multi_scale_deformable_attn(*args)
+        torch.cuda.synchronize()
+    finally:
+        lib.bevops_msda_set_variant(0)
+    return out
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512"])
+def test_hm_vs_oracle(ctx, oracle_mod, name, variant):
+    args = gen(SHAPES[name])
+    out = run(ctx, args, VARIANTS[variant]).float().cpu().numpy()
+    v, sh, r, o, w = (a.float().cpu().numpy() if a.is_floating_point() else a.cpu().numpy() for a in args)
+    want = oracle_mod.msda_f32(v, sh, r, o, w)
+    assert np.abs(out - want).max() <= 1e-2
+
+
+@pytest.mark.parametrize("shape", ["base_sca", "base_tsa"])
+def test_hm_matches_layout_preserving_kernel_at_full_size(ctx, shape):
+    full = {"base_sca": (6, [[116, 200], [58, 100], [29, 50], [15, 25]], 40000, 8, 4),
+            "base_tsa": (2, [[200, 200]], 40000, 4, 1)}[shape]
+    args = gen(full, ref_lo=0.0, ref_hi=1.0, off_std=1.0)
+    base = run(ctx, args, VARIANTS["layout_preserving"]).float()
+    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512"):
+        o = run(ctx, args, VARIANTS[name]).float()
+        assert (o - base).abs().max().item() <= 2e-3, name   # both fp32-accumulate, fp16 store
+    # automatic choice == one of the above, and deterministic
+    a = run(ctx, args, 0)
+    assert torch.equal(a, run(ctx, args, 0))
+    assert (a.float() - base).abs().max().item() <= 2e-3
+
+
+def test_hm_out_of_view_and_zero_pads(ctx):
+    """All samples out of range -> exact zeros; and NaNs planted in unrelated workspace bytes
+    (previous larger call) never leak: pads are rewritten as zeros by the repack kernel."""
+    bev, lib = ctx
+    big = gen(SHAPES["small_sca"])
+    run(ctx, big, 12)                                   # leaves a large, dirty workspace behind
+    args = gen(SHAPES["odd_widths"])
+    args[2] = args[2] + 7.0
+    out = run(ctx, args, 12)
+    assert torch.count_nonzero(out).item() == 0
+    args = gen(SHAPES["odd_widths"])
+    a, b = run(ctx, args, 12), run(ctx, args, 10)
+    assert torch.isfinite(a).all() and (a.float() - b.float()).abs().max().item() <= 2e-3

@@ -61,9 +61,9 @@ def time_call(fn, iters=30, warm=5):
 def main():
     lib = load_library()
     rows = []
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,99").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,10,11,12,13").split(",")]
     for name, shape in SHAPES.items():
-        for dtype in (torch.float16, torch.float32):
+        for dtype in [getattr(torch, d) for d in os.environ.get('DTYPES', 'float16').split(',')]:
             for dist in (("uniform", "oov") if name.endswith("sca") else ("uniform",)):
                 args, byt = gen(shape, dtype, dist)
                 for v in variants:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools_resusage.sh file.hip  -> one line per kernel: name vgpr sgpr scratch occupancy lds
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -c "$1" -o /tmp/_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -std=c++17 --offload-arch=gfx950 -c "$1" -o /tmp/_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re,subprocess
 cur=None;rows=[]
 for line in sys.stdin:
