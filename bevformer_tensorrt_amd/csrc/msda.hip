@@ -685,9 +685,15 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       // head-major path (msda_hm.hip) when the caller lends a workspace and the call is big
       // enough to amortise the re-layout; variants 10 (never) / 11 (no LDS staging) / 12 (force)
       if (workspace && g_variant != 10 && g_variant != 99 && g_variant != 1 && g_variant != 2) {
+        // pays when a batch's maps overflow an XCD's 4 MiB L2 and there are enough samples per
+        // pixel to amortise the re-layout (profiles/r01: base SCA 1.75x, base TSA 1.1x; small /
+        // tiny maps are L2-resident already and stay on the layout-preserving kernel)
         const double samples = (double)bs * num_query * heads * num_levels * num_point;
         const double pixels = (double)bs * nk * heads;
-        if (g_variant == 11 || g_variant == 12 || g_variant == 13 || samples >= 4.0 * pixels) {
+        const double plane_mb = (double)nk * heads * channels * 2 / 1048576.0;
+        const bool pays = (samples >= 16.0 * pixels && plane_mb >= 4.0) ||
+                          (samples >= 4.0 * pixels && plane_mb >= 16.0);
+        if ((g_variant >= 11 && g_variant <= 14) || pays) {
           const int rc = msda_hm_forward_f16(
               (const __half *)value, spatial_shapes, spatial_shapes_host,
               (const __half *)reference_points, (const __half *)sampling_offsets,

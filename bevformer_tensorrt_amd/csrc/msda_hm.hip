@@ -46,7 +46,8 @@ __device__ __forceinline__ void build_levels(const int32_t *shapes, int L, int4 
 __global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              __half *__restrict__ vh, int bs,
-                                                             int nk, int heads, int L, int nkp) {
+                                                             int nk, int heads, int L, int nkp,
+                                                             unsigned copy_b) {
   __shared__ int4 tab[kMaxLevels + 1];
   if (threadIdx.x == 0) build_levels(shapes, L, tab);
   __syncthreads();
@@ -67,7 +68,11 @@ __global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__res
   uint4 v = make_uint4(0, 0, 0, 0);
   if (src >= 0)
     v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + src) * heads + h) * 32 + c * 8);
-  *reinterpret_cast<uint4 *>(vh + (((size_t)b * heads + h) * nkp + p) * 32 + c * 8) = v;
+  const size_t o = (((size_t)b * heads + h) * nkp + p) * 32 + c * 8;
+  *reinterpret_cast<uint4 *>(vh + o) = v;
+  // second copy, placed 64 B off 128-byte alignment: pixel pairs that START ON AN ODD pixel
+  // are one aligned line there (copy A serves the even ones)
+  if (copy_b) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(vh) + copy_b + o * 2) = v;
 }
 
 // N dwords (= N (x, y) half pairs) starting at p
@@ -101,12 +106,12 @@ __device__ __forceinline__ float row_shl4(float v) {  // lane i <- lane i+4 (wit
 // ---- 2. main kernel ------------------------------------------------------------------
 // PPL = points per quad lane (L*P/4), CH = own points prepared per pass, STAGE = serve the
 // levels >= stage_level from LDS.  Block = (batch*head, query chunk).
-template <int PPL, int CH, bool STAGE, int THREADS>
+template <int PPL, int CH, bool STAGE, int THREADS, bool TWO = false>
 __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
     const __half *__restrict__ vh, unsigned vh_bytes, const int32_t *__restrict__ shapes,
     const __half *__restrict__ ref, const __half *__restrict__ off,
     const __half *__restrict__ logit, __half *__restrict__ out, MsdaDims d, int nkp, int chunk,
-    int nchunk, int stage_level) {
+    int nchunk, int stage_level, unsigned copy_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int4 *lvl = reinterpret_cast<int4 *>(smem);
   if (threadIdx.x == 0) build_levels(shapes, d.L, lvl);
@@ -197,6 +202,11 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
         const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
         oo[kk][0] = (unsigned)(t.z + y0c * W + cc);
         oo[kk][1] = (unsigned)(t.z + y1c * W + cc);
+        if constexpr (TWO) {  // pick the copy in which this row's pair (xb, xb+1) is one line
+          const unsigned f0 = (unsigned)(t.z + y0c * W + xb), f1 = (unsigned)(t.z + y1c * W + xb);
+          oo[kk][0] = oo[kk][0] * kPixBytes + ((f0 & 1u) ? copy_b : 0u);
+          oo[kk][1] = oo[kk][1] * kPixBytes + ((f1 & 1u) ? copy_b : 0u);
+        }
         ++p; ++g;
         if (g == d.ppg) g = 0;
         if (p == d.P) { p = 0; g = 0; ++l; }
@@ -212,8 +222,8 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
           r0 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p0 - stage_pix0) * kPixBytes + sub * 16u); \
           r1 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p1 - stage_pix0) * kPixBytes + sub * 16u); \
         } else {                                                                             \
-          r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p0 * kPixBytes + sub * 16u), 0, 0); \
-          r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p1 * kPixBytes + sub * 16u), 0, 0); \
+          r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + (TWO ? p0 : p0 * kPixBytes) + sub * 16u), 0, 0); \
+          r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + (TWO ? p1 : p1 * kPixBytes) + sub * 16u), 0, 0); \
         }                                                                                    \
         fma8(r0, w0, acc);                                                                   \
         fma8(r1, w1, acc);                                                                   \
@@ -242,7 +252,8 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
 template <int PPL, int CH>
 int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __half *ref,
               const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp,
-              int stage_level, size_t stage_bytes, bool threads512, hipStream_t st) {
+              int stage_level, size_t stage_bytes, bool threads512, unsigned copy_b,
+              hipStream_t st) {
   const bool stage = stage_level < d.L && stage_bytes > 0;
   if (stage) {
     const int chunk = 1024;
@@ -254,7 +265,7 @@ int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __
         return (int)BEVOPS_FAILURE;
       hipLaunchKernelGGL(kern, dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(T), lds, st, vh,
                          (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk,
-                         stage_level);
+                         stage_level, 0u);
       return launch_status();
     };
     // one block per CU (the staged pyramid tail fills the LDS): 16 waves at <=128 VGPR, or
@@ -265,40 +276,58 @@ int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __
     constexpr int T = 256;
     const int chunk = 128;
     const int nchunk = (d.nq + chunk - 1) / chunk;
-    hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
-                       dim3(T), kTabBytes, st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d,
-                       nkp, chunk, nchunk, d.L);
+    if (copy_b)
+      hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T, true>),
+                         dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(T), kTabBytes, st, vh,
+                         (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk, d.L,
+                         copy_b);
+    else
+      hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
+                         dim3(T), kTabBytes, st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d,
+                         nkp, chunk, nchunk, d.L, 0u);
   }
   return launch_status();
 }
 
 }  // namespace
 
+size_t hm_copy_bytes(int bs, int nk, int heads, int L) {
+  return (((size_t)bs * heads * hm_nkp(nk, L) * kPixBytes) + 127) & ~size_t(127);
+}
+
 size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L) {
   if (C != 32 || L > kMaxLevels - 1) return 0;
-  const size_t bytes = (size_t)bs * heads * hm_nkp(nk, L) * kPixBytes;
-  return bytes < 0xFFFFFF00ull ? bytes : 0;
+  const size_t one = hm_copy_bytes(bs, nk, heads, L);
+  const size_t two = 2 * one + 128;  // room for the second, 64-byte-shifted copy
+  if (two < 0xFFFFFF00ull) return two;
+  return one < 0xFFFFFF00ull ? one : 0;
 }
 
 int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_t *shapes_host,
                         const __half *ref, const __half *off, const __half *logit, __half *out,
                         int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
                         void *workspace, size_t workspace_bytes, int variant, hipStream_t st) {
-  const size_t need = msda_hm_workspace_bytes(bs, nk, heads, C, L);
+  if (C != 32 || L > kMaxLevels - 1) return BEVOPS_NOT_SUPPORTED;
+  const size_t one = hm_copy_bytes(bs, nk, heads, L);
   const int LP = L * P;
-  if (need == 0 || !workspace || workspace_bytes < need || LP % 4 != 0 || !aligned16(workspace))
+  if (!workspace || workspace_bytes < one || one >= 0xFFFFFF00ull || LP % 4 != 0 ||
+      (reinterpret_cast<uintptr_t>(workspace) & 127u))
     return BEVOPS_NOT_SUPPORTED;
   const int nkp = hm_nkp(nk, L);
   __half *vh = static_cast<__half *>(workspace);
+  // variant 14: two copies (A: even-start pairs, B: odd-start pairs) -> 2 lines per sample
+  const bool two = variant == 14 && workspace_bytes >= 2 * one + 128 && 2 * one + 128 < 0xFFFFFF00ull;
+  const unsigned copy_b = two ? (unsigned)(one + 64) : 0u;
+  const size_t need = two ? 2 * one + 128 : one;
   {
     const size_t threads = (size_t)bs * nkp * heads * 4;
     hipLaunchKernelGGL(msda_hm_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                       value, shapes, vh, bs, nk, heads, L, nkp);
+                       value, shapes, vh, bs, nk, heads, L, nkp, copy_b);
   }
   // LDS staging needs the shapes on the host: stage the longest tail of levels that fits
   int stage_level = L;
   size_t stage_bytes = 0;
-  if (shapes_host && variant != 11) {
+  if (shapes_host && (variant == 12 || variant == 13)) {  // staging is opt-in
     int dst = 0;
     int starts[kMaxLevels + 1];
     for (int l = 0; l < L; ++l) {
@@ -319,11 +348,11 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg};
   const bool t512 = variant == 13;
   switch (LP / 4) {
-    case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
-    case 2: return launch_hm<2, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
-    case 4: return launch_hm<4, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
-    case 8: return launch_hm<8, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
-    case 16: return launch_hm<16, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, st);
+    case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
+    case 2: return launch_hm<2, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
+    case 4: return launch_hm<4, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
+    case 8: return launch_hm<8, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
+    case 16: return launch_hm<16, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
     default: return BEVOPS_NOT_SUPPORTED;
   }
 }

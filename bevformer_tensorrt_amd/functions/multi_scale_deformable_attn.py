@@ -7,25 +7,64 @@ plugin instead.  Here both are one fused HIP kernel (csrc/msda.hip) reached
 through `bevops_msda_forward`.  fp16 inputs are upcast inside the kernel (fp32
 location/softmax/accumulate), output returned in the input dtype like :123.
 """
+import weakref
+
 import torch
 
 from ..utils import lib as _lib
 
-_SHAPE_CACHE = {}
-_HOST_SHAPES = {}
+# Caches are keyed by the tensor OBJECT (weakly) + its in-place version counter: a live
+# tensor cannot have its storage recycled, unlike a (data_ptr) key.
+class _TensorCache:
+    """id(tensor) -> value, validated by a weak reference to the tensor and its version
+    (WeakKeyDictionary cannot be used: Tensor.__eq__ is element-wise)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, t):
+        hit = self._d.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version:
+            return hit[2]
+        return None
+
+    def put(self, t, value):
+        if len(self._d) > 256:
+            self._d = {k: v for k, v in self._d.items() if v[0]() is not None}
+        self._d[id(t)] = (weakref.ref(t), t._version, value)
+        return value
+
+
+_CPU_SHAPES = {}
+_DEV_I32 = _TensorCache()
+_HOST_SHAPES = _TensorCache()
 _WORKSPACES = {}
 
 
-def _host_shapes(shapes_dev):
-    """Host copy of a device-resident value_spatial_shapes (enables LDS staging of the small
-    pyramid levels).  One blocking .cpu() per distinct tensor, then cached."""
-    key = (shapes_dev.data_ptr(), shapes_dev._version, tuple(shapes_dev.shape))
-    hit = _HOST_SHAPES.get(key)
+def _shapes_i32(shapes, device):
+    """int32 device copy (+ host copy when free) of value_spatial_shapes."""
+    if shapes.device.type == "cpu":
+        key = (tuple(shapes.flatten().tolist()), str(device))
+        hit = _CPU_SHAPES.get(key)
+        if hit is None:
+            host = shapes.to(torch.int32).contiguous()
+            hit = (host.to(device), host)
+            _CPU_SHAPES[key] = hit
+        return hit
+    if shapes.dtype == torch.int32 and shapes.is_contiguous():
+        return shapes, None
+    hit = _DEV_I32.get(shapes)
     if hit is None:
-        if len(_HOST_SHAPES) > 64:
-            _HOST_SHAPES.clear()
-        hit = shapes_dev.to("cpu", torch.int32).contiguous()
-        _HOST_SHAPES[key] = hit
+        hit = _DEV_I32.put(shapes, shapes.to(torch.int32).contiguous())
+    return hit, None
+
+
+def _host_shapes(shapes_dev):
+    """Host copy of a device-resident value_spatial_shapes (lets the library stage the small
+    pyramid levels in LDS).  One blocking .cpu() per distinct tensor object, then cached."""
+    hit = _HOST_SHAPES.get(shapes_dev)
+    if hit is None:
+        hit = _HOST_SHAPES.put(shapes_dev, shapes_dev.to("cpu", torch.int32).contiguous())
     return hit
 
 
@@ -38,28 +77,6 @@ def _workspace(nbytes, device, stream_ptr):
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _WORKSPACES[key] = buf
     return buf
-
-
-def _shapes_i32(shapes, device):
-    """int32 device copy (+ host copy when free) of value_spatial_shapes."""
-    if shapes.device.type == "cpu":
-        key = ("cpu", tuple(shapes.flatten().tolist()), str(device))
-        hit = _SHAPE_CACHE.get(key)
-        if hit is None:
-            host = shapes.to(torch.int32).contiguous()
-            hit = (host.to(device), host)
-            _SHAPE_CACHE[key] = hit
-        return hit
-    if shapes.dtype == torch.int32 and shapes.is_contiguous():
-        return shapes, None
-    key = (shapes.data_ptr(), shapes._version, shapes.dtype, tuple(shapes.shape))
-    hit = _SHAPE_CACHE.get(key)
-    if hit is None:
-        if len(_SHAPE_CACHE) > 64:
-            _SHAPE_CACHE.clear()
-        hit = (shapes.to(torch.int32).contiguous(), None)
-        _SHAPE_CACHE[key] = hit
-    return hit
 
 
 def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights,

@@ -7,7 +7,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"layout_preserving": 10, "hm_no_staging": 11, "hm_staged_1024": 12, "hm_staged_512": 13}
+VARIANTS = {"layout_preserving": 10, "hm_no_staging": 11, "hm_staged_1024": 12, "hm_staged_512": 13,
+            "hm_two_copies": 14}
 
 SHAPES = {
     # (bs, levels, nq, P, ppg)
@@ -54,7 +55,7 @@ def run(ctx, args, variant):
 
 
 @pytest.mark.parametrize("name", list(SHAPES))
-@pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512"])
+@pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies"])
 def test_hm_vs_oracle(ctx, oracle_mod, name, variant):
     args = gen(SHAPES[name])
     out = run(ctx, args, VARIANTS[variant]).float().cpu().numpy()
@@ -69,7 +70,7 @@ def test_hm_matches_layout_preserving_kernel_at_full_size(ctx, shape):
             "base_tsa": (2, [[200, 200]], 40000, 4, 1)}[shape]
     args = gen(full, ref_lo=0.0, ref_hi=1.0, off_std=1.0)
     base = run(ctx, args, VARIANTS["layout_preserving"]).float()
-    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512"):
+    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies"):
         o = run(ctx, args, VARIANTS[name]).float()
         assert (o - base).abs().max().item() <= 2e-3, name   # both fp32-accumulate, fp16 store
     # automatic choice == one of the above, and deterministic

@@ -31,6 +31,14 @@ def gen(shape, dtype, dist="uniform"):
     nk = sum(h * w for h, w in levels)
     value = torch.randn(bs, nk, heads, C, generator=g)
     ref = torch.rand(bs, nq, 1, 2 * ppg, generator=g)
+    if dist == "rig":  # reference points from the model's own projection of BEV pillars
+        from bevformer_tensorrt_amd import geometry as G
+        bh = int(round(nq ** 0.5))
+        img = {2500: (480, 800), 22500: (736, 1280), 40000: (928, 1600)}[nq]
+        ref3d = G.reference_points_3d(bh, bh, 8, 4, device="cpu")
+        cam, _ = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0],
+                                  G.synthetic_lidar2img(img), img)
+        ref = cam.reshape(6, nq, 1, 8).contiguous()     # spatial_cross_attention.py:254-262
     if dist == "oov":  # ~2/3 of (camera, query) pairs out of view, like a real rig
         shift = (torch.rand(bs, nq, 1, 1, generator=g) < 0.67).float() * 3.0
         ref = ref + shift
@@ -64,7 +72,7 @@ def main():
     variants = [int(v) for v in os.environ.get("VARIANTS", "0,10,11,12,13").split(",")]
     for name, shape in SHAPES.items():
         for dtype in [getattr(torch, d) for d in os.environ.get('DTYPES', 'float16').split(',')]:
-            for dist in (("uniform", "oov") if name.endswith("sca") else ("uniform",)):
+            for dist in (("uniform", "rig") if name.endswith("sca") else ("uniform",)):
                 args, byt = gen(shape, dtype, dist)
                 for v in variants:
                     if v == 99 and name == "base_sca" and dtype == torch.float32:
