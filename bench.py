@@ -196,18 +196,22 @@ def main():
     fps = args.steps / elapsed
 
     def pmc_traffic():
-        """HBM/fabric bytes per SCA launch from the committed rocprofv3 PMC passes
+        """HBM/fabric bytes per base-SCA call from the newest committed rocprofv3 PMC passes
         (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
-        correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM")."""
+        correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM").  The call is two
+        launches since round 1b (re-layout + gather); both are summed."""
         try:
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel.json")))[-1]
+            total = 0.0
             for k, v in json.load(open(f)).items():
-                if "msda" in k and "grid=7680000" in k and "FETCH_SIZE_KiB_avg" in v:
-                    return int((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024), os.path.relpath(f, ROOT)
+                sca = ("msda_hm2_kernel<32>" in k or "msda_hm2_repack_kernel" in k or
+                       ("msda_quad_kernel<__half, 8" in k))
+                if sca and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
+                    total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
+            return (int(total) if total else None), os.path.relpath(f, ROOT)
         except Exception:
-            pass
-        return None, None
+            return None, None
 
     roofline = None
     if sca_events:
@@ -215,7 +219,7 @@ def main():
         avg_ms = sum(ms) / len(ms)
         byt = msda_bytes(BASE["sca"], esize, bs=sca_bs)
         achieved = byt / (avg_ms * 1e-3) / 1e9
-        roofline = {"kernel": "msda_quad_kernel (base SCA call)", "bound": "hbm",
+        roofline = {"kernel": "base SCA MSDA call = msda_hm2_repack_kernel + msda_hm2_kernel<32>", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
                     "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),

@@ -693,7 +693,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         const double plane_mb = (double)nk * heads * channels * 2 / 1048576.0;
         const bool pays = (samples >= 16.0 * pixels && plane_mb >= 4.0) ||
                           (samples >= 4.0 * pixels && plane_mb >= 16.0);
-        if ((g_variant >= 11 && g_variant <= 14) || pays) {
+        if ((g_variant >= 11 && g_variant <= 15) || pays) {
           const int rc = msda_hm_forward_f16(
               (const __half *)value, spatial_shapes, spatial_shapes_host,
               (const __half *)reference_points, (const __half *)sampling_offsets,

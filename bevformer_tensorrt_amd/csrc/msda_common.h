@@ -54,6 +54,52 @@ __device__ __forceinline__ void load_f(const __half *p, float (&d)[N]) {
     }
   }
 }
+// streaming (read-once) operands: non-temporal so they do not evict the gathered value maps
+// from the XCD's L2
+template <typename V>
+__device__ __forceinline__ V ld_nt(const void *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+}
+template <int N>
+__device__ __forceinline__ void load_f_nt(const __half *p, float (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = __half2float(__ushort_as_half(ld_nt<unsigned short>(p)));
+  } else if constexpr (N == 2) {
+    const unsigned v = ld_nt<unsigned>(p);
+    d[0] = h2f_lo(v); d[1] = h2f_hi(v);
+  } else if constexpr (N == 4) {
+    const unsigned long long v = ld_nt<unsigned long long>(p);
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    d[0] = h2f_lo(lo); d[1] = h2f_hi(lo); d[2] = h2f_lo(hi); d[3] = h2f_hi(hi);
+  } else {
+    static_assert(N % 8 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      const u32x4 v = ld_nt<u32x4>(p + 8 * i);
+      d[8 * i] = h2f_lo(v.x); d[8 * i + 1] = h2f_hi(v.x);
+      d[8 * i + 2] = h2f_lo(v.y); d[8 * i + 3] = h2f_hi(v.y);
+      d[8 * i + 4] = h2f_lo(v.z); d[8 * i + 5] = h2f_hi(v.z);
+      d[8 * i + 6] = h2f_lo(v.w); d[8 * i + 7] = h2f_hi(v.w);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void load_raw_nt(const __half *p, unsigned (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = ld_nt<unsigned>(p);
+  } else if constexpr (N == 2) {
+    const unsigned long long v = ld_nt<unsigned long long>(p);
+    d[0] = (unsigned)v; d[1] = (unsigned)(v >> 32);
+  } else {
+    static_assert(N % 4 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const u32x4 v = ld_nt<u32x4>(p + 8 * i);
+      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+  }
+}
+
 __device__ __forceinline__ float2 load_ref(const float *p) {
   return *reinterpret_cast<const float2 *>(p);
 }

@@ -249,6 +249,219 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
   }
 }
 
+
+// =======================================================================================
+// hm2 -- second generation of the head-major path.  PMC on hm (profiles/r01) showed the
+// kernel ~75 % VALU-bound (3.2e8 wave-instructions per base SCA call: 16 v_fma_mix + 4 DPP
+// movs + 4 address ops + ~14 redundant owner-math ops per point step), so hm2 removes
+// instructions as well as cache lines:
+//   * layout: pixel PAIRS, channel-interleaved -- 128 B = 32 x half2(v[p][c], v[p+1][c]) --
+//     in two copies (pairs starting on even / odd pixels), so every x-pair of a bilinear row
+//     is ONE aligned line and one v_dot2c_f32_f16 does both x-corners of a channel
+//     (8 dot2 per point instead of 16 fma_mix; weights ride as half2, accumulate fp32);
+//   * all 8 lanes of an octet are equal (4 channels each); the L*P points are split 8 ways
+//     (no redundant owner math) and handed over through a wave-private LDS mailbox
+//     (one ds_write_b128 per point, one broadcast ds_read_b128 per point step) instead of
+//     4 DPP movs.
+// =======================================================================================
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+constexpr int kPairBytes = 128;
+
+__host__ __device__ inline int hm2_npairs(int nk, int L) { return (hm_nkp(nk, L) >> 1) + 1; }
+
+__device__ __forceinline__ int hm_lookup(const int4 *tab, int L, int p) {
+  int src = -1;
+  for (int l = 0; l < L; ++l) {
+    const int4 t = tab[l];
+    const int rel = p - t.z;
+    if (rel >= 0 && rel < t.x * t.y) src = t.w + rel;
+  }
+  return src;
+}
+
+__global__ __launch_bounds__(256) void msda_hm2_repack_kernel(const __half *__restrict__ value,
+                                                              const int32_t *__restrict__ shapes,
+                                                              char *__restrict__ vh2, int bs, int nk,
+                                                              int heads, int L, int npairs,
+                                                              unsigned copy_b) {
+  __shared__ int4 tab[kMaxLevels + 1];
+  if (threadIdx.x == 0) build_levels(shapes, L, tab);
+  __syncthreads();
+  // thread = (b, pair k, copy, head h, 4-channel group c8): c8, h fastest
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(idx & 7);
+  const int h = (int)((idx >> 3) % heads);
+  size_t r = (idx >> 3) / heads;
+  const int copy = (int)(r & 1);
+  r >>= 1;
+  const int k = (int)(r % npairs);
+  const size_t b = r / npairs;
+  if (b >= (size_t)bs) return;
+  const int f = 2 * k + copy;
+  const int s0 = hm_lookup(tab, L, f), s1 = hm_lookup(tab, L, f + 1);
+  uint2 a = make_uint2(0, 0), c = make_uint2(0, 0);
+  if (s0 >= 0) a = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c8 * 4);
+  if (s1 >= 0) c = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s1) * heads + h) * 32 + c8 * 4);
+  uint4 o;
+  o.x = (a.x & 0xffffu) | (c.x << 16);
+  o.y = (a.x >> 16) | (c.x & 0xffff0000u);
+  o.z = (a.y & 0xffffu) | (c.y << 16);
+  o.w = (a.y >> 16) | (c.y & 0xffff0000u);
+  *reinterpret_cast<uint4 *>(vh2 + (copy ? copy_b : 0u) +
+                             (((size_t)b * heads + h) * npairs + k) * kPairBytes + c8 * 16) = o;
+}
+
+__device__ __forceinline__ float octet_max(float v) {
+  v = quad_max(v);
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
+}
+__device__ __forceinline__ float octet_sum(float v) {
+  v = quad_sum(v);
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dot2(unsigned pair, unsigned w, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, pair), __builtin_bit_cast(h2_t, w), acc, false);
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void msda_hm2_kernel(
+    const char *__restrict__ vh2, unsigned vh_bytes, const int32_t *__restrict__ shapes,
+    const __half *__restrict__ ref, const __half *__restrict__ off,
+    const __half *__restrict__ logit, __half *__restrict__ out, MsdaDims d, int npairs, int chunk,
+    int nchunk, unsigned copy_b) {
+  constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
+  constexpr int PP = LP / NOWN;           // points per owner
+  constexpr int kBox = LP * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int4 *lvl = reinterpret_cast<int4 *>(smem);
+  if (threadIdx.x == 0) build_levels(shapes, d.L, lvl);
+  __syncthreads();
+
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bh = vb / (unsigned)nchunk, ck = vb - bh * (unsigned)nchunk;
+  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  const unsigned plane = bh * (unsigned)npairs * kPairBytes;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vh2), 0, vh_bytes, 0x00020000);
+  const unsigned lane8 = threadIdx.x & 7u;
+  char *box = smem + kTabBytes + (threadIdx.x >> 3) * kBox;
+  const unsigned q_end = min((ck + 1u) * (unsigned)chunk, (unsigned)d.nq);
+
+  for (unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3); q < q_end; q += 32) {
+    const size_t item = ((size_t)b * d.nq + q) * d.heads + h;
+    const bool owner = lane8 < (unsigned)NOWN;
+    float e[PP];
+    unsigned offraw[PP];
+#pragma unroll
+    for (int k = 0; k < PP; ++k) { e[k] = -INFINITY; offraw[k] = 0; }
+    if (owner) {
+      // offsets are read once; when an item's offsets fill whole 128-byte lines (LP >= 32)
+      // stream them non-temporally so they do not evict the value maps from L2.  Narrower
+      // rows share lines with the neighbouring heads' items -> keep those cacheable
+      // (measured: nt on half-lines costs +50 % on the small-model SCA call).
+      if constexpr (LP >= 32) {
+        load_f_nt<PP>(logit + item * LP + lane8 * PP, e);
+        load_raw_nt<PP>(off + (item * LP + lane8 * PP) * 2, offraw);
+      } else {
+        load_f<PP>(logit + item * LP + lane8 * PP, e);
+        load_raw<PP>(off + (item * LP + lane8 * PP) * 2, offraw);
+      }
+    }
+    float m = e[0];
+#pragma unroll
+    for (int k = 1; k < PP; ++k) m = fmaxf(m, e[k]);
+    m = octet_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      e[k] = owner ? __expf(e[k] - m) : 0.f;
+      s += e[k];
+    }
+    s = octet_sum(s);
+
+    bool any_valid = false;
+    if (owner) {
+      const __half *refp = ref + ((size_t)b * d.nq + q) * (unsigned)d.ppg * 2u;
+      const int j0 = (int)lane8 * PP;
+      int l = j0 / d.P;
+      int p = j0 - l * d.P;
+      int g = p % d.ppg;
+#pragma unroll
+      for (int k = 0; k < PP; ++k) {
+        const int4 t = lvl[l];
+        const int H = t.x, W = t.y;
+        const float2 r = load_ref(refp + 2 * g);
+        const float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
+        const float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
+        const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
+        any_valid |= valid;
+        const float xf = floorf(x), yf = floorf(y);
+        const float lx = x - xf, ly = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        // the row pair read is pixels (xb, xb+1), xb = x0 clamped into [0, W-2]
+        const int xb = min(max(x0, 0), max(W - 2, 0));
+        const float wa = (xb == x0) ? (1.f - lx) : ((xb == x0 + 1) ? lx : 0.f);
+        const float wb = (xb + 1 > W - 1) ? 0.f : ((xb + 1 == x0) ? (1.f - lx) : ((xb + 1 == x0 + 1) ? lx : 0.f));
+        const float ev = valid ? e[k] : 0.f;
+        const float wr0 = (y0 >= 0) ? (1.f - ly) * ev : 0.f;
+        const float wr1 = (y0 + 1 <= H - 1) ? ly * ev : 0.f;
+        const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+        const unsigned f0 = (unsigned)(t.z + y0c * W + xb), f1 = (unsigned)(t.z + y1c * W + xb);
+        uint4 pl;
+        pl.x = pack_h2(wr0 * wa, wr0 * wb);
+        pl.y = pack_h2(wr1 * wa, wr1 * wb);
+        pl.z = plane + (f0 >> 1) * kPairBytes + ((f0 & 1u) ? copy_b : 0u);
+        pl.w = plane + (f1 >> 1) * kPairBytes + ((f1 & 1u) ? copy_b : 0u);
+        *reinterpret_cast<uint4 *>(box + (j0 + k) * 16) = pl;
+        ++p; ++g;
+        if (g == d.ppg) g = 0;
+        if (p == d.P) { p = 0; g = 0; ++l; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // mailbox: same wave writes & reads
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (__any(any_valid)) {
+#pragma unroll 8
+      for (int j = 0; j < LP; ++j) {
+        const uint4 pl = *reinterpret_cast<const uint4 *>(box + j * 16);
+        const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(pl.z + lane8 * 16u), 0, 0);
+        const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(pl.w + lane8 * 16u), 0, 0);
+        acc[0] = dot2(r0.x, pl.x, acc[0]); acc[1] = dot2(r0.y, pl.x, acc[1]);
+        acc[2] = dot2(r0.z, pl.x, acc[2]); acc[3] = dot2(r0.w, pl.x, acc[3]);
+        acc[0] = dot2(r1.x, pl.y, acc[0]); acc[1] = dot2(r1.y, pl.y, acc[1]);
+        acc[2] = dot2(r1.z, pl.y, acc[2]); acc[3] = dot2(r1.w, pl.y, acc[3]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float inv = 1.0f / s;
+    uint2 v;
+    v.x = pack_h2(acc[0] * inv, acc[1] * inv);
+    v.y = pack_h2(acc[2] * inv, acc[3] * inv);
+    if constexpr (LP >= 32)
+      __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x,
+                                  reinterpret_cast<unsigned long long *>(out + item * 32u + lane8 * 4u));
+    else
+      *reinterpret_cast<uint2 *>(out + item * 32u + lane8 * 4u) = v;
+  }
+}
+
+template <int LP>
+int launch_hm2(const char *vh2, size_t vh_bytes, const int32_t *shapes, const __half *ref,
+               const __half *off, const __half *logit, __half *out, const MsdaDims &d, int npairs,
+               unsigned copy_b, hipStream_t st) {
+  const int chunk = 128;
+  const int nchunk = (d.nq + chunk - 1) / chunk;
+  const size_t lds = kTabBytes + 32 * (LP * 16 + 16);
+  hipLaunchKernelGGL((msda_hm2_kernel<LP>), dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(256), lds,
+                     st, vh2, (unsigned)vh_bytes, shapes, ref, off, logit, out, d, npairs, chunk, nchunk,
+                     copy_b);
+  return launch_status();
+}
+
+size_t hm2_bytes(int bs, int nk, int heads, int L) {
+  return 2 * (size_t)bs * heads * hm2_npairs(nk, L) * kPairBytes;
+}
+
 template <int PPL, int CH>
 int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __half *ref,
               const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp,
@@ -299,7 +512,9 @@ size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L) {
   if (C != 32 || L > kMaxLevels - 1) return 0;
   const size_t one = hm_copy_bytes(bs, nk, heads, L);
   const size_t two = 2 * one + 128;  // room for the second, 64-byte-shifted copy
-  if (two < 0xFFFFFF00ull) return two;
+  const size_t v2 = hm2_bytes(bs, nk, heads, L);
+  const size_t want = two > v2 ? two : v2;
+  if (want < 0xFFFFFF00ull) return want;
   return one < 0xFFFFFF00ull ? one : 0;
 }
 
@@ -310,6 +525,31 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
   if (C != 32 || L > kMaxLevels - 1) return BEVOPS_NOT_SUPPORTED;
   const size_t one = hm_copy_bytes(bs, nk, heads, L);
   const int LP = L * P;
+  // default: hm2 for the many-point calls (SCA: L*P >= 16), hm for the few-point ones (TSA:
+  // only half of an hm2 octet would own a point, and its two-copy re-layout costs more than
+  // it saves); variants 11-14 force hm flavours, 15 forces hm2
+  if ((variant == 15 || LP >= 16) && !(variant >= 11 && variant <= 14)) {
+    const size_t need2 = hm2_bytes(bs, nk, heads, L);
+    const bool lp_ok = LP == 4 || LP == 8 || LP == 16 || LP == 32 || LP == 64;
+    if (workspace && workspace_bytes >= need2 && need2 < 0xFFFFFF00ull && lp_ok &&
+        !(reinterpret_cast<uintptr_t>(workspace) & 127u)) {
+      const int npairs = hm2_npairs(nk, L);
+      char *vh2 = static_cast<char *>(workspace);
+      const unsigned copy_b = (unsigned)(need2 / 2);
+      const size_t threads = (size_t)bs * npairs * 2 * heads * 8;
+      hipLaunchKernelGGL(msda_hm2_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                         st, value, shapes, vh2, bs, nk, heads, L, npairs, copy_b);
+      const MsdaDims d2{bs, nk, heads, C, L, nq, P, ppg};
+      switch (LP) {
+        case 4: return launch_hm2<4>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
+        case 8: return launch_hm2<8>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
+        case 16: return launch_hm2<16>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
+        case 32: return launch_hm2<32>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
+        default: return launch_hm2<64>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
+      }
+    }
+    if (variant == 15) return BEVOPS_NOT_SUPPORTED;
+  }
   if (!workspace || workspace_bytes < one || one >= 0xFFFFFF00ull || LP % 4 != 0 ||
       (reinterpret_cast<uintptr_t>(workspace) & 127u))
     return BEVOPS_NOT_SUPPORTED;

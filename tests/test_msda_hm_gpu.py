@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {"layout_preserving": 10, "hm_no_staging": 11, "hm_staged_1024": 12, "hm_staged_512": 13,
-            "hm_two_copies": 14}
+            "hm_two_copies": 14, "hm2_dot2_mailbox": 15}
 
 SHAPES = {
     # (bs, levels, nq, P, ppg)
@@ -55,7 +55,8 @@ def run(ctx, args, variant):
 
 
 @pytest.mark.parametrize("name", list(SHAPES))
-@pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies"])
+@pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies",
+                                     "hm2_dot2_mailbox"])
 def test_hm_vs_oracle(ctx, oracle_mod, name, variant):
     args = gen(SHAPES[name])
     out = run(ctx, args, VARIANTS[variant]).float().cpu().numpy()
@@ -70,13 +71,16 @@ def test_hm_matches_layout_preserving_kernel_at_full_size(ctx, shape):
             "base_tsa": (2, [[200, 200]], 40000, 4, 1)}[shape]
     args = gen(full, ref_lo=0.0, ref_hi=1.0, off_std=1.0)
     base = run(ctx, args, VARIANTS["layout_preserving"]).float()
-    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies"):
+    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies", "hm2_dot2_mailbox"):
         o = run(ctx, args, VARIANTS[name]).float()
-        assert (o - base).abs().max().item() <= 2e-3, name   # both fp32-accumulate, fp16 store
+        # all accumulate in fp32 and store fp16; hm2 additionally carries the per-corner weights
+        # as half2 into v_dot2c_f32_f16
+        tol = 6e-3 if name.startswith("hm2") else 2e-3
+        assert (o - base).abs().max().item() <= tol, name
     # automatic choice == one of the above, and deterministic
     a = run(ctx, args, 0)
     assert torch.equal(a, run(ctx, args, 0))
-    assert (a.float() - base).abs().max().item() <= 2e-3
+    assert (a.float() - base).abs().max().item() <= 6e-3
 
 
 def test_hm_out_of_view_and_zero_pads(ctx):
@@ -92,3 +96,7 @@ def test_hm_out_of_view_and_zero_pads(ctx):
     args = gen(SHAPES["odd_widths"])
     a, b = run(ctx, args, 12), run(ctx, args, 10)
     assert torch.isfinite(a).all() and (a.float() - b.float()).abs().max().item() <= 2e-3
+    c = run(ctx, args, 15)
+    assert torch.isfinite(c).all() and (c.float() - b.float()).abs().max().item() <= 6e-3
+    args[2] = args[2] + 7.0
+    assert torch.count_nonzero(run(ctx, args, 15)).item() == 0
