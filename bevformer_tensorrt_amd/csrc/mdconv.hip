@@ -299,6 +299,172 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restric
   }
 }
 
+
+// ---- 5. fused deformable implicit GEMM (fp16) ------------------------------------------
+// out[b, co, pix] = bias[co] + sum_{tap, ci} W[co][tap][ci] * col(pix, tap, ci), where the
+// column element is produced on the fly: the B-tile loader bilinearly samples the NHWC image
+// (4 x 128-byte lines per (pixel, tap, 64-channel chunk)), scales by the mask and writes the
+// MFMA operand tile straight into LDS -- no column buffer in HBM (160 MB written + read per
+// stage-3 call in the two-kernel version).
+//   block tile 256 (Cout) x 64 (pixels) x 64 (one tap, 64 input channels); 4 waves, each
+//   64 x 64 = 2x2 v_mfma_f32_32x32x16_f16 tiles x 4 k-substeps; footprint (4 corner indices
+//   + weights*mask) computed once per (pixel, tap) and reused across the channel chunks;
+//   bilinear blend in packed fp16 (v_pk_fma_f16, as the reference's half2 kernel does,
+//   modulatedDeformableConv2dKernel.cu:390-461), accumulation in fp32 on the matrix cores.
+// Arithmetic intensity is capped by the gather at BM/4 flop per gathered byte, hence the
+// full-Cout M tile.
+constexpr int kFM = 256, kFN = 64, kFK = 64, kFLd = kFK + 8;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_fma(unsigned a, unsigned w, unsigned c) {
+  const f16x2 r = __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, w) + __builtin_bit_cast(f16x2, c);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned w) {
+  const f16x2 r = __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, w);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
+    const __half *__restrict__ xt, const __half *__restrict__ offset,
+    const __half *__restrict__ mask, const __half *__restrict__ wt,
+    const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g) {
+  __shared__ __attribute__((aligned(16))) __half As[kFM][kFLd];
+  __shared__ __attribute__((aligned(16))) __half Bs[kFN][kFLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
+  const int HoWo = d.Ho * d.Wo;
+  const int N = d.B * HoWo;
+  const int n0 = blockIdx.x * kFN, m0 = blockIdx.y * kFM;
+  const int Kg = KK * cin_g;
+  const __half *A = wt + (size_t)g * cout_g * Kg;
+
+  // B-producer role: pixel n0 + (tid >> 2), channels [cq*16, cq*16+16) of the 64-chunk
+  const int pn = n0 + (tid >> 2), cq = tid & 3;
+  const bool pvalid = pn < N;
+  const int pb = pvalid ? pn / HoWo : 0;
+  const int ppix = pvalid ? pn - pb * HoWo : 0;
+  const int pho = ppix / d.Wo, pwo = ppix - pho * d.Wo;
+  const __half *ximg = xt + (size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 16;
+  // A-loader role: rows (tid >> 3) + 32*i, 16-byte chunk (tid & 7)
+  const int ar = tid >> 3, ac = (tid & 7) * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int chunks = cin_g / kFK;
+  const int nsteps = KK * chunks;
+  int fidx[4];
+  unsigned fw[4];  // half2 (w, w) = bilinear weight * mask
+  int cur_tap = -1, cur_dg = -1;
+  uint4 ra[8], rb[8];
+
+  auto prefetch = [&](int step) {
+    const int tap = step / chunks, c0 = (step - tap * chunks) * kFK;
+    const int dg = (g * cin_g + c0) / (d.Cin / d.DG);
+    if (tap != cur_tap || dg != cur_dg) {
+      cur_tap = tap;
+      cur_dg = dg;
+      const int i = tap / d.Kw, j = tap - i * d.Kw;
+      const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
+      const float off_h = __half2float(offset[ob + (size_t)(2 * tap) * HoWo]);
+      const float off_w = __half2float(offset[ob + (size_t)(2 * tap + 1) * HoWo]);
+      const float m = __half2float(mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix]);
+      const float h_im = (float)(pho * d.sh - d.ph + i * d.dh) + off_h;
+      const float w_im = (float)(pwo * d.sw - d.pw + j * d.dw) + off_w;
+      const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h0 = (int)hf, w0 = (int)wf;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const float wq[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+      const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = in && hs[q] >= 0 && hs[q] <= d.H - 1 && ws[q] >= 0 && ws[q] <= d.W - 1;
+        fidx[q] = ok ? hs[q] * d.W + ws[q] : 0;
+        const float w = ok ? wq[q] * m : 0.f;
+        fw[q] = pack_h2(w, w);
+      }
+    }
+    const __half *xp = ximg + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(xp + (size_t)fidx[q] * d.Cin);
+      rb[2 * q] = p[0];
+      rb[2 * q + 1] = p[1];
+    }
+    const __half *ap = A + (size_t)tap * cin_g + c0 + ac;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = m0 + ar + 32 * i;
+      ra[i] = r < cout_g ? *reinterpret_cast<const uint4 *>(ap + (size_t)r * Kg) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  prefetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    // blend the 4 corners (packed fp16), 16 channels per thread
+    uint4 b0, b1;
+    b0.x = pk_mul(rb[0].x, fw[0]); b0.y = pk_mul(rb[0].y, fw[0]); b0.z = pk_mul(rb[0].z, fw[0]); b0.w = pk_mul(rb[0].w, fw[0]);
+    b1.x = pk_mul(rb[1].x, fw[0]); b1.y = pk_mul(rb[1].y, fw[0]); b1.z = pk_mul(rb[1].z, fw[0]); b1.w = pk_mul(rb[1].w, fw[0]);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      b0.x = pk_fma(rb[2 * q].x, fw[q], b0.x); b0.y = pk_fma(rb[2 * q].y, fw[q], b0.y);
+      b0.z = pk_fma(rb[2 * q].z, fw[q], b0.z); b0.w = pk_fma(rb[2 * q].w, fw[q], b0.w);
+      b1.x = pk_fma(rb[2 * q + 1].x, fw[q], b1.x); b1.y = pk_fma(rb[2 * q + 1].y, fw[q], b1.y);
+      b1.z = pk_fma(rb[2 * q + 1].z, fw[q], b1.z); b1.w = pk_fma(rb[2 * q + 1].w, fw[q], b1.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(&As[ar + 32 * i][ac]) = ra[i];
+    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16]) = b0;
+    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16 + 8]) = b1;
+    __syncthreads();
+    if (step + 1 < nsteps) prefetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 16 + (lane >> 5) * 8;
+      f16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const f16x8 *>(&As[wave * 64 + i * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const f16x8 *>(&Bs[j * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    const int b = n / HoWo, pix = n - b * HoWo;
+    __half *ob = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < cout_g) {
+          float v = acc[i][j][r];
+          if (bias) v += __half2float(bias[g * cout_g + m]);
+          ob[(size_t)m * HoWo] = __float2half_rn(v);
+        }
+      }
+  }
+}
+
+thread_local int g_mdconv_variant = 0;
+
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 bool make_dims(ConvDims &d, int B, int Cin, int H, int W, int Cout, int Kh, int Kw, int sh, int sw,
@@ -342,6 +508,16 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   hipLaunchKernelGGL((repack_weight_kernel<T>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
                      (const T *)weight, wt, d.Cout, cin_g, KK);
+  if constexpr (sizeof(T) == 2) {
+    // fused implicit GEMM: a 64-channel K chunk must sit inside one group and one deform group
+    if (g_mdconv_variant != 1 && cin_g % kFK == 0 && (d.Cin / d.DG) % kFK == 0) {
+      for (int g = 0; g < d.G; ++g)
+        hipLaunchKernelGGL(dcn_fused_f16_kernel, dim3((unsigned)((N + kFN - 1) / kFN), (cout_g + kFM - 1) / kFM),
+                           dim3(256), 0, st, (const __half *)xt, (const __half *)offset, (const __half *)mask,
+                           (const __half *)wt, (const __half *)bias, (__half *)output, d, g);
+      return launch_status();
+    }
+  }
   constexpr int VMAX = sizeof(T) == 2 ? 8 : 4;
   const bool vec = cin_g % VMAX == 0 && (d.Cin / d.DG) % VMAX == 0;
   {
@@ -382,6 +558,12 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
 }  // namespace bevops
 
 using namespace bevops;
+
+extern "C" int bevops_mdconv_set_variant(int variant) {
+  const int prev = g_mdconv_variant;
+  g_mdconv_variant = variant;
+  return prev;
+}
 
 extern "C" size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout,
                                                int Kh, int Kw, int stride_h, int stride_w,

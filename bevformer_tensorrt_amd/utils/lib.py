@@ -32,6 +32,7 @@ SIGNATURES = {
                                        [c_float] * 3 + [c_void_p]),
     "bevops_bev_pool_v2_forward": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float] * 3 +
                                    [c_void_p]),
+    "bevops_mdconv_set_variant": (c_int, [c_int]),
     "bevops_mdconv_workspace_size": (c_size_t, [c_int] * 16),
     "bevops_mdconv_forward": (c_int, [c_int] + [c_void_p] * 7 + [c_size_t] + [c_int] * 15 +
                               [c_void_p]),

@@ -183,6 +183,9 @@ int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
  * F32 and F16 (F16 needs (Cin/groups*Kh*Kw) % 8 == 0); INT8 is not built yet
  * (BEVOPS_NOT_SUPPORTED).
  * ------------------------------------------------------------------------ */
+/* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
+ * channel counts allow), 1 = force the im2col + GEMM pipeline.  Returns the previous value. */
+int bevops_mdconv_set_variant(int variant);
 size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout, int Kh,
                                     int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
                                     int dil_h, int dil_w, int groups, int deform_groups);

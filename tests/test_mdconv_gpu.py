@@ -91,3 +91,21 @@ def test_mdconv_bad_shapes_raise(bev):
     from bevformer_tensorrt_amd.utils.lib import BevopsError
     with pytest.raises(BevopsError):   # Cin not divisible by groups
         bev.modulated_deformable_conv2d(x, off, mask, w[:, :3], b, 1, 1, 1, 3, 1)
+
+
+@pytest.mark.parametrize("name", ["ref_test_like", "r101_stage3", "r101_stage4", "stride2"])
+def test_fused_matches_im2col_pipeline(bev, name):
+    """fp16: the fused implicit-GEMM kernel (default) vs the im2col + GEMM pipeline (variant 1)."""
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    c = CASES[name]
+    x, off, mask, w, b = (t.half().cuda() for t in make(**c))
+    args = (x, off, mask, w, b, c["stride"], c["pad"], c["dil"], c["g"], c["dg"])
+    fused = bev.modulated_deformable_conv2d(*args).float()
+    try:
+        lib.bevops_mdconv_set_variant(1)
+        two = bev.modulated_deformable_conv2d(*args).float()
+    finally:
+        lib.bevops_mdconv_set_variant(0)
+    scale = max(1.0, two.abs().max().item())
+    assert (fused - two).abs().max().item() <= 1e-2 * scale
