@@ -1,0 +1,400 @@
+"""mmcv-free re-host of the reference's BEVFormer `*TRTP` inference wrappers (SURVEY.md
+section 8f-1), so that the sampling hot path can be measured inside the model it serves.
+
+Call-compatible with `BEVFormerTRT.forward_trt(image, prev_bev, use_prev_bev, can_bus,
+lidar2img)` (det2trt/models/detector/bevformer.py:37-44).  Structure and tensor shapes follow
+
+  detector   det2trt/models/detector/bevformer.py:12-44         (ResNet + FPN, forward_trt)
+  head       det2trt/models/dense_heads/bevformer_head.py:211-282
+  transformer det2trt/models/modules/transformer.py:245-398     (shift, rotate prev_bev, can_bus
+                                                                   MLP, level/camera embeds)
+  encoder    det2trt/models/modules/encoder.py:261-334,510-636  (TSA -> norm -> SCA -> norm -> FFN -> norm)
+  TSA        det2trt/models/modules/temporal_self_attention.py:350-457
+  SCA        det2trt/models/modules/spatial_cross_attention.py:200-273,694-768
+  decoder    det2trt/models/modules/decoder.py:52-112,381-471   (MHA, CustomMSDeformableAttention, FFN,
+                                                                   reference-point refinement)
+  DCNv2 pack det2trt/models/modules/cnn/dcn.py:31-86
+  configs    configs/bevformer/bevformer_{tiny,small,base}.py
+
+The sampling operators come from `ops` (default: this package's HIP operators); the dense
+layers (convolutions, Linear, LayerNorm, MultiheadAttention) are torch modules, i.e. MIOpen /
+hipBLASLt on ROCm.  Weights are random (seeded): no checkpoints exist in this environment,
+the purpose is the device-side dataflow and its speed, not detection quality.
+
+Differences from the reference that do not change results:
+  * `query.repeat(num_cams, 1, 1)` followed by per-camera Linear layers
+    (spatial_cross_attention.py:254, :754-755) is computed once and passed as a stride-0
+    expanded view: the MSDA operator reads the single copy (`shared_offsets`);
+  * `prev_bev` stays on the device between frames (the reference round-trips it through host
+    numpy, tools/bevformer/evaluate_trt.py:126,144);
+  * frozen BatchNorm is folded into the preceding convolution.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functions as _hip_ops
+from . import geometry as G
+
+CONFIGS = {
+    # name: backbone depth, DCN stages, FPN inputs/outs, padded image (h, w), BEV size, encoder layers
+    "tiny": dict(depth=50, dcn=(False, False, False, False), fpn_in=[2048], out_indices=(3,), levels=1,
+                 image=(480, 800), bev=(50, 50), enc_layers=3),
+    "small": dict(depth=101, dcn=(False, False, True, True), fpn_in=[2048], out_indices=(3,), levels=1,
+                  image=(736, 1280), bev=(150, 150), enc_layers=3),
+    "base": dict(depth=101, dcn=(False, False, True, True), fpn_in=[512, 1024, 2048], out_indices=(1, 2, 3),
+                 levels=4, image=(928, 1600), bev=(200, 200), enc_layers=6),
+}
+PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+EMBED, HEADS, NUM_QUERY, NUM_CAMS = 256, 8, 900, 6
+
+
+def inverse_sigmoid(x, eps=1e-5):  # decoder.py:24-40
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+# --------------------------------------------------------------------------- backbone
+class DCNv2Pack(nn.Module):
+    """ModulatedDeformConv2dPackPlugin (cnn/dcn.py:31-86): conv_offset -> (o1, o2, mask) ->
+    modulated_deformable_conv2d."""
+
+    def __init__(self, cin, cout, ops, stride=1):
+        super().__init__()
+        self.ops, self.stride = ops, stride
+        self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9))
+        self.bias = nn.Parameter(torch.zeros(cout))  # carries the folded BN shift
+        self.conv_offset = nn.Conv2d(cin, 27, 3, stride, 1)
+        nn.init.normal_(self.conv_offset.weight, std=0.01)   # non-zero so the sampler really deforms
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        return self.ops.modulated_deformable_conv2d(x, offset, torch.sigmoid(mask), self.weight,
+                                                    self.bias, self.stride, 1, 1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    """ResNet bottleneck, caffe style (stride on the first 1x1), BN folded."""
+
+    def __init__(self, cin, planes, stride, dcn, ops, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, stride)
+        self.conv2 = DCNv2Pack(planes, planes, ops) if dcn else nn.Conv2d(planes, planes, 3, 1, 1)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1)
+        self.downsample = nn.Conv2d(cin, planes * 4, 1, stride) if downsample else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.conv1(x), inplace=True)
+        out = F.relu(self.conv2(out), inplace=True)
+        return F.relu(self.conv3(out) + idt, inplace=True)
+
+
+class ResNet(nn.Module):
+    def __init__(self, depth, dcn, out_indices, ops):
+        super().__init__()
+        blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+        self.out_indices = out_indices
+        self.stem = nn.Conv2d(3, 64, 7, 2, 3)
+        cin, stages = 64, []
+        for i, n in enumerate(blocks):
+            planes, layers = 64 * 2 ** i, []
+            for j in range(n):
+                layers.append(Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, dcn[i], ops, j == 0))
+                cin = planes * 4
+            stages.append(nn.Sequential(*layers))
+        self.stages = nn.ModuleList(stages)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.stem(x), inplace=True), 3, 2, 1)
+        outs = []
+        for i, st in enumerate(self.stages):
+            x = st(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs
+
+
+class FPN(nn.Module):
+    """mmdet FPN with add_extra_convs='on_output', relu_before_extra_convs (bevformer_base.py:55-63)."""
+
+    def __init__(self, cins, cout, num_outs):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, cout, 1) for c in cins)
+        self.fpn = nn.ModuleList(nn.Conv2d(cout, cout, 3, 1, 1) for _ in cins)
+        self.extra = nn.ModuleList(nn.Conv2d(cout, cout, 3, 2, 1) for _ in range(num_outs - len(cins)))
+
+    def forward(self, feats):
+        lat = [l(f) for l, f in zip(self.lateral, feats)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        outs = [c(x) for c, x in zip(self.fpn, lat)]
+        for e in self.extra:
+            outs.append(e(F.relu(outs[-1])))
+        return outs
+
+
+# --------------------------------------------------------------------------- attention blocks
+class FFN(nn.Module):
+    def __init__(self, dim=EMBED, hidden=2 * EMBED):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return x + self.fc2(F.relu(self.fc1(x), inplace=True))
+
+
+class TemporalSelfAttention(nn.Module):
+    """temporal_self_attention.py:350-457 (num_bev_queue 2, 1 level, 4 points)."""
+
+    def __init__(self, ops, points=4):
+        super().__init__()
+        self.ops, self.points = ops, points
+        self.sampling_offsets = nn.Linear(EMBED * 2, 2 * HEADS * points * 2)
+        self.attention_weights = nn.Linear(EMBED * 2, 2 * HEADS * points)
+        self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
+
+    def forward(self, query, value, bev_pos, ref_2d, spatial_shapes):
+        identity = query
+        query = query + bev_pos
+        nq = query.shape[1]
+        query = torch.cat([value[:1], query], -1)
+        value = self.value_proj(value).view(2, nq, HEADS, EMBED // HEADS)
+        off = self.sampling_offsets(query).view(1, nq, HEADS, 2, 1, self.points, 2)
+        w = self.attention_weights(query).view(1, nq, HEADS, 2, 1, self.points)
+        w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
+        off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
+        out = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref_2d, off, w).flatten(2)
+        out = torch.mean(out, keepdim=True, dim=0)
+        return self.output_proj(out) + identity
+
+
+class SpatialCrossAttention(nn.Module):
+    """spatial_cross_attention.py:200-273 + MSDeformableAttention3DTRTP :694-768."""
+
+    def __init__(self, ops, levels, points=8):
+        super().__init__()
+        self.ops = ops
+        self.sampling_offsets = nn.Linear(EMBED, HEADS * levels * points * 2)
+        self.attention_weights = nn.Linear(EMBED, HEADS * levels * points)
+        self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
+
+    def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None):
+        inp_residual = query
+        ncam, nq = value.shape[0], query.shape[1]
+        value = self.value_proj(value.view(ncam, -1, EMBED)).view(ncam, -1, HEADS, EMBED // HEADS)
+        # the per-camera copies of `query` are identical: project once, expand (stride 0)
+        off = self.sampling_offsets(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
+        w = self.attention_weights(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
+        ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
+        if cams is not None:  # camera-sharded: this rank's cameras only
+            ref = ref[cams]
+        queries = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
+        if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
+            queries = gather(queries)
+        slots = (queries * bev_mask).sum(0, keepdim=True)
+        return self.output_proj(slots) + inp_residual
+
+
+class BEVFormerLayer(nn.Module):
+    def __init__(self, ops, levels):
+        super().__init__()
+        self.tsa, self.sca, self.ffn = TemporalSelfAttention(ops), SpatialCrossAttention(ops, levels), FFN()
+        self.norms = nn.ModuleList(nn.LayerNorm(EMBED) for _ in range(3))
+
+    def forward(self, query, value, bev_pos, ref_2d, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev_bev,
+                use_prev_bev, cams, gather):
+        prev = use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1)   # encoder.py:586-588
+        query = self.norms[0](self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
+        query = self.norms[1](self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather))
+        return self.norms[2](self.ffn(query))
+
+
+class CustomMSDeformableAttention(nn.Module):
+    """decoder.py:381-471 (1 level, 4 points)."""
+
+    def __init__(self, ops, points=4):
+        super().__init__()
+        self.ops = ops
+        self.sampling_offsets = nn.Linear(EMBED, HEADS * points * 2)
+        self.attention_weights = nn.Linear(EMBED, HEADS * points)
+        self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
+
+    def forward(self, query, value, query_pos, reference_points, spatial_shapes):
+        identity = query                               # [900, 1, 256]
+        q = (query + query_pos).view(1, -1, EMBED)
+        value = self.value_proj(value.view(1, -1, EMBED)).view(1, -1, HEADS, EMBED // HEADS)
+        off = self.sampling_offsets(q).view(1, q.shape[1], HEADS, -1)
+        w = self.attention_weights(q).view(1, q.shape[1], HEADS, -1)
+        out = self.ops.multi_scale_deformable_attn(value, spatial_shapes, reference_points, off, w).flatten(2)
+        return self.output_proj(out).permute(1, 0, 2) + identity
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, ops):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(EMBED, HEADS)
+        self.cross_attn, self.ffn = CustomMSDeformableAttention(ops), FFN()
+        self.norms = nn.ModuleList(nn.LayerNorm(EMBED) for _ in range(3))
+
+    def forward(self, query, value, query_pos, reference_points, spatial_shapes):
+        qk = query + query_pos
+        query = self.norms[0](query + self.self_attn(qk, qk, query, need_weights=False)[0])
+        query = self.norms[1](self.cross_attn(query, value, query_pos, reference_points, spatial_shapes))
+        return self.norms[2](self.ffn(query))
+
+
+# --------------------------------------------------------------------------- the model
+class BEVFormer(nn.Module):
+    """forward(image [1,6,3,H,W], prev_bev [nq,1,256], use_prev_bev (0/1 tensor), can_bus [18],
+    lidar2img [1,6,4,4]) -> bev_embed [nq,1,256], outputs_classes [6,1,900,10], outputs_coords [6,1,900,10]."""
+
+    def __init__(self, name="base", ops=None, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        cfg = CONFIGS[name]
+        self.cfg, self.name = cfg, name
+        self.ops = ops = ops if ops is not None else _hip_ops
+        self.bev_h, self.bev_w = cfg["bev"]
+        nq = self.bev_h * self.bev_w
+        self.backbone = ResNet(cfg["depth"], cfg["dcn"], cfg["out_indices"], ops)
+        self.neck = FPN(cfg["fpn_in"], EMBED, cfg["levels"])
+        # head (bevformer_head.py): embeddings, learned positional encoding, branches
+        self.bev_embedding = nn.Embedding(nq, EMBED)
+        self.query_embedding = nn.Embedding(NUM_QUERY, EMBED * 2)
+        self.row_embed, self.col_embed = nn.Embedding(self.bev_h, EMBED // 2), nn.Embedding(self.bev_w, EMBED // 2)
+        self.cls_branches = nn.ModuleList(nn.Sequential(
+            nn.Linear(EMBED, EMBED), nn.LayerNorm(EMBED), nn.ReLU(inplace=True),
+            nn.Linear(EMBED, EMBED), nn.LayerNorm(EMBED), nn.ReLU(inplace=True), nn.Linear(EMBED, 10)) for _ in range(6))
+        self.reg_branches = nn.ModuleList(nn.Sequential(
+            nn.Linear(EMBED, EMBED), nn.ReLU(inplace=True), nn.Linear(EMBED, EMBED), nn.ReLU(inplace=True),
+            nn.Linear(EMBED, 10)) for _ in range(6))
+        # transformer (transformer.py)
+        self.level_embeds = nn.Parameter(torch.randn(cfg["levels"], EMBED) * 0.02)
+        self.cams_embeds = nn.Parameter(torch.randn(NUM_CAMS, EMBED) * 0.02)
+        self.reference_points = nn.Linear(EMBED, 3)
+        self.can_bus_mlp = nn.Sequential(nn.Linear(18, EMBED // 2), nn.ReLU(inplace=True),
+                                         nn.Linear(EMBED // 2, EMBED), nn.ReLU(inplace=True), nn.LayerNorm(EMBED))
+        self.encoder = nn.ModuleList(BEVFormerLayer(ops, cfg["levels"]) for _ in range(cfg["enc_layers"]))
+        self.decoder = nn.ModuleList(DecoderLayer(ops) for _ in range(6))
+        self.rotate_center = [100, 100]   # transformer.py:26
+        self.eval()
+
+    # ---- detector/bevformer.py:12-35
+    def extract_feat(self, image, cams=None):
+        B, N, C, H, W = image.shape
+        img = image.view(B * N, C, H, W)
+        if cams is not None:
+            img = img[cams]
+        return self.neck(self.backbone(img))    # list of [cams, 256, h_l, w_l]
+
+    def positional_encoding(self, dtype, device):   # mmdet LearnedPositionalEncoding
+        x = self.col_embed(torch.arange(self.bev_w, device=device))
+        y = self.row_embed(torch.arange(self.bev_h, device=device))
+        pos = torch.cat((x.unsqueeze(0).repeat(self.bev_h, 1, 1), y.unsqueeze(1).repeat(1, self.bev_w, 1)), dim=-1)
+        return pos.permute(2, 0, 1).unsqueeze(0).to(dtype)   # [1, 256, h, w]
+
+    @torch.no_grad()
+    def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None):
+        dev, dtype = image.device, image.dtype
+        image_shape = image.shape[-2:]
+        mlvl = self.extract_feat(image, cams)
+        bev_h, bev_w, nq = self.bev_h, self.bev_w, self.bev_h * self.bev_w
+        bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(1)           # [nq, 1, 256]
+        bev_pos = self.positional_encoding(dtype, dev).flatten(2).permute(2, 0, 1)  # [nq, 1, 256]
+
+        # ---- transformer.get_bev_features_trt (:245-341); index/grid math in fp32 (a6)
+        grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / bev_h, (PC_RANGE[3] - PC_RANGE[0]) / bev_w)
+        shift = G.bev_shift(can_bus.float(), bev_h, bev_w, grid_length).to(dtype)
+        prev_bev = self.ops.rotate(prev_bev.view(bev_h, bev_w, -1).permute(2, 0, 1), can_bus[-1].float().reshape(1),
+                                   prev_bev.new_tensor(self.rotate_center).float())
+        prev_bev = prev_bev.permute(1, 2, 0).reshape(nq, 1, -1)
+        bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
+        feats, level_hw = [], []
+        cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]
+        for lvl, feat in enumerate(mlvl):
+            level_hw.append(feat.shape[-2:])
+            f = feat.flatten(2).permute(0, 2, 1)                                  # [cams, hw, 256]
+            feats.append(f + cam_embed.to(dtype)[:, None, :] + self.level_embeds[lvl].to(dtype)[None, None, :])
+        feat_flatten = torch.cat(feats, dim=1)                                   # [cams, sum hw, 256]
+        # shape tensors live on the HOST: the operators cache a device copy per distinct value
+        # and never have to synchronise to learn the pyramid geometry
+        spatial_shapes, _ = G.level_layout(level_hw, "cpu")
+        bev_shapes = torch.tensor([[bev_h, bev_w]])
+
+        # ---- encoder.forward_trt (:261-334)
+        ref_3d = G.reference_points_3d(bev_h, bev_w, PC_RANGE[5] - PC_RANGE[2], 4, device=dev, dtype=torch.float)
+        ref_2d = G.reference_points_2d(ref_3d)
+        ref_cam, bev_mask = G.point_sampling(ref_3d, PC_RANGE, lidar2img.float(), image_shape)
+        hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
+        ref_cam, bev_mask = ref_cam.to(dtype), bev_mask.to(dtype)
+        q = bev_queries.view(1, nq, EMBED)
+        pos = bev_pos.view(1, nq, EMBED)
+        prev = torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
+        for layer in self.encoder:
+            q = layer(q, feat_flatten, pos, hybrid, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev,
+                      use_prev_bev, cams, gather)
+        bev_embed = q.view(nq, 1, EMBED)
+
+        # ---- decoder (transformer.forward_trt :375-398, decoder.py:52-112)
+        query_pos, query = torch.split(self.query_embedding.weight.to(dtype).unsqueeze(1), EMBED, dim=2)
+        reference_points = self.reference_points(query_pos).sigmoid().view(1, NUM_QUERY, 3)
+        init_reference = reference_points
+        inter, inter_refs = [], []
+        out = query
+        for lid, layer in enumerate(self.decoder):
+            out = layer(out, bev_embed, query_pos, reference_points[..., :2].unsqueeze(2).contiguous(), bev_shapes)
+            tmp = self.reg_branches[lid](out).view(1, -1, 10)
+            reference_points = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points[..., :2]),
+                                          tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])], dim=-1).sigmoid()
+            inter.append(out)
+            inter_refs.append(reference_points)
+
+        # ---- head (bevformer_head.py:247-282)
+        classes, coords = [], []
+        for lvl in range(6):
+            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_refs[lvl - 1])
+            hs = inter[lvl].view(1, NUM_QUERY, EMBED)
+            cls = self.cls_branches[lvl](hs)
+            crd = self.reg_branches[lvl](hs).clone()
+            crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
+            crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
+            crd[..., 0:1] = crd[..., 0:1] * (PC_RANGE[3] - PC_RANGE[0]) + PC_RANGE[0]
+            crd[..., 1:2] = crd[..., 1:2] * (PC_RANGE[4] - PC_RANGE[1]) + PC_RANGE[1]
+            crd[..., 4:5] = crd[..., 4:5] * (PC_RANGE[5] - PC_RANGE[2]) + PC_RANGE[2]
+            classes.append(cls)
+            coords.append(crd)
+        return bev_embed, torch.stack(classes), torch.stack(coords)
+
+
+class FrameRunner:
+    """Stateful frame loop of tools/bevformer/evaluate_trt.py:76-154 with `prev_bev` kept on the
+    device: can_bus position/angle deltas against the previous frame, `use_prev_bev = 0` and a
+    fresh random-free (zero) prev_bev on a scene change."""
+
+    def __init__(self, model, device, dtype):
+        self.model, self.device, self.dtype = model, device, dtype
+        nq = model.bev_h * model.bev_w
+        self.prev_bev = torch.zeros(nq, 1, EMBED, device=device, dtype=dtype)
+        self.prev = {"scene": None, "pos": None, "angle": None}
+
+    def step(self, image, can_bus, lidar2img, scene_token, cams=None, gather=None):
+        can_bus = can_bus.clone().float()
+        use_prev = 0.0 if scene_token != self.prev["scene"] else 1.0          # evaluate_trt.py:86-88
+        pos, angle = can_bus[:3].clone(), can_bus[-1].clone()
+        if use_prev:
+            can_bus[:3] -= self.prev["pos"]                                     # :92-98
+            can_bus[-1] -= self.prev["angle"]
+        else:
+            can_bus[:3] = 0
+            can_bus[-1] = 0
+        self.prev.update(scene=scene_token, pos=pos, angle=angle)
+        use = torch.tensor(use_prev, device=self.device, dtype=self.dtype)
+        bev_embed, cls, crd = self.model(image, self.prev_bev, use, can_bus.to(self.device), lidar2img, cams, gather)
+        self.prev_bev = bev_embed                                               # stays on device (:144)
+        return cls, crd

@@ -66,8 +66,10 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
       __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value), 0, value_bytes, 0x00020000);
 
   // ---- own logits -> softmax numerators ----
+  // row of this item in sampling_offsets / attention_weights (camera-shared when d.shared)
+  const size_t in_item = d.shared ? (size_t)(item - b * (unsigned)d.nq * (unsigned)d.heads) : (size_t)item;
   float e[PPL];
-  load_f<PPL>(logit + (size_t)item * LP + sub * PPL, e);
+  load_f<PPL>(logit + in_item * LP + sub * PPL, e);
   float m = e[0];
 #pragma unroll
   for (int k = 1; k < PPL; ++k) m = fmaxf(m, e[k]);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
   s = quad_sum(s);
 
   float offs[2 * PPL];
-  load_f<2 * PPL>(off + ((size_t)item * LP + sub * PPL) * 2, offs);
+  load_f<2 * PPL>(off + (in_item * LP + sub * PPL) * 2, offs);
   const T *refp = ref + (size_t)bq * (unsigned)d.ppg * 2u;
 
   // running (level, point-in-level, point-in-group) of this lane's next own point
@@ -186,8 +188,9 @@ __global__ __launch_bounds__(kBlock) void msda_generic_kernel(
   const size_t bq = item / d.heads;
   const size_t b = bq / d.nq;
   const int LP = d.L * d.P;
-  const T *lg = logit + item * LP;
-  const T *of = off + item * LP * 2;
+  const size_t in_item = d.shared ? item - b * (size_t)d.nq * d.heads : item;
+  const T *lg = logit + in_item * LP;
+  const T *of = off + in_item * LP * 2;
   const T *rp = ref + bq * d.ppg * 2;
   const size_t step = (size_t)d.heads * d.C;
   const T *vp = value + (b * d.nk * d.heads + h) * (size_t)d.C + c;
@@ -306,8 +309,9 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(value), 0, value_bytes, 0x00020000);
 
+  const size_t in_item = d.shared ? (size_t)(item - b * (unsigned)d.nq * (unsigned)d.heads) : (size_t)item;
   float e[PPL];
-  load_i8<PPL>(logit + (size_t)item * LP + sub * PPL, e);
+  load_i8<PPL>(logit + in_item * LP + sub * PPL, e);
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
   s = quad_sum(s);
 
   float offs[2 * PPL];
-  load_i8<2 * PPL>(off + ((size_t)item * LP + sub * PPL) * 2, offs);
+  load_i8<2 * PPL>(off + (in_item * LP + sub * PPL) * 2, offs);
   const RefT *refp = ref + (size_t)bq * (unsigned)d.ppg * 2u;
   int j0 = (int)sub * PPL;
   int l = j0 / d.P;
@@ -458,8 +462,9 @@ __global__ __launch_bounds__(kBlock) void msda_generic_int8_kernel(
   const size_t bq = item / d.heads;
   const size_t b = bq / d.nq;
   const int LP = d.L * d.P;
-  const int8_t *lg = logit + item * LP;
-  const int8_t *of = off + item * LP * 2;
+  const size_t in_item = d.shared ? item - b * (size_t)d.nq * d.heads : item;
+  const int8_t *lg = logit + in_item * LP;
+  const int8_t *of = off + in_item * LP * 2;
   const RefT *rp = ref + bq * d.ppg * 2;
   const size_t step = (size_t)d.heads * d.C;
   const int8_t *vp = value + (b * d.nk * d.heads + h) * (size_t)d.C + c;
@@ -645,7 +650,7 @@ extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *
                                 reference_points, ref_dtype, sampling_offsets, attention_weights,
                                 output, bs, nk, heads, channels, num_levels, num_query, num_point,
                                 points_per_group, scale_value, scale_offset, scale_weight,
-                                scale_out, nullptr, 0, stream);
+                                scale_out, 0, nullptr, 0, stream);
 }
 
 extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,
@@ -655,8 +660,8 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
                                       void *output, int bs, int nk, int heads, int channels,
                                       int num_levels, int num_query, int num_point,
                                       int points_per_group, float scale_value, float scale_offset,
-                                      float scale_weight, float scale_out, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
+                                      float scale_weight, float scale_out, int shared_offsets,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
   if (!value || !spatial_shapes || !reference_points || !sampling_offsets || !attention_weights ||
       !output)
     return BEVOPS_BAD_PARAM;
@@ -672,7 +677,8 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
     }
     if (total != nk) return BEVOPS_BAD_PARAM;
   }
-  const MsdaDims d{bs, nk, heads, channels, num_levels, num_query, num_point, points_per_group};
+  const MsdaDims d{bs, nk, heads, channels, num_levels, num_query, num_point, points_per_group,
+                   shared_offsets ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case BEVOPS_F32:
@@ -698,8 +704,8 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
               (const __half *)value, spatial_shapes, spatial_shapes_host,
               (const __half *)reference_points, (const __half *)sampling_offsets,
               (const __half *)attention_weights, (__half *)output, bs, nk, heads, channels,
-              num_levels, num_query, num_point, points_per_group, workspace, workspace_bytes,
-              g_variant, st);
+              num_levels, num_query, num_point, points_per_group, shared_offsets ? 1 : 0, workspace,
+              workspace_bytes, g_variant, st);
           if (rc != BEVOPS_NOT_SUPPORTED) return rc;
         }
       }

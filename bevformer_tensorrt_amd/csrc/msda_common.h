@@ -11,6 +11,7 @@ constexpr int kBlock = 256;
 
 struct MsdaDims {
   int bs, nk, heads, C, L, nq, P, ppg;
+  int shared;  // 1: sampling_offsets / attention_weights are [1, nq, heads, .] shared by all bs
 };
 
 // ---------------------------------------------------------------------------
@@ -154,6 +155,6 @@ __device__ __forceinline__ float loc_im(float ref, float size, float off) {
 size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L);
 int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_t *shapes_host,
                         const __half *ref, const __half *off, const __half *logit, __half *out,
-                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
+                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg, int shared,
                         void *workspace, size_t workspace_bytes, int variant, hipStream_t st);
 }  // namespace bevops

@@ -143,8 +143,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
 
   for (unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3); q < q_end; q += IPP) {
     const size_t item = ((size_t)b * d.nq + q) * d.heads + h;
+    const size_t in_item = ((size_t)(d.shared ? 0u : b) * d.nq + q) * d.heads + h;
     float e[PPL];
-    load_f<PPL>(logit + item * LP + sub * PPL, e);
+    load_f<PPL>(logit + in_item * LP + sub * PPL, e);
     float m = e[0];
 #pragma unroll
     for (int k = 1; k < PPL; ++k) m = fmaxf(m, e[k]);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
     s = quad_sum(s);
     // this lane's 2*PPL offsets stay packed (one dword = the (x, y) pair of a point)
     unsigned offraw[PPL];
-    load_raw<PPL>(off + (item * LP + sub * PPL) * 2, offraw);
+    load_raw<PPL>(off + (in_item * LP + sub * PPL) * 2, offraw);
     const __half *refp = ref + ((size_t)b * d.nq + q) * (unsigned)d.ppg * 2u;
 
     int j0 = (int)sub * PPL;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void msda_hm2_kernel(
 
   for (unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3); q < q_end; q += 32) {
     const size_t item = ((size_t)b * d.nq + q) * d.heads + h;
+    const size_t in_item = ((size_t)(d.shared ? 0u : b) * d.nq + q) * d.heads + h;
     const bool owner = lane8 < (unsigned)NOWN;
     float e[PP];
     unsigned offraw[PP];
@@ -359,12 +361,12 @@ __global__ __launch_bounds__(256) void msda_hm2_kernel(
       // stream them non-temporally so they do not evict the value maps from L2.  Narrower
       // rows share lines with the neighbouring heads' items -> keep those cacheable
       // (measured: nt on half-lines costs +50 % on the small-model SCA call).
-      if constexpr (LP >= 32) {
-        load_f_nt<PP>(logit + item * LP + lane8 * PP, e);
-        load_raw_nt<PP>(off + (item * LP + lane8 * PP) * 2, offraw);
+      if (LP >= 32 && !d.shared) {  // camera-shared rows are re-read by the other cameras
+        load_f_nt<PP>(logit + in_item * LP + lane8 * PP, e);
+        load_raw_nt<PP>(off + (in_item * LP + lane8 * PP) * 2, offraw);
       } else {
-        load_f<PP>(logit + item * LP + lane8 * PP, e);
-        load_raw<PP>(off + (item * LP + lane8 * PP) * 2, offraw);
+        load_f<PP>(logit + in_item * LP + lane8 * PP, e);
+        load_raw<PP>(off + (in_item * LP + lane8 * PP) * 2, offraw);
       }
     }
     float m = e[0];
@@ -520,7 +522,7 @@ size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L) {
 
 int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_t *shapes_host,
                         const __half *ref, const __half *off, const __half *logit, __half *out,
-                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
+                        int bs, int nk, int heads, int C, int L, int nq, int P, int ppg, int shared,
                         void *workspace, size_t workspace_bytes, int variant, hipStream_t st) {
   if (C != 32 || L > kMaxLevels - 1) return BEVOPS_NOT_SUPPORTED;
   const size_t one = hm_copy_bytes(bs, nk, heads, L);
@@ -539,7 +541,7 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
       const size_t threads = (size_t)bs * npairs * 2 * heads * 8;
       hipLaunchKernelGGL(msda_hm2_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                          st, value, shapes, vh2, bs, nk, heads, L, npairs, copy_b);
-      const MsdaDims d2{bs, nk, heads, C, L, nq, P, ppg};
+      const MsdaDims d2{bs, nk, heads, C, L, nq, P, ppg, shared};
       switch (LP) {
         case 4: return launch_hm2<4>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
         case 8: return launch_hm2<8>(vh2, need2, shapes, ref, off, logit, out, d2, npairs, copy_b, st);
@@ -585,7 +587,7 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
     // staging one whole plane per 1024-query block only pays when a plane has many queries
     if (nq < 2048) { stage_level = L; stage_bytes = 0; }
   }
-  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg};
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
   const bool t512 = variant == 13;
   switch (LP / 4) {
     case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);

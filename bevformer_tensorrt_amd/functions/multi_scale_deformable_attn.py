@@ -99,6 +99,12 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
         if t.dtype != value.dtype:
             raise TypeError(f"{name} dtype {t.dtype} != value dtype {value.dtype}")
     rdt = _lib.torch_dtype_code(reference_points)
+    # offsets / logits expanded over the batch (stride 0 views, e.g. the SCA query repeated for
+    # every camera): hand the single copy to the kernel instead of materialising bs copies
+    shared = (bs > 1 and sampling_offsets.dim() == 4 and attention_weights.dim() == 4
+              and sampling_offsets.stride(0) == 0 and attention_weights.stride(0) == 0)
+    if shared:
+        sampling_offsets, attention_weights = sampling_offsets[:1], attention_weights[:1]
     value, reference_points, sampling_offsets, attention_weights = (
         t.contiguous() for t in (value, reference_points, sampling_offsets, attention_weights))
     shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, value.device)
@@ -117,7 +123,7 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
             shapes_host.data_ptr() if shapes_host is not None else None,
             reference_points.data_ptr(), rdt, sampling_offsets.data_ptr(),
             attention_weights.data_ptr(), out.data_ptr(), bs, nk, heads, ch, L, nq, P, ppg,
-            float(scales[0]), float(scales[1]), float(scales[2]), float(scales[3]),
+            float(scales[0]), float(scales[1]), float(scales[2]), float(scales[3]), int(shared),
             ws.data_ptr() if ws is not None else None, ws_bytes if ws is not None else 0, stream)
     _lib.check(st, "bevops_msda_forward_ws")
     return out

@@ -97,7 +97,11 @@ int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_sha
  * x-corners of a sample share one cache line and each XCD's L2 holds the (camera, head)
  * plane it gathers from.  bevops_msda_workspace_size returns the bytes required (0 = the
  * path does not apply: non-fp16, channels != 32, ...); a NULL / too small workspace simply
- * selects the layout-preserving kernels, results are identical within fp32 rounding. */
+ * selects the layout-preserving kernels, results are identical within fp32 rounding.
+ * shared_offsets = 1: sampling_offsets / attention_weights are [1, num_query, heads, .] and
+ * apply to every one of the bs value batches (BEVFormer's SCA repeats the same query for
+ * all cameras, det2trt/models/modules/spatial_cross_attention.py:254) -- identical result
+ * to passing them repeated bs times, without the 6x redundant HBM reads. */
 size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
                                   int num_levels, int num_query, int num_point);
 int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,
@@ -107,7 +111,8 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
                            int heads, int channels, int num_levels, int num_query,
                            int num_point, int points_per_group, float scale_value,
                            float scale_offset, float scale_weight, float scale_out,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           int shared_offsets, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* Tuning hook: selects an internal MSDA kernel variant for subsequent calls from
  * this thread (0 = automatic).  Results are identical across variants; exists so

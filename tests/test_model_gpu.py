@@ -1,0 +1,70 @@
+"""Model-level dataflow check: the re-hosted BEVFormer wrappers evaluated with
+the HIP operators must agree with the same network (same random weights) evaluated with the
+reference's PyTorch formulations of those operators, over a 3-frame sequence with a scene
+reset, for the tiny config (no DCN) in fp32, and a DCN-bearing cut-down config."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def frames(cfg_image, n, dev, dtype):
+    g = torch.Generator().manual_seed(0)
+    H, W = cfg_image
+    out = []
+    for i in range(n):
+        img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+        can = torch.zeros(18)
+        can[0], can[1], can[-2], can[-1] = 0.4 * i, -0.15 * i, 0.02 * i, 1.1 * i
+        out.append((img, can, "scene0" if i < 2 else "scene1"))
+    return out
+
+
+def run_sequence(name, ops, dtype, n=3):
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    dev = torch.device("cuda")
+    model = B.BEVFormer(name, ops=ops, seed=0).to(dev, dtype)
+    runner = B.FrameRunner(model, dev, dtype)
+    l2i = G.synthetic_lidar2img(B.CONFIGS[name]["image"]).to(dev)
+    outs = []
+    for img, can, scene in frames(B.CONFIGS[name]["image"], n, dev, dtype):
+        cls, crd = runner.step(img, can, l2i, scene)
+        outs.append((runner.prev_bev.float().clone(), cls.float().clone(), crd.float().clone()))
+    return outs
+
+
+def test_tiny_fp32_matches_reference_formulation():
+    import bevformer_tensorrt_amd.functions as hip_ops
+    from util_refops import RefOps
+    a = run_sequence("tiny", hip_ops, torch.float32)
+    b = run_sequence("tiny", RefOps, torch.float32)
+    for (bev_a, cls_a, crd_a), (bev_b, cls_b, crd_b) in zip(a, b):
+        assert bev_a.shape == (2500, 1, 256) and cls_a.shape == (6, 1, 900, 10) and crd_a.shape == (6, 1, 900, 10)
+        assert torch.isfinite(bev_a).all()
+        assert (bev_a - bev_b).abs().max().item() <= 2e-3
+        assert (cls_a - cls_b).abs().max().item() <= 2e-3
+        assert (crd_a - crd_b).abs().max().item() <= 5e-3
+
+
+def test_tiny_fp16_runs_and_tracks_fp32():
+    import bevformer_tensorrt_amd.functions as hip_ops
+    a = run_sequence("tiny", hip_ops, torch.float16)
+    b = run_sequence("tiny", hip_ops, torch.float32)
+    for (bev_a, cls_a, _), (bev_b, cls_b, _) in zip(a, b):
+        assert torch.isfinite(bev_a).all()
+        assert (bev_a - bev_b).abs().mean().item() <= 5e-2   # 3-6 transformer layers in fp16
+
+
+def test_dcn_backbone_block_matches_reference_formulation():
+    """ResNet bottleneck with DCNv2Pack (stage-3 style) vs the oracle DCN, fp32, small map."""
+    import bevformer_tensorrt_amd.functions as hip_ops
+    from bevformer_tensorrt_amd import bevformer as B
+    from util_refops import RefOps
+    torch.manual_seed(0)
+    x = torch.randn(2, 256, 20, 28).cuda()
+    blk_a = B.Bottleneck(256, 64, 1, True, hip_ops, True).cuda().eval()
+    blk_b = B.Bottleneck(256, 64, 1, True, RefOps, True).cuda().eval()
+    blk_b.load_state_dict(blk_a.state_dict())
+    with torch.no_grad():
+        ya, yb = blk_a(x), blk_b(x)
+    assert (ya - yb).abs().max().item() <= 1e-3

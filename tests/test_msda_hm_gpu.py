@@ -100,3 +100,22 @@ def test_hm_out_of_view_and_zero_pads(ctx):
     assert torch.isfinite(c).all() and (c.float() - b.float()).abs().max().item() <= 6e-3
     args[2] = args[2] + 7.0
     assert torch.count_nonzero(run(ctx, args, 15)).item() == 0
+
+
+@pytest.mark.parametrize("variant", [0, 10, 11, 15, 99])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_camera_shared_offsets_equal_repeated(ctx, variant, dtype):
+    """sampling_offsets / attention_weights passed as stride-0 expanded views (the SCA query is
+    the same for every camera, spatial_cross_attention.py:254) must give exactly what the
+    materialised repeat gives, on every kernel family."""
+    if dtype == torch.float32 and variant in (11, 15):
+        pytest.skip("head-major path is fp16-only")
+    bev, lib = ctx
+    args = gen((6, [[20, 32], [10, 16], [5, 8], [3, 4]], 2500, 8, 4), ref_lo=-0.2, ref_hi=1.2)
+    args = [a.to(dtype) if a.is_floating_point() else a for a in args]
+    off1, w1 = args[3][:1].contiguous(), args[4][:1].contiguous()
+    rep = [args[0], args[1], args[2], off1.repeat(6, 1, 1, 1), w1.repeat(6, 1, 1, 1)]
+    exp = [args[0], args[1], args[2], off1.expand(6, -1, -1, -1), w1.expand(6, -1, -1, -1)]
+    a = run(ctx, rep, variant)
+    b = run(ctx, exp, variant)
+    assert torch.equal(a, b)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""End-to-end frames/s of the re-hosted BEVFormer (random weights, synthetic 6-camera frames),
+measured like the reference: device forward of one frame between two stream syncs, H2D excluded,
+first and last frame dropped, FPS = 1000 / mean ms (det2trt/utils/tensorrt.py:72-76,
+tools/bevformer/evaluate_trt.py:166-168).
+usage: model_bench.py [tiny|small|base ...] [--frames N] [--dtype fp16|fp32] [--profile]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
+
+
+def run(name, frames, dtype):
+    dev = torch.device("cuda")
+    model = B.BEVFormer(name).to(dev, dtype)
+    runner = B.FrameRunner(model, dev, dtype)
+    H, W = B.CONFIGS[name]["image"]
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+    ts = []
+    for i in range(frames):
+        can = torch.zeros(18)
+        can[0], can[1], can[-2], can[-1] = 0.5 * i, 0.1 * i, 0.01 * i, 0.8 * i
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.step(img, can, l2i, "scene")
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    core = ts[1:-1]
+    ms = sum(core) / len(core)
+    return dict(model=name, dtype=str(dtype)[6:], frames=frames, ms_per_frame=round(ms, 3),
+                fps=round(1000.0 / ms, 2), first_frame_ms=round(ts[0], 1))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("models", nargs="*", default=["tiny", "small", "base"])
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--dtype", default="fp16")
+    a = ap.parse_args()
+    dt = torch.float16 if a.dtype == "fp16" else torch.float32
+    for m in a.models:
+        print(json.dumps(run(m, a.frames, dt)), flush=True)
