@@ -16,10 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
 
 
-def run(name, frames, dtype):
+def run(name, frames, dtype, graph=False):
     dev = torch.device("cuda")
     model = B.BEVFormer(name).to(dev, dtype)
-    runner = B.FrameRunner(model, dev, dtype)
+    runner = B.FrameRunner(model, dev, dtype, graph=graph)
     H, W = B.CONFIGS[name]["image"]
     l2i = G.synthetic_lidar2img((H, W)).to(dev)
     g = torch.Generator().manual_seed(0)
@@ -35,7 +35,7 @@ def run(name, frames, dtype):
         ts.append((time.perf_counter() - t0) * 1e3)
     core = ts[1:-1]
     ms = sum(core) / len(core)
-    return dict(model=name, dtype=str(dtype)[6:], frames=frames, ms_per_frame=round(ms, 3),
+    return dict(model=name, dtype=str(dtype)[6:], graph=graph, frames=frames, ms_per_frame=round(ms, 3),
                 fps=round(1000.0 / ms, 2), first_frame_ms=round(ts[0], 1))
 
 
@@ -44,7 +44,8 @@ if __name__ == "__main__":
     ap.add_argument("models", nargs="*", default=["tiny", "small", "base"])
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
-        print(json.dumps(run(m, a.frames, dt)), flush=True)
+        print(json.dumps(run(m, a.frames, dt, a.graph)), flush=True)
