@@ -10,8 +10,8 @@ nproc >> $OUT/rocminfo.txt
 ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -10 ) > $OUT/smoke.log
 ( VARIANTS=0 timeout 900 python tools/msda_sweep.py 2>&1 ) > $OUT/sweep.jsonl
 ( timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -5 ) > $OUT/bench.json
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | tail -5 ) > $OUT/rocprof.log
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3 ) > $OUT/rocprof_pmc_fetch.log
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3 ) > $OUT/rocprof_pmc_write.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -5 ) > $OUT/rocprof.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -3 ) > $OUT/rocprof_pmc_fetch.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -3 ) > $OUT/rocprof_pmc_write.log
 find $OUT -name "*.csv" | head -20; du -sh $OUT
 tail -5 $OUT/pytest.log; cat $OUT/smoke.log; cat $OUT/bench.json
