@@ -43,6 +43,7 @@ const Entry kTable[] = {
     {"BEVPoolV2TRT2", (void *)&bevops_bev_pool_v2_forward},
     {"bevops_mdconv_forward", (void *)&bevops_mdconv_forward},
     {"bevops_mdconv_workspace_size", (void *)&bevops_mdconv_workspace_size},
+    {"bevops_mdconv_forward_int8", (void *)&bevops_mdconv_forward_int8},
     {"ModulatedDeformableConv2dTRT", (void *)&bevops_mdconv_forward},
     {"ModulatedDeformableConv2dTRT2", (void *)&bevops_mdconv_forward},
 };

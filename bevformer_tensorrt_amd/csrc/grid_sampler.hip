@@ -95,7 +95,36 @@ __global__ __launch_bounds__(kBlock) void grid_sampler_2d_kernel(
         st<T>(op, 0.f, 1.f);
       }
     }
-  } else {  // bicubic (fp only)
+  } else if constexpr (kInt8) {
+    // int8 bicubic (gridSamplerKernel.cu:581-613,1205-1262): coefficients quantised by
+    // truncation int8(c*127), int32 4-tap dot, temp/127 with C integer division, rows then
+    // columns, final T2int8(v * s_in/s_out)
+    const float ix = gs_unnormalize(gx, d.W, align), iy = gs_unnormalize(gy, d.H, align);
+    const float ix_nw = floorf(ix), iy_nw = floorf(iy);
+    float cxf[4], cyf[4];
+    cubic_coeffs(cxf, ix - ix_nw);
+    cubic_coeffs(cyf, iy - iy_nw);
+    int cx[4], cy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cx[k] = (int)(int8_t)(cxf[k] * 127.f);
+      cy[k] = (int)(int8_t)(cyf[k] * 127.f);
+    }
+    const float os = s_in / s_out;
+    for (int c = c0; c < c1; ++c, ip += HW, op += plane_o) {
+      int col[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          t += (int)bounded2d(ip, ix_nw - 1 + k, iy_nw - 1 + i, d.W, d.H, pad, align) * cx[k];
+        col[i] = (int)(int8_t)(t / 127);
+      }
+      const int t = col[0] * cy[0] + col[1] * cy[1] + col[2] * cy[2] + col[3] * cy[3];
+      *op = t2int8((float)(int)(int8_t)(t / 127) * os);
+    }
+  } else {  // bicubic (fp)
     const float ix = gs_unnormalize(gx, d.W, align), iy = gs_unnormalize(gy, d.H, align);
     const float ix_nw = floorf(ix), iy_nw = floorf(iy);
     float cx[4], cy[4];
@@ -225,7 +254,6 @@ extern "C" int bevops_grid_sampler_2d_forward(int dtype, const void *input, cons
                          interpolation, padding, align_corners, 1.f, 1.f, 1.f);
       return launch_status();
     case BEVOPS_I8:
-      if (interpolation == BEVOPS_BICUBIC) return BEVOPS_NOT_SUPPORTED;
       if (!(scale_in > 0.f) || !(scale_grid > 0.f) || !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
       hipLaunchKernelGGL((grid_sampler_2d_kernel<int8_t>), g, dim3(kBlock), 0, st,
                          (const int8_t *)input, (const int8_t *)grid, (int8_t *)output, d,

@@ -463,6 +463,175 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
   }
 }
 
+
+// ---- 6. INT8 flavour (modulatedDeformableConv2dKernel.cu:190-257,463-607,897-978) ----------
+// im2col on the NHWC int8 image (16 channels per lane = one 16-byte load per corner; unsigned
+// x255 area weights, int32 4-corner dot, T2int8(t/255), then T2int8(val * mask)), one batched
+// int8 GEMM on the matrix cores (v_mfma_i32_32x32x32_i8, int32 accumulate), epilogue
+// T2int8((acc * s_in*s_w + bias) / s_out) scattered to NCHW.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int q_away(float a) {
+  a = fminf(fmaxf(a, -128.f), 127.f);
+  return (int)(a + (a > 0.f ? 0.5f : -0.5f));
+}
+__device__ __forceinline__ int u8w(float a) { return (int)fminf(fmaxf(rintf(a * 255.f), 0.f), 255.f); }
+
+template <int V>
+__global__ __launch_bounds__(256) void im2col_nhwc_s8_kernel(const int8_t *__restrict__ xt,
+                                                             const int8_t *__restrict__ offset,
+                                                             const int8_t *__restrict__ mask,
+                                                             int8_t *__restrict__ col, ConvDims d,
+                                                             float s_off, float s_mask) {
+  const int vec_per_pix = d.Cin / V;
+  const int KK = d.Kh * d.Kw;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int cv = (int)(idx % vec_per_pix);
+  const size_t r = idx / vec_per_pix;
+  const int t = (int)(r % KK);
+  const size_t n = r / KK;
+  const int HoWo = d.Ho * d.Wo;
+  const size_t N = (size_t)d.B * HoWo;
+  if (n >= N) return;
+  const int b = (int)(n / HoWo);
+  const int pix = (int)(n - (size_t)b * HoWo);
+  const int ho = pix / d.Wo, wo = pix - ho * d.Wo;
+  const int c = cv * V;
+  const int dg = c / (d.Cin / d.DG);
+  const int i = t / d.Kw, j = t - i * d.Kw;
+  const size_t obase = (((size_t)b * d.DG + dg) * 2 * KK) * HoWo + pix;
+  float h_im, w_im, m;
+  {
+#pragma clang fp contract(off)
+    const float off_h = (float)offset[obase + (size_t)(2 * t) * HoWo] * s_off;
+    const float off_w = (float)offset[obase + (size_t)(2 * t + 1) * HoWo] * s_off;
+    m = (float)mask[(((size_t)b * d.DG + dg) * KK + t) * HoWo + pix] * s_mask;
+    h_im = off_h + (float)(ho * d.sh - d.ph + i * d.dh);
+    w_im = off_w + (float)(wo * d.sw - d.pw + j * d.dw);
+  }
+  int acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0;
+  const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
+  if (in) {
+#pragma clang fp contract(off)
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h0 = (int)hf, w0 = (int)wf;
+    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int aw[4] = {u8w(hh * hw), u8w(hh * lw), u8w(lh * hw), u8w(lh * lw)};
+    const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 < d.W, h0 + 1 < d.H && w0 >= 0,
+                        h0 + 1 < d.H && w0 + 1 < d.W};
+    const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
+    const int8_t *xb = xt + (size_t)b * d.H * d.W * d.Cin + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!ok[q]) continue;
+      const int8_t *p = xb + ((size_t)hs[q] * d.W + ws[q]) * d.Cin;
+      int8_t v[V];
+      if constexpr (V == 16) *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(p);
+      else if constexpr (V == 4) *reinterpret_cast<unsigned *>(v) = *reinterpret_cast<const unsigned *>(p);
+      else v[0] = p[0];
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += (int)v[k] * aw[q];
+    }
+  }
+  int8_t res[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+#pragma clang fp contract(off)
+    const int val = in ? q_away((float)acc[k] * (1 / 255.f)) : 0;
+    res[k] = (int8_t)q_away((float)val * m);
+  }
+  const int cin_g = d.Cin / d.G;
+  const int g = c / cin_g, cg = c - g * cin_g;
+  int8_t *o = col + (((size_t)g * N + n) * KK + t) * cin_g + cg;
+  if constexpr (V == 16) *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(res);
+  else if constexpr (V == 4) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(res);
+  else o[0] = res[0];
+}
+
+// C[m][n] = sum_k A[m][k] * B[n][k] on int8, 128x128x64 tiles, requantising epilogue
+constexpr int kIK = 64, kILd = kIK + 16;  // bytes per LDS row (+16: conflict-free b128 reads)
+__global__ __launch_bounds__(256) void gemm_tn_s8_kernel(const int8_t *__restrict__ A,
+                                                         const int8_t *__restrict__ Bm,
+                                                         const float *__restrict__ bias,
+                                                         int8_t *__restrict__ out, int M, int N, int K,
+                                                         GemmEpi e, float s_iw, float s_out) {
+  __shared__ __attribute__((aligned(16))) int8_t As[kBM][kILd];
+  __shared__ __attribute__((aligned(16))) int8_t Bs[kBN][kILd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int r0 = tid >> 2, kc = (tid & 3) * 16, r1 = r0 + 64;  // 128 rows x 4 chunks of 16 B
+  i32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+  const int nk = (K + kIK - 1) / kIK;
+  uint4 ra0, ra1, rb0, rb1;
+  auto ld = [&](const int8_t *p, bool ok) { return ok ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0); };
+  auto gload = [&](int kt) {
+    const int k = kt * kIK + kc;
+    const bool kok = k < K;  // K % 16 == 0 guaranteed by the launcher
+    ra0 = ld(A + (size_t)(m0 + r0) * K + k, kok && m0 + r0 < M);
+    ra1 = ld(A + (size_t)(m0 + r1) * K + k, kok && m0 + r1 < M);
+    rb0 = ld(Bm + (size_t)(n0 + r0) * K + k, kok && n0 + r0 < N);
+    rb1 = ld(Bm + (size_t)(n0 + r1) * K + k, kok && n0 + r1 < N);
+  };
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    *reinterpret_cast<uint4 *>(&As[r0][kc]) = ra0;
+    *reinterpret_cast<uint4 *>(&As[r1][kc]) = ra1;
+    *reinterpret_cast<uint4 *>(&Bs[r0][kc]) = rb0;
+    *reinterpret_cast<uint4 *>(&Bs[r1][kc]) = rb1;
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 32 + (lane >> 5) * 16;
+      i32x4_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const i32x4_t *>(&As[wm * 64 + i * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const i32x4_t *>(&Bs[wn * 64 + j * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    const int b = n / e.HoWo, pix = n - b * e.HoWo;
+    int8_t *ob = out + ((size_t)b * e.Cout + e.co0) * e.HoWo + pix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) {
+#pragma clang fp contract(off)
+          const float v = ((float)acc[i][j][r] * s_iw + (bias ? bias[e.co0 + m] : 0.f)) / s_out;
+          ob[(size_t)m * e.HoWo] = (int8_t)q_away(v);
+        }
+      }
+  }
+}
+
+int run_s8(const void *input, const void *offset, const void *mask, const void *weight,
+           const void *bias, void *output, void *workspace, const ConvDims &d, float s_in, float s_off,
+           float s_mask, float s_w, float s_out, hipStream_t st);
+
 thread_local int g_mdconv_variant = 0;
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -554,6 +723,49 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   return launch_status();
 }
 
+int run_s8(const void *input, const void *offset, const void *mask, const void *weight,
+           const void *bias, void *output, void *workspace, const ConvDims &d, float s_in, float s_off,
+           float s_mask, float s_w, float s_out, hipStream_t st) {
+  const WsLayout w = ws_layout(d, 1);
+  char *ws = static_cast<char *>(workspace);
+  int8_t *xt = reinterpret_cast<int8_t *>(ws + w.xt);
+  int8_t *wt = reinterpret_cast<int8_t *>(ws + w.wt);
+  int8_t *col = reinterpret_cast<int8_t *>(ws + w.col);
+  const int HW = d.H * d.W, KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
+  const size_t N = (size_t)d.B * d.Ho * d.Wo;
+  if (N > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+  // multiScale...Plugin-style precondition (modulatedDeformableConv2dPlugin.cpp:217-219)
+  if (d.Cin % 4 != 0 || cout_g % 4 != 0) return BEVOPS_NOT_SUPPORTED;
+  const int Kg = KK * cin_g;
+  if (Kg % 16 != 0) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
+                     0, st, (const int8_t *)input, xt, d.Cin, HW);
+  const size_t wtot = (size_t)d.Cout * cin_g * KK;
+  hipLaunchKernelGGL((repack_weight_kernel<int8_t>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
+                     (const int8_t *)weight, wt, d.Cout, cin_g, KK);
+  const bool v16 = cin_g % 16 == 0 && (d.Cin / d.DG) % 16 == 0;
+  const bool v4 = cin_g % 4 == 0 && (d.Cin / d.DG) % 4 == 0;
+  const int V = v16 ? 16 : (v4 ? 4 : 1);
+  const size_t blocks = (N * KK * (d.Cin / V) + 255) / 256;
+  if (blocks > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+  if (v16)
+    hipLaunchKernelGGL((im2col_nhwc_s8_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+  else if (v4)
+    hipLaunchKernelGGL((im2col_nhwc_s8_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+  else
+    hipLaunchKernelGGL((im2col_nhwc_s8_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+  for (int g = 0; g < d.G; ++g) {
+    const GemmEpi e{d.Ho * d.Wo, d.Cout, g * cout_g};
+    hipLaunchKernelGGL(gemm_tn_s8_kernel, dim3((unsigned)((N + kBN - 1) / kBN), (cout_g + kBM - 1) / kBM),
+                       dim3(256), 0, st, wt + (size_t)g * cout_g * Kg, col + (size_t)g * N * Kg,
+                       (const float *)bias, (int8_t *)output, cout_g, (int)N, Kg, e, s_in * s_w, s_out);
+  }
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace bevops
 
@@ -573,8 +785,29 @@ extern "C" size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H,
   if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
                  groups, deform_groups))
     return 0;
-  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16) return 0;
-  return ws_layout(d, dtype == BEVOPS_F32 ? 4 : 2).total;
+  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16 && dtype != BEVOPS_I8) return 0;
+  return ws_layout(d, dtype == BEVOPS_F32 ? 4 : (dtype == BEVOPS_F16 ? 2 : 1)).total;
+}
+
+extern "C" int bevops_mdconv_forward_int8(const void *input, float scale_in, const void *offset,
+                                          float scale_offset, const void *mask, float scale_mask,
+                                          const void *weight, float scale_weight, const float *bias,
+                                          void *output, float scale_out, void *workspace,
+                                          size_t workspace_bytes, int B, int Cin, int H, int W, int Cout,
+                                          int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                                          int dil_h, int dil_w, int groups, int deform_groups,
+                                          void *stream) {
+  if (!input || !offset || !mask || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
+  if (!(scale_in > 0.f) || !(scale_offset > 0.f) || !(scale_mask > 0.f) || !(scale_weight > 0.f) ||
+      !(scale_out > 0.f))
+    return BEVOPS_BAD_PARAM;
+  ConvDims d;
+  if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                 groups, deform_groups))
+    return BEVOPS_BAD_PARAM;
+  if (workspace_bytes < ws_layout(d, 1).total || !aligned16(workspace)) return BEVOPS_BAD_PARAM;
+  return run_s8(input, offset, mask, weight, bias, output, workspace, d, scale_in, scale_offset,
+                scale_mask, scale_weight, scale_out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bevops_mdconv_forward(int dtype, const void *input, const void *offset,

@@ -54,3 +54,37 @@ def modulated_deformable_conv2d2(input, offset, mask, weight, bias=None, stride=
                                  dilation=1, groups=1, deform_groups=1):
     """Same op under the half2 plugin name ModulatedDeformableConv2dTRT2."""
     return _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups)
+
+
+def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in, scale_offset, scale_mask,
+                                     scale_weight, scale_out, stride=1, padding=0, dilation=1, groups=1,
+                                     deform_groups=1):
+    """INT8 flavour (modulatedDeformableConv2dKernel.cu:463-607): int8 input / offset / mask / weight
+    with per-tensor scales, fp32 bias, int8 output."""
+    assert input.is_cuda and input.dtype == torch.int8
+    handle = _lib.load_library()
+    input, offset, mask, weight = (t.contiguous() for t in (input, offset, mask, weight))
+    for name, t in (("offset", offset), ("mask", mask), ("weight", weight)):
+        if t.dtype != torch.int8:
+            raise TypeError(f"{name} must be int8")
+    if bias is not None:
+        bias = bias.float().contiguous()
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, Cin, H, W = input.shape
+    Cout, _, Kh, Kw = weight.shape
+    Ho = (H + 2 * ph - (dh * (Kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) // sw + 1
+    dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
+    ws_bytes = handle.bevops_mdconv_workspace_size(_lib.I8, *dims)
+    if ws_bytes == 0:
+        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.int8, device=input.device)
+    with torch.cuda.device(input.device):
+        st = handle.bevops_mdconv_forward_int8(
+            input.data_ptr(), float(scale_in), offset.data_ptr(), float(scale_offset), mask.data_ptr(),
+            float(scale_mask), weight.data_ptr(), float(scale_weight),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), float(scale_out),
+            ws.data_ptr(), ws_bytes, *dims, _lib.current_stream_ptr(input.device))
+    _lib.check(st, "bevops_mdconv_forward_int8")
+    return out

@@ -34,6 +34,9 @@ SIGNATURES = {
                                    [c_void_p]),
     "bevops_mdconv_set_variant": (c_int, [c_int]),
     "bevops_mdconv_workspace_size": (c_size_t, [c_int] * 16),
+    "bevops_mdconv_forward_int8": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
+                                           c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_size_t] + [c_int] * 15 + [c_void_p]),
     "bevops_mdconv_forward": (c_int, [c_int] + [c_void_p] * 7 + [c_size_t] + [c_int] * 15 +
                               [c_void_p]),
     "bevops_grid_sampler_3d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +

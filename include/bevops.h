@@ -141,7 +141,7 @@ int bevops_rotate_forward(int dtype, const void *img, const void *angle, const v
  * Replaces GridSamplerPlugin::enqueue (TensorRT/plugin/grid_sampler/gridSamplerPlugin.cpp:110-156),
  * grid_sample<T> and grid_sample_int8 (gridSamplerKernel.h:14-26, gridSamplerKernel.cu:1933-2043).
  *   interpolation : bilinear | nearest | bicubic;  padding : zeros | border | reflection
- *   I8 : bilinear / nearest only here; grid is int8 with scale_grid.
+ *   I8 : all three interpolation modes; grid is int8 with scale_grid.
  * 3-D: input [N,C,D,H,W], grid [N,3,D_out,H_out,W_out] (x, y, z); F32 / F16;
  *      bilinear (trilinear) | nearest.
  * ------------------------------------------------------------------------ */
@@ -185,8 +185,12 @@ int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
  *   bias   [Cout] or NULL, output [B,Cout,Ho,Wo];  Ho/Wo from the usual conv formula.
  *   workspace: caller-owned scratch of at least bevops_mdconv_workspace_size(...) bytes
  *   (mirrors getWorkspaceSize; 0 = unsupported arguments), 16-byte aligned.
- * F32 and F16 (F16 needs (Cin/groups*Kh*Kw) % 8 == 0); INT8 is not built yet
- * (BEVOPS_NOT_SUPPORTED).
+ * F32 and F16 (F16 needs (Cin/groups*Kh*Kw) % 8 == 0) through bevops_mdconv_forward; INT8
+ * through bevops_mdconv_forward_int8 (int8 input / offset / mask / weight with per-tensor
+ * scales, fp32 bias, int8 output: out = T2int8((acc*scale_in*scale_weight + bias)/scale_out),
+ * modulatedDeformableConv2dKernel.cu:463-607,897-978; needs Cin % 4 == 0,
+ * (Cout/groups) % 4 == 0 like ...Plugin.cpp:217-219, and (Cin/groups*Kh*Kw) % 16 == 0).
+ * bevops_mdconv_workspace_size(BEVOPS_I8, ...) sizes its workspace.
  * ------------------------------------------------------------------------ */
 /* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
  * channel counts allow), 1 = force the im2col + GEMM pipeline.  Returns the previous value. */
@@ -194,6 +198,13 @@ int bevops_mdconv_set_variant(int variant);
 size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout, int Kh,
                                     int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
                                     int dil_h, int dil_w, int groups, int deform_groups);
+int bevops_mdconv_forward_int8(const void *input, float scale_in, const void *offset,
+                               float scale_offset, const void *mask, float scale_mask,
+                               const void *weight, float scale_weight, const float *bias,
+                               void *output, float scale_out, void *workspace,
+                               size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
+                               int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                               int dil_w, int groups, int deform_groups, void *stream);
 int bevops_mdconv_forward(int dtype, const void *input, const void *offset, const void *mask,
                           const void *weight, const void *bias, void *output, void *workspace,
                           size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,

@@ -171,3 +171,21 @@ def mdconv(x, offset, mask, weight, bias, stride, padding, dilation, groups, def
                             i(stride[1]), i(padding[0]), i(padding[1]), i(dilation[0]), i(dilation[1]),
                             i(groups), i(deform_groups))
     return out
+
+
+def mdconv_s8(x, s_in, offset, s_off, mask, s_mask, weight, s_w, bias, s_out, stride, padding, dilation,
+              groups, deform_groups):
+    """mdconv_ref.c: INT8 DCNv2 forward (modulatedDeformableConv2dKernel.cu:190-257,463-607)."""
+    x, offset, mask, weight = (_c(a, np.int8) for a in (x, offset, mask, weight))
+    B, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (Kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (Kw - 1) + 1)) // stride[1] + 1
+    out = np.empty((B, Cout, Ho, Wo), np.int8)
+    b = _c(bias, np.float32) if bias is not None else None
+    i, f = ctypes.c_int, ctypes.c_float
+    lib().oracle_mdconv_s8(_p(x), f(s_in), _p(offset), f(s_off), _p(mask), f(s_mask), _p(weight), f(s_w),
+                           _p(b) if b is not None else None, _p(out), f(s_out), i(B), i(Cin), i(H), i(W),
+                           i(Cout), i(Kh), i(Kw), i(stride[0]), i(stride[1]), i(padding[0]), i(padding[1]),
+                           i(dilation[0]), i(dilation[1]), i(groups), i(deform_groups))
+    return out

@@ -80,3 +80,81 @@ void oracle_mdconv_f32(const float *input, const float *offset, const float *mas
     free(col);
   }
 }
+
+/* ---- INT8 flavour -------------------------------------------------------------------
+ * modulatedDeformableConv2dKernel.cu:190-257 (dmcn_im2col_bilinear_int8: unsigned x255 area
+ * weights via half2uint8 = RNE, int32 dot over the 4 corners, T2int8(t/255)), :463-548 (offsets
+ * and mask de-quantised with their scales, range gate, qmulf(val, mask)), :569-607 (epilogue
+ * T2int8((acc * s_i*s_w + bias) / s_o)), host flow :897-978.
+ * Coordinates are evaluated in fp32 here (the reference uses half2).  PARITY UNPINNED (CUDA only);
+ * tests check it against the fp32 op within the quantisation error.
+ * input int8 [B,Cin,H,W] (s_in), offset int8 (s_off), mask int8 (s_mask), weight int8 (s_w),
+ * bias fp32 or NULL, out int8 (s_out).  Dense NCHW (the reference used kCHW4). */
+static inline int8_t q_away(float a) {
+  a = a > 127 ? 127 : a;
+  a = a < -128 ? -128 : a;
+  return (int8_t)(a + (a > 0 ? 0.5f : -0.5f));
+}
+static inline int u8w(float a) {
+  float r = nearbyintf(a * 255.f);
+  r = r < 0 ? 0 : r;
+  r = r > 255 ? 255 : r;
+  return (int)r;
+}
+
+void oracle_mdconv_s8(const int8_t *input, float s_in, const int8_t *offset, float s_off,
+                      const int8_t *mask, float s_mask, const int8_t *weight, float s_w,
+                      const float *bias, int8_t *out, float s_out, int B, int Cin, int H, int W,
+                      int Cout, int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                      int dil_h, int dil_w, int groups, int dg) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (Kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (Kw - 1) + 1)) / stride_w + 1;
+  const int KK = Kh * Kw, cin_g = Cin / groups, cout_g = Cout / groups, cpdg = Cin / dg;
+  const long n = (long)Ho * Wo;
+  const float s_iw = s_in * s_w;
+  for (int b = 0; b < B; ++b) {
+    int8_t *col = (int8_t *)malloc((size_t)Cin * KK * n);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < Cin; ++c)
+      for (int ho = 0; ho < Ho; ++ho)
+        for (int wo = 0; wo < Wo; ++wo) {
+          const int g = c / cpdg;
+          const int8_t *im = input + ((long)b * Cin + c) * H * W;
+          const int8_t *op = offset + ((long)b * dg + g) * 2 * KK * n;
+          const int8_t *mp = mask + ((long)b * dg + g) * KK * n;
+          const int h_in = ho * stride_h - pad_h, w_in = wo * stride_w - pad_w;
+          for (int i = 0; i < Kh; ++i)
+            for (int j = 0; j < Kw; ++j) {
+              const int t = i * Kw + j;
+              const float off_h = op[(long)(2 * t) * n + ho * Wo + wo] * s_off;
+              const float off_w = op[(long)(2 * t + 1) * n + ho * Wo + wo] * s_off;
+              const float m = mp[(long)t * n + ho * Wo + wo] * s_mask;
+              const float h_im = off_h + (float)(h_in + i * dil_h), w_im = off_w + (float)(w_in + j * dil_w);
+              int val = 0;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h0 = (int)hf, w0 = (int)wf;
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+                int acc = 0;
+                if (h0 >= 0 && w0 >= 0) acc += im[h0 * W + w0] * u8w(hh * hw);
+                if (h0 >= 0 && w0 + 1 < W) acc += im[h0 * W + w0 + 1] * u8w(hh * lw);
+                if (h0 + 1 < H && w0 >= 0) acc += im[(h0 + 1) * W + w0] * u8w(lh * hw);
+                if (h0 + 1 < H && w0 + 1 < W) acc += im[(h0 + 1) * W + w0 + 1] * u8w(lh * lw);
+                val = q_away(acc * (1 / 255.f));
+              }
+              col[((long)c * KK + t) * n + ho * Wo + wo] = q_away(val * m);
+            }
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int co = 0; co < Cout; ++co)
+      for (long p = 0; p < n; ++p) {
+        const int g = co / cout_g;
+        const int8_t *wrow = weight + (long)co * cin_g * KK;
+        const int8_t *cg = col + (long)g * cin_g * KK * n;
+        int32_t acc = 0;
+        for (int k = 0; k < cin_g * KK; ++k) acc += (int)wrow[k] * (int)cg[(long)k * n + p];
+        out[((long)b * Cout + co) * n + p] = q_away((acc * s_iw + (bias ? bias[co] : 0.f)) / s_out);
+      }
+    free(col);
+  }
+}

@@ -220,8 +220,32 @@ static inline int q127_rne(float area) {
   r = r < -128 ? -128 : r;
   return (int)r;
 }
+static inline int bounded_s8(const int8_t *p, float x, float y, int W, int H, int pad, int align) {
+  x = compute_coord(x, W, pad, align);
+  y = compute_coord(y, H, pad, align);
+  const int ix = (int)x, iy = (int)y;
+  return in2d(iy, ix, H, W) ? p[iy * W + ix] : 0;
+}
+
 static int8_t sample2d_s8(const int8_t *p, int H, int W, float gx, float gy, int interp, int pad,
                           int align, float s_in, float s_out) {
+  if (interp == BICUBIC) { /* gridSamplerKernel.cu:581-613,1205-1262 */
+    const float ux = unnormalize(gx, W, align), uy = unnormalize(gy, H, align);
+    const float x_nw = floorf(ux), y_nw = floorf(uy);
+    float cxf[4], cyf[4];
+    cubic_coeffs(cxf, ux - x_nw);
+    cubic_coeffs(cyf, uy - y_nw);
+    int col[4];
+    for (int i = 0; i < 4; ++i) {
+      int t = 0;
+      for (int k = 0; k < 4; ++k)
+        t += bounded_s8(p, x_nw - 1 + k, y_nw - 1 + i, W, H, pad, align) * (int)(int8_t)(cxf[k] * 127);
+      col[i] = (int8_t)(t / 127);
+    }
+    int t = 0;
+    for (int i = 0; i < 4; ++i) t += col[i] * (int)(int8_t)(cyf[i] * 127);
+    return t2int8_f((float)(int8_t)(t / 127) * (s_in / s_out));
+  }
   const float ix = source_index(gx, W, pad, align), iy = source_index(gy, H, pad, align);
   if (interp == NEAREST) {
     const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);

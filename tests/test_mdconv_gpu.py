@@ -109,3 +109,34 @@ def test_fused_matches_im2col_pipeline(bev, name):
         lib.bevops_mdconv_set_variant(0)
     scale = max(1.0, two.abs().max().item())
     assert (fused - two).abs().max().item() <= 1e-2 * scale
+
+
+def _q(x, s=None):
+    s = float(x.abs().max()) / 127.0 if s is None else s
+    return torch.clamp(torch.round(x / s), -127, 127).to(torch.int8), s
+
+
+@pytest.mark.parametrize("name", ["ref_test_like", "r101_stage3", "stride2", "dilated_groups"])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_mdconv_int8_vs_oracle(bev, oracle_mod, name, with_bias):
+    """INT8 flavour: bit-level agreement with the C restatement of the reference's integer
+    pipeline (+-1 LSB on <1 % of outputs: fp32 rounding of coordinates), and within the
+    reference test's int8 tolerance of the fp32 op (mean abs 1.5 at K = 1152,
+    test_modulated_deformable_conv2d.py:105-108, here scaled to the output range)."""
+    c = CASES[name]
+    x, off, mask, w, b = make(**c)
+    qx, s_x = _q(x); qo, s_o = _q(off); qm, s_m = _q(mask); qw, s_w = _q(w)
+    ref = oracle_mod.mdconv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy() if with_bias else None,
+                            (c["stride"],) * 2, (c["pad"],) * 2, (c["dil"],) * 2, c["g"], c["dg"])
+    s_out = float(np.abs(ref).max()) / 127.0
+    out = bev.modulated_deformable_conv2d_int8(qx.cuda(), qo.cuda(), qm.cuda(), qw.cuda(),
+                                               b.cuda() if with_bias else None, s_x, s_o, s_m, s_w, s_out,
+                                               c["stride"], c["pad"], c["dil"], c["g"], c["dg"])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.int32)
+    want = oracle_mod.mdconv_s8(qx.numpy(), s_x, qo.numpy(), s_o, qm.numpy(), s_m, qw.numpy(), s_w,
+                                b.numpy() if with_bias else None, s_out, (c["stride"],) * 2, (c["pad"],) * 2,
+                                (c["dil"],) * 2, c["g"], c["dg"]).astype(np.int32)
+    d = np.abs(got - want)
+    assert d.max() <= 1 and (d > 0).mean() <= 0.01, (d.max(), (d > 0).mean())
+    assert np.abs(got * s_out - ref).mean() <= 0.05 * float(np.abs(ref).max())

@@ -137,7 +137,7 @@ def test_grid_sampler_bicubic_3d_not_supported(bev):
                          "bicubic", "zeros", False)
 
 
-@pytest.mark.parametrize("mode", range(2))
+@pytest.mark.parametrize("mode", range(3))
 @pytest.mark.parametrize("pad", range(3))
 def test_grid_sampler_int8(bev, oracle_mod, mode, pad):
     g = torch.Generator().manual_seed(0)
@@ -154,7 +154,7 @@ def test_grid_sampler_int8(bev, oracle_mod, mode, pad):
     # and the int8 result tracks the fp32 op within the quantisation error
     f = oracle_mod.grid_sampler(inp.numpy().astype(np.float32) * s_in,
                                 grid.numpy().astype(np.float32) * s_grid, mode, pad, False)
-    assert np.abs(np.clip(f / s_out, -128, 127) - out).mean() <= 1.0
+    assert np.abs(np.clip(f / s_out, -128, 127) - out).mean() <= (1.0 if mode < 2 else 2.5)  # bicubic truncates twice
 
 
 # ------------------------------------------------------------------ rotate
