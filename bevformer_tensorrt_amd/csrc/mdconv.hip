@@ -64,14 +64,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T *__restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void repack_weight_kernel(const T *__restrict__ w,
                                                             T *__restrict__ wt, int Cout,
-                                                            int cin_g, int KK) {
+                                                            int cin_g, int KK, int row_stride) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t total = (size_t)Cout * cin_g * KK;
   if (i >= total) return;
   const int ci = (int)(i % cin_g);
   const int t = (int)((i / cin_g) % KK);
   const size_t co = i / ((size_t)cin_g * KK);
-  wt[i] = w[(co * cin_g + ci) * KK + t];
+  wt[co * row_stride + (size_t)t * cin_g + ci] = w[(co * cin_g + ci) * KK + t];
 }
 
 // ---- 3. deformable + modulated im2col on NHWC --------------------------------------
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void im2col_nhwc_s8_kernel(const int8_t *__res
                                                              const int8_t *__restrict__ offset,
                                                              const int8_t *__restrict__ mask,
                                                              int8_t *__restrict__ col, ConvDims d,
-                                                             float s_off, float s_mask) {
+                                                             float s_off, float s_mask, int kp) {
   const int vec_per_pix = d.Cin / V;
   const int KK = d.Kh * d.Kw;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void im2col_nhwc_s8_kernel(const int8_t *__res
   }
   const int cin_g = d.Cin / d.G;
   const int g = c / cin_g, cg = c - g * cin_g;
-  int8_t *o = col + (((size_t)g * N + n) * KK + t) * cin_g + cg;
+  int8_t *o = col + ((size_t)g * N + n) * kp + (size_t)t * cin_g + cg;
   if constexpr (V == 16) *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(res);
   else if constexpr (V == 4) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(res);
   else o[0] = res[0];
@@ -652,12 +652,18 @@ bool make_dims(ConvDims &d, int B, int Cin, int H, int W, int Cout, int Kh, int 
 struct WsLayout {
   size_t xt, wt, col, total;
 };
+// int8 GEMM rows are padded to a multiple of 16 bytes (zero filled)
+inline size_t kpad(const ConvDims &d, size_t es) {
+  const size_t kg = (size_t)(d.Cin / d.G) * d.Kh * d.Kw;
+  return es == 1 ? ((kg + 15) & ~size_t(15)) : kg;
+}
 WsLayout ws_layout(const ConvDims &d, size_t es) {
   WsLayout w;
+  const size_t kp = kpad(d, es);
   w.xt = 0;
   w.wt = align256((size_t)d.B * d.Cin * d.H * d.W * es);
-  w.col = w.wt + align256((size_t)d.Cout * (d.Cin / d.G) * d.Kh * d.Kw * es);
-  w.total = w.col + align256((size_t)d.B * d.Ho * d.Wo * d.Cin * d.Kh * d.Kw * es);
+  w.col = w.wt + align256((size_t)d.Cout * kp * es);
+  w.total = w.col + align256((size_t)d.B * d.Ho * d.Wo * d.G * kp * es);
   return w;
 }
 
@@ -676,7 +682,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
                      0, st, (const T *)input, xt, d.Cin, HW);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   hipLaunchKernelGGL((repack_weight_kernel<T>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
-                     (const T *)weight, wt, d.Cout, cin_g, KK);
+                     (const T *)weight, wt, d.Cout, cin_g, KK, KK * cin_g);
   if constexpr (sizeof(T) == 2) {
     // fused implicit GEMM: a 64-channel K chunk must sit inside one group and one deform group
     if (g_mdconv_variant != 1 && cin_g % kFK == 0 && (d.Cin / d.DG) % kFK == 0) {
@@ -737,12 +743,15 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
   // multiScale...Plugin-style precondition (modulatedDeformableConv2dPlugin.cpp:217-219)
   if (d.Cin % 4 != 0 || cout_g % 4 != 0) return BEVOPS_NOT_SUPPORTED;
   const int Kg = KK * cin_g;
-  if (Kg % 16 != 0) return BEVOPS_NOT_SUPPORTED;
+  const int Kp = (int)kpad(d, 1);
+  if (Kp != Kg) {  // zero the padding columns once (packed weights + column buffer)
+    if (hipMemsetAsync(ws + w.wt, 0, w.total - w.wt, st) != hipSuccess) return BEVOPS_FAILURE;
+  }
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
                      0, st, (const int8_t *)input, xt, d.Cin, HW);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   hipLaunchKernelGGL((repack_weight_kernel<int8_t>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
-                     (const int8_t *)weight, wt, d.Cout, cin_g, KK);
+                     (const int8_t *)weight, wt, d.Cout, cin_g, KK, Kp);
   const bool v16 = cin_g % 16 == 0 && (d.Cin / d.DG) % 16 == 0;
   const bool v4 = cin_g % 4 == 0 && (d.Cin / d.DG) % 4 == 0;
   const int V = v16 ? 16 : (v4 ? 4 : 1);
@@ -750,18 +759,18 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
   if (blocks > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
   if (v16)
     hipLaunchKernelGGL((im2col_nhwc_s8_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
-                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask, Kp);
   else if (v4)
     hipLaunchKernelGGL((im2col_nhwc_s8_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
-                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask, Kp);
   else
     hipLaunchKernelGGL((im2col_nhwc_s8_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, xt,
-                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask);
+                       (const int8_t *)offset, (const int8_t *)mask, col, d, s_off, s_mask, Kp);
   for (int g = 0; g < d.G; ++g) {
     const GemmEpi e{d.Ho * d.Wo, d.Cout, g * cout_g};
     hipLaunchKernelGGL(gemm_tn_s8_kernel, dim3((unsigned)((N + kBN - 1) / kBN), (cout_g + kBM - 1) / kBM),
-                       dim3(256), 0, st, wt + (size_t)g * cout_g * Kg, col + (size_t)g * N * Kg,
-                       (const float *)bias, (int8_t *)output, cout_g, (int)N, Kg, e, s_in * s_w, s_out);
+                       dim3(256), 0, st, wt + (size_t)g * cout_g * Kp, col + (size_t)g * N * Kp,
+                       (const float *)bias, (int8_t *)output, cout_g, (int)N, Kp, e, s_in * s_w, s_out);
   }
   return launch_status();
 }

@@ -189,7 +189,7 @@ int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
  * through bevops_mdconv_forward_int8 (int8 input / offset / mask / weight with per-tensor
  * scales, fp32 bias, int8 output: out = T2int8((acc*scale_in*scale_weight + bias)/scale_out),
  * modulatedDeformableConv2dKernel.cu:463-607,897-978; needs Cin % 4 == 0,
- * (Cout/groups) % 4 == 0 like ...Plugin.cpp:217-219, and (Cin/groups*Kh*Kw) % 16 == 0).
+ * (Cout/groups) % 4 == 0 like ...Plugin.cpp:217-219).
  * bevops_mdconv_workspace_size(BEVOPS_I8, ...) sizes its workspace.
  * ------------------------------------------------------------------------ */
 /* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
