@@ -206,7 +206,8 @@ def main():
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel.json")))[-1]
             total = 0.0
             for k, v in json.load(open(f)).items():
-                sca = ("msda_hm2_kernel<32>" in k or "msda_hm2_repack_kernel" in k or
+                sca = ("msda_hm3_kernel<32" in k or "msda_hm3_repack_kernel" in k or
+                       "msda_hm2_kernel<32>" in k or "msda_hm2_repack_kernel" in k or
                        ("msda_quad_kernel<__half, 8" in k))
                 if sca and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
                     total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
@@ -220,7 +221,7 @@ def main():
         avg_ms = sum(ms) / len(ms)
         byt = msda_bytes(BASE["sca"], esize, bs=sca_bs)
         achieved = byt / (avg_ms * 1e-3) / 1e9
-        roofline = {"kernel": "base SCA MSDA call = msda_hm2_repack_kernel + msda_hm2_kernel<32>", "bound": "hbm",
+        roofline = {"kernel": "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
                     "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),

@@ -61,9 +61,11 @@ __device__ __forceinline__ float h2f_lo(unsigned u) {
 __device__ __forceinline__ float h2f_hi(unsigned u) {
   return __half2float(__ushort_as_half((unsigned short)(u >> 16)));
 }
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {
-  return (unsigned)__half_as_ushort(__float2half_rn(a)) |
-         ((unsigned)__half_as_ushort(__float2half_rn(b)) << 16);
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {  // one v_cvt_pk_f16_f32 (RNE)
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  const f2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2v));
 }
 
 inline int launch_status() {

@@ -638,6 +638,17 @@ extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int head
   return msda_hm_workspace_bytes(bs, nk, heads, channels, num_levels);
 }
 
+extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *spatial_shapes_host,
+                                                    int bs, int nk, int heads, int channels,
+                                                    int num_levels, int num_query, int num_point) {
+  const size_t a = bevops_msda_workspace_size(dtype, bs, nk, heads, channels, num_levels, num_query,
+                                              num_point);
+  if (a == 0 || !spatial_shapes_host) return a;
+  const size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
+                                            num_query, num_point);
+  return a > b ? a : b;
+}
+
 extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
                                    const int32_t *spatial_shapes_host,
                                    const void *reference_points, int ref_dtype,
@@ -699,6 +710,15 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         const double plane_mb = (double)nk * heads * channels * 2 / 1048576.0;
         const bool pays = (samples >= 16.0 * pixels && plane_mb >= 4.0) ||
                           (samples >= 4.0 * pixels && plane_mb >= 16.0);
+        const int LP = num_levels * num_point;
+        if (spatial_shapes_host && (g_variant == 16 || (g_variant == 0 && pays && LP >= 16))) {
+          const int rc = msda_hm3_forward_f16(
+              (const __half *)value, spatial_shapes_host, (const __half *)reference_points,
+              (const __half *)sampling_offsets, (const __half *)attention_weights, (__half *)output,
+              bs, nk, heads, channels, num_levels, num_query, num_point, points_per_group,
+              shared_offsets ? 1 : 0, workspace, workspace_bytes, st);
+          if (rc != BEVOPS_NOT_SUPPORTED || g_variant == 16) return rc;
+        }
         if ((g_variant >= 11 && g_variant <= 15) || pays) {
           const int rc = msda_hm_forward_f16(
               (const __half *)value, spatial_shapes, spatial_shapes_host,

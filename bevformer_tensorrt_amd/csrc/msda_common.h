@@ -101,6 +101,24 @@ __device__ __forceinline__ void load_raw_nt(const __half *p, unsigned (&d)[N]) {
   }
 }
 
+// N dwords (= N (x, y) half pairs) starting at p
+template <int N>
+__device__ __forceinline__ void load_raw(const __half *p, unsigned (&d)[N]) {
+  if constexpr (N == 1) {
+    d[0] = *reinterpret_cast<const unsigned *>(p);
+  } else if constexpr (N == 2) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    d[0] = v.x; d[1] = v.y;
+  } else {
+    static_assert(N % 4 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+  }
+}
+
 __device__ __forceinline__ float2 load_ref(const float *p) {
   return *reinterpret_cast<const float2 *>(p);
 }
@@ -157,4 +175,12 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
                         const __half *ref, const __half *off, const __half *logit, __half *out,
                         int bs, int nk, int heads, int C, int L, int nq, int P, int ppg, int shared,
                         void *workspace, size_t workspace_bytes, int variant, hipStream_t st);
+// msda_hm3.hip -- padded head-major path with LDS-resident small levels; needs the shapes on
+// the host.  workspace_bytes == 0 / NOT_SUPPORTED when the shape is outside its domain.
+size_t msda_hm3_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
+                                int P);
+int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,
+                         const __half *off, const __half *logit, __half *out, int bs, int nk,
+                         int heads, int C, int L, int nq, int P, int ppg, int shared,
+                         void *workspace, size_t workspace_bytes, hipStream_t st);
 }  // namespace bevops

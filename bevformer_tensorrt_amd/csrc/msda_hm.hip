@@ -75,24 +75,6 @@ __global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__res
   if (copy_b) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(vh) + copy_b + o * 2) = v;
 }
 
-// N dwords (= N (x, y) half pairs) starting at p
-template <int N>
-__device__ __forceinline__ void load_raw(const __half *p, unsigned (&d)[N]) {
-  if constexpr (N == 1) {
-    d[0] = *reinterpret_cast<const unsigned *>(p);
-  } else if constexpr (N == 2) {
-    const uint2 v = *reinterpret_cast<const uint2 *>(p);
-    d[0] = v.x; d[1] = v.y;
-  } else {
-    static_assert(N % 4 == 0, "N");
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
-      const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-      d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
-    }
-  }
-}
-
 __device__ __forceinline__ void fma8(const u32x4 r, float w, float (&acc)[8]) {
   acc[0] = fmaf(w, h2f_lo(r.x), acc[0]); acc[1] = fmaf(w, h2f_hi(r.x), acc[1]);
   acc[2] = fmaf(w, h2f_lo(r.y), acc[2]); acc[3] = fmaf(w, h2f_hi(r.y), acc[3]);

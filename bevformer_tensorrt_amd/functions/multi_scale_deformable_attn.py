@@ -115,9 +115,11 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
         ws_bytes = handle.bevops_msda_workspace_size(dt, bs, nk, heads, ch, L, nq, P)
         ws = None
         if ws_bytes:
-            ws = _workspace(ws_bytes, value.device, stream)
             if shapes_host is None:
                 shapes_host = _host_shapes(shapes_dev)
+            ws_bytes = handle.bevops_msda_workspace_size_shapes(
+                dt, shapes_host.data_ptr(), bs, nk, heads, ch, L, nq, P)
+            ws = _workspace(ws_bytes, value.device, stream)
         st = handle.bevops_msda_forward_ws(
             dt, value.data_ptr(), shapes_dev.data_ptr(),
             shapes_host.data_ptr() if shapes_host is not None else None,

@@ -104,6 +104,12 @@ int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_sha
  * to passing them repeated bs times, without the 6x redundant HBM reads. */
 size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
                                   int num_levels, int num_query, int num_point);
+/* Same, for a caller that knows the level shapes on the host ([num_levels][2] = (H, W)):
+ * also covers the zero-padded re-layout with LDS-resident small levels (msda_hm3.hip), whose
+ * size depends on the level shapes.  >= bevops_msda_workspace_size. */
+size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *spatial_shapes_host, int bs,
+                                         int nk, int heads, int channels, int num_levels,
+                                         int num_query, int num_point);
 int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,
                            const int32_t *spatial_shapes_host, const void *reference_points,
                            int ref_dtype, const void *sampling_offsets,

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {"layout_preserving": 10, "hm_no_staging": 11, "hm_staged_1024": 12, "hm_staged_512": 13,
-            "hm_two_copies": 14, "hm2_dot2_mailbox": 15}
+            "hm_two_copies": 14, "hm2_dot2_mailbox": 15, "hm3_padded_lds": 16}
 
 SHAPES = {
     # (bs, levels, nq, P, ppg)
@@ -56,7 +56,7 @@ def run(ctx, args, variant):
 
 @pytest.mark.parametrize("name", list(SHAPES))
 @pytest.mark.parametrize("variant", ["hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies",
-                                     "hm2_dot2_mailbox"])
+                                     "hm2_dot2_mailbox", "hm3_padded_lds"])
 def test_hm_vs_oracle(ctx, oracle_mod, name, variant):
     args = gen(SHAPES[name])
     out = run(ctx, args, VARIANTS[variant]).float().cpu().numpy()
@@ -71,11 +71,12 @@ def test_hm_matches_layout_preserving_kernel_at_full_size(ctx, shape):
             "base_tsa": (2, [[200, 200]], 40000, 4, 1)}[shape]
     args = gen(full, ref_lo=0.0, ref_hi=1.0, off_std=1.0)
     base = run(ctx, args, VARIANTS["layout_preserving"]).float()
-    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies", "hm2_dot2_mailbox"):
+    for name in ("hm_no_staging", "hm_staged_1024", "hm_staged_512", "hm_two_copies", "hm2_dot2_mailbox",
+                 "hm3_padded_lds"):
         o = run(ctx, args, VARIANTS[name]).float()
         # all accumulate in fp32 and store fp16; hm2 additionally carries the per-corner weights
         # as half2 into v_dot2c_f32_f16
-        tol = 6e-3 if name.startswith("hm2") else 2e-3
+        tol = 6e-3 if name.startswith(("hm2", "hm3")) else 2e-3
         assert (o - base).abs().max().item() <= tol, name
     # automatic choice == one of the above, and deterministic
     a = run(ctx, args, 0)
@@ -100,15 +101,21 @@ def test_hm_out_of_view_and_zero_pads(ctx):
     assert torch.isfinite(c).all() and (c.float() - b.float()).abs().max().item() <= 6e-3
     args[2] = args[2] + 7.0
     assert torch.count_nonzero(run(ctx, args, 15)).item() == 0
+    assert torch.count_nonzero(run(ctx, args, 16)).item() == 0
+    for name in ("odd_widths", "small_sca"):            # small_sca: the whole plane lives in LDS
+        args = gen(SHAPES[name])
+        d = run(ctx, args, 16)
+        assert torch.isfinite(d).all()
+        assert (d.float() - run(ctx, args, 10).float()).abs().max().item() <= 6e-3
 
 
-@pytest.mark.parametrize("variant", [0, 10, 11, 15, 99])
+@pytest.mark.parametrize("variant", [0, 10, 11, 15, 16, 99])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 def test_camera_shared_offsets_equal_repeated(ctx, variant, dtype):
     """sampling_offsets / attention_weights passed as stride-0 expanded views (the SCA query is
     the same for every camera, spatial_cross_attention.py:254) must give exactly what the
     materialised repeat gives, on every kernel family."""
-    if dtype == torch.float32 and variant in (11, 15):
+    if dtype == torch.float32 and variant in (11, 15, 16):
         pytest.skip("head-major path is fp16-only")
     bev, lib = ctx
     args = gen((6, [[20, 32], [10, 16], [5, 8], [3, 4]], 2500, 8, 4), ref_lo=-0.2, ref_hi=1.2)
