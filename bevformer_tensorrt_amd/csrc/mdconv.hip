@@ -325,35 +325,63 @@ __device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned w) {
   return __builtin_bit_cast(unsigned, r);
 }
 
-__global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
+// THREADS = 256: 4 waves, each 64 x 64 outputs (the r01c kernel, 206 VGPR, 8 waves per CU).
+// THREADS = 512: 8 waves in a 4 (Cout) x 2 (pixels) grid, each 64 x 32 outputs: half the
+// accumulators, prefetch registers and blend work per thread -> 16 waves per CU to hide the
+// gather / weight-load latency between the two barriers of a k-step.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void dcn_fused_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
     const __half *__restrict__ mask, const __half *__restrict__ wt,
     const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g) {
+  constexpr int NW = THREADS / 64;        // waves
+  constexpr int WN = NW / 4;              // waves along the pixel dimension (1 or 2)
+  constexpr int NJ = kFN / WN / 32;       // 32-pixel MFMA tiles per wave (2 or 1)
+  constexpr int LPP = THREADS / kFN;      // producer lanes per pixel (4 or 8)
+  constexpr int NB = kFK / LPP / 8;       // 16-byte vectors per corner per thread (2 or 1)
+  constexpr int RPP = THREADS / 8;        // weight rows per loader pass (32 or 64)
+  constexpr int NA = kFM / RPP;           // loader passes (8 or 4)
   __shared__ __attribute__((aligned(16))) __half As[kFM][kFLd];
   __shared__ __attribute__((aligned(16))) __half Bs[kFN][kFLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
   const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
   const int HoWo = d.Ho * d.Wo;
   const int N = d.B * HoWo;
-  const int n0 = blockIdx.x * kFN, m0 = blockIdx.y * kFM;
+  // consecutive pixel tiles share input lines (3x3 footprints, neighbouring rows): keep them on
+  // one XCD so its 4 MiB L2 holds ~1/8 of the images + the weights instead of all of it
+  const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * kFN, m0 = blockIdx.y * kFM;
   const int Kg = KK * cin_g;
   const __half *A = wt + (size_t)g * cout_g * Kg;
 
-  // B-producer role: pixel n0 + (tid >> 2), channels [cq*16, cq*16+16) of the 64-chunk
-  const int pn = n0 + (tid >> 2), cq = tid & 3;
+  // B-producer role: pixel n0 + tid / LPP, channels [cq * 8 * NB, +8 * NB) of the 64-chunk
+  const int pn = n0 + tid / LPP, cq = tid % LPP;
   const bool pvalid = pn < N;
   const int pb = pvalid ? pn / HoWo : 0;
   const int ppix = pvalid ? pn - pb * HoWo : 0;
   const int pho = ppix / d.Wo, pwo = ppix - pho * d.Wo;
-  const __half *ximg = xt + (size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 16;
-  // A-loader role: rows (tid >> 3) + 32*i, 16-byte chunk (tid & 7)
+  // A-loader role: rows (tid >> 3) + RPP*i, 16-byte chunk (tid & 7)
   const int ar = tid >> 3, ac = (tid & 7) * 8;
+  // both operands are fetched through buffer descriptors: per-thread byte offsets that only
+  // change with the tap (image) or never (weights) plus a scalar offset per k-step -- no
+  // 64-bit address arithmetic in the k-loop; rows past Cout read as zero (range check)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(xt), 0, (unsigned)((size_t)d.B * d.H * d.W * d.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(A), 0, (unsigned)((size_t)cout_g * Kg * 2), 0x00020000);
+  const unsigned ximg_off = (unsigned)(((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 8 * NB) * 2);
+  unsigned a_off[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = m0 + ar + RPP * i;
+    a_off[i] = r < cout_g ? (unsigned)(((size_t)r * Kg + ac) * 2) : 0xFFFFFFF0u;
+  }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -362,7 +390,30 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
   int fidx[4];
   unsigned fw[4];  // half2 (w, w) = bilinear weight * mask
   int cur_tap = -1, cur_dg = -1;
-  uint4 ra[8], rb[8];
+  uint4 ra[NA], rb[4][NB];
+
+  // all offsets / masks of the tile's 64 pixels (3 * KK values per deform group) are fetched
+  // once into LDS: a tap change then costs ALU only instead of a dependent global round trip
+  // in front of the gather
+  constexpr int kOmMax = 64;
+  __shared__ __half Om[kOmMax][kFN];
+  const int om_per_dg = 3 * KK;
+  const bool om_ok = d.DG * om_per_dg <= kOmMax;
+  if (om_ok) {
+    for (int idx = tid; idx < d.DG * om_per_dg * kFN; idx += THREADS) {
+      const int p = idx % kFN, t = idx / kFN;
+      const int dgi = t / om_per_dg, tt = t - dgi * om_per_dg;
+      const int n = n0 + p;
+      __half v = __float2half(0.f);
+      if (n < N) {
+        const int b = n / HoWo, pix = n - b * HoWo;
+        v = tt < 2 * KK ? offset[(((size_t)b * d.DG + dgi) * 2 * KK + tt) * HoWo + pix]
+                        : mask[(((size_t)b * d.DG + dgi) * KK + (tt - 2 * KK)) * HoWo + pix];
+      }
+      Om[t][p] = v;
+    }
+    __syncthreads();
+  }
 
   auto prefetch = [&](int step) {
     const int tap = step / chunks, c0 = (step - tap * chunks) * kFK;
@@ -371,10 +422,18 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
       cur_tap = tap;
       cur_dg = dg;
       const int i = tap / d.Kw, j = tap - i * d.Kw;
-      const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
-      const float off_h = __half2float(offset[ob + (size_t)(2 * tap) * HoWo]);
-      const float off_w = __half2float(offset[ob + (size_t)(2 * tap + 1) * HoWo]);
-      const float m = __half2float(mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix]);
+      float off_h, off_w, m;
+      if (om_ok) {
+        const int p = tid / LPP;
+        off_h = __half2float(Om[dg * om_per_dg + 2 * tap][p]);
+        off_w = __half2float(Om[dg * om_per_dg + 2 * tap + 1][p]);
+        m = __half2float(Om[dg * om_per_dg + 2 * KK + tap][p]);
+      } else {
+        const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
+        off_h = __half2float(offset[ob + (size_t)(2 * tap) * HoWo]);
+        off_w = __half2float(offset[ob + (size_t)(2 * tap + 1) * HoWo]);
+        m = __half2float(mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix]);
+      }
       const float h_im = (float)(pho * d.sh - d.ph + i * d.dh) + off_h;
       const float w_im = (float)(pwo * d.sw - d.pw + j * d.dw) + off_w;
       const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
@@ -386,66 +445,81 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bool ok = in && hs[q] >= 0 && hs[q] <= d.H - 1 && ws[q] >= 0 && ws[q] <= d.W - 1;
-        fidx[q] = ok ? hs[q] * d.W + ws[q] : 0;
+        fidx[q] = (int)(ximg_off + (unsigned)(ok ? hs[q] * d.W + ws[q] : 0) * (unsigned)(d.Cin * 2));
         const float w = ok ? wq[q] * m : 0.f;
         fw[q] = pack_h2(w, w);
       }
     }
-    const __half *xp = ximg + c0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(xp + (size_t)fidx[q] * d.Cin);
-      rb[2 * q] = p[0];
-      rb[2 * q + 1] = p[1];
-    }
-    const __half *ap = A + (size_t)tap * cin_g + c0 + ac;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = m0 + ar + 32 * i;
-      ra[i] = r < cout_g ? *reinterpret_cast<const uint4 *>(ap + (size_t)r * Kg) : make_uint4(0, 0, 0, 0);
-    }
+      for (int v = 0; v < NB; ++v)
+        rb[q][v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q] + 16 * v, c0 * 2, 0));
+    const int a_s = (tap * cin_g + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
   };
 
+#ifdef DCN_PROFILE
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime(), t1;
+#define TICK(i) { t1 = __builtin_amdgcn_s_memtime(); tacc[i] += t1 - t0; t0 = t1; }
+#else
+#define TICK(i)
+#endif
   prefetch(0);
+  TICK(0)
   for (int step = 0; step < nsteps; ++step) {
-    // blend the 4 corners (packed fp16), 16 channels per thread
-    uint4 b0, b1;
-    b0.x = pk_mul(rb[0].x, fw[0]); b0.y = pk_mul(rb[0].y, fw[0]); b0.z = pk_mul(rb[0].z, fw[0]); b0.w = pk_mul(rb[0].w, fw[0]);
-    b1.x = pk_mul(rb[1].x, fw[0]); b1.y = pk_mul(rb[1].y, fw[0]); b1.z = pk_mul(rb[1].z, fw[0]); b1.w = pk_mul(rb[1].w, fw[0]);
+    // blend the 4 corners (packed fp16), 8 * NB channels per thread
+    uint4 bl[NB];
 #pragma unroll
-    for (int q = 1; q < 4; ++q) {
-      b0.x = pk_fma(rb[2 * q].x, fw[q], b0.x); b0.y = pk_fma(rb[2 * q].y, fw[q], b0.y);
-      b0.z = pk_fma(rb[2 * q].z, fw[q], b0.z); b0.w = pk_fma(rb[2 * q].w, fw[q], b0.w);
-      b1.x = pk_fma(rb[2 * q + 1].x, fw[q], b1.x); b1.y = pk_fma(rb[2 * q + 1].y, fw[q], b1.y);
-      b1.z = pk_fma(rb[2 * q + 1].z, fw[q], b1.z); b1.w = pk_fma(rb[2 * q + 1].w, fw[q], b1.w);
+    for (int v = 0; v < NB; ++v) {
+      bl[v].x = pk_mul(rb[0][v].x, fw[0]); bl[v].y = pk_mul(rb[0][v].y, fw[0]);
+      bl[v].z = pk_mul(rb[0][v].z, fw[0]); bl[v].w = pk_mul(rb[0][v].w, fw[0]);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        bl[v].x = pk_fma(rb[q][v].x, fw[q], bl[v].x); bl[v].y = pk_fma(rb[q][v].y, fw[q], bl[v].y);
+        bl[v].z = pk_fma(rb[q][v].z, fw[q], bl[v].z); bl[v].w = pk_fma(rb[q][v].w, fw[q], bl[v].w);
+      }
     }
+    TICK(1)
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(&As[ar + 32 * i][ac]) = ra[i];
-    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16]) = b0;
-    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16 + 8]) = b1;
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4 *>(&As[ar + RPP * i][ac]) = ra[i];
+#pragma unroll
+    for (int v = 0; v < NB; ++v) *reinterpret_cast<uint4 *>(&Bs[tid / LPP][cq * 8 * NB + 8 * v]) = bl[v];
     __syncthreads();
+    TICK(2)
     if (step + 1 < nsteps) prefetch(step + 1);
+    TICK(3)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kk = ks * 16 + (lane >> 5) * 8;
-      f16x8 a[2], b[2];
+      f16x8 a[2], b[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const f16x8 *>(&As[wave * 64 + i * 32 + (lane & 31)][kk]);
+        a[i] = *reinterpret_cast<const f16x8 *>(&As[wm * 64 + i * 32 + (lane & 31)][kk]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b[j] = *reinterpret_cast<const f16x8 *>(&Bs[j * 32 + (lane & 31)][kk]);
+      for (int j = 0; j < NJ; ++j)
+        b[j] = *reinterpret_cast<const f16x8 *>(&Bs[wn * (kFN / WN) + j * 32 + (lane & 31)][kk]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    TICK(4)
   }
+#ifdef DCN_PROFILE
+  if ((tid & 63) == 0 && blockIdx.x < 64) {
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<__half *>(wt)) + 1000000 +
+                              (blockIdx.x * (THREADS / 64) + wave) * 8;
+    for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
+  }
+#endif
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + j * 32 + (lane & 31);
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wn * (kFN / WN) + j * 32 + (lane & 31);
     if (n >= N) continue;
     const int b = n / HoWo, pix = n - b * HoWo;
     __half *ob = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
@@ -453,13 +527,199 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_f16_kernel(
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < cout_g) {
           float v = acc[i][j][r];
           if (bias) v += __half2float(bias[g * cout_g + m]);
           ob[(size_t)m * HoWo] = __float2half_rn(v);
         }
       }
+  }
+}
+
+
+// ---- 5c. pipelined fused kernel: weights by LDS-DMA, two LDS buffers, one barrier per k-step ----
+// The register-staged kernel above spends a k-step as  wait loads -> blend -> barrier -> 40 KB of
+// ds_write_b128 (13 cycles per wave-instruction) -> barrier -> MFMA: the phase probe
+// (tools/dcn_phase_probe.py) showed 1/3 of the time in the write + barrier phase and the matrix
+// cores 12 % busy.  Here the weight tile (80 % of the staged bytes) goes global -> LDS directly
+// (buffer_load_dwordx4 ... lds, no VGPRs, no ds_write) one step ahead into the other LDS
+// buffer while the MFMAs of the current step run; only the blended pixel tile (8 KB) is
+// written by the threads.  LDS image: 128-byte rows (64 k-values), 16-byte chunks XOR-swizzled
+// by (row ^ row >> 3) & 7 -- the DMA is lane-linear, so the swizzle is applied to the SOURCE
+// address; fragment reads (ds_read_b128) are bank-conflict free.
+//   512 threads = 8 waves, 4 (Cout) x 2 (pixels), wave tile 64 x 32; 80 KB LDS -> 2 blocks per CU.
+// Domain: one deform group per conv group (dg constant over a block's k-loop); else the
+// register-staged kernel runs.
+constexpr int kGA = kFM * kFK * 2;  // 32 KB weight tile image
+constexpr int kGB = kFN * kFK * 2;  // 8 KB pixel tile image
+constexpr int kGldsLds = 2 * (kGA + kGB);
+
+__device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7u; }
+
+__global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
+    const __half *__restrict__ xt, const __half *__restrict__ offset,
+    const __half *__restrict__ mask, const __half *__restrict__ wt,
+    const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
+  const int HoWo = d.Ho * d.Wo;
+  const int N = d.B * HoWo;
+  const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * kFN, m0 = blockIdx.y * kFM;
+  const int Kg = KK * cin_g;
+  const __half *A = wt + (size_t)g * cout_g * Kg;
+  const int dg = (g * cin_g) / (d.Cin / d.DG);
+
+  // pixel-producer role: pixel n0 + (tid >> 3), 8 channels (16 B) cq of the 64-chunk
+  const int pp = tid >> 3, cq = tid & 7;
+  const int pn = n0 + pp;
+  const bool pvalid = pn < N;
+  const int pb = pvalid ? pn / HoWo : 0;
+  const int ppix = pvalid ? pn - pb * HoWo : 0;
+  const int pho = ppix / d.Wo, pwo = ppix - pho * d.Wo;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(xt), 0, (unsigned)((size_t)d.B * d.H * d.W * d.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(A), 0, (unsigned)((size_t)cout_g * Kg * 2), 0x00020000);
+  const unsigned ximg_off = (unsigned)(((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 8) * 2);
+  const unsigned b_dst = (unsigned)(pp * 128 + ((cq ^ swz8(pp)) << 4));
+  // weight DMA role: piece j of this wave = rows (wave*4 + j)*8 .. +8, lane -> (row, chunk)
+  unsigned a_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned row = (unsigned)((wave * 4 + j) * 8 + (lane >> 3));
+    const unsigned chunk = (lane & 7u) ^ swz8(row);
+    a_off[j] = (m0 + (int)row) < cout_g ? (unsigned)(((size_t)(m0 + row) * Kg) * 2 + chunk * 16) : 0xFFFFFFF0u;
+  }
+  // fragment read offsets inside a buffer (k-substep ks adds chunk 2*ks: XOR into the swizzle)
+  unsigned fa[2], fb;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = (unsigned)(wm * 64 + i * 32 + (lane & 31));
+  fb = (unsigned)(wn * 32 + (lane & 31));
+  const unsigned hi = lane >> 5;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int chunks = cin_g / kFK;
+  const int nsteps = KK * chunks;
+  // offsets / mask of the pixel, one tap ahead in registers
+  const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
+  const size_t mb = (((size_t)pb * d.DG + dg) * KK) * HoWo + ppix;
+  auto load_om = [&](int tap, __half &oh, __half &ow, __half &mm) {
+    oh = offset[ob + (size_t)(2 * tap) * HoWo];
+    ow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
+    mm = mask[mb + (size_t)tap * HoWo];
+  };
+  __half n_oh, n_ow, n_mm;
+  load_om(0, n_oh, n_ow, n_mm);
+  int fidx[4];
+  unsigned fw[4];
+  uint4 rb[4];
+  auto footprint = [&](int tap) {
+    const float off_h = __half2float(n_oh), off_w = __half2float(n_ow), m = __half2float(n_mm);
+    if (tap + 1 < KK) load_om(tap + 1, n_oh, n_ow, n_mm);
+    const int i = tap / d.Kw, j = tap - i * d.Kw;
+    const float h_im = (float)(pho * d.sh - d.ph + i * d.dh) + off_h;
+    const float w_im = (float)(pwo * d.sw - d.pw + j * d.dw) + off_w;
+    const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h0 = (int)hf, w0 = (int)wf;
+    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const float wq[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+    const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = in && hs[q] >= 0 && hs[q] <= d.H - 1 && ws[q] >= 0 && ws[q] <= d.W - 1;
+      fidx[q] = (int)(ximg_off + (unsigned)(ok ? hs[q] * d.W + ws[q] : 0) * (unsigned)(d.Cin * 2));
+      const float w = ok ? wq[q] * m : 0.f;
+      fw[q] = pack_h2(w, w);
+    }
+  };
+  typedef __attribute__((address_space(3))) void lds_void;
+  // stage k-step (tap, chunk) into buffer `buf`: weight DMA + gather loads (into rb)
+  auto stage_issue = [&](int tap, int chunk, int buf) {
+    const int c0 = chunk * kFK;
+    const int a_s = (tap * cin_g + c0) * 2;
+    char *adst = smem + buf * kGA + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+  };
+  auto blend_write = [&](int buf) {
+    uint4 bl;
+    bl.x = pk_mul(rb[0].x, fw[0]); bl.y = pk_mul(rb[0].y, fw[0]);
+    bl.z = pk_mul(rb[0].z, fw[0]); bl.w = pk_mul(rb[0].w, fw[0]);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      bl.x = pk_fma(rb[q].x, fw[q], bl.x); bl.y = pk_fma(rb[q].y, fw[q], bl.y);
+      bl.z = pk_fma(rb[q].z, fw[q], bl.z); bl.w = pk_fma(rb[q].w, fw[q], bl.w);
+    }
+    *reinterpret_cast<uint4 *>(smem + 2 * kGA + buf * kGB + b_dst) = bl;
+  };
+
+  // prologue: step 0 -> buffer 0
+  footprint(0);
+  stage_issue(0, 0, 0);
+  blend_write(0);  // (the compiler waits for rb here)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int tap = 0, chunk = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    // next step's coordinates
+    int ntap = tap, nchunk = chunk + 1;
+    if (nchunk == chunks) { nchunk = 0; ++ntap; }
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      if (ntap != tap) footprint(ntap);
+      stage_issue(ntap, nchunk, buf ^ 1);
+    }
+    const char *Ab = smem + buf * kGA;
+    const char *Bb = smem + 2 * kGA + buf * kGB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned c = 2u * ks + hi;
+      f16x8 a[2], b;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const f16x8 *>(Ab + fa[i] * 128 + ((c ^ swz8(fa[i])) << 4));
+      b = *reinterpret_cast<const f16x8 *>(Bb + fb * 128 + ((c ^ swz8(fb)) << 4));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b, acc[i], 0, 0, 0);
+    }
+    if (more) blend_write(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    tap = ntap;
+    chunk = nchunk;
+  }
+  {
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < N) {
+      const int b = n / HoWo, pix = n - b * HoWo;
+      __half *obp = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < cout_g) {
+            float v = acc[i][r];
+            if (bias) v += __half2float(bias[g * cout_g + m]);
+            obp[(size_t)m * HoWo] = __float2half_rn(v);
+          }
+        }
+    }
   }
 }
 
@@ -678,6 +938,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   const int HW = d.H * d.W, KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
   const size_t N = (size_t)d.B * d.Ho * d.Wo;
   if (N > 0x7FFFFFFFull || (size_t)d.B * d.Cin * HW > 0x7FFFFFFF00ull) return BEVOPS_NOT_SUPPORTED;
+  const bool fits32 = (size_t)d.B * d.Cin * HW * 2 < 0xFFFFFF00ull && (size_t)d.Cout * cin_g * KK * 2 < 0xFFFFFF00ull;
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
                      0, st, (const T *)input, xt, d.Cin, HW);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
@@ -685,11 +946,30 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
                      (const T *)weight, wt, d.Cout, cin_g, KK, KK * cin_g);
   if constexpr (sizeof(T) == 2) {
     // fused implicit GEMM: a 64-channel K chunk must sit inside one group and one deform group
-    if (g_mdconv_variant != 1 && cin_g % kFK == 0 && (d.Cin / d.DG) % kFK == 0) {
-      for (int g = 0; g < d.G; ++g)
-        hipLaunchKernelGGL(dcn_fused_f16_kernel, dim3((unsigned)((N + kFN - 1) / kFN), (cout_g + kFM - 1) / kFM),
-                           dim3(256), 0, st, (const __half *)xt, (const __half *)offset, (const __half *)mask,
-                           (const __half *)wt, (const __half *)bias, (__half *)output, d, g);
+    if (g_mdconv_variant != 1 && fits32 && cin_g % kFK == 0 && (d.Cin / d.DG) % kFK == 0) {
+      const dim3 grid((unsigned)((N + kFN - 1) / kFN), (cout_g + kFM - 1) / kFM);
+      for (int g = 0; g < d.G; ++g) {
+        const bool one_dg = cin_g <= d.Cin / d.DG && (g * cin_g) / (d.Cin / d.DG) == (g * cin_g + cin_g - 1) / (d.Cin / d.DG);
+        if (g_mdconv_variant == 0 && one_dg) {
+          static thread_local bool attr_set = false;
+          if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_f16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kGldsLds) != hipSuccess)
+              return BEVOPS_FAILURE;
+            attr_set = true;
+          }
+          hipLaunchKernelGGL(dcn_glds_f16_kernel, grid, dim3(512), kGldsLds, st, (const __half *)xt,
+                             (const __half *)offset, (const __half *)mask, (const __half *)wt,
+                             (const __half *)bias, (__half *)output, d, g);
+        } else if (g_mdconv_variant == 2)  // A/B: the 4-wave block of r01c
+          hipLaunchKernelGGL(dcn_fused_f16_kernel<256>, grid, dim3(256), 0, st, (const __half *)xt,
+                             (const __half *)offset, (const __half *)mask, (const __half *)wt,
+                             (const __half *)bias, (__half *)output, d, g);
+        else
+          hipLaunchKernelGGL(dcn_fused_f16_kernel<512>, grid, dim3(512), 0, st, (const __half *)xt,
+                             (const __half *)offset, (const __half *)mask, (const __half *)wt,
+                             (const __half *)bias, (__half *)output, d, g);
+      }
       return launch_status();
     }
   }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage: tools/pmc_dcn.sh <tag> <variant>  -> gpurun_out/<tag>/
+TAG=$1; VAR=$2
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+           "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE" \
+           "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
+           "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_INSTS_WAVE32_LDS"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o x -- python $GRAFT_REPO_ROOT/tools/dcn_one.py $VAR 3 > $OUT/p$i.log 2>&1
+done
+python3 - <<PY
+import csv,glob,collections
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in agg.items():
+    if "dcn" not in k: continue
+    print(k)
+    for c,vals in sorted(v.items()): print("   %-36s %.4g  (n=%d)"%(c,sum(vals)/len(vals),len(vals)))
+PY
+grep -l "rror" $OUT/p*.log | head
