@@ -557,17 +557,37 @@ constexpr int kGldsLds = 2 * (kGA + kGB);
 
 __device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7u; }
 
+// Tail handling: when the tile count leaves a sparsely filled last round (base stage 3: 544 tiles
+// on 512 resident blocks -- a round costs the same ~36 dependent k-steps however few blocks run),
+// the leftover `tail_tiles` tiles are split `split` ways along K (whole taps) into short blocks
+// that come FIRST in the grid; each writes its fp32 partial accumulators to the workspace and
+// dcn_tail_finish_kernel adds them in a fixed order (deterministic, no atomics).
+struct TailPlan {
+  int tail_tiles, split, main_tiles;  // grid.x = tail_tiles * split + main_tiles
+  float *partial;                     // [split][tail_tiles][512 threads][32]
+};
+
 __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
     const __half *__restrict__ mask, const __half *__restrict__ wt,
-    const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g) {
+    const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g, TailPlan tp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
   const int HoWo = d.Ho * d.Wo;
   const int N = d.B * HoWo;
-  const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * kFN, m0 = blockIdx.y * kFM;
+  // block -> (pixel tile, k-range)
+  const int n_tail_blocks = tp.tail_tiles * tp.split;
+  const bool is_tail = (int)blockIdx.x < n_tail_blocks;
+  int ntile, part = 0;
+  if (is_tail) {
+    ntile = tp.main_tiles + (int)blockIdx.x / tp.split;
+    part = (int)blockIdx.x % tp.split;
+  } else {
+    ntile = (int)xcd_remap(blockIdx.x - n_tail_blocks, tp.main_tiles);
+  }
+  const int n0 = ntile * kFN, m0 = blockIdx.y * kFM;
   const int Kg = KK * cin_g;
   const __half *A = wt + (size_t)g * cout_g * Kg;
   const int dg = (g * cin_g) / (d.Cin / d.DG);
@@ -607,7 +627,6 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int chunks = cin_g / kFK;
-  const int nsteps = KK * chunks;
   // offsets / mask of the pixel, one tap ahead in registers
   const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
   const size_t mb = (((size_t)pb * d.DG + dg) * KK) * HoWo + ppix;
@@ -616,14 +635,20 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     ow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
     mm = mask[mb + (size_t)tap * HoWo];
   };
+  const int taps_per_part = is_tail ? KK / tp.split : KK;
+  // all resident blocks walk the same 1.2 MB weight matrix: start each tile at a different tap
+  // (and wrap) so that they do not all pull the same 32 KB slice from the same L2 channels in
+  // the same k-step.  The fp32 summation order then depends on the tile index only.
+  const int tap_begin = is_tail ? part * taps_per_part : ntile % KK;
+  const int n_my_steps = taps_per_part * chunks;
   __half n_oh, n_ow, n_mm;
-  load_om(0, n_oh, n_ow, n_mm);
+  load_om(tap_begin, n_oh, n_ow, n_mm);
   int fidx[4];
   unsigned fw[4];
   uint4 rb[4];
   auto footprint = [&](int tap) {
     const float off_h = __half2float(n_oh), off_w = __half2float(n_ow), m = __half2float(n_mm);
-    if (tap + 1 < KK) load_om(tap + 1, n_oh, n_ow, n_mm);
+    load_om(tap + 1 < KK ? tap + 1 : 0, n_oh, n_ow, n_mm);
     const int i = tap / d.Kw, j = tap - i * d.Kw;
     const float h_im = (float)(pho * d.sh - d.ph + i * d.dh) + off_h;
     const float w_im = (float)(pwo * d.sw - d.pw + j * d.dw) + off_w;
@@ -666,20 +691,20 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     *reinterpret_cast<uint4 *>(smem + 2 * kGA + buf * kGB + b_dst) = bl;
   };
 
-  // prologue: step 0 -> buffer 0
-  footprint(0);
-  stage_issue(0, 0, 0);
+  // prologue: first step -> buffer 0
+  footprint(tap_begin);
+  stage_issue(tap_begin, 0, 0);
   blend_write(0);  // (the compiler waits for rb here)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  int tap = 0, chunk = 0;
-  for (int step = 0; step < nsteps; ++step) {
+  int tap = tap_begin, chunk = 0;
+  for (int step = 0; step < n_my_steps; ++step) {
     const int buf = step & 1;
     // next step's coordinates
     int ntap = tap, nchunk = chunk + 1;
-    if (nchunk == chunks) { nchunk = 0; ++ntap; }
-    const bool more = step + 1 < nsteps;
+    if (nchunk == chunks) { nchunk = 0; ntap = tap + 1 < KK ? tap + 1 : 0; }
+    const bool more = step + 1 < n_my_steps;
     if (more) {
       if (ntap != tap) footprint(ntap);
       stage_issue(ntap, nchunk, buf ^ 1);
@@ -703,6 +728,16 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     tap = ntap;
     chunk = nchunk;
   }
+  if (is_tail) {  // fp32 partials, thread-private order (the finish kernel uses the same mapping)
+    float4 *pp = reinterpret_cast<float4 *>(tp.partial) +
+                 ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * 512 + tid;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pp[(i * 4 + r) * 512] = make_float4(acc[i][4 * r], acc[i][4 * r + 1], acc[i][4 * r + 2], acc[i][4 * r + 3]);
+    return;
+  }
   {
     const int n = n0 + wn * 32 + (lane & 31);
     if (n < N) {
@@ -719,6 +754,40 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
             obp[(size_t)m * HoWo] = __float2half_rn(v);
           }
         }
+    }
+  }
+}
+
+
+// grid (tail tiles, Cout tiles, 8): block z sums accumulator quad z = i*4 + r of every thread
+__global__ __launch_bounds__(512) void dcn_tail_finish_kernel(const __half *__restrict__ bias,
+                                                              __half *__restrict__ out, ConvDims d,
+                                                              int g, TailPlan tp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int cout_g = d.Cout / d.G, HoWo = d.Ho * d.Wo, N = d.B * HoWo;
+  const int ntile = tp.main_tiles + blockIdx.x;
+  const int n0 = ntile * kFN, m0 = blockIdx.y * kFM;
+  const int quad = blockIdx.z, i = quad >> 2, rq = quad & 3;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int part = 0; part < tp.split; ++part) {
+    const float4 v = reinterpret_cast<const float4 *>(tp.partial)[
+        ((((size_t)part * tp.tail_tiles + blockIdx.x) * gridDim.y + blockIdx.y) * 8 + quad) * 512 + tid];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int n = n0 + wn * 32 + (lane & 31);
+  if (n >= N) return;
+  const int b = n / HoWo, pix = n - b * HoWo;
+  __half *obp = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
+  const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = rq * 4 + e;
+    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < cout_g) {
+      float v = av[e];
+      if (bias) v += __half2float(bias[g * cout_g + m]);
+      obp[(size_t)m * HoWo] = __float2half_rn(v);
     }
   }
 }
@@ -893,6 +962,7 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
            float s_mask, float s_w, float s_out, hipStream_t st);
 
 thread_local int g_mdconv_variant = 0;
+thread_local bool g_mdconv_no_tail = false;  // variant 4: LDS-DMA kernel without the split-K tail
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -908,6 +978,8 @@ bool make_dims(ConvDims &d, int B, int Cin, int H, int W, int Cout, int Kh, int 
   d = ConvDims{B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo};
   return true;
 }
+
+int glds_resident_blocks();
 
 struct WsLayout {
   size_t xt, wt, col, total;
@@ -925,6 +997,20 @@ WsLayout ws_layout(const ConvDims &d, size_t es) {
   w.col = w.wt + align256((size_t)d.Cout * kp * es);
   w.total = w.col + align256((size_t)d.B * d.Ho * d.Wo * d.G * kp * es);
   return w;
+}
+
+int glds_resident_blocks() {
+  static thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev == cached_dev) return cached;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_f16_kernel, 512, kGldsLds) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  cached_dev = dev;
+  cached = per_cu * cus;
+  return cached;
 }
 
 template <typename T>
@@ -958,9 +1044,30 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
               return BEVOPS_FAILURE;
             attr_set = true;
           }
-          hipLaunchKernelGGL(dcn_glds_f16_kernel, grid, dim3(512), kGldsLds, st, (const __half *)xt,
+          // tail plan: leftover tiles of a sparsely filled last round are split along K
+          TailPlan tp{0, 1, (int)grid.x, nullptr};
+          const int slots = glds_resident_blocks();
+          const int blocks = (int)(grid.x * grid.y);
+          if (g_mdconv_variant == 0 && !g_mdconv_no_tail && slots > 0 && blocks > slots && grid.y == 1) {
+            const int left = blocks % slots;
+            int split = 0;
+            for (int f = KK; f >= 2; --f)
+              if (KK % f == 0 && left * f <= slots) { split = f; break; }
+            const size_t need = (size_t)split * left * 512 * 32 * sizeof(float);
+            if (left > 0 && left * 2 <= slots && split >= 2 && w.total - w.col >= need) {
+              tp.tail_tiles = left;
+              tp.split = split;
+              tp.main_tiles = (int)grid.x - left;
+              tp.partial = reinterpret_cast<float *>(ws + w.col);
+            }
+          }
+          const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
+          hipLaunchKernelGGL(dcn_glds_f16_kernel, grid2, dim3(512), kGldsLds, st, (const __half *)xt,
                              (const __half *)offset, (const __half *)mask, (const __half *)wt,
-                             (const __half *)bias, (__half *)output, d, g);
+                             (const __half *)bias, (__half *)output, d, g, tp);
+          if (tp.tail_tiles)
+            hipLaunchKernelGGL(dcn_tail_finish_kernel, dim3((unsigned)tp.tail_tiles, grid.y, 8), dim3(512), 0, st,
+                               (const __half *)bias, (__half *)output, d, g, tp);
         } else if (g_mdconv_variant == 2)  // A/B: the 4-wave block of r01c
           hipLaunchKernelGGL(dcn_fused_f16_kernel<256>, grid, dim3(256), 0, st, (const __half *)xt,
                              (const __half *)offset, (const __half *)mask, (const __half *)wt,
@@ -1061,8 +1168,9 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
 using namespace bevops;
 
 extern "C" int bevops_mdconv_set_variant(int variant) {
-  const int prev = g_mdconv_variant;
-  g_mdconv_variant = variant;
+  const int prev = g_mdconv_no_tail ? 4 : g_mdconv_variant;
+  g_mdconv_no_tail = variant == 4;
+  g_mdconv_variant = variant == 4 ? 0 : variant;
   return prev;
 }
 

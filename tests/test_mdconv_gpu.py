@@ -111,6 +111,31 @@ def test_fused_matches_im2col_pipeline(bev, name):
     assert (fused - two).abs().max().item() <= 1e-2 * scale
 
 
+@pytest.mark.parametrize("shape", [(6, 256, 256, 58, 100), (6, 512, 512, 29, 50), (5, 64, 128, 61, 93)])
+def test_lds_dma_kernel_and_split_k_tail_match_register_staged_kernel(bev, shape):
+    """Full-size fp16 calls: the default (weights by LDS-DMA; leftover tiles of a sparse last round
+    split along K, partials summed in a fixed order by a finish kernel) vs the same kernel
+    without the tail split (variant 4) vs the register-staged kernel of r01c (variant 2).  Same
+    fp16 blend; the tail only changes the fp32 summation order.  Deterministic run to run."""
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    B, Cin, Cout, H, W = shape
+    x, off, mask, w, b = (t.half().cuda() for t in make(B, Cin, Cout, H, W, 3, 1, 1, 1, 1, 1, off_std=2.0))
+    args = (x, off, mask, w, b, 1, 1, 1, 1, 1)
+    outs = {}
+    for v in (0, 4, 2):
+        try:
+            lib.bevops_mdconv_set_variant(v)
+            outs[v] = bev.modulated_deformable_conv2d(*args)
+        finally:
+            lib.bevops_mdconv_set_variant(0)
+    scale = max(1.0, outs[2].abs().max().item())
+    assert (outs[0].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale
+    assert (outs[4].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale
+    for _ in range(3):
+        assert torch.equal(bev.modulated_deformable_conv2d(*args), outs[0])
+
+
 def _q(x, s=None):
     s = float(x.abs().max()) / 127.0 if s is None else s
     return torch.clamp(torch.round(x / s), -127, 127).to(torch.int8), s
