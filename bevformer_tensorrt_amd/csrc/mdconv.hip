@@ -1015,7 +1015,8 @@ int glds_resident_blocks() {
 
 template <typename T>
 int run(const void *input, const void *offset, const void *mask, const void *weight,
-        const void *bias, void *output, void *workspace, const ConvDims &d, hipStream_t st) {
+        const void *bias, void *output, void *workspace, const ConvDims &d, hipStream_t st,
+        bool weight_is_packed = false) {
   const WsLayout w = ws_layout(d, sizeof(T));
   char *ws = static_cast<char *>(workspace);
   T *xt = reinterpret_cast<T *>(ws + w.xt);
@@ -1028,8 +1029,11 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
                      0, st, (const T *)input, xt, d.Cin, HW);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
-  hipLaunchKernelGGL((repack_weight_kernel<T>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
-                     (const T *)weight, wt, d.Cout, cin_g, KK, KK * cin_g);
+  if (weight_is_packed)  // [Cout][tap][Cin/groups] image made by bevops_mdconv_pack_weight
+    wt = const_cast<T *>(static_cast<const T *>(weight));
+  else
+    hipLaunchKernelGGL((repack_weight_kernel<T>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
+                       (const T *)weight, wt, d.Cout, cin_g, KK, KK * cin_g);
   if constexpr (sizeof(T) == 2) {
     // fused implicit GEMM: a 64-channel K chunk must sit inside one group and one deform group
     if (g_mdconv_variant != 1 && fits32 && cin_g % kFK == 0 && (d.Cin / d.DG) % kFK == 0) {
@@ -1207,12 +1211,35 @@ extern "C" int bevops_mdconv_forward_int8(const void *input, float scale_in, con
                 scale_mask, scale_weight, scale_out, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int bevops_mdconv_forward(int dtype, const void *input, const void *offset,
-                                     const void *mask, const void *weight, const void *bias,
-                                     void *output, void *workspace, size_t workspace_bytes, int B,
-                                     int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
-                                     int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                                     int groups, int deform_groups, void *stream) {
+extern "C" size_t bevops_mdconv_packed_weight_size(int dtype, int Cout, int Cin_per_group, int Kh,
+                                                   int Kw) {
+  if ((dtype != BEVOPS_F32 && dtype != BEVOPS_F16) || Cout <= 0 || Cin_per_group <= 0 || Kh <= 0 || Kw <= 0)
+    return 0;
+  return (size_t)Cout * Cin_per_group * Kh * Kw * (dtype == BEVOPS_F32 ? 4 : 2);
+}
+
+extern "C" int bevops_mdconv_pack_weight(int dtype, const void *weight, void *packed, int Cout,
+                                         int Cin_per_group, int Kh, int Kw, void *stream) {
+  if (!weight || !packed) return BEVOPS_BAD_PARAM;
+  if (bevops_mdconv_packed_weight_size(dtype, Cout, Cin_per_group, Kh, Kw) == 0) return BEVOPS_BAD_PARAM;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int KK = Kh * Kw;
+  const size_t wtot = (size_t)Cout * Cin_per_group * KK;
+  const dim3 grid((unsigned)((wtot + 255) / 256));
+  if (dtype == BEVOPS_F32)
+    hipLaunchKernelGGL((repack_weight_kernel<float>), grid, dim3(256), 0, st, (const float *)weight,
+                       (float *)packed, Cout, Cin_per_group, KK, KK * Cin_per_group);
+  else
+    hipLaunchKernelGGL((repack_weight_kernel<__half>), grid, dim3(256), 0, st, (const __half *)weight,
+                       (__half *)packed, Cout, Cin_per_group, KK, KK * Cin_per_group);
+  return launch_status();
+}
+
+static int mdconv_forward_impl(int dtype, const void *input, const void *offset, const void *mask,
+                               const void *weight, const void *bias, void *output, void *workspace,
+                               size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
+                               int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                               int dil_w, int groups, int deform_groups, void *stream, bool packed) {
   if (!input || !offset || !mask || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
   ConvDims d;
   if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
@@ -1220,9 +1247,32 @@ extern "C" int bevops_mdconv_forward(int dtype, const void *input, const void *o
     return BEVOPS_BAD_PARAM;
   if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
   if (workspace_bytes < ws_layout(d, dtype == BEVOPS_F32 ? 4 : 2).total) return BEVOPS_BAD_PARAM;
-  if (!aligned16(workspace)) return BEVOPS_BAD_PARAM;
+  if (!aligned16(workspace) || (packed && !aligned16(weight))) return BEVOPS_BAD_PARAM;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == BEVOPS_F32)
-    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st);
-  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st);
+    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st, packed);
+  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st, packed);
+}
+
+extern "C" int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,
+                                            const void *mask, const void *packed_weight,
+                                            const void *bias, void *output, void *workspace,
+                                            size_t workspace_bytes, int B, int Cin, int H, int W,
+                                            int Cout, int Kh, int Kw, int stride_h, int stride_w,
+                                            int pad_h, int pad_w, int dil_h, int dil_w, int groups,
+                                            int deform_groups, void *stream) {
+  return mdconv_forward_impl(dtype, input, offset, mask, packed_weight, bias, output, workspace,
+                             workspace_bytes, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h,
+                             pad_w, dil_h, dil_w, groups, deform_groups, stream, true);
+}
+
+extern "C" int bevops_mdconv_forward(int dtype, const void *input, const void *offset,
+                                     const void *mask, const void *weight, const void *bias,
+                                     void *output, void *workspace, size_t workspace_bytes, int B,
+                                     int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
+                                     int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                     int groups, int deform_groups, void *stream) {
+  return mdconv_forward_impl(dtype, input, offset, mask, weight, bias, output, workspace, workspace_bytes,
+                             B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                             groups, deform_groups, stream, false);
 }

@@ -4,6 +4,25 @@ import torch
 from torch.nn.modules.utils import _pair
 
 from ..utils import lib as _lib
+from .multi_scale_deformable_attn import _TensorCache
+
+# weight tensor -> its [Cout][tap][Cin/groups] image (made once per weight version; inference
+# calls the op with the same parameters frame after frame)
+_PACKED = _TensorCache()
+
+
+def _packed_weight(handle, weight, dt):
+    hit = _PACKED.get(weight)
+    if hit is not None:
+        return hit
+    Cout, cin_g, Kh, Kw = weight.shape
+    nbytes = handle.bevops_mdconv_packed_weight_size(dt, Cout, cin_g, Kh, Kw)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        st = handle.bevops_mdconv_pack_weight(dt, weight.data_ptr(), packed.data_ptr(), Cout, cin_g, Kh, Kw,
+                                              _lib.current_stream_ptr(weight.device))
+    _lib.check(st, "bevops_mdconv_pack_weight")
+    return _PACKED.put(weight, packed)
 
 
 def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups, deform_groups):
@@ -13,6 +32,7 @@ def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups
     handle = _lib.load_library()
     # dtype follows `offset`, as the reference does (:73-75)
     input = input.type_as(offset).contiguous()
+    w_src = weight
     weight = weight.type_as(input).contiguous()
     mask = mask.type_as(input).contiguous()
     offset = offset.contiguous()
@@ -34,11 +54,19 @@ def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups
         raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device)
+    # the cache is keyed on the caller's tensor object; a converted / re-laid-out temporary
+    # (weight is not w_src) would never hit, so it takes the per-call path
+    packed = None
+    if weight is w_src:
+        packed = _PACKED.get(weight)
+        if packed is None and not torch.cuda.is_current_stream_capturing():
+            packed = _packed_weight(handle, weight, dt)
     with torch.cuda.device(input.device):
-        st = handle.bevops_mdconv_forward(
-            dt, input.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(), ws.data_ptr(), ws_bytes,
-            *dims, _lib.current_stream_ptr(input.device))
+        fn = handle.bevops_mdconv_forward_packed if packed is not None else handle.bevops_mdconv_forward
+        st = fn(dt, input.data_ptr(), offset.data_ptr(), mask.data_ptr(),
+                packed.data_ptr() if packed is not None else weight.data_ptr(),
+                bias.data_ptr() if bias is not None else None, out.data_ptr(), ws.data_ptr(), ws_bytes,
+                *dims, _lib.current_stream_ptr(input.device))
     _lib.check(st, "bevops_mdconv_forward")
     return out
 

@@ -216,6 +216,20 @@ int bevops_mdconv_forward(int dtype, const void *input, const void *offset, cons
                           size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
                           int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                           int dil_w, int groups, int deform_groups, void *stream);
+/* Inference keeps the same weights call after call: the [Cout][tap][Cin/groups] re-layout that
+ * bevops_mdconv_forward makes inside its workspace on every call can be made once
+ * (the reference builds its weight tensors once in the plugin constructor,
+ * modulatedDeformableConv2dPlugin.cpp:33-71).  F32 / F16; `packed` holds
+ * bevops_mdconv_packed_weight_size bytes, 16-byte aligned. */
+size_t bevops_mdconv_packed_weight_size(int dtype, int Cout, int Cin_per_group, int Kh, int Kw);
+int bevops_mdconv_pack_weight(int dtype, const void *weight, void *packed, int Cout,
+                              int Cin_per_group, int Kh, int Kw, void *stream);
+int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,
+                                 const void *mask, const void *packed_weight, const void *bias,
+                                 void *output, void *workspace, size_t workspace_bytes, int B,
+                                 int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
+                                 int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                 int groups, int deform_groups, void *stream);
 
 #ifdef __cplusplus
 }

@@ -165,3 +165,19 @@ def test_mdconv_int8_vs_oracle(bev, oracle_mod, name, with_bias):
     d = np.abs(got - want)
     assert d.max() <= 1 and (d > 0).mean() <= 0.01, (d.max(), (d > 0).mean())
     assert np.abs(got * s_out - ref).mean() <= 0.05 * float(np.abs(ref).max())
+
+
+def test_packed_weight_cache_tracks_weight_updates(bev):
+    """The functional wrapper caches the re-laid-out weights per weight tensor; an in-place
+    update of the weights (new version) must not serve the stale image."""
+    c = CASES["r101_stage3"]
+    x, off, mask, w, b = (t.half().cuda() for t in make(**c))
+    args = lambda ww: (x, off, mask, ww, b, c["stride"], c["pad"], c["dil"], c["g"], c["dg"])
+    a1 = bev.modulated_deformable_conv2d(*args(w))
+    a2 = bev.modulated_deformable_conv2d(*args(w))          # cache hit
+    assert torch.equal(a1, a2)
+    w.mul_(0.5)                                             # same object, new version
+    a3 = bev.modulated_deformable_conv2d(*args(w))
+    fresh = bev.modulated_deformable_conv2d(*args(w.clone()))
+    assert torch.equal(a3, fresh)
+    assert not torch.equal(a3, a1)
