@@ -79,8 +79,10 @@ def test_graph_replay_equals_eager():
     for (bev_a, cls_a, crd_a), (bev_b, cls_b, crd_b) in zip(a, b):
         # same kernels, but MIOpen / hipBLASLt may pick other algorithms under capture:
         # fp16 rounding noise through 3 transformer layers, not a dataflow difference
-        assert (bev_a - bev_b).abs().max().item() <= 2e-2
-        assert (cls_a - cls_b).abs().max().item() <= 2e-2
+        for x, y in ((bev_a, bev_b), (cls_a, cls_b)):
+            scale = max(1.0, x.abs().max().item())
+            assert (x - y).abs().max().item() <= 4e-2 * scale
+            assert (x - y).abs().mean().item() <= 4e-3 * scale
 
 
 def test_point_sampling_fma_projection_matches_matmul():

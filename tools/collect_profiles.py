@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copy the judged evidence of one tools/gpu_round.sh visit into profiles/<round>/.
+usage: tools/collect_profiles.py gpurun_out/<tag> profiles/<round>"""
+import collections, csv, glob, json, os, re, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return name.split("(")[0].strip()
+
+
+stats = glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "rocprofv3_bench_kernel_stats.csv"))
+per = collections.defaultdict(dict)
+for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    vals = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            key = f'{short(r["Kernel_Name"])} grid={r.get("Grid_Size", "?")}'
+            vals[key].append(float(r["Counter_Value"]))
+    for k, v in vals.items():
+        per[k][f"{counter}_KiB_avg"] = round(sum(v) / len(v), 1)
+        per[k][f"dispatches_{counter}"] = len(v)
+if per:
+    json.dump(per, open(os.path.join(dst, "rocprofv3_pmc_fetch_write_per_kernel.json"), "w"), indent=1)
+for name, out in (("bench.json", "bench_n1.json"), ("sweep.jsonl", "msda_sweep.jsonl"),
+                  ("model_bench.jsonl", "model_bench.jsonl"), ("dcn_time.jsonl", "dcn_time.jsonl"),
+                  ("pytest.log", "pytest_gpu_tail.log")):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        lines = [l for l in open(p) if "amdgpu.ids" not in l]
+        open(os.path.join(dst, out), "w").writelines(lines)
+print(sorted(os.listdir(dst)))
