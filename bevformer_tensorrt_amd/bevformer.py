@@ -194,10 +194,15 @@ class SpatialCrossAttention(nn.Module):
         ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
         if cams is not None:  # camera-sharded: this rank's cameras only
             ref = ref[cams]
-        queries = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
-        if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
-            queries = gather(queries)
-        slots = (queries * bev_mask).sum(0, keepdim=True)
+        fused = getattr(self.ops, "spatial_cross_attention_sample", None)
+        if fused is not None and gather is None and value.dtype == torch.float16:
+            # one call: camera-shared offsets, invisible (camera, query) pairs skipped, masked sum
+            slots = fused(value, spatial_shapes, ref, off[:1], w[:1], bev_mask)
+        else:
+            queries = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
+            if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
+                queries = gather(queries)
+            slots = (queries * bev_mask).sum(0, keepdim=True)
         return self.output_proj(slots) + inp_residual
 
 

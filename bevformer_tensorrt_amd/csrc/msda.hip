@@ -649,6 +649,44 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
   return a > b ? a : b;
 }
 
+extern "C" size_t bevops_sca_workspace_size(int dtype, const int32_t *spatial_shapes_host, int num_cams,
+                                            int nk, int heads, int channels, int num_levels,
+                                            int num_query, int num_point) {
+  if (dtype != BEVOPS_F16 || !spatial_shapes_host || num_cams <= 0 || nk <= 0 || heads <= 0 ||
+      num_levels <= 0 || num_query <= 0 || num_point <= 0)
+    return 0;
+  return msda_hm3_sca_workspace_bytes(spatial_shapes_host, num_cams, heads, channels, num_levels,
+                                      num_query, num_point);
+}
+
+extern "C" int bevops_sca_forward(int dtype, const void *value, const int32_t *spatial_shapes_host,
+                                  const void *reference_points_cam, const void *sampling_offsets,
+                                  const void *attention_weights, const void *bev_mask, void *output,
+                                  int num_cams, int nk, int heads, int channels, int num_levels,
+                                  int num_query, int num_point, int points_per_group,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (!value || !spatial_shapes_host || !reference_points_cam || !sampling_offsets ||
+      !attention_weights || !bev_mask || !output)
+    return BEVOPS_BAD_PARAM;
+  if (num_cams <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0 || points_per_group <= 0)
+    return BEVOPS_BAD_PARAM;
+  long total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const long H = spatial_shapes_host[2 * l], W = spatial_shapes_host[2 * l + 1];
+    if (H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
+    total += H * W;
+  }
+  if (total != nk) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  return msda_hm3_sca_forward_f16((const __half *)value, spatial_shapes_host,
+                                  (const __half *)reference_points_cam, (const __half *)sampling_offsets,
+                                  (const __half *)attention_weights, (const __half *)bev_mask,
+                                  (__half *)output, num_cams, nk, heads, channels, num_levels, num_query,
+                                  num_point, points_per_group, workspace, workspace_bytes,
+                                  static_cast<hipStream_t>(stream));
+}
+
 extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
                                    const int32_t *spatial_shapes_host,
                                    const void *reference_points, int ref_dtype,

@@ -183,4 +183,10 @@ int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const 
                          const __half *off, const __half *logit, __half *out, int bs, int nk,
                          int heads, int C, int L, int nq, int P, int ppg, int shared,
                          void *workspace, size_t workspace_bytes, hipStream_t st);
+size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
+                                    int P);
+int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,
+                             const __half *off, const __half *logit, const __half *qmask,
+                             __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
+                             int ppg, void *workspace, size_t workspace_bytes, hipStream_t st);
 }  // namespace bevops

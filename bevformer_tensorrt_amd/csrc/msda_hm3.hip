@@ -172,12 +172,16 @@ __device__ __forceinline__ void taps_lds(const char *smem, const char *box, unsi
 constexpr int kTabEnt = 32;
 constexpr int kTab = kHm3MaxLevels * kTabEnt;
 
-template <int LP, int THREADS>
+// MASKED (fused SCA, bevops_sca_forward): `qmask` [bs, nq] holds the camera-visibility weight of
+// every (batch = camera, query) pair; pairs with weight 0 are skipped altogether (no loads, no
+// math, no store) -- the block first compacts its chunk of queries to the visible ones, the
+// way the original PyTorch SCA rebatches (third_party/.../spatial_cross_attention.py:143-191).
+template <int LP, int THREADS, bool MASKED>
 __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off,
     const __half *__restrict__ logit, __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk,
-    int nchunk, int stage_bytes) {
+    int nchunk, int stage_bytes, const __half *__restrict__ qmask) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
   constexpr int PP = LP / NOWN;           // points per owner
   constexpr int MB = LP >= 8 ? 8 : LP;    // points per mailbox phase
@@ -252,15 +256,45 @@ __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
   struct Pre { unsigned lg[NLG], of[PP], rf[PP]; };
   const int aux = (LP >= 32 && !d.shared) ? 2 : 0;  // read-once full lines: non-temporal
   constexpr unsigned kStride = THREADS / 8;
-  unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3);
-  const unsigned item0 = (b * (unsigned)d.nq + q) * (unsigned)d.heads + h;
-  const unsigned in0 = ((d.shared ? 0u : b) * (unsigned)d.nq + q) * (unsigned)d.heads + h;
-  unsigned o_lg = (in0 * LP + lane8 * PP) * 2u, o_of = (in0 * LP + lane8 * PP) * 4u;
-  unsigned o_rf = (b * (unsigned)d.nq + q) * (unsigned)d.ppg * 4u;
-  __half *outp = out + (size_t)item0 * 32u + lane8 * 4u;
-  const unsigned s_lg = kStride * (unsigned)d.heads * LP * 2u, s_of = 2u * s_lg;
-  const unsigned s_rf = kStride * (unsigned)d.ppg * 4u;
-  const size_t s_out = (size_t)kStride * d.heads * 32u;
+  const unsigned q0 = ck * (unsigned)chunk;
+  // items of this block: ordinal i -> query q0 + i, or q0 + list[i] after compaction
+  unsigned n_items = q_end - q0;
+  const unsigned short *qlist = reinterpret_cast<const unsigned short *>(
+      smem + kTab + stage_bytes + (THREADS / 8) * kBox);
+  if constexpr (MASKED) {
+    unsigned short *wl = const_cast<unsigned short *>(qlist);
+    unsigned *wtot = reinterpret_cast<unsigned *>(smem + kTab + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
+    unsigned base_count = 0;
+    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
+      const unsigned i = t0 + threadIdx.x;
+      const bool vis = i < n_items && __half2float(qmask[(size_t)b * d.nq + q0 + i]) != 0.f;
+      const unsigned long long bal = __ballot(vis);
+      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
+      __syncthreads();
+      unsigned before = base_count, all = 0;
+      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
+        const unsigned c = wtot[w2];
+        if (w2 < wv) before += c;
+        all += c;
+      }
+      if (vis) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      base_count += all;
+      __syncthreads();
+    }
+    n_items = base_count;
+  }
+  auto query_of = [&](unsigned i) { return MASKED ? q0 + (unsigned)qlist[i] : q0 + i; };
+  const unsigned b_in = d.shared ? 0u : b;
+  const unsigned lg_base = ((b_in * (unsigned)d.nq * (unsigned)d.heads + h) * LP + lane8 * PP) * 2u;
+  const unsigned lg_q = (unsigned)d.heads * LP * 2u;
+  const unsigned rf_base = b * (unsigned)d.nq * (unsigned)d.ppg * 4u, rf_q = (unsigned)d.ppg * 4u;
+  unsigned o_lg = 0, o_of = 0, o_rf = 0;
+  auto locate = [&](unsigned q) {
+    o_lg = lg_base + q * lg_q;
+    o_of = 2u * o_lg;
+    o_rf = rf_base + q * rf_q;
+  };
   auto request = [&](Pre &r) {
 #pragma unroll
     for (int k = 0; k < NLG; ++k) r.lg[k] = 0xfc00fc00u;  // -inf, -inf
@@ -305,13 +339,15 @@ __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
         r.rf[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_rf, (int)(o_rf + gof[k]), 0, 0);
     }
   };
-  auto advance = [&]() { o_lg += s_lg; o_of += s_of; o_rf += s_rf; };
   const int rot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPH;
   Pre cur;
-  if (q < q_end) { request(cur); advance(); }
-  for (; q < q_end; q += kStride, outp += s_out) {
+  unsigned i = threadIdx.x >> 3;
+  if (i < n_items) { locate(query_of(i)); request(cur); }
+  for (; i < n_items; i += kStride) {
+    const unsigned q = query_of(i);
     Pre nxt;
-    if (q + kStride < q_end) { request(nxt); advance(); }
+    if (i + kStride < n_items) { locate(query_of(i + kStride)); request(nxt); }
+    __half *outp = out + (((size_t)b * d.nq + q) * d.heads + h) * 32u + lane8 * 4u;
     float e[PP];
 #pragma unroll
     for (int k = 0; k < PP; ++k) e[k] = (k & 1) ? h2f_hi(cur.lg[k / 2]) : h2f_lo(cur.lg[k / 2]);
@@ -447,27 +483,54 @@ bool hm3_plan(const int32_t *shapes_host, int bs, int heads, int L, int LP, int 
 template <int LP>
 int launch_hm3(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref,
                const __half *off, const __half *logit, __half *out, const MsdaDims &d,
-               hipStream_t st) {
+               const __half *qmask, hipStream_t st) {
   constexpr int MB = LP >= 8 ? 8 : LP;
   const int octets = pl.threads / 8;
-  const size_t lds = kTab + pl.stage_bytes + (size_t)octets * (MB * 16 + 16);
   // staged: long blocks (the plane copy is amortised over 10 items per octet); else hm2's
   const int chunk = pl.threads == 1024 ? 1280 : 128;
   const int nchunk = (d.nq + chunk - 1) / chunk;
+  const size_t lds = kTab + pl.stage_bytes + (size_t)octets * (MB * 16 + 16) + (qmask ? chunk * 2 + 64 : 0);
   const dim3 grid((unsigned)(d.bs * d.heads * nchunk));
   const unsigned gb = (unsigned)pl.g_bytes;
-  if (pl.threads == 1024) {
-    auto kern = msda_hm3_kernel<LP, 1024>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return BEVOPS_FAILURE;
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, gset, gb, sset, ref, off, logit, out, d, pl.t,
-                       chunk, nchunk, pl.stage_bytes);
-  } else {
-    hipLaunchKernelGGL((msda_hm3_kernel<LP, 256>), grid, dim3(256), lds, st, gset, gb, sset, ref, off,
-                       logit, out, d, pl.t, chunk, nchunk, 0);
+  auto go = [&](auto kern, int threads) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return (int)BEVOPS_FAILURE;
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, gset, gb, sset, ref, off, logit, out, d, pl.t,
+                       chunk, nchunk, pl.threads == 1024 ? pl.stage_bytes : 0, qmask);
+    return launch_status();
+  };
+  if (pl.threads == 1024)
+    return qmask ? go(msda_hm3_kernel<LP, 1024, true>, 1024) : go(msda_hm3_kernel<LP, 1024, false>, 1024);
+  return qmask ? go(msda_hm3_kernel<LP, 256, true>, 256) : go(msda_hm3_kernel<LP, 256, false>, 256);
+}
+
+// fused SCA, second step: slots[q, :] = sum over cameras of mask[b, q] * sampled[b, q, :], reading
+// only the visible (camera, query) pairs.  thread = (query, 8-channel vector)
+__global__ __launch_bounds__(256) void sca_camera_reduce_kernel(const __half *__restrict__ sampled,
+                                                                const __half *__restrict__ qmask,
+                                                                __half *__restrict__ out, int bs, int nq,
+                                                                int width) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int vecs = width / 8;
+  const size_t q = idx / vecs;
+  const int c = (int)(idx - q * vecs);
+  if (q >= (size_t)nq) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < bs; ++b) {
+    const float m = __half2float(qmask[(size_t)b * nq + q]);
+    if (m == 0.f) continue;
+    const uint4 v = *reinterpret_cast<const uint4 *>(sampled + ((size_t)b * nq + q) * width + c * 8);
+    acc[0] = fmaf(m, h2f_lo(v.x), acc[0]); acc[1] = fmaf(m, h2f_hi(v.x), acc[1]);
+    acc[2] = fmaf(m, h2f_lo(v.y), acc[2]); acc[3] = fmaf(m, h2f_hi(v.y), acc[3]);
+    acc[4] = fmaf(m, h2f_lo(v.z), acc[4]); acc[5] = fmaf(m, h2f_hi(v.z), acc[5]);
+    acc[6] = fmaf(m, h2f_lo(v.w), acc[6]); acc[7] = fmaf(m, h2f_hi(v.w), acc[7]);
   }
-  return launch_status();
+  uint4 o;
+  o.x = pack_h2(acc[0], acc[1]); o.y = pack_h2(acc[2], acc[3]);
+  o.z = pack_h2(acc[4], acc[5]); o.w = pack_h2(acc[6], acc[7]);
+  *reinterpret_cast<uint4 *>(out + q * width + c * 8) = o;
 }
 
 }  // namespace
@@ -501,12 +564,61 @@ int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const 
   }
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
   switch (LP) {
-    case 4: return launch_hm3<4>(pl, gset, sset, ref, off, logit, out, d, st);
-    case 8: return launch_hm3<8>(pl, gset, sset, ref, off, logit, out, d, st);
-    case 16: return launch_hm3<16>(pl, gset, sset, ref, off, logit, out, d, st);
-    case 32: return launch_hm3<32>(pl, gset, sset, ref, off, logit, out, d, st);
-    default: return launch_hm3<64>(pl, gset, sset, ref, off, logit, out, d, st);
+    case 4: return launch_hm3<4>(pl, gset, sset, ref, off, logit, out, d, nullptr, st);
+    case 8: return launch_hm3<8>(pl, gset, sset, ref, off, logit, out, d, nullptr, st);
+    case 16: return launch_hm3<16>(pl, gset, sset, ref, off, logit, out, d, nullptr, st);
+    case 32: return launch_hm3<32>(pl, gset, sset, ref, off, logit, out, d, nullptr, st);
+    default: return launch_hm3<64>(pl, gset, sset, ref, off, logit, out, d, nullptr, st);
   }
+}
+
+// ---- fused SCA: camera-shared offsets / logits, visibility-masked sampling, masked
+// camera sum.  workspace = [big set][staged set][sampled: bs * nq * heads * 32 fp16]
+size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
+                                    int P) {
+  const size_t a = msda_hm3_workspace_bytes(shapes_host, bs, heads, C, L, nq, P);
+  if (a == 0) return 0;
+  return ((a + 255) & ~size_t(255)) + (size_t)bs * nq * heads * C * sizeof(__half);
+}
+
+int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,
+                             const __half *off, const __half *logit, const __half *qmask,
+                             __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
+                             int ppg, void *workspace, size_t workspace_bytes, hipStream_t st) {
+  const int LP = L * P;
+  const bool lp_ok = LP == 4 || LP == 8 || LP == 16 || LP == 32 || LP == 64;
+  Hm3Plan pl;
+  if (C != 32 || !lp_ok || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) ||
+      !hm3_plan(shapes_host, bs, heads, L, LP, nq, pl))
+    return BEVOPS_NOT_SUPPORTED;
+  if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;
+  const size_t need = msda_hm3_sca_workspace_bytes(shapes_host, bs, heads, C, L, nq, P);
+  if (workspace_bytes < need) return BEVOPS_BAD_PARAM;
+  const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
+  char *gset = static_cast<char *>(workspace);
+  char *sset = gset + g_room;
+  __half *sampled = reinterpret_cast<__half *>(
+      gset + ((msda_hm3_workspace_bytes(shapes_host, bs, heads, C, L, nq, P) + 255) & ~size_t(255)));
+  {
+    const size_t threads = (size_t)bs * pl.t.g_entries * heads * 8 + (size_t)bs * pl.t.s_entries * heads * 4;
+    hipLaunchKernelGGL(msda_hm3_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                       value, gset, sset, pl.t, bs, nk, heads);
+  }
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
+  int rc;
+  switch (LP) {
+    case 4: rc = launch_hm3<4>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
+    case 8: rc = launch_hm3<8>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
+    case 16: rc = launch_hm3<16>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
+    case 32: rc = launch_hm3<32>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
+    default: rc = launch_hm3<64>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
+  }
+  if (rc != BEVOPS_SUCCESS) return rc;
+  const int width = heads * C;
+  const size_t threads = (size_t)nq * (width / 8);
+  hipLaunchKernelGGL(sca_camera_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                     sampled, qmask, out, bs, nq, width);
+  return launch_status();
 }
 
 }  // namespace bevops

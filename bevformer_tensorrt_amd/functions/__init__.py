@@ -10,6 +10,7 @@ from .grid_sampler import grid_sampler, grid_sampler2, grid_sampler_int8
 from .bev_pool_v2 import bev_pool_v2, bev_pool_v2_2, bev_pool_v2_int8
 from .modulated_deformable_conv2d import (modulated_deformable_conv2d, modulated_deformable_conv2d2,
                                           modulated_deformable_conv2d_int8)
+from .spatial_cross_attention import spatial_cross_attention_sample
 from ..utils.register import TRT_FUNCTIONS
 
 TRT_FUNCTIONS.register_module(module=multi_scale_deformable_attn)
@@ -17,7 +18,8 @@ TRT_FUNCTIONS.register_module(module=multi_scale_deformable_attn2)
 TRT_FUNCTIONS.register_module(module=multi_scale_deformable_attn_int8)
 for _f in (rotate, rotate2, rotate_int8, grid_sampler, grid_sampler2, grid_sampler_int8,
            bev_pool_v2, bev_pool_v2_2, bev_pool_v2_int8, modulated_deformable_conv2d,
-           modulated_deformable_conv2d2, modulated_deformable_conv2d_int8):
+           modulated_deformable_conv2d2, modulated_deformable_conv2d_int8,
+           spatial_cross_attention_sample):
     TRT_FUNCTIONS.register_module(module=_f)
 
 __all__ = [
@@ -28,4 +30,5 @@ __all__ = [
     "grid_sampler", "grid_sampler2", "grid_sampler_int8",
     "bev_pool_v2", "bev_pool_v2_2", "bev_pool_v2_int8",
     "modulated_deformable_conv2d", "modulated_deformable_conv2d2", "modulated_deformable_conv2d_int8",
+    "spatial_cross_attention_sample",
 ]

@@ -1,0 +1,63 @@
+"""spatial_cross_attention_sample -- fused sampling step of BEVFormer's spatial cross-attention
+(SURVEY.md 8f-3).  NOT one of the reference's plugin functions: it stands for the sequence
+
+    queries = multi_scale_deformable_attn(value, shapes, ref_cam, offsets.repeat(num_cams), weights.repeat(num_cams))
+    slots   = (queries.flatten(2) * bev_mask).sum(0, keepdim=True)
+
+of det2trt/models/modules/spatial_cross_attention.py:254-270 (offsets / weights are identical for
+every camera because the query is repeated, :254), skipping the (camera, query) pairs whose
+bev_mask weight is zero like the original PyTorch implementation's rebatching
+(third_party/bev_mmdet3d/models/modules/spatial_cross_attention.py:143-191).
+"""
+import torch
+
+from ..utils import lib as _lib
+from .multi_scale_deformable_attn import _host_shapes, _shapes_i32, _workspace
+
+
+def spatial_cross_attention_sample(value, value_spatial_shapes, reference_points_cam, sampling_offsets,
+                                   attention_weights, bev_mask):
+    """
+    Args:
+        value: (num_cams, num_keys, num_heads, 32) fp16
+        value_spatial_shapes: (num_levels, 2)
+        reference_points_cam: (num_cams, num_query, 1, 2 * points_per_group), normalised
+        sampling_offsets: (1, num_query, num_heads, num_levels * num_points * 2), shared by the cameras
+        attention_weights: (1, num_query, num_heads, num_levels * num_points), pre-softmax
+        bev_mask: (num_cams, num_query[, 1]) visibility weight of each (camera, query); 0 = skip
+    Returns: (1, num_query, num_heads * 32) = sum over cameras of bev_mask * sampled
+    """
+    assert value.is_cuda, "spatial_cross_attention_sample: value must be on the GPU"
+    if value.dtype != torch.float16:
+        raise TypeError("spatial_cross_attention_sample is fp16-only; compose "
+                        "multi_scale_deformable_attn + the masked sum for other dtypes")
+    handle = _lib.load_library()
+    ncam, nk, heads, ch = value.shape
+    nq = sampling_offsets.shape[1]
+    L = value_spatial_shapes.shape[0]
+    ppg = reference_points_cam.shape[-1] // 2
+    if sampling_offsets.shape[0] != 1 or attention_weights.shape[0] != 1:
+        raise ValueError("sampling_offsets / attention_weights must be the camera-shared [1, nq, heads, .] tensors")
+    P = attention_weights.numel() // (nq * heads * L)
+    if sampling_offsets.numel() != nq * heads * L * P * 2:
+        raise ValueError("sampling_offsets / attention_weights shapes disagree")
+    if reference_points_cam.numel() != ncam * nq * ppg * 2:
+        raise ValueError("reference_points_cam must be [num_cams, num_query, 1, 2*points_per_group]")
+    mask = bev_mask.reshape(ncam, nq)
+    value, ref, off, w, mask = (t.to(torch.float16).contiguous()
+                                for t in (value, reference_points_cam, sampling_offsets, attention_weights, mask))
+    shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, value.device)
+    if shapes_host is None:
+        shapes_host = _host_shapes(shapes_dev)
+    out = torch.empty((1, nq, heads * ch), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = _lib.current_stream_ptr(value.device)
+        ws_bytes = handle.bevops_sca_workspace_size(_lib.F16, shapes_host.data_ptr(), ncam, nk, heads, ch, L, nq, P)
+        if ws_bytes == 0:
+            raise _lib.BevopsError("bevops_sca_workspace_size: unsupported arguments (needs 32 channels per head)")
+        ws = _workspace(ws_bytes, value.device, stream)
+        st = handle.bevops_sca_forward(_lib.F16, value.data_ptr(), shapes_host.data_ptr(), ref.data_ptr(),
+                                       off.data_ptr(), w.data_ptr(), mask.data_ptr(), out.data_ptr(), ncam, nk,
+                                       heads, ch, L, nq, P, ppg, ws.data_ptr(), ws.numel(), stream)
+    _lib.check(st, "bevops_sca_forward")
+    return out

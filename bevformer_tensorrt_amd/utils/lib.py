@@ -27,6 +27,8 @@ SIGNATURES = {
     "bevops_msda_forward_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                                [c_float] * 4 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "bevops_sca_workspace_size": (c_size_t, [c_int, c_void_p] + [c_int] * 7),
+    "bevops_sca_forward": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "bevops_rotate_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                       c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "bevops_grid_sampler_2d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +

@@ -180,6 +180,30 @@ int bevops_bev_pool_v2_forward(int dtype, const void *depth, const void *feat,
                                float scale_depth, float scale_feat, float scale_out,
                                void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused spatial cross-attention sampling.  NOT a reference plugin: it replaces the
+ * sequence of det2trt/models/modules/spatial_cross_attention.py:254-270 --
+ *   query.repeat(num_cams) -> MultiScaleDeformableAttnTRT on [num_cams, nq, ...] ->
+ *   slots = (queries * bev_mask).sum(0)
+ * -- with one call that (a) takes the camera-independent sampling_offsets / attention_weights
+ * once ([1, nq, heads, L*P*2] / [1, nq, heads, L*P]), (b) skips every (camera, query) pair whose
+ * bev_mask weight is 0 (the rebatching of the original PyTorch SCA,
+ * third_party/bev_mmdet3d/models/modules/spatial_cross_attention.py:143-191) and (c) returns the
+ * masked camera sum  output[q, heads, C] = sum_cam bev_mask[cam, q] * sample(cam, q).
+ *   value [num_cams, nk, heads, C] fp16, reference_points_cam [num_cams, nq, 1, 2*ppg] fp16,
+ *   bev_mask [num_cams, nq] fp16 (0 = not visible, else the weight), output [nq, heads, C] fp16.
+ * F16, C == 32 only (NOT_SUPPORTED otherwise: compose the reference sequence instead).
+ * ------------------------------------------------------------------------ */
+size_t bevops_sca_workspace_size(int dtype, const int32_t *spatial_shapes_host, int num_cams, int nk,
+                                 int heads, int channels, int num_levels, int num_query,
+                                 int num_point);
+int bevops_sca_forward(int dtype, const void *value, const int32_t *spatial_shapes_host,
+                       const void *reference_points_cam, const void *sampling_offsets,
+                       const void *attention_weights, const void *bev_mask, void *output,
+                       int num_cams, int nk, int heads, int channels, int num_levels, int num_query,
+                       int num_point, int points_per_group, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* ------------------------------------------------------------------------
  * Modulated deformable convolution (DCNv2) forward.
  * Replaces ModulatedDeformableConv2dPlugin::enqueue / getWorkspaceSize

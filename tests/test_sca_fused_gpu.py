@@ -1,0 +1,74 @@
+"""GPU parity of the fused SCA sampling op: bevops_sca_forward must equal the
+reference sequence  MSDA on the repeated query -> (queries * bev_mask).sum(0)  that it replaces
+(det2trt/models/modules/spatial_cross_attention.py:254-270), evaluated with the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # (num_cams, levels, nq, P, ppg)
+    "tiny_sca": (6, [[15, 25]], 2500, 8, 4),
+    "small_sca": (6, [[23, 40]], 22500, 8, 4),
+    "base_sca_q4k": (6, [[116, 200], [58, 100], [29, 50], [15, 25]], 4000, 8, 4),
+    "odd": (3, [[7, 9], [5, 3], [3, 1], [1, 1]], 2100, 4, 2),
+    "ragged_chunk": (2, [[12, 17], [6, 9]], 2049 + 1280, 2, 1),
+}
+
+
+def gen(shape, seed=0, vis=0.3):
+    ncam, levels, nq, P, ppg = shape
+    heads, C = 8, 32
+    g = torch.Generator().manual_seed(seed)
+    L = len(levels)
+    nk = sum(h * w for h, w in levels)
+    value = torch.randn(ncam, nk, heads, C, generator=g)
+    ref = torch.rand(ncam, nq, 1, 2 * ppg, generator=g) * 1.2 - 0.1
+    off = torch.randn(1, nq, heads, L * P * 2, generator=g) * 1.5
+    logit = torch.randn(1, nq, heads, L * P, generator=g)
+    visible = torch.rand(ncam, nq, generator=g) < vis
+    # visibility comes in runs along the BEV raster (like a camera frustum): whole runs on / off
+    runs = torch.rand(ncam, (nq + 63) // 64, generator=g) < 0.5
+    visible &= runs.repeat_interleave(64, dim=1)[:, :nq]
+    count = visible.sum(0).clamp(min=1)
+    mask = visible.float() / count                      # encoder.py:255-258 style weights
+    sh = torch.tensor(levels, dtype=torch.int32)
+    return [value.half().cuda(), sh.cuda(), ref.half().cuda(), off.half().cuda(), logit.half().cuda(),
+            mask.half().cuda()]
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_fused_sca_vs_oracle_composition(oracle_mod, name):
+    import bevformer_tensorrt_amd as bev
+    value, sh, ref, off, logit, mask = gen(SHAPES[name])
+    ncam = value.shape[0]
+    out = bev.spatial_cross_attention_sample(value, sh, ref, off, logit, mask.unsqueeze(-1))
+    torch.cuda.synchronize()
+    v, s, r, o, w = (a.float().cpu().numpy() if a.is_floating_point() else a.cpu().numpy()
+                     for a in (value, sh, ref, off.expand(ncam, -1, -1, -1).contiguous(),
+                               logit.expand(ncam, -1, -1, -1).contiguous()))
+    q = oracle_mod.msda_f32(v, s, r, o, w).reshape(ncam, -1, 256)
+    want = (q * mask.float().cpu().numpy()[:, :, None]).sum(0, keepdims=True)
+    assert out.shape == (1, q.shape[1], 256)
+    assert np.abs(out.float().cpu().numpy() - want).max() <= 1e-2
+
+
+def test_fused_sca_equals_unfused_ops_and_ignores_masked_refs():
+    """Against the op sequence on the GPU; and NaN reference points planted in masked-out
+    (camera, query) pairs must not matter (those pairs are never read)."""
+    import bevformer_tensorrt_amd as bev
+    value, sh, ref, off, logit, mask = gen(SHAPES["base_sca_q4k"], seed=3)
+    ncam = value.shape[0]
+    queries = bev.multi_scale_deformable_attn(value, sh, ref, off.expand(ncam, -1, -1, -1),
+                                              logit.expand(ncam, -1, -1, -1)).flatten(2)
+    want = (queries.float() * mask.float().unsqueeze(-1)).sum(0, keepdim=True)
+    got = bev.spatial_cross_attention_sample(value, sh, ref, off, logit, mask)
+    assert (got.float() - want).abs().max().item() <= 4e-3
+    ref2 = ref.clone()
+    ref2[mask == 0] = float("nan")
+    got2 = bev.spatial_cross_attention_sample(value, sh, ref2, off, logit, mask)
+    assert torch.equal(got, got2)
+    # all pairs masked out -> exact zeros
+    z = bev.spatial_cross_attention_sample(value, sh, ref, off, logit, torch.zeros_like(mask))
+    assert torch.count_nonzero(z).item() == 0
