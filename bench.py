@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "int8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -125,8 +125,9 @@ def main():
     import bevformer_tensorrt_amd as bev
     from bevformer_tensorrt_amd.camera_shard import camera_shards, gather_camera_features
 
-    dtype = torch.float16 if args.dtype == "fp16" else torch.float32
-    esize = 2 if dtype == torch.float16 else 4
+    int8 = args.dtype == "int8"
+    dtype = torch.float32 if args.dtype == "fp32" else torch.float16
+    esize = 1 if int8 else (2 if dtype == torch.float16 else 4)
     gen = torch.Generator().manual_seed(0)
     my_cams = camera_shards(BASE["sca"]["bs"], world)[rank]
     sca, sca_bs = msda_inputs(BASE["sca"], dtype, dev, gen, cams=my_cams)
@@ -147,23 +148,56 @@ def main():
         b = torch.randn(C, generator=gen).to(dtype).to(dev)
         dcn.append((count, (x, off, mask, w, b, 1, 1, 1, 1, 1)))
 
+    if int8:
+        # INT8 flavour of the same step: every plugin-boundary tensor quantised per tensor with the
+        # scale the native entropy (KL) calibrator gives for it (quantization.py; the reference
+        # gets them from TensorRT's IInt8EntropyCalibrator2, calibrator_trt.py:6-92); reference
+        # points stay fp16 (the u8 x255 weight flavour); fp32 DCN bias
+        from bevformer_tensorrt_amd.quantization import EntropyCalibrator
+        cal = EntropyCalibrator()
+
+        def q(name, t):
+            cal.collect(name, t)
+            sc = cal.scale(name)
+            return cal.quantize(t, sc), sc
+
+        def q_msda(name, a):
+            v, sv = q(name + ".value", a[0])
+            o, so = q(name + ".offsets", a[3])
+            w, sw = q(name + ".weights", a[4])
+            return (v, a[1], a[2], o, w, sv, so, sw, 1.0 / 127)   # |out| <= max|value| <= ~ 4 sigma
+
+        sca, tsa, dec = q_msda("sca", sca), q_msda("tsa", tsa), q_msda("dec", dec)
+        pq, ps = q("prev_bev", prev_bev)
+        rot = (pq, rot[1], rot[2], ps, ps)
+        dcn_q = []
+        for count, a in dcn:
+            x, sx = q("dcn.x", a[0]); o, so = q("dcn.off", a[1]); m, sm = q("dcn.mask", a[2]); w, sw = q("dcn.w", a[3])
+            dcn_q.append((count, (x, o, m, w, a[4].float(), sx, so, sm, sw, 4.0 / 127, 1, 1, 1, 1, 1)))
+        dcn = dcn_q
+        op_msda, op_dcn, op_rot = (bev.multi_scale_deformable_attn_int8, bev.modulated_deformable_conv2d_int8,
+                                   bev.rotate_int8)
+    else:
+        op_msda, op_dcn, op_rot = bev.multi_scale_deformable_attn, bev.modulated_deformable_conv2d, bev.rotate
+
     nq, embed = BASE["sca"]["nq"], BASE["embed"]
-    sca_out = torch.empty((max(sca_bs, 1), nq, BASE["heads"], BASE["C"]), dtype=dtype, device=dev)
+    sca_out = torch.empty((max(sca_bs, 1), nq, BASE["heads"], BASE["C"]), dtype=torch.int8 if int8 else dtype,
+                          device=dev)
     gathered = None
     sca_events = []
 
     def step(record):
         for count, a in dcn:
             for _ in range(count):
-                bev.modulated_deformable_conv2d(*a)
-        bev.rotate(*rot)
+                op_dcn(*a)
+        op_rot(*rot)
         for _ in range(BASE["enc_layers"]):
-            bev.multi_scale_deformable_attn(*tsa)
+            op_msda(*tsa)
             if sca_bs:
                 if record:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                out = bev.multi_scale_deformable_attn(*sca)
+                out = op_msda(*sca)
                 if record:
                     e1.record()
                     sca_events.append((e0, e1))
@@ -172,7 +206,7 @@ def main():
             if world > 1:
                 gather_camera_features(out.view(out.shape[0], nq, embed), BASE["sca"]["bs"], dist)
         for _ in range(BASE["dec_layers"]):
-            bev.multi_scale_deformable_attn(*dec)
+            op_msda(*dec)
 
     def fence():
         torch.cuda.synchronize()
@@ -221,16 +255,18 @@ def main():
         avg_ms = sum(ms) / len(ms)
         byt = msda_bytes(BASE["sca"], esize, bs=sca_bs)
         achieved = byt / (avg_ms * 1e-3) / 1e9
-        roofline = {"kernel": "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>", "bound": "hbm",
+        kern = ("base SCA MSDA call = msda_int8_quad_kernel (u8 x255 weights)" if int8 else
+                "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>")
+        roofline = {"kernel": kern, "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
                     "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches": len(ms)}
-        if sca_bs == BASE["sca"]["bs"]:
+        if sca_bs == BASE["sca"]["bs"] and not int8:
             roofline["traffic"], roofline["traffic_src"] = pmc_traffic()
 
     end_to_end = None
-    if world == 1 and not args.no_end_to_end:
+    if world == 1 and not args.no_end_to_end and not int8:
         # the whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random
         # weights, synthetic 6-camera frames), frame loop replayed from a HIP graph; protocol of
         # det2trt/utils/tensorrt.py:72-76 (device time of a frame between syncs, first/last dropped)
@@ -269,11 +305,11 @@ def main():
                              "TSA + decoder calls in full and 1/8 of the SCA queries, scaled to "
                              "6+6+6 calls per frame; per-call " + sample}
         line = {
-            "metric": "frames/sec BEVFormer-base bs=1 fp16 sampling hot path (synthetic)",
+            "metric": f"frames/sec BEVFormer-base bs=1 {'int8' if int8 else args.dtype} sampling hot path (synthetic)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16" if dtype == torch.float16 else "f32", "data": "synthetic",
+            "dtype": "i8" if int8 else ("f16" if dtype == torch.float16 else "f32"), "data": "synthetic",
             "config": {"workload": "BEVFormer-base hot path per frame: "
                                    + "+".join(extra + ["6x(TSA+SCA) MSDA", "6x decoder MSDA"]),
                        "shapes": "SCA(6,30825,40000,4x8) TSA(2,40000,40000,1x4) dec(1,40000,900,1x4)",
