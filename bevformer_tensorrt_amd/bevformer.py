@@ -57,6 +57,45 @@ def inverse_sigmoid(x, eps=1e-5):  # decoder.py:24-40
 
 
 # --------------------------------------------------------------------------- backbone
+# Two data paths through the same modules and weights:
+#  * forward():      reference layout (NCHW), library convolutions + framework element-wise ops;
+#  * forward_nhwc(): channels-last activations end to end (MI355X path, fp16): 1x1 convolutions are
+#    row-major GEMMs with the folded-BN shift / ReLU in the hipBLASLt epilogue, 3x3 convolutions
+#    run MIOpen's NHWC kernels without layout transposes, every remaining shift / residual / ReLU
+#    chain is ONE bevops_bias_act_nhwc pass, DCNv2 reads and writes NHWC directly, and the FPN
+#    outputs already are the [cams, keys, 256] value layout of the encoder.
+def _rows(x):
+    """[N, C, H, W] channels-last -> [N*H*W, C] view."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+def _from_rows(y, n, h, w):
+    return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
+    s = conv.stride[0]
+    if s > 1:
+        x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    wt = conv.weight.view(conv.out_channels, c).t()
+    if residual is not None:   # residual enters through the GEMM's beta term, shift + ReLU in one pass
+        y = torch.addmm(_rows(residual), _rows(x), wt)
+        ops.bias_act_nhwc_(y, conv.bias, None, relu)
+    elif relu:
+        y = torch._addmm_activation(conv.bias, _rows(x), wt)
+    else:
+        y = torch.addmm(conv.bias, _rows(x), wt)
+    return _from_rows(y, n, h, w)
+
+
+def _conv_nhwc(ops, x, conv, relu, residual=None):
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    return ops.bias_act_nhwc_(y, conv.bias, residual, relu)
+
+
 class DCNv2Pack(nn.Module):
     """ModulatedDeformConv2dPackPlugin (cnn/dcn.py:31-86): conv_offset -> (o1, o2, mask) ->
     modulated_deformable_conv2d."""
@@ -77,6 +116,12 @@ class DCNv2Pack(nn.Module):
         return self.ops.modulated_deformable_conv2d(x, offset, torch.sigmoid(mask), self.weight,
                                                     self.bias, self.stride, 1, 1, 1, 1)
 
+    def forward_nhwc(self, x, relu):
+        out = self.conv_offset(x).contiguous()          # [B, 27, H, W] planar, as the op expects
+        # (o1, o2) are the first 18 channels already in the order cat((o1, o2)) gives
+        return self.ops.modulated_deformable_conv2d_nhwc(x, out[:, :18], torch.sigmoid(out[:, 18:]), self.weight,
+                                                         self.bias, self.stride, 1, 1, 1, 1, relu=relu)
+
 
 class Bottleneck(nn.Module):
     """ResNet bottleneck, caffe style (stride on the first 1x1), BN folded."""
@@ -93,6 +138,15 @@ class Bottleneck(nn.Module):
         out = F.relu(self.conv1(x), inplace=True)
         out = F.relu(self.conv2(out), inplace=True)
         return F.relu(self.conv3(out) + idt, inplace=True)
+
+    def forward_nhwc(self, x, ops):
+        idt = x if self.downsample is None else _conv1x1_nhwc(ops, x, self.downsample, False)
+        out = _conv1x1_nhwc(ops, x, self.conv1, True)
+        if isinstance(self.conv2, DCNv2Pack):
+            out = self.conv2.forward_nhwc(out, True)
+        else:
+            out = _conv_nhwc(ops, out, self.conv2, True)
+        return _conv1x1_nhwc(ops, out, self.conv3, True, residual=idt)
 
 
 class ResNet(nn.Module):
@@ -119,6 +173,17 @@ class ResNet(nn.Module):
                 outs.append(x)
         return outs
 
+    def forward_nhwc(self, x, ops):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = F.max_pool2d(_conv_nhwc(ops, x, self.stem, True), 3, 2, 1)
+        outs = []
+        for i, st in enumerate(self.stages):
+            for blk in st:
+                x = blk.forward_nhwc(x, ops)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs
+
 
 class FPN(nn.Module):
     """mmdet FPN with add_extra_convs='on_output', relu_before_extra_convs (bevformer_base.py:55-63)."""
@@ -136,6 +201,15 @@ class FPN(nn.Module):
         outs = [c(x) for c, x in zip(self.fpn, lat)]
         for e in self.extra:
             outs.append(e(F.relu(outs[-1])))
+        return outs
+
+    def forward_nhwc(self, feats, ops):
+        lat = [_conv1x1_nhwc(ops, f, l, False) for l, f in zip(self.lateral, feats)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        outs = [_conv_nhwc(ops, x.contiguous(memory_format=torch.channels_last), c, False) for c, x in zip(self.fpn, lat)]
+        for e in self.extra:
+            outs.append(_conv_nhwc(ops, F.relu(outs[-1]), e, False))
         return outs
 
 
@@ -259,12 +333,15 @@ class BEVFormer(nn.Module):
     """forward(image [1,6,3,H,W], prev_bev [nq,1,256], use_prev_bev (0/1 tensor), can_bus [18],
     lidar2img [1,6,4,4]) -> bev_embed [nq,1,256], outputs_classes [6,1,900,10], outputs_coords [6,1,900,10]."""
 
-    def __init__(self, name="base", ops=None, seed=0):
+    def __init__(self, name="base", ops=None, seed=0, backbone_layout="auto"):
         super().__init__()
         torch.manual_seed(seed)
         cfg = CONFIGS[name]
         self.cfg, self.name = cfg, name
         self.ops = ops = ops if ops is not None else _hip_ops
+        # "auto": channels-last backbone when the MI355X operators are in use and the frame is fp16
+        self.backbone_layout = backbone_layout
+        self._nhwc_ready = False
         self.bev_h, self.bev_w = cfg["bev"]
         nq = self.bev_h * self.bev_w
         self.backbone = ResNet(cfg["depth"], cfg["dcn"], cfg["out_indices"], ops)
@@ -297,6 +374,14 @@ class BEVFormer(nn.Module):
         img = image.view(B * N, C, H, W)
         if cams is not None:
             img = img[cams]
+        nhwc = self.backbone_layout == "nhwc" or (self.backbone_layout == "auto" and self.ops is _hip_ops)
+        if nhwc and img.dtype == torch.float16 and img.is_cuda:
+            if not self._nhwc_ready:   # MIOpen picks its NHWC kernels when the filters are channels-last too
+                for m in list(self.backbone.modules()) + list(self.neck.modules()):
+                    if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+                self._nhwc_ready = True
+            return self.neck.forward_nhwc(self.backbone.forward_nhwc(img, self.ops), self.ops)
         return self.neck(self.backbone(img))    # list of [cams, 256, h_l, w_l]
 
     def positional_encoding(self, dtype, device):   # mmdet LearnedPositionalEncoding
@@ -325,7 +410,10 @@ class BEVFormer(nn.Module):
         cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]
         for lvl, feat in enumerate(mlvl):
             level_hw.append(feat.shape[-2:])
-            f = feat.flatten(2).permute(0, 2, 1)                                  # [cams, hw, 256]
+            if feat.is_contiguous(memory_format=torch.channels_last):            # already [cams, h, w, 256]
+                f = feat.permute(0, 2, 3, 1).reshape(feat.shape[0], -1, feat.shape[1])
+            else:
+                f = feat.flatten(2).permute(0, 2, 1)                              # [cams, hw, 256]
             feats.append(f + cam_embed.to(dtype)[:, None, :] + self.level_embeds[lvl].to(dtype)[None, None, :])
         feat_flatten = torch.cat(feats, dim=1)                                   # [cams, sum hw, 256]
         # shape tensors live on the HOST: the operators cache a device copy per distinct value

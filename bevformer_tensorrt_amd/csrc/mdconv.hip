@@ -565,7 +565,39 @@ __device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7
 struct TailPlan {
   int tail_tiles, split, main_tiles;  // grid.x = tail_tiles * split + main_tiles
   float *partial;                     // [split][tail_tiles][512 threads][32]
+  int out_nhwc, relu;                 // epilogue: output layout [B,Ho,Wo,Cout], fused ReLU
 };
+
+// 4 consecutive output channels m..m+3 of pixel (b, pix): bias, optional ReLU, NCHW or NHWC store
+__device__ __forceinline__ void dcn_store4(__half *__restrict__ out, const __half *__restrict__ bias,
+                                           const float (&v)[4], int b, int pix, int m, int g,
+                                           int cout_g, int Cout, int HoWo, const TailPlan &tp) {
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = v[e];
+    if (bias && m + e < cout_g) o[e] += __half2float(bias[g * cout_g + m + e]);
+    if (tp.relu) o[e] = fmaxf(o[e], 0.f);
+  }
+  if (tp.out_nhwc) {
+    __half *p = out + ((size_t)b * HoWo + pix) * Cout + g * cout_g + m;
+    if (m + 3 < cout_g && (((g * cout_g + m) | Cout) & 3) == 0) {
+      uint2 w;
+      w.x = pack_h2(o[0], o[1]);
+      w.y = pack_h2(o[2], o[3]);
+      *reinterpret_cast<uint2 *>(p) = w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (m + e < cout_g) p[e] = __float2half_rn(o[e]);
+    }
+  } else {
+    __half *p = out + ((size_t)b * Cout + g * cout_g + m) * HoWo + pix;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (m + e < cout_g) p[(size_t)e * HoWo] = __float2half_rn(o[e]);
+  }
+}
 
 __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
@@ -742,17 +774,13 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
     const int n = n0 + wn * 32 + (lane & 31);
     if (n < N) {
       const int b = n / HoWo, pix = n - b * HoWo;
-      __half *obp = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < cout_g) {
-            float v = acc[i][r];
-            if (bias) v += __half2float(bias[g * cout_g + m]);
-            obp[(size_t)m * HoWo] = __float2half_rn(v);
-          }
+        for (int rq = 0; rq < 4; ++rq) {
+          const int m = m0 + wm * 64 + i * 32 + 8 * rq + 4 * (lane >> 5);
+          const float v[4] = {acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]};
+          dcn_store4(out, bias, v, b, pix, m, g, cout_g, d.Cout, HoWo, tp);
         }
     }
   }
@@ -778,18 +806,8 @@ __global__ __launch_bounds__(512) void dcn_tail_finish_kernel(const __half *__re
   const int n = n0 + wn * 32 + (lane & 31);
   if (n >= N) return;
   const int b = n / HoWo, pix = n - b * HoWo;
-  __half *obp = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
   const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int r = rq * 4 + e;
-    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m < cout_g) {
-      float v = av[e];
-      if (bias) v += __half2float(bias[g * cout_g + m]);
-      obp[(size_t)m * HoWo] = __float2half_rn(v);
-    }
-  }
+  dcn_store4(out, bias, av, b, pix, m0 + wm * 64 + i * 32 + 8 * rq + 4 * (lane >> 5), g, cout_g, d.Cout, HoWo, tp);
 }
 
 
@@ -1016,7 +1034,7 @@ int glds_resident_blocks() {
 template <typename T>
 int run(const void *input, const void *offset, const void *mask, const void *weight,
         const void *bias, void *output, void *workspace, const ConvDims &d, hipStream_t st,
-        bool weight_is_packed = false) {
+        bool weight_is_packed = false, bool nhwc_io = false, bool relu = false) {
   const WsLayout w = ws_layout(d, sizeof(T));
   char *ws = static_cast<char *>(workspace);
   T *xt = reinterpret_cast<T *>(ws + w.xt);
@@ -1026,8 +1044,11 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   const size_t N = (size_t)d.B * d.Ho * d.Wo;
   if (N > 0x7FFFFFFFull || (size_t)d.B * d.Cin * HW > 0x7FFFFFFF00ull) return BEVOPS_NOT_SUPPORTED;
   const bool fits32 = (size_t)d.B * d.Cin * HW * 2 < 0xFFFFFF00ull && (size_t)d.Cout * cin_g * KK * 2 < 0xFFFFFF00ull;
-  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
-                     0, st, (const T *)input, xt, d.Cin, HW);
+  if (nhwc_io)  // the caller's tensor already is the [B, H, W, Cin] image the gather wants
+    xt = const_cast<T *>(static_cast<const T *>(input));
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
+                       0, st, (const T *)input, xt, d.Cin, HW);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   if (weight_is_packed)  // [Cout][tap][Cin/groups] image made by bevops_mdconv_pack_weight
     wt = const_cast<T *>(static_cast<const T *>(weight));
@@ -1040,6 +1061,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
       const dim3 grid((unsigned)((N + kFN - 1) / kFN), (cout_g + kFM - 1) / kFM);
       for (int g = 0; g < d.G; ++g) {
         const bool one_dg = cin_g <= d.Cin / d.DG && (g * cin_g) / (d.Cin / d.DG) == (g * cin_g + cin_g - 1) / (d.Cin / d.DG);
+        if ((nhwc_io || relu) && !(g_mdconv_variant == 0 && one_dg)) return BEVOPS_NOT_SUPPORTED;
         if (g_mdconv_variant == 0 && one_dg) {
           static thread_local bool attr_set = false;
           if (!attr_set) {
@@ -1049,7 +1071,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
             attr_set = true;
           }
           // tail plan: leftover tiles of a sparsely filled last round are split along K
-          TailPlan tp{0, 1, (int)grid.x, nullptr};
+          TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0};
           const int slots = glds_resident_blocks();
           const int blocks = (int)(grid.x * grid.y);
           if (g_mdconv_variant == 0 && !g_mdconv_no_tail && slots > 0 && blocks > slots && grid.y == 1) {
@@ -1084,6 +1106,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
       return launch_status();
     }
   }
+  if (nhwc_io || relu) return BEVOPS_NOT_SUPPORTED;  // only the fused fp16 kernel has these epilogues
   constexpr int VMAX = sizeof(T) == 2 ? 8 : 4;
   const bool vec = cin_g % VMAX == 0 && (d.Cin / d.DG) % VMAX == 0;
   {
@@ -1239,7 +1262,8 @@ static int mdconv_forward_impl(int dtype, const void *input, const void *offset,
                                const void *weight, const void *bias, void *output, void *workspace,
                                size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
                                int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
-                               int dil_w, int groups, int deform_groups, void *stream, bool packed) {
+                               int dil_w, int groups, int deform_groups, void *stream, bool packed,
+                               bool nhwc_io = false, bool relu = false) {
   if (!input || !offset || !mask || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
   ConvDims d;
   if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
@@ -1250,8 +1274,23 @@ static int mdconv_forward_impl(int dtype, const void *input, const void *offset,
   if (!aligned16(workspace) || (packed && !aligned16(weight))) return BEVOPS_BAD_PARAM;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == BEVOPS_F32)
-    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st, packed);
-  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st, packed);
+    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu);
+  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu);
+}
+
+extern "C" int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *offset,
+                                          const void *mask, const void *packed_weight,
+                                          const void *bias, void *output_nhwc, int relu,
+                                          void *workspace, size_t workspace_bytes, int B, int Cin,
+                                          int H, int W, int Cout, int Kh, int Kw, int stride_h,
+                                          int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                          int groups, int deform_groups, void *stream) {
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (input_nhwc && !aligned16(input_nhwc)) return BEVOPS_BAD_PARAM;
+  return mdconv_forward_impl(dtype, input_nhwc, offset, mask, packed_weight, bias, output_nhwc,
+                             workspace, workspace_bytes, B, Cin, H, W, Cout, Kh, Kw, stride_h,
+                             stride_w, pad_h, pad_w, dil_h, dil_w, groups, deform_groups, stream, true,
+                             true, relu != 0);
 }
 
 extern "C" int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,

@@ -116,3 +116,63 @@ def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in
             ws.data_ptr(), ws_bytes, *dims, _lib.current_stream_ptr(input.device))
     _lib.check(st, "bevops_mdconv_forward_int8")
     return out
+
+
+def modulated_deformable_conv2d_nhwc(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
+                                     groups=1, deform_groups=1, relu=False):
+    """Channels-last DCNv2 for the re-hosted backbone (not a reference plugin): `input` is an
+    NCHW-shaped tensor in torch.channels_last memory format (= [B, H, W, C] in memory), the
+    result likewise; offset / mask keep the reference's planar layout; optional fused ReLU.
+    fp16, fused-kernel domain only (raises BevopsError otherwise)."""
+    assert input.is_cuda and input.dtype == torch.float16
+    handle = _lib.load_library()
+    if not input.is_contiguous(memory_format=torch.channels_last):
+        input = input.contiguous(memory_format=torch.channels_last)
+    offset, mask = offset.to(input.dtype).contiguous(), mask.to(input.dtype).contiguous()
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, Cin, H, W = input.shape
+    Cout, _, Kh, Kw = weight.shape
+    Ho = (H + 2 * ph - (dh * (Kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) // sw + 1
+    dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
+    if weight.dtype != torch.float16 or not weight.is_contiguous():
+        raise _lib.BevopsError("modulated_deformable_conv2d_nhwc: weight must be a contiguous fp16 tensor")
+    packed = _PACKED.get(weight)
+    if packed is None:
+        packed = _packed_weight(handle, weight, _lib.F16)
+    ws_bytes = handle.bevops_mdconv_workspace_size(_lib.F16, *dims)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+    out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device,
+                      memory_format=torch.channels_last)
+    if bias is not None:
+        bias = bias.to(input.dtype).contiguous()
+    with torch.cuda.device(input.device):
+        st = handle.bevops_mdconv_forward_nhwc(
+            _lib.F16, input.data_ptr(), offset.data_ptr(), mask.data_ptr(), packed.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), int(relu), ws.data_ptr(), ws_bytes,
+            *dims, _lib.current_stream_ptr(input.device))
+    _lib.check(st, "bevops_mdconv_forward_nhwc")
+    return out
+
+
+def bias_act_nhwc_(x, bias=None, residual=None, relu=False):
+    """In place on a channels-last activation (or any [rows, C] row-major tensor):
+    x += bias (+ residual); optional ReLU -- one pass (bevops_bias_act_nhwc)."""
+    assert x.is_cuda and x.dtype == torch.float16
+    if x.dim() == 4:
+        assert x.is_contiguous(memory_format=torch.channels_last)
+        C = x.shape[1]
+    else:
+        assert x.is_contiguous()
+        C = x.shape[-1]
+    rows = x.numel() // C
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+        assert residual.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4 else residual.is_contiguous()
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_bias_act_nhwc(_lib.F16, x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         residual.data_ptr() if residual is not None else None, rows, C,
+                                         int(relu), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_bias_act_nhwc")
+    return x

@@ -248,6 +248,19 @@ int bevops_mdconv_forward(int dtype, const void *input, const void *offset, cons
 size_t bevops_mdconv_packed_weight_size(int dtype, int Cout, int Cin_per_group, int Kh, int Kw);
 int bevops_mdconv_pack_weight(int dtype, const void *weight, void *packed, int Cout,
                               int Cin_per_group, int Kh, int Kw, void *stream);
+/* Channels-last variant for a caller whose activations are [B, H, W, C] (the re-hosted backbone):
+ * input and output NHWC, packed weights, optional fused ReLU; fp16 fused-kernel domain only
+ * (NOT_SUPPORTED otherwise).  offset / mask keep the reference's planar [B, ., Ho, Wo] layout. */
+int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *offset,
+                               const void *mask, const void *packed_weight, const void *bias,
+                               void *output_nhwc, int relu, void *workspace, size_t workspace_bytes,
+                               int B, int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
+                               int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int groups,
+                               int deform_groups, void *stream);
+/* x[rows, channels] += bias[channels] (+ residual[rows, channels]), optional ReLU, in place: the
+ * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
+int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
+                         int channels, int relu, void *stream);
 int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,
                                  const void *mask, const void *packed_weight, const void *bias,
                                  void *output, void *workspace, size_t workspace_bytes, int B,

@@ -94,3 +94,41 @@ def test_point_sampling_fma_projection_matches_matmul():
     cam_b, mask_b = G.point_sampling(ref3d, pc, l2i, (480, 800), projection="fma")
     assert (cam_a - cam_b).abs().max().item() <= 1e-5 * max(1.0, cam_a.abs().max().item())
     assert (mask_a != mask_b).float().mean().item() <= 1e-4   # only points within 1 ulp of a frustum edge
+
+
+def test_channels_last_backbone_matches_reference_layout_path():
+    """ResNet(+DCNv2)+FPN: the NHWC data path (1x1 convs as GEMMs with fused shift/ReLU, NHWC
+    library convs + one bias_act pass, NHWC DCNv2) against the plain NCHW path, same weights."""
+    import bevformer_tensorrt_amd.functions as hip_ops
+    from bevformer_tensorrt_amd import bevformer as B
+    torch.manual_seed(0)
+    net = B.ResNet(50, (False, False, True, True), (1, 2, 3), hip_ops).cuda().half().eval()
+    neck = B.FPN([512, 1024, 2048], 256, 4).cuda().half().eval()
+    x = torch.randn(2, 3, 192, 256, device="cuda", dtype=torch.half)
+    with torch.no_grad():
+        ref = neck(net(x))
+        for m in list(net.modules()) + list(neck.modules()):
+            if isinstance(m, torch.nn.Conv2d) and m.kernel_size != (1, 1):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        got = neck.forward_nhwc(net.forward_nhwc(x, hip_ops), hip_ops)
+    assert len(ref) == len(got) == 4
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and b.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, a.abs().max().item())
+        assert (a.float() - b.float()).abs().max().item() <= 3e-2 * scale
+        assert (a.float() - b.float()).abs().mean().item() <= 3e-3 * scale
+
+
+def test_bias_act_nhwc_matches_torch():
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(0)
+    for shape in ((2, 64, 17, 23), (1, 256, 5, 7), (3, 24, 9, 4)):
+        x = torch.randn(*shape, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+        r = torch.randn(*shape, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+        b = torch.randn(shape[1], generator=g).half().cuda()
+        for res in (None, r):
+            for relu in (False, True):
+                want = x.float() + b.float().view(1, -1, 1, 1) + (res.float() if res is not None else 0)
+                want = torch.relu(want) if relu else want
+                got = bev.bias_act_nhwc_(x.clone(memory_format=torch.preserve_format), b, res, relu)
+                assert (got.float() - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
