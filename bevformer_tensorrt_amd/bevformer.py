@@ -117,9 +117,18 @@ class DCNv2Pack(nn.Module):
                                                     self.bias, self.stride, 1, 1, 1, 1)
 
     def forward_nhwc(self, x, relu):
-        out = self.conv_offset(x).contiguous()          # [B, 27, H, W] planar, as the op expects
+        # MIOpen's NHWC kernels are 3-8x slower at 27 output channels than at 32 (170 vs 52 us at
+        # stage 3): run the offset conv with the filters zero-padded to 32 and drop the extra planes
+        w = self.conv_offset.weight
+        if getattr(self, "_w32", None) is None or self._w32[2] != (w._version, w.dtype, w.device):
+            w32 = torch.zeros(32, *w.shape[1:], dtype=w.dtype, device=w.device)
+            w32[:27] = w.detach()
+            b32 = torch.zeros(32, dtype=w.dtype, device=w.device)
+            b32[:27] = self.conv_offset.bias.detach()
+            self._w32 = (w32.contiguous(memory_format=torch.channels_last), b32, (w._version, w.dtype, w.device))
+        out = F.conv2d(x, self._w32[0], self._w32[1], self.stride, 1).contiguous()   # planar, as the op expects
         # (o1, o2) are the first 18 channels already in the order cat((o1, o2)) gives
-        return self.ops.modulated_deformable_conv2d_nhwc(x, out[:, :18], torch.sigmoid(out[:, 18:]), self.weight,
+        return self.ops.modulated_deformable_conv2d_nhwc(x, out[:, :18], torch.sigmoid(out[:, 18:27]), self.weight,
                                                          self.bias, self.stride, 1, 1, 1, 1, relu=relu)
 
 
