@@ -552,8 +552,16 @@ __global__ __launch_bounds__(THREADS, 2) void dcn_fused_f16_kernel(
 // Domain: one deform group per conv group (dg constant over a block's k-loop); else the
 // register-staged kernel runs.
 constexpr int kGA = kFM * kFK * 2;  // 32 KB weight tile image
-constexpr int kGB = kFN * kFK * 2;  // 8 KB pixel tile image
-constexpr int kGldsLds = 2 * (kGA + kGB);
+// WN = wave columns (each 32 pixels): 2 -> 512 threads, 64-pixel tile, 80 KB LDS, 2 blocks per CU;
+//                                      4 -> 1024 threads, 128-pixel tile, 96 KB LDS, 1 block per CU
+//                                           (the weight tile is fetched once per 128 pixels)
+template <int WN> struct Glds {
+  static constexpr int kN = 32 * WN;          // pixels per tile
+  static constexpr int kThreads = 256 * WN;
+  static constexpr int kB = kN * kFK * 2;     // pixel tile image bytes
+  static constexpr int kLds = 2 * (kGA + kB);
+  static constexpr int kPieces = 32 / (4 * WN);  // 1 KB weight DMA pieces per wave
+};
 
 __device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7u; }
 
@@ -564,7 +572,7 @@ __device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7
 // dcn_tail_finish_kernel adds them in a fixed order (deterministic, no atomics).
 struct TailPlan {
   int tail_tiles, split, main_tiles;  // grid.x = tail_tiles * split + main_tiles
-  float *partial;                     // [split][tail_tiles][512 threads][32]
+  float *partial;                     // [split][tail_tiles][Cout tiles][8 quads][threads] float4
   int out_nhwc, relu;                 // epilogue: output layout [B,Ho,Wo,Cout], fused ReLU
 };
 
@@ -599,7 +607,8 @@ __device__ __forceinline__ void dcn_store4(__half *__restrict__ out, const __hal
   }
 }
 
-__global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
+template <int WN>
+__global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
     const __half *__restrict__ mask, const __half *__restrict__ wt,
     const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g, TailPlan tp) {
@@ -619,7 +628,8 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
   } else {
     ntile = (int)xcd_remap(blockIdx.x - n_tail_blocks, tp.main_tiles);
   }
-  const int n0 = ntile * kFN, m0 = blockIdx.y * kFM;
+  constexpr int kN = Glds<WN>::kN, kGB = Glds<WN>::kB, kTh = Glds<WN>::kThreads, kPc = Glds<WN>::kPieces;
+  const int n0 = ntile * kN, m0 = blockIdx.y * kFM;
   const int Kg = KK * cin_g;
   const __half *A = wt + (size_t)g * cout_g * Kg;
   const int dg = (g * cin_g) / (d.Cin / d.DG);
@@ -638,10 +648,10 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
   const unsigned ximg_off = (unsigned)(((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 8) * 2);
   const unsigned b_dst = (unsigned)(pp * 128 + ((cq ^ swz8(pp)) << 4));
   // weight DMA role: piece j of this wave = rows (wave*4 + j)*8 .. +8, lane -> (row, chunk)
-  unsigned a_off[4];
+  unsigned a_off[kPc];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned row = (unsigned)((wave * 4 + j) * 8 + (lane >> 3));
+  for (int j = 0; j < kPc; ++j) {
+    const unsigned row = (unsigned)((wave * kPc + j) * 8 + (lane >> 3));
     const unsigned chunk = (lane & 7u) ^ swz8(row);
     a_off[j] = (m0 + (int)row) < cout_g ? (unsigned)(((size_t)(m0 + row) * Kg) * 2 + chunk * 16) : 0xFFFFFFF0u;
   }
@@ -703,9 +713,9 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
   auto stage_issue = [&](int tap, int chunk, int buf) {
     const int c0 = chunk * kFK;
     const int a_s = (tap * cin_g + c0) * 2;
-    char *adst = smem + buf * kGA + wave * 4096;
+    char *adst = smem + buf * kGA + wave * (kPc * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kPc; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -762,12 +772,12 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
   }
   if (is_tail) {  // fp32 partials, thread-private order (the finish kernel uses the same mapping)
     float4 *pp = reinterpret_cast<float4 *>(tp.partial) +
-                 ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * 512 + tid;
+                 ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * kTh + tid;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pp[(i * 4 + r) * 512] = make_float4(acc[i][4 * r], acc[i][4 * r + 1], acc[i][4 * r + 2], acc[i][4 * r + 3]);
+        pp[(i * 4 + r) * kTh] = make_float4(acc[i][4 * r], acc[i][4 * r + 1], acc[i][4 * r + 2], acc[i][4 * r + 3]);
     return;
   }
   {
@@ -788,19 +798,21 @@ __global__ __launch_bounds__(512, 2) void dcn_glds_f16_kernel(
 
 
 // grid (tail tiles, Cout tiles, 8): block z sums accumulator quad z = i*4 + r of every thread
-__global__ __launch_bounds__(512) void dcn_tail_finish_kernel(const __half *__restrict__ bias,
+template <int WN>
+__global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half *__restrict__ bias,
                                                               __half *__restrict__ out, ConvDims d,
                                                               int g, TailPlan tp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int cout_g = d.Cout / d.G, HoWo = d.Ho * d.Wo, N = d.B * HoWo;
   const int ntile = tp.main_tiles + blockIdx.x;
-  const int n0 = ntile * kFN, m0 = blockIdx.y * kFM;
+  constexpr int kTh = Glds<WN>::kThreads;
+  const int n0 = ntile * Glds<WN>::kN, m0 = blockIdx.y * kFM;
   const int quad = blockIdx.z, i = quad >> 2, rq = quad & 3;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int part = 0; part < tp.split; ++part) {
     const float4 v = reinterpret_cast<const float4 *>(tp.partial)[
-        ((((size_t)part * tp.tail_tiles + blockIdx.x) * gridDim.y + blockIdx.y) * 8 + quad) * 512 + tid];
+        ((((size_t)part * tp.tail_tiles + blockIdx.x) * gridDim.y + blockIdx.y) * 8 + quad) * kTh + tid];
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
   const int n = n0 + wn * 32 + (lane & 31);
@@ -980,7 +992,8 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
            float s_mask, float s_w, float s_out, hipStream_t st);
 
 thread_local int g_mdconv_variant = 0;
-thread_local bool g_mdconv_no_tail = false;  // variant 4: LDS-DMA kernel without the split-K tail
+thread_local bool g_mdconv_no_tail = false;
+thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles  // variant 4: LDS-DMA kernel without the split-K tail
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -996,8 +1009,6 @@ bool make_dims(ConvDims &d, int B, int Cin, int H, int W, int Cout, int Kh, int 
   d = ConvDims{B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo};
   return true;
 }
-
-int glds_resident_blocks();
 
 struct WsLayout {
   size_t xt, wt, col, total;
@@ -1017,18 +1028,58 @@ WsLayout ws_layout(const ConvDims &d, size_t es) {
   return w;
 }
 
+template <int WN>
 int glds_resident_blocks() {
   static thread_local int cached_dev = -1, cached = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev == cached_dev) return cached;
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_f16_kernel, 512, kGldsLds) != hipSuccess ||
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_f16_kernel<WN>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, Glds<WN>::kLds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_f16_kernel<WN>, Glds<WN>::kThreads,
+                                                   Glds<WN>::kLds) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
   cached_dev = dev;
   cached = per_cu * cus;
   return cached;
+}
+
+// launch of the LDS-DMA kernel with its tail plan
+template <int WN>
+int launch_glds(const __half *xt, const void *offset, const void *mask, const __half *wt, const void *bias,
+                void *output, const ConvDims &d, int g, char *part_ws, size_t part_room, bool nhwc_io,
+                bool relu, bool allow_tail, hipStream_t st) {
+  const int KK = d.Kh * d.Kw, cout_g = d.Cout / d.G;
+  const size_t N = (size_t)d.B * d.Ho * d.Wo;
+  const dim3 grid((unsigned)((N + Glds<WN>::kN - 1) / Glds<WN>::kN), (cout_g + kFM - 1) / kFM);
+  const int slots = glds_resident_blocks<WN>();
+  if (slots <= 0) return BEVOPS_FAILURE;
+  // tail plan: leftover tiles of a sparsely filled last round are split along K
+  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0};
+  const int blocks = (int)(grid.x * grid.y);
+  if (allow_tail && blocks > slots && grid.y == 1) {
+    const int left = blocks % slots;
+    int split = 0;
+    for (int f = KK; f >= 2; --f)
+      if (KK % f == 0 && left * f <= slots) { split = f; break; }
+    const size_t need = (size_t)split * left * Glds<WN>::kThreads * 32 * sizeof(float);
+    if (left > 0 && left * 2 <= slots && split >= 2 && part_room >= need) {
+      tp.tail_tiles = left;
+      tp.split = split;
+      tp.main_tiles = (int)grid.x - left;
+      tp.partial = reinterpret_cast<float *>(part_ws);
+    }
+  }
+  const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
+  hipLaunchKernelGGL(dcn_glds_f16_kernel<WN>, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
+                     (const __half *)offset, (const __half *)mask, wt, (const __half *)bias, (__half *)output, d,
+                     g, tp);
+  if (tp.tail_tiles)
+    hipLaunchKernelGGL(dcn_tail_finish_kernel<WN>, dim3((unsigned)tp.tail_tiles, grid.y, 8),
+                       dim3(Glds<WN>::kThreads), 0, st, (const __half *)bias, (__half *)output, d, g, tp);
+  return launch_status();
 }
 
 template <typename T>
@@ -1063,37 +1114,19 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
         const bool one_dg = cin_g <= d.Cin / d.DG && (g * cin_g) / (d.Cin / d.DG) == (g * cin_g + cin_g - 1) / (d.Cin / d.DG);
         if ((nhwc_io || relu) && !(g_mdconv_variant == 0 && one_dg)) return BEVOPS_NOT_SUPPORTED;
         if (g_mdconv_variant == 0 && one_dg) {
-          static thread_local bool attr_set = false;
-          if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_f16_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kGldsLds) != hipSuccess)
-              return BEVOPS_FAILURE;
-            attr_set = true;
-          }
-          // tail plan: leftover tiles of a sparsely filled last round are split along K
-          TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0};
-          const int slots = glds_resident_blocks();
-          const int blocks = (int)(grid.x * grid.y);
-          if (g_mdconv_variant == 0 && !g_mdconv_no_tail && slots > 0 && blocks > slots && grid.y == 1) {
-            const int left = blocks % slots;
-            int split = 0;
-            for (int f = KK; f >= 2; --f)
-              if (KK % f == 0 && left * f <= slots) { split = f; break; }
-            const size_t need = (size_t)split * left * 512 * 32 * sizeof(float);
-            if (left > 0 && left * 2 <= slots && split >= 2 && w.total - w.col >= need) {
-              tp.tail_tiles = left;
-              tp.split = split;
-              tp.main_tiles = (int)grid.x - left;
-              tp.partial = reinterpret_cast<float *>(ws + w.col);
-            }
-          }
-          const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
-          hipLaunchKernelGGL(dcn_glds_f16_kernel, grid2, dim3(512), kGldsLds, st, (const __half *)xt,
-                             (const __half *)offset, (const __half *)mask, (const __half *)wt,
-                             (const __half *)bias, (__half *)output, d, g, tp);
-          if (tp.tail_tiles)
-            hipLaunchKernelGGL(dcn_tail_finish_kernel, dim3((unsigned)tp.tail_tiles, grid.y, 8), dim3(512), 0, st,
-                               (const __half *)bias, (__half *)output, d, g, tp);
+          // 128-pixel tiles (weights fetched once per 128 pixels) when they still give every CU a block
+          int cus = 0, dev = 0;
+          if (hipGetDevice(&dev) != hipSuccess ||
+              hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return BEVOPS_FAILURE;
+          const size_t wide_blocks = ((N + Glds<4>::kN - 1) / Glds<4>::kN) * ((cout_g + kFM - 1) / kFM);
+          const bool wide = g_mdconv_wide || (!g_mdconv_no_tail && wide_blocks >= (size_t)cus);
+          const int rc = wide
+                             ? launch_glds<4>((const __half *)xt, offset, mask, (const __half *)wt, bias, output, d, g,
+                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, st)
+                             : launch_glds<2>((const __half *)xt, offset, mask, (const __half *)wt, bias, output, d, g,
+                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, st);
+          if (rc != BEVOPS_SUCCESS) return rc;
         } else if (g_mdconv_variant == 2)  // A/B: the 4-wave block of r01c
           hipLaunchKernelGGL(dcn_fused_f16_kernel<256>, grid, dim3(256), 0, st, (const __half *)xt,
                              (const __half *)offset, (const __half *)mask, (const __half *)wt,
@@ -1195,9 +1228,10 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
 using namespace bevops;
 
 extern "C" int bevops_mdconv_set_variant(int variant) {
-  const int prev = g_mdconv_no_tail ? 4 : g_mdconv_variant;
+  const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
-  g_mdconv_variant = variant == 4 ? 0 : variant;
+  g_mdconv_wide = variant == 5;
+  g_mdconv_variant = (variant == 4 || variant == 5) ? 0 : variant;
   return prev;
 }
 

@@ -223,7 +223,9 @@ int bevops_sca_forward(int dtype, const void *value, const int32_t *spatial_shap
  * bevops_mdconv_workspace_size(BEVOPS_I8, ...) sizes its workspace.
  * ------------------------------------------------------------------------ */
 /* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
- * channel counts allow), 1 = force the im2col + GEMM pipeline.  Returns the previous value. */
+ * channel counts allow), 1 = force the im2col + GEMM pipeline, 2 / 3 = the register-staged
+ * fused kernels (256 / 512 threads), 4 = LDS-DMA kernel with 64-pixel tiles and no split-K
+ * tail, 5 = LDS-DMA kernel with 128-pixel tiles.  Returns the previous value. */
 int bevops_mdconv_set_variant(int variant);
 size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout, int Kh,
                                     int Kw, int stride_h, int stride_w, int pad_h, int pad_w,

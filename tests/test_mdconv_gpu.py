@@ -123,7 +123,7 @@ def test_lds_dma_kernel_and_split_k_tail_match_register_staged_kernel(bev, shape
     x, off, mask, w, b = (t.half().cuda() for t in make(B, Cin, Cout, H, W, 3, 1, 1, 1, 1, 1, off_std=2.0))
     args = (x, off, mask, w, b, 1, 1, 1, 1, 1)
     outs = {}
-    for v in (0, 4, 2):
+    for v in (0, 4, 5, 2):
         try:
             lib.bevops_mdconv_set_variant(v)
             outs[v] = bev.modulated_deformable_conv2d(*args)
@@ -132,6 +132,7 @@ def test_lds_dma_kernel_and_split_k_tail_match_register_staged_kernel(bev, shape
     scale = max(1.0, outs[2].abs().max().item())
     assert (outs[0].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale
     assert (outs[4].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale
+    assert (outs[5].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale   # 1024-thread / 128-pixel tiles
     for _ in range(3):
         assert torch.equal(bev.modulated_deformable_conv2d(*args), outs[0])
 
