@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // all resident blocks walk the same 1.2 MB weight matrix: start each tile at a different tap
   // (and wrap) so that they do not all pull the same 32 KB slice from the same L2 channels in
   // the same k-step.  The fp32 summation order then depends on the tile index only.
-  const int tap_begin = is_tail ? part * taps_per_part : ntile % KK;
+  // (only while all taps' slices fit an XCD's L2 together: 4.7 MB at stage 4 would thrash it)
+  const bool stagger = (size_t)cout_g * Kg * 2 <= (size_t)(2 << 20);
+  const int tap_begin = is_tail ? part * taps_per_part : (stagger ? ntile % KK : 0);
   const int n_my_steps = taps_per_part * chunks;
   __half n_oh, n_ow, n_mm;
   load_om(tap_begin, n_oh, n_ow, n_mm);

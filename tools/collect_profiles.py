@@ -12,7 +12,7 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-stats = glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True)
+stats = glob.glob(os.path.join(src, "prof", "**", "bench_kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "rocprofv3_bench_kernel_stats.csv"))
 per = collections.defaultdict(dict)
