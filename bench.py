@@ -265,6 +265,31 @@ def main():
         if sca_bs == BASE["sca"]["bs"] and not int8:
             roofline["traffic"], roofline["traffic_src"] = pmc_traffic()
 
+    # the same SCA call on the reference points the model itself produces (BEV pillars projected
+    # into a 6-camera rig, geometry.py): extra information, not the contract figure above
+    if roofline is not None and world == 1 and not int8:
+        try:
+            from bevformer_tensorrt_amd import geometry as G
+            img_hw = (928, 1600)
+            ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
+            cam, _ = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img(img_hw), img_hw)
+            rig = list(sca)
+            rig[2] = torch.nan_to_num(cam.reshape(6, BASE["sca"]["nq"], 1, 8), nan=-5.0, posinf=5.0, neginf=-5.0).to(dtype).to(dev)
+            for _ in range(3):
+                bev.multi_scale_deformable_attn(*rig)
+            evs = []
+            for _ in range(10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); bev.multi_scale_deformable_attn(*rig); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
+            byt = roofline["bytes_per_launch"]
+            roofline["model_geometry_refs"] = {"avg_launch_us": round(us, 2), "achieved": round(byt / us / 1e3, 1),
+                                               "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}
+        except Exception as exc:
+            roofline["model_geometry_refs"] = {"error": repr(exc)[:120]}
+
     end_to_end = None
     if world == 1 and not args.no_end_to_end and not int8:
         # the whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random
