@@ -190,8 +190,21 @@ __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
   constexpr int kBox = MB * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // smem: [level table] [staged planes] [mailboxes]
-  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned bh = vb / (unsigned)nchunk, ck = vb - bh * (unsigned)nchunk;
+  // block -> ((batch, head) plane, chunk of queries).  With 8 heads the dispatcher's round robin
+  // (block i -> XCD i % 8) is used as is: XCD x keeps head x, and all 8 XCDs walk the same
+  // (batch, chunk) sequence together -- the 8 heads' 128-byte pieces of one 1 KB offsets row (and
+  // the two halves of a logits line) are then requested at about the same time instead of by
+  // XCDs that are whole planes apart.  Otherwise: contiguous plane ranges per XCD.
+  unsigned bh, ck;
+  if (d.heads == 8) {
+    const unsigned rest = blockIdx.x >> 3;
+    bh = (rest / (unsigned)nchunk) * 8u + (blockIdx.x & 7u);
+    ck = rest % (unsigned)nchunk;
+  } else {
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    bh = vb / (unsigned)nchunk;
+    ck = vb - bh * (unsigned)nchunk;
+  }
   const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
   if (threadIdx.x < (unsigned)t.L) {
     const int l = threadIdx.x;
