@@ -126,3 +126,22 @@ def test_camera_shared_offsets_equal_repeated(ctx, variant, dtype):
     a = run(ctx, rep, variant)
     b = run(ctx, exp, variant)
     assert torch.equal(a, b)
+
+
+def test_full_size_properties_linearity_and_partition_of_unity(ctx):
+    """Size-independent properties of the default fp16 path at the full base SCA size
+    (6 cams x 30 825 keys x 40 000 queries x 4 levels x 8 points):
+      * partition of unity: a constant value map with every sample strictly inside its level
+        gives exactly that constant (softmax weights and bilinear weights both sum to 1);
+      * linearity in `value`: out(a + b) = out(a) + out(b) up to fp16 rounding."""
+    full = (6, [[116, 200], [58, 100], [29, 50], [15, 25]], 40000, 8, 4)
+    args = gen(full, ref_lo=0.25, ref_hi=0.75, off_std=0.5)
+    ones = [torch.full_like(args[0], 0.75)] + args[1:]
+    out = run(ctx, ones, 0).float()
+    assert (out - 0.75).abs().max().item() <= 2e-3
+    a = args[0]
+    b = torch.randn(a.shape, generator=torch.Generator().manual_seed(7)).half().cuda()
+    oa = run(ctx, [a] + args[1:], 0).float()
+    ob = run(ctx, [b] + args[1:], 0).float()
+    oab = run(ctx, [(a.float() + b.float()).half()] + args[1:], 0).float()
+    assert (oab - (oa + ob)).abs().max().item() <= 1e-2
