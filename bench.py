@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "int8"])
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
+                    help="N>1: all-gather of per-camera features (BASELINE config 4) or all-reduce of "
+                         "each rank's camera sum (SURVEY 8e alternative, 6x less data)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -123,7 +126,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import bevformer_tensorrt_amd as bev
-    from bevformer_tensorrt_amd.camera_shard import camera_shards, gather_camera_features
+    from bevformer_tensorrt_amd.camera_shard import camera_shards, gather_camera_features, reduce_camera_slots
 
     int8 = args.dtype == "int8"
     dtype = torch.float32 if args.dtype == "fp32" else torch.float16
@@ -203,8 +206,12 @@ def main():
                     sca_events.append((e0, e1))
             else:
                 out = sca_out[:0]
-            if world > 1:
+            if world > 1 and args.exchange == "gather":
                 gather_camera_features(out.view(out.shape[0], nq, embed), BASE["sca"]["bs"], dist)
+            elif world > 1:
+                part = out.view(out.shape[0], nq, embed).sum(0, keepdim=True) if out.shape[0] else \
+                    torch.zeros((1, nq, embed), dtype=out.dtype, device=dev)
+                reduce_camera_slots(part, dist)
         for _ in range(BASE["dec_layers"]):
             op_msda(*dec)
 
@@ -338,7 +345,7 @@ def main():
             "config": {"workload": "BEVFormer-base hot path per frame: "
                                    + "+".join(extra + ["6x(TSA+SCA) MSDA", "6x decoder MSDA"]),
                        "shapes": "SCA(6,30825,40000,4x8) TSA(2,40000,40000,1x4) dec(1,40000,900,1x4)",
-                       "parallelism": f"cameras/{world}" if world > 1 else "single"},
+                       "parallelism": f"cameras/{world}+all-{args.exchange}" if world > 1 else "single"},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end,
         }
         print(json.dumps(line), flush=True)

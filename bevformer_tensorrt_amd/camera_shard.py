@@ -48,3 +48,13 @@ def gather_camera_features(local, n_cams, dist, group=None):
     dist.all_gather_into_tensor(recv.view(-1), src.view(-1), group=group)
     # recv[r, i] is camera r + world*i  ->  camera-major order
     return recv.transpose(0, 1).reshape((max_local * world,) + tail)[:n_cams]
+
+
+def reduce_camera_slots(local_weighted_sum, dist, group=None):
+    """The cheaper exchange of SURVEY.md 8e ("note for the builder"): every rank first reduces ITS
+    cameras -- sum over local cameras of bev_mask * sampled, [1, nq, embed] = 20.5 MB at base fp16
+    -- and ONE all-reduce per encoder layer adds the partial sums (6x less data than gathering the
+    per-camera features; bev_mask is known on every rank because it only depends on lidar2img).
+    In place on `local_weighted_sum`; ranks without cameras pass zeros."""
+    dist.all_reduce(local_weighted_sum, op=dist.ReduceOp.SUM, group=group)
+    return local_weighted_sum

@@ -26,7 +26,15 @@ def _worker(rank, world, port, n_cams, q):
     local = full[mine] if mine else full[:0]
     for _ in range(2):  # second call reuses cached buffers
         got = gather_camera_features(local, n_cams, dist)
-    q.put((rank, bool(torch.equal(got, full))))
+    ok = bool(torch.equal(got, full))
+    # the all-reduce alternative: every rank reduces its cameras with the mask weights, the ranks'
+    # partial sums add up to the masked camera sum of the gathered features
+    from bevformer_tensorrt_amd.camera_shard import reduce_camera_slots
+    mask = (torch.arange(n_cams * 5, dtype=torch.float32).view(n_cams, 5, 1) % 3) / 2.0
+    want = (full * mask).sum(0, keepdim=True)
+    part = (local * mask[mine]).sum(0, keepdim=True) if mine else torch.zeros(1, 5, 3)
+    ok = ok and bool(torch.allclose(reduce_camera_slots(part, dist), want))
+    q.put((rank, ok))
     dist.destroy_process_group()
 
 
