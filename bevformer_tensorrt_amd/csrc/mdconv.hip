@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T *__restrict__
   }
 }
 
+// fp16, HW % 8 == 0 and C % 8 == 0: 64 channels x 64 pixels per block, 16-byte global accesses on
+// both sides (8 pixels of a channel in, 8 channels of a pixel out), 2-byte transposed LDS writes
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f16v_kernel(const __half *__restrict__ in,
+                                                                __half *__restrict__ out, int C, int HW) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];  // [pixel][channel], padded rows
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const __half *ib = in + (size_t)b * C * HW;
+  __half *ob = out + (size_t)b * C * HW;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int v = threadIdx.x + it * 256;  // 64 channels x 8 pixel-vectors
+    const int c = v >> 3, pv = (v & 7) * 8;
+    if (c0 + c < C && p0 + pv < HW) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(ib + (size_t)(c0 + c) * HW + p0 + pv);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tile[pv + 2 * k][c] = (unsigned short)(w[k] & 0xffffu);
+        tile[pv + 2 * k + 1][c] = (unsigned short)(w[k] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int v = threadIdx.x + it * 256;  // 64 pixels x 8 channel-vectors
+    const int p = v >> 3, cv = (v & 7) * 8;
+    if (p0 + p < HW && c0 + cv < C)
+      *reinterpret_cast<uint4 *>(ob + (size_t)(p0 + p) * C + c0 + cv) = *reinterpret_cast<const uint4 *>(&tile[p][cv]);
+  }
+}
+
 // ---- 2. weight [Cout][Cin/g][KK] -> [Cout][KK][Cin/g] ------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void repack_weight_kernel(const T *__restrict__ w,
@@ -1099,6 +1132,9 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   const bool fits32 = (size_t)d.B * d.Cin * HW * 2 < 0xFFFFFF00ull && (size_t)d.Cout * cin_g * KK * 2 < 0xFFFFFF00ull;
   if (nhwc_io)  // the caller's tensor already is the [B, H, W, Cin] image the gather wants
     xt = const_cast<T *>(static_cast<const T *>(input));
+  else if (sizeof(T) == 2 && HW % 8 == 0 && d.Cin % 8 == 0 && aligned16(input))
+    hipLaunchKernelGGL(nchw_to_nhwc_f16v_kernel, dim3((HW + 63) / 64, (d.Cin + 63) / 64, d.B), dim3(256), 0, st,
+                       (const __half *)input, (__half *)xt, d.Cin, HW);
   else
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
                        0, st, (const T *)input, xt, d.Cin, HW);
