@@ -477,6 +477,27 @@ class BEVFormer(nn.Module):
         return bev_embed, torch.stack(classes), torch.stack(coords)
 
 
+def use_tuned_gemms(path=None):
+    """Dense layers stay on hipBLASLt / rocBLAS; their per-shape solution choice
+    was tuned once on an MI355X with PyTorch's TunableOp (36 s for the 35 GEMM shapes of
+    BEVFormer-base, e.g. the 34800x256x1024 layer-3 1x1 convolution 61 -> 44 us) and is shipped as
+    bevformer_tensorrt_amd/tunableop_gfx950.csv; this only reads it (no tuning at run time; the
+    file is ignored by PyTorch if its library-version validators do not match)."""
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+    try:
+        if not os.path.exists(path) or os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None:
+            return False          # the user drives TunableOp through the environment
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(path)
+        tunable.read_file(path)
+        return True
+    except Exception:
+        return False
+
+
 class FrameRunner:
     """Stateful frame loop of tools/bevformer/evaluate_trt.py:76-154 with `prev_bev` kept on the
     device: can_bus position/angle deltas against the previous frame, `use_prev_bev = 0` on a
@@ -487,6 +508,7 @@ class FrameRunner:
     def __init__(self, model, device, dtype, graph=False, cams=None, gather=None):
         self.model, self.device, self.dtype = model, device, dtype
         self.cams, self.gather = cams, gather
+        self.tuned_gemms = use_tuned_gemms() if device.type == "cuda" else False
         nq = model.bev_h * model.bev_w
         self.prev_bev = torch.zeros(nq, 1, EMBED, device=device, dtype=dtype)
         self.prev = {"scene": None, "pos": None, "angle": None}
