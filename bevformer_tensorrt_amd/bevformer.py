@@ -79,9 +79,9 @@ def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
         x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
     wt = conv.weight.view(conv.out_channels, c).t()
-    if residual is not None:   # residual enters through the GEMM's beta term, shift + ReLU in one pass
-        y = torch.addmm(_rows(residual), _rows(x), wt)
-        ops.bias_act_nhwc_(y, conv.bias, None, relu)
+    if residual is not None:   # GEMM, then shift + identity + ReLU in one pass (addmm with the identity
+        y = torch.mm(_rows(x), wt)   # as its beta term would first memcpy it into the output: +21 us at layer 3)
+        ops.bias_act_nhwc_(y, conv.bias, _rows(residual), relu)
     elif relu:
         y = torch._addmm_activation(conv.bias, _rows(x), wt)
     else:
@@ -126,7 +126,10 @@ class DCNv2Pack(nn.Module):
             b32 = torch.zeros(32, dtype=w.dtype, device=w.device)
             b32[:27] = self.conv_offset.bias.detach()
             self._w32 = (w32.contiguous(memory_format=torch.channels_last), b32, (w._version, w.dtype, w.device))
-        out = F.conv2d(x, self._w32[0], self._w32[1], self.stride, 1).contiguous()   # planar, as the op expects
+        out = F.conv2d(x, self._w32[0], None, self.stride, 1)
+        if not out.is_contiguous(memory_format=torch.channels_last):
+            out = out.contiguous(memory_format=torch.channels_last)
+        out = self.ops.bias_act_nhwc_(out, self._w32[1], None, False).contiguous()   # planar, as the op expects
         # (o1, o2) are the first 18 channels already in the order cat((o1, o2)) gives
         return self.ops.modulated_deformable_conv2d_nhwc(x, out[:, :18], torch.sigmoid(out[:, 18:27]), self.weight,
                                                          self.bias, self.stride, 1, 1, 1, 1, relu=relu)
