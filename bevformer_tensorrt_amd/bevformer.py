@@ -129,10 +129,11 @@ class DCNv2Pack(nn.Module):
         out = F.conv2d(x, self._w32[0], None, self.stride, 1)
         if not out.is_contiguous(memory_format=torch.channels_last):
             out = out.contiguous(memory_format=torch.channels_last)
-        out = self.ops.bias_act_nhwc_(out, self._w32[1], None, False).contiguous()   # planar, as the op expects
-        # (o1, o2) are the first 18 channels already in the order cat((o1, o2)) gives
-        return self.ops.modulated_deformable_conv2d_nhwc(x, out[:, :18], torch.sigmoid(out[:, 18:27]), self.weight,
-                                                         self.bias, self.stride, 1, 1, 1, 1, relu=relu)
+        out = self.ops.bias_act_nhwc_(out, self._w32[1], None, False)
+        # the raw [B, H, W, 32] tensor goes to the operator: (o1, o2) are its first 18 channels in the
+        # order cat((o1, o2)) gives, the mask logits the next 9; sigmoid fused
+        return self.ops.modulated_deformable_conv2d_nhwc(x, None, None, self.weight, self.bias, self.stride, 1, 1,
+                                                         1, 1, relu=relu, offset_mask_nhwc=out)
 
 
 class Bottleneck(nn.Module):

@@ -607,6 +607,8 @@ struct TailPlan {
   int tail_tiles, split, main_tiles;  // grid.x = tail_tiles * split + main_tiles
   float *partial;                     // [split][tail_tiles][Cout tiles][8 quads][threads] float4
   int out_nhwc, relu;                 // epilogue: output layout [B,Ho,Wo,Cout], fused ReLU
+  int om_channels;                    // > 0: `offset` is the raw [B,Ho,Wo,om_channels] output of the pack's
+                                      // offset convolution (2*KK offsets, then KK mask logits): sigmoid here
 };
 
 // 4 consecutive output channels m..m+3 of pixel (b, pix): bias, optional ReLU, NCHW or NHWC store
@@ -705,10 +707,19 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // offsets / mask of the pixel, one tap ahead in registers
   const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
   const size_t mb = (((size_t)pb * d.DG + dg) * KK) * HoWo + ppix;
+  const size_t omb = ((size_t)pb * HoWo + ppix) * (size_t)tp.om_channels + (size_t)dg * 3 * KK;
   auto load_om = [&](int tap, __half &oh, __half &ow, __half &mm) {
-    oh = offset[ob + (size_t)(2 * tap) * HoWo];
-    ow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
-    mm = mask[mb + (size_t)tap * HoWo];
+    if (tp.om_channels) {  // channels-last: one pixel's values are contiguous; mask = sigmoid(logit)
+      const unsigned o2 = *reinterpret_cast<const unsigned *>(offset + omb + 2 * tap);
+      oh = __ushort_as_half((unsigned short)(o2 & 0xffffu));
+      ow = __ushort_as_half((unsigned short)(o2 >> 16));
+      const float z = __half2float(offset[omb + 2 * KK + tap]);
+      mm = __float2half_rn(1.f / (1.f + __expf(-z)));
+    } else {
+      oh = offset[ob + (size_t)(2 * tap) * HoWo];
+      ow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
+      mm = mask[mb + (size_t)tap * HoWo];
+    }
   };
   const int taps_per_part = is_tail ? KK / tp.split : KK;
   // all resident blocks walk the same 1.2 MB weight matrix: start each tile at a different tap
@@ -1085,14 +1096,14 @@ int glds_resident_blocks() {
 template <int WN>
 int launch_glds(const __half *xt, const void *offset, const void *mask, const __half *wt, const void *bias,
                 void *output, const ConvDims &d, int g, char *part_ws, size_t part_room, bool nhwc_io,
-                bool relu, bool allow_tail, hipStream_t st) {
+                bool relu, bool allow_tail, int om_channels, hipStream_t st) {
   const int KK = d.Kh * d.Kw, cout_g = d.Cout / d.G;
   const size_t N = (size_t)d.B * d.Ho * d.Wo;
   const dim3 grid((unsigned)((N + Glds<WN>::kN - 1) / Glds<WN>::kN), (cout_g + kFM - 1) / kFM);
   const int slots = glds_resident_blocks<WN>();
   if (slots <= 0) return BEVOPS_FAILURE;
   // tail plan: leftover tiles of a sparsely filled last round are split along K
-  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0};
+  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0, om_channels};
   const int blocks = (int)(grid.x * grid.y);
   if (allow_tail && blocks > slots && grid.y == 1) {
     const int left = blocks % slots;
@@ -1120,7 +1131,7 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
 template <typename T>
 int run(const void *input, const void *offset, const void *mask, const void *weight,
         const void *bias, void *output, void *workspace, const ConvDims &d, hipStream_t st,
-        bool weight_is_packed = false, bool nhwc_io = false, bool relu = false) {
+        bool weight_is_packed = false, bool nhwc_io = false, bool relu = false, int om_channels = 0) {
   const WsLayout w = ws_layout(d, sizeof(T));
   char *ws = static_cast<char *>(workspace);
   T *xt = reinterpret_cast<T *>(ws + w.xt);
@@ -1150,7 +1161,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
       const dim3 grid((unsigned)((N + kFN - 1) / kFN), (cout_g + kFM - 1) / kFM);
       for (int g = 0; g < d.G; ++g) {
         const bool one_dg = cin_g <= d.Cin / d.DG && (g * cin_g) / (d.Cin / d.DG) == (g * cin_g + cin_g - 1) / (d.Cin / d.DG);
-        if ((nhwc_io || relu) && !(g_mdconv_variant == 0 && one_dg)) return BEVOPS_NOT_SUPPORTED;
+        if ((nhwc_io || relu || om_channels) && !(g_mdconv_variant == 0 && one_dg)) return BEVOPS_NOT_SUPPORTED;
         if (g_mdconv_variant == 0 && one_dg) {
           // 128-pixel tiles (weights fetched once per 128 pixels) when they still give every CU a block
           int cus = 0, dev = 0;
@@ -1161,9 +1172,9 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
           const bool wide = g_mdconv_wide || (!g_mdconv_no_tail && wide_blocks >= (size_t)cus);
           const int rc = wide
                              ? launch_glds<4>((const __half *)xt, offset, mask, (const __half *)wt, bias, output, d, g,
-                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, st)
+                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, om_channels, st)
                              : launch_glds<2>((const __half *)xt, offset, mask, (const __half *)wt, bias, output, d, g,
-                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, st);
+                                              ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, om_channels, st);
           if (rc != BEVOPS_SUCCESS) return rc;
         } else if (g_mdconv_variant == 2)  // A/B: the 4-wave block of r01c
           hipLaunchKernelGGL(dcn_fused_f16_kernel<256>, grid, dim3(256), 0, st, (const __half *)xt,
@@ -1177,7 +1188,7 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
       return launch_status();
     }
   }
-  if (nhwc_io || relu) return BEVOPS_NOT_SUPPORTED;  // only the fused fp16 kernel has these epilogues
+  if (nhwc_io || relu || om_channels) return BEVOPS_NOT_SUPPORTED;  // only the fused fp16 kernel has these
   constexpr int VMAX = sizeof(T) == 2 ? 8 : 4;
   const bool vec = cin_g % VMAX == 0 && (d.Cin / d.DG) % VMAX == 0;
   {
@@ -1335,8 +1346,9 @@ static int mdconv_forward_impl(int dtype, const void *input, const void *offset,
                                size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
                                int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                                int dil_w, int groups, int deform_groups, void *stream, bool packed,
-                               bool nhwc_io = false, bool relu = false) {
-  if (!input || !offset || !mask || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
+                               bool nhwc_io = false, bool relu = false, int om_channels = 0) {
+  if (!input || !offset || (!mask && !om_channels) || !weight || !output || !workspace) return BEVOPS_BAD_PARAM;
+  if (om_channels && (om_channels < deform_groups * 3 * Kh * Kw || (om_channels & 1))) return BEVOPS_BAD_PARAM;
   ConvDims d;
   if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
                  groups, deform_groups))
@@ -1346,14 +1358,15 @@ static int mdconv_forward_impl(int dtype, const void *input, const void *offset,
   if (!aligned16(workspace) || (packed && !aligned16(weight))) return BEVOPS_BAD_PARAM;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == BEVOPS_F32)
-    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu);
-  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu);
+    return run<float>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu, om_channels);
+  return run<__half>(input, offset, mask, weight, bias, output, workspace, d, st, packed, nhwc_io, relu, om_channels);
 }
 
 extern "C" int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *offset,
                                           const void *mask, const void *packed_weight,
                                           const void *bias, void *output_nhwc, int relu,
-                                          void *workspace, size_t workspace_bytes, int B, int Cin,
+                                          int offset_mask_channels, void *workspace,
+                                          size_t workspace_bytes, int B, int Cin,
                                           int H, int W, int Cout, int Kh, int Kw, int stride_h,
                                           int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                                           int groups, int deform_groups, void *stream) {
@@ -1362,7 +1375,7 @@ extern "C" int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, con
   return mdconv_forward_impl(dtype, input_nhwc, offset, mask, packed_weight, bias, output_nhwc,
                              workspace, workspace_bytes, B, Cin, H, W, Cout, Kh, Kw, stride_h,
                              stride_w, pad_h, pad_w, dil_h, dil_w, groups, deform_groups, stream, true,
-                             true, relu != 0);
+                             true, relu != 0, offset_mask_channels);
 }
 
 extern "C" int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,

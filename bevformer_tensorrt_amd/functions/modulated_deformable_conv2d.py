@@ -119,16 +119,26 @@ def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in
 
 
 def modulated_deformable_conv2d_nhwc(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
-                                     groups=1, deform_groups=1, relu=False):
+                                     groups=1, deform_groups=1, relu=False, offset_mask_nhwc=None):
     """Channels-last DCNv2 for the re-hosted backbone (not a reference plugin): `input` is an
     NCHW-shaped tensor in torch.channels_last memory format (= [B, H, W, C] in memory), the
     result likewise; offset / mask keep the reference's planar layout; optional fused ReLU.
-    fp16, fused-kernel domain only (raises BevopsError otherwise)."""
+    fp16, fused-kernel domain only (raises BevopsError otherwise).
+    offset_mask_nhwc: instead of (offset, mask), the raw channels-last output [B, OC, Ho, Wo] of
+    the pack's offset convolution (2*KK offsets then KK mask logits); the sigmoid is fused."""
     assert input.is_cuda and input.dtype == torch.float16
     handle = _lib.load_library()
     if not input.is_contiguous(memory_format=torch.channels_last):
         input = input.contiguous(memory_format=torch.channels_last)
-    offset, mask = offset.to(input.dtype).contiguous(), mask.to(input.dtype).contiguous()
+    om_ch = 0
+    if offset_mask_nhwc is not None:
+        assert offset_mask_nhwc.dtype == torch.float16
+        if not offset_mask_nhwc.is_contiguous(memory_format=torch.channels_last):
+            offset_mask_nhwc = offset_mask_nhwc.contiguous(memory_format=torch.channels_last)
+        om_ch = offset_mask_nhwc.shape[1]
+        offset, mask = offset_mask_nhwc, None
+    else:
+        offset, mask = offset.to(input.dtype).contiguous(), mask.to(input.dtype).contiguous()
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     B, Cin, H, W = input.shape
     Cout, _, Kh, Kw = weight.shape
@@ -148,8 +158,9 @@ def modulated_deformable_conv2d_nhwc(input, offset, mask, weight, bias=None, str
         bias = bias.to(input.dtype).contiguous()
     with torch.cuda.device(input.device):
         st = handle.bevops_mdconv_forward_nhwc(
-            _lib.F16, input.data_ptr(), offset.data_ptr(), mask.data_ptr(), packed.data_ptr(),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(), int(relu), ws.data_ptr(), ws_bytes,
+            _lib.F16, input.data_ptr(), offset.data_ptr(), mask.data_ptr() if mask is not None else None,
+            packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), int(relu), om_ch,
+            ws.data_ptr(), ws_bytes,
             *dims, _lib.current_stream_ptr(input.device))
     _lib.check(st, "bevops_mdconv_forward_nhwc")
     return out

@@ -44,7 +44,7 @@ SIGNATURES = {
                               [c_void_p]),
     "bevops_mdconv_forward_packed": (c_int, [c_int] + [c_void_p] * 7 + [c_size_t] + [c_int] * 15 +
                                      [c_void_p]),
-    "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_size_t] + [c_int] * 15 +
+    "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                    [c_void_p]),
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),

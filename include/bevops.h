@@ -252,10 +252,15 @@ int bevops_mdconv_pack_weight(int dtype, const void *weight, void *packed, int C
                               int Cin_per_group, int Kh, int Kw, void *stream);
 /* Channels-last variant for a caller whose activations are [B, H, W, C] (the re-hosted backbone):
  * input and output NHWC, packed weights, optional fused ReLU; fp16 fused-kernel domain only
- * (NOT_SUPPORTED otherwise).  offset / mask keep the reference's planar [B, ., Ho, Wo] layout. */
+ * (NOT_SUPPORTED otherwise).  offset_mask_channels == 0: offset / mask keep the reference's
+ * planar [B, ., Ho, Wo] layout.  offset_mask_channels == OC > 0: `offset` is the raw channels-last
+ * output [B, Ho, Wo, OC] of the pack's offset convolution (cnn/dcn.py:62-70: 2*KK offset channels
+ * then KK mask logits per deform group, OC >= deform_groups*3*KK, even), `mask` is ignored and
+ * the sigmoid is applied in the kernel. */
 int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *offset,
                                const void *mask, const void *packed_weight, const void *bias,
-                               void *output_nhwc, int relu, void *workspace, size_t workspace_bytes,
+                               void *output_nhwc, int relu, int offset_mask_channels,
+                               void *workspace, size_t workspace_bytes,
                                int B, int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h,
                                int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int groups,
                                int deform_groups, void *stream);
