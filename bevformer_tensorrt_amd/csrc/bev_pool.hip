@@ -86,6 +86,91 @@ __global__ __launch_bounds__(kBlock) void bev_pool_kernel(
   }
 }
 
+// Split-interval variant (fp16 V=8, int8 V=16; channels/V a power of two <= 32): a wave's 64 lanes =
+// S point-slices x (channels/V) channel vectors of ONE or more intervals; slice s takes points
+// s, s+S, ... of the interval (each step of a wave reads S whole feature rows), the partial sums are
+// combined with wave shuffles.  The one-thread-per-(interval, vector) kernel above serialises the
+// 100+ point intervals near the ego vehicle (BEVDet-R50: 82 us for 5 MB of traffic).
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void bev_pool_split_kernel(
+    const T *__restrict__ depth, const T *__restrict__ feat, const int *__restrict__ ranks_depth,
+    const int *__restrict__ ranks_feat, const int *__restrict__ ranks_bev,
+    const int *__restrict__ interval_starts, const int *__restrict__ interval_lengths,
+    T *__restrict__ out, int c, int n_intervals, float scale_io, int S) {
+  const int vpr = c / V;                 // lanes per point slice
+  const int lanes_per_k = vpr * S;       // power of two, <= 64
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long k = idx / lanes_per_k;
+  const int within = (int)(idx - k * lanes_per_k);
+  const int sl = within / vpr, cv = (within - sl * vpr) * V;
+  const bool live = k < n_intervals;
+  const int s = live ? interval_starts[k] : 0, len = live ? interval_lengths[k] : 0;
+  if constexpr (sizeof(T) == 1) {
+    int acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0;
+    for (int i = sl; i < len; i += S) {
+      const int d = (int)depth[ranks_depth[s + i]];
+      int8_t fv[V];
+      *reinterpret_cast<uint4 *>(fv) =
+          *reinterpret_cast<const uint4 *>((const int8_t *)feat + (size_t)ranks_feat[s + i] * c + cv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += (int)fv[j] * d;
+    }
+    for (int m = vpr; m < lanes_per_k; m <<= 1)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += __shfl_xor(acc[j], m);
+    if (live && sl == 0) {
+      int8_t r[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) r[j] = t2int8((float)acc[j] * scale_io);
+      *reinterpret_cast<uint4 *>(out + (size_t)ranks_bev[s] * c + cv) = *reinterpret_cast<const uint4 *>(r);
+    }
+  } else {
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int i = sl; i < len; i += S) {
+      const float d = ld<T>(depth + ranks_depth[s + i]);
+      const uint4 r = *reinterpret_cast<const uint4 *>(feat + (size_t)ranks_feat[s + i] * c + cv);
+      acc[0] = fmaf(h2f_lo(r.x), d, acc[0]); acc[1] = fmaf(h2f_hi(r.x), d, acc[1]);
+      acc[2] = fmaf(h2f_lo(r.y), d, acc[2]); acc[3] = fmaf(h2f_hi(r.y), d, acc[3]);
+      acc[4] = fmaf(h2f_lo(r.z), d, acc[4]); acc[5] = fmaf(h2f_hi(r.z), d, acc[5]);
+      acc[6] = fmaf(h2f_lo(r.w), d, acc[6]); acc[7] = fmaf(h2f_hi(r.w), d, acc[7]);
+    }
+    for (int m = vpr; m < lanes_per_k; m <<= 1)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += __shfl_xor(acc[j], m);
+    if (live && sl == 0) {
+      uint4 r;
+      r.x = pack_h2(acc[0], acc[1]); r.y = pack_h2(acc[2], acc[3]);
+      r.z = pack_h2(acc[4], acc[5]); r.w = pack_h2(acc[6], acc[7]);
+      *reinterpret_cast<uint4 *>(out + (size_t)ranks_bev[s] * c + cv) = r;
+    }
+  }
+}
+
+template <typename T, int V>
+int launch_split(const void *depth, const void *feat, const int *rd, const int *rf, const int *rb,
+                 const int *is, const int *il, void *out, int c, int n_intervals, float scale_io,
+                 hipStream_t st) {
+  const int vpr = c / V;
+  const int S = 64 / vpr < 8 ? 64 / vpr : 8;
+  const long threads = (long)n_intervals * vpr * S;
+  const long blocks = (threads + kBlock - 1) / kBlock;
+  if (blocks > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL((bev_pool_split_kernel<T, V>), dim3((unsigned)blocks), dim3(kBlock), 0, st,
+                     (const T *)depth, (const T *)feat, rd, rf, rb, is, il, (T *)out, c, n_intervals,
+                     scale_io, S);
+  return launch_status();
+}
+
+inline bool split_ok(int channels, int V) {
+  if (channels % V) return false;
+  const int vpr = channels / V;
+  return vpr <= 32 && (vpr & (vpr - 1)) == 0;
+}
+
 template <typename T, int V>
 int launch(const void *depth, const void *feat, const int *rd, const int *rf, const int *rb,
            const int *is, const int *il, void *out, int c, int n_intervals, float scale_io,
@@ -131,6 +216,9 @@ extern "C" int bevops_bev_pool_v2_forward(int dtype, const void *depth, const vo
       return launch<float, 1>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
                               interval_lengths, output, channels, n_intervals, 1.f, st);
     case BEVOPS_F16:
+      if (al && split_ok(channels, 8))
+        return launch_split<__half, 8>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                                       interval_lengths, output, channels, n_intervals, 1.f, st);
       if (channels % 8 == 0 && al)
         return launch<__half, 8>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
                                  interval_lengths, output, channels, n_intervals, 1.f, st);
@@ -139,6 +227,9 @@ extern "C" int bevops_bev_pool_v2_forward(int dtype, const void *depth, const vo
     case BEVOPS_I8: {
       if (!(scale_depth > 0.f) || !(scale_feat > 0.f) || !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
       const float sio = scale_depth * scale_feat / scale_out;  // bevPoolKernel.cu:188
+      if (al && split_ok(channels, 16))
+        return launch_split<int8_t, 16>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                                        interval_lengths, output, channels, n_intervals, sio, st);
       if (channels % 16 == 0 && al)
         return launch<int8_t, 16>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
                                   interval_lengths, output, channels, n_intervals, sio, st);
