@@ -72,3 +72,35 @@ def test_fused_sca_equals_unfused_ops_and_ignores_masked_refs():
     # all pairs masked out -> exact zeros
     z = bev.spatial_cross_attention_sample(value, sh, ref, off, logit, torch.zeros_like(mask))
     assert torch.count_nonzero(z).item() == 0
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of the additions to the C ABI: status codes, never a crash."""
+    import ctypes
+    from bevformer_tensorrt_amd.utils import lib as L
+    h = L.load_library()
+    value, sh, ref, off, logit, mask = gen(SHAPES["odd"])
+    shapes_host = sh.cpu().contiguous()
+    ncam, nk, heads, ch = value.shape
+    nq = off.shape[1]
+    out = torch.empty(1, nq, 256, dtype=torch.half, device="cuda")
+    n = h.bevops_sca_workspace_size(L.F16, shapes_host.data_ptr(), ncam, nk, heads, ch, 4, nq, 4)
+    assert n > 0
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = L.current_stream_ptr(value.device)
+    args = lambda **kw: [kw.get("dtype", L.F16), value.data_ptr(), shapes_host.data_ptr(), ref.data_ptr(),
+                         off.data_ptr(), logit.data_ptr(), kw.get("mask", mask.data_ptr()), out.data_ptr(), ncam,
+                         kw.get("nk", nk), heads, ch, 4, nq, 4, 2, ws.data_ptr(), kw.get("bytes", n), st]
+    assert h.bevops_sca_forward(*args()) == 0
+    BAD, UNSUP = 2, 3                                              # include/bevops.h status codes
+    assert h.bevops_sca_forward(*args(mask=None)) == BAD           # null pointer
+    assert h.bevops_sca_forward(*args(nk=nk + 1)) == BAD           # level shapes do not add up to nk
+    assert h.bevops_sca_forward(*args(bytes=n // 2)) == BAD        # workspace too small
+    assert h.bevops_sca_forward(*args(dtype=L.F32)) == UNSUP
+    assert h.bevops_sca_workspace_size(L.F32, shapes_host.data_ptr(), ncam, nk, heads, ch, 4, nq, 4) == 0
+    x = torch.zeros(4, 24, dtype=torch.half, device="cuda")
+    assert h.bevops_bias_act_nhwc(L.F16, x.data_ptr(), None, None, 4, 24, 1, st) == 0
+    assert h.bevops_bias_act_nhwc(L.F16, x.data_ptr(), None, None, 4, 20, 1, st) == UNSUP  # channels % 8
+    assert h.bevops_bias_act_nhwc(L.F16, x.data_ptr() + 2, None, None, 4, 24, 1, st) == BAD  # misaligned
+    assert h.bevops_bias_act_nhwc(L.F32, x.data_ptr(), None, None, 4, 24, 1, st) == UNSUP
+    torch.cuda.synchronize()
