@@ -6,9 +6,10 @@
  *   TensorRT/plugin/bev_pool_v2/bevPoolKernel.cu:115-149,188            (int8 flavour)
  * out[ranks_bev[s_k], c] = sum_{i<len_k} depth[ranks_depth[s_k+i]] * feat[ranks_feat[s_k+i], c];
  * every other output cell is 0 (the reference memsets the output, bevPoolKernel.cu:156).
- * The source of the fp32 op is a CUDA extension that cannot run here; the oracle is
- * pinned by tests against an independent torch.index_add_ statement of the same sum
- * on the reference test's own index tensors (tests/golden/bev_pool_ref_ranks.npz).
+ * Pinned BIT-EXACT (fp32 and int8) against the reference's plugin kernels run on the host
+ * (oracle/_ref, tests/test_ref_kernels_cpu.py) and against an independent
+ * torch.index_add_ statement of the same sum on the reference test's own index tensors
+ * (tests/golden/bev_pool_ref_ranks.npz).
  */
 #include <stdint.h>
 #include <string.h>

@@ -17,9 +17,12 @@
  *           accurate; see DESIGN.md "int8 numerics")
  *
  * Pinning: tests/test_oracle_golden.py checks oracle_msda_f32 against the golden
- * vectors produced by the reference's own Python code (tests/golden/make_golden.py).
- * The int8 flavours have no runnable reference in this container (CUDA only):
- * "parity unpinned" for int8 beyond the reference test's tolerance against fp32.
+ * vectors produced by the reference's own Python code (tests/golden/make_golden.py);
+ * tests/test_ref_kernels_cpu.py checks every function here against the outputs of the
+ * reference's own kernels run on the host (oracle/_ref, tests/golden/refk_msda_*.npz):
+ * oracle_msda_f32 and oracle_msda_s8 are BIT-EXACT against them; oracle_msda_s8_u8w
+ * shares the integer pipeline of the <__half2> kernel and differs where that kernel
+ * sums / requantises in binary16 (>= 80 % identical, >= 99.9 % within 3 LSB).
  *
  * Layouts (all contiguous, row-major):
  *   value  [bs, nk, heads, C]           nk = sum_l H_l*W_l, levels concatenated in order

@@ -16,7 +16,11 @@
  *                  plugin kernel TensorRT/plugin/rotate/rotateKernel.cu:128-210.
  *
  * Pinned by tests/test_oracle_golden.py against golden vectors produced by the
- * reference's own Python functions (tests/golden/make_golden.py).
+ * reference's own Python functions (tests/golden/make_golden.py) and by
+ * tests/test_ref_kernels_cpu.py against the reference's own kernels run on the host
+ * (oracle/_ref, tests/golden/refk_{grid_sampler,rotate}_*.npz): nearest bit-exact,
+ * bilinear / bicubic within 2e-5; int8 within 1-4 LSB of kernels that evaluate their
+ * coordinates in binary16.
  *
  * Layout: input [N,C,(D,)H,W], grid channel-first [N,2,Ho,Wo] / [N,3,Do,Ho,Wo] in
  * [-10,10] units (x, y[, z]), output [N,C,(Do,)Ho,Wo].
@@ -206,9 +210,9 @@ void oracle_rotate(const float *img, float angle_deg, float center_x, float cent
  * out = T2int8(t * (1/127) * s_in / s_out); nearest: out = T2int8(v * s_in / s_out).
  * Coordinates are evaluated in fp32 here (the reference uses half2) and out-of-range
  * corners contribute 0 (the reference leaves `inps[]` stale there -- SURVEY.md
- * Appendix B, "reference behaviours not to copy").  No runnable reference exists for
- * these in this container: parity unpinned beyond the fp32 op + the reference test's
- * tolerance.  Dense [C,H,W] int8 layout. */
+ * Appendix B, "reference behaviours not to copy").  Pinned against the reference's int8
+ * kernels run on the host (tests/test_ref_kernels_cpu.py): nearest grid_sampler identical,
+ * the rest >= 97 % within 1 LSB, max 3-4.  Dense [C,H,W] int8 layout. */
 static inline int8_t t2int8_f(float a) {
   a = a > 127 ? 127 : a;
   a = a < -128 ? -128 : a;
