@@ -280,6 +280,26 @@ __global__ __launch_bounds__(256) void gemm_tn_f16_kernel(const __half *__restri
   }
 }
 
+// ---- 4a'. fp16 GEMM for ragged K (K % 8 != 0: rows are not 16-byte aligned) -----------
+// One thread per output element, 2-byte loads, fp32 accumulate.  Only reached by shapes such as
+// Cin/groups = 4 with a 3x3 kernel (K = 36); the reference's half kernel accepts them, so the
+// drop-in must too.  Lanes run along the pixels so the column reads of a k step are one row apart.
+__global__ __launch_bounds__(256) void gemm_tn_f16_ragged_kernel(const __half *__restrict__ A,
+                                                                 const __half *__restrict__ B,
+                                                                 const __half *__restrict__ bias,
+                                                                 __half *__restrict__ out, int M, int N, int K,
+                                                                 GemmEpi e) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * N) return;
+  const int n = (int)(idx % N), m = (int)(idx / N);
+  const __half *a = A + (size_t)m * K, *b = B + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(__half2float(a[k]), __half2float(b[k]), acc);
+  if (bias) acc += __half2float(bias[e.co0 + m]);
+  const int bi = n / e.HoWo, pix = n - bi * e.HoWo;
+  out[((size_t)bi * e.Cout + e.co0 + m) * e.HoWo + pix] = __float2half_rn(acc);
+}
+
 // ---- 4b. fp32 GEMM (exact fp32 FMA tiles; parity path) -------------------------------
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A,
                                                           const float *__restrict__ Bm,
@@ -1215,7 +1235,11 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
                            (__half *)output, cout_g, (int)N, Kg, e);
         continue;
       }
-      return BEVOPS_NOT_SUPPORTED;  // fp16 needs (Cin/groups * Kh * Kw) % 8 == 0
+      const size_t outs = (size_t)cout_g * N;  // ragged K: scalar fallback
+      if ((outs + 255) / 256 > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+      hipLaunchKernelGGL(gemm_tn_f16_ragged_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st,
+                         (const __half *)Ag, (const __half *)Bg, (const __half *)bias, (__half *)output, cout_g,
+                         (int)N, Kg, e);
     } else {
       hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)((N + 63) / 64), (cout_g + 63) / 64), dim3(256),
                          0, st, (const float *)Ag, (const float *)Bg, (const float *)bias, (float *)output,

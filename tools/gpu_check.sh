@@ -1,0 +1,13 @@
+#!/bin/bash
+# Short GPU visit: the whole GPU suite (no -x, every failure listed), the reference-kernel
+# checker on this host, and a kernel-level breakdown of one end-to-end frame.
+# usage: tools/gpu_check.sh <tag>
+TAG=${1:-chk}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -60 ) > $OUT/pytest.log
+( timeout 300 python -m pytest tests/test_ref_kernels_cpu.py -q 2>&1 | tail -5 ) > $OUT/pytest_refk_cpu.log
+( timeout 600 bash tools/model_profile.sh $TAG/trace base 2>&1 | tail -60 ) > $OUT/model_trace.txt
+rm -rf $OUT/trace/prof
+tail -15 $OUT/pytest.log; cat $OUT/pytest_refk_cpu.log; head -30 $OUT/model_trace.txt
