@@ -73,15 +73,38 @@ def _from_rows(y, n, h, w):
     return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
 
+_FUSED_LINEAR = {"enabled": True}
+
+
+def _fused_linear(ops, x, weight, bias, residual, relu):
+    """out = act(x @ weight.T + bias + residual) in ONE GEMM (ops.linear_bias_act: hipBLASLt with
+    the shift + identity + ReLU epilogue) -- or None when the operator set has no such entry, the
+    tensors are not fp16, or the library has no algorithm for the shape (then the caller's
+    two-launch path runs)."""
+    fn = getattr(ops, "linear_bias_act", None)
+    if fn is None or not _FUSED_LINEAR["enabled"] or x.dtype != torch.float16 or not x.is_cuda:
+        return None
+    try:
+        return fn(x, weight, bias, residual, relu)
+    except RuntimeError as exc:   # BevopsError: NOT_SUPPORTED for this shape
+        if "status 3" not in str(exc):
+            raise
+        return None
+
+
 def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
     s = conv.stride[0]
     if s > 1:
         x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
     wt = conv.weight.view(conv.out_channels, c).t()
-    if residual is not None:   # GEMM, then shift + identity + ReLU in one pass (addmm with the identity
-        y = torch.mm(_rows(x), wt)   # as its beta term would first memcpy it into the output: +21 us at layer 3)
-        ops.bias_act_nhwc_(y, conv.bias, _rows(residual), relu)
+    if residual is not None:
+        # one GEMM with shift + identity + ReLU in its epilogue; else GEMM, then one fused pass (addmm
+        # with the identity as its beta term would first memcpy it into the output: +21 us at layer 3)
+        y = _fused_linear(ops, _rows(x), conv.weight.view(conv.out_channels, c), conv.bias, _rows(residual), relu)
+        if y is None:
+            y = torch.mm(_rows(x), wt)
+            ops.bias_act_nhwc_(y, conv.bias, _rows(residual), relu)
     elif relu:
         y = torch._addmm_activation(conv.bias, _rows(x), wt)
     else:
@@ -232,7 +255,12 @@ class FFN(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
 
-    def forward(self, x):
+    def forward(self, x, ops=None):
+        if ops is not None:
+            h = _fused_linear(ops, x, self.fc1.weight, self.fc1.bias, None, True)
+            y = None if h is None else _fused_linear(ops, h, self.fc2.weight, self.fc2.bias, x, False)
+            if y is not None:
+                return y
         return x + self.fc2(F.relu(self.fc1(x), inplace=True))
 
 
@@ -258,7 +286,8 @@ class TemporalSelfAttention(nn.Module):
         off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
         out = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref_2d, off, w).flatten(2)
         out = torch.mean(out, keepdim=True, dim=0)
-        return self.output_proj(out) + identity
+        y = _fused_linear(self.ops, out, self.output_proj.weight, self.output_proj.bias, identity, False)
+        return y if y is not None else self.output_proj(out) + identity
 
 
 class SpatialCrossAttention(nn.Module):
@@ -290,7 +319,8 @@ class SpatialCrossAttention(nn.Module):
             if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
                 queries = gather(queries)
             slots = (queries * bev_mask).sum(0, keepdim=True)
-        return self.output_proj(slots) + inp_residual
+        y = _fused_linear(self.ops, slots, self.output_proj.weight, self.output_proj.bias, inp_residual, False)
+        return y if y is not None else self.output_proj(slots) + inp_residual
 
 
 class BEVFormerLayer(nn.Module):
@@ -301,10 +331,15 @@ class BEVFormerLayer(nn.Module):
 
     def forward(self, query, value, bev_pos, ref_2d, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev_bev,
                 use_prev_bev, cams, gather):
-        prev = use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1)   # encoder.py:586-588
+        # encoder.py:586-588: use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1) with
+        # use_prev_bev in {0, 1} -- a select (one pass, exact) instead of two scalings, a copy and an add
+        if torch.is_tensor(use_prev_bev):
+            prev = torch.where(use_prev_bev.to(torch.bool), prev_bev, query.expand(2, -1, -1))
+        else:
+            prev = prev_bev if use_prev_bev else query.repeat(2, 1, 1)
         query = self.norms[0](self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
         query = self.norms[1](self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather))
-        return self.norms[2](self.ffn(query))
+        return self.norms[2](self.ffn(query, self.tsa.ops))
 
 
 class CustomMSDeformableAttention(nn.Module):

@@ -1,0 +1,58 @@
+"""linear_bias_act -- the dense layers that wrap the sampler with their whole
+epilogue in the GEMM: out = act(x @ weight.T + bias + residual) as one `bevops_linear_bias_act`
+call (hipBLASLt MFMA kernel, shift + identity + ReLU in its epilogue).  Not a reference plugin:
+the reference leaves these layers to cuBLAS / TensorRT."""
+import torch
+
+from ..utils import lib as _lib
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, nbytes)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
+    """x [..., K] fp16 (contiguous rows), weight [N, K], bias [N] or None, residual [..., N] or None
+    -> [..., N].  `out` may be given (and may be `residual` itself).  Raises BevopsError with status
+    NOT_SUPPORTED when hipBLASLt has no algorithm for the shape (callers fall back to
+    mm + bias_act_nhwc_)."""
+    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {K}]")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    weight = weight.contiguous()
+    M = x2.shape[0]
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.numel() != M * N:
+            raise ValueError("residual must be fp16 with M*N elements")
+        r2 = residual.reshape(M, N)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    else:
+        r2 = None
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
+    handle = _lib.load_library()
+    nbytes = handle.bevops_linear_workspace_size()
+    ws = _workspace(x.device, nbytes)
+    with torch.cuda.device(x.device):
+        st = handle.bevops_linear_bias_act(
+            _lib.F16, x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+            r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K, int(bool(relu)), ws.data_ptr(),
+            nbytes, _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_linear_bias_act")
+    return out.view(*x.shape[:-1], N)

@@ -47,6 +47,9 @@ SIGNATURES = {
     "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                    [c_void_p]),
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "bevops_linear_workspace_size": (c_size_t, []),
+    "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
+                                                                  c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),
     "bevops_mdconv_pack_weight": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "bevops_grid_sampler_3d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +

@@ -268,6 +268,17 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+/* out[M, N] = act(a[M, K] . weight[N, K]^T + bias[N] + residual[M, N]) -- the dense layers around the
+ * sampler (value_proj / output_proj / FFN) and the 1x1 convolutions of the
+ * channels-last backbone as ONE hipBLASLt GEMM whose epilogue carries shift + identity + ReLU
+ * (D = relu(A B + C + bias)).  fp16 tensors, fp32 accumulate; `bias`, `residual` optional;
+ * `out` may alias `residual`.  `workspace`: caller-lent, bevops_linear_workspace_size() bytes (may be
+ * NULL/0: only workspace-free algorithms are then considered).  NOT_SUPPORTED if the library has
+ * no algorithm for the shape -- the caller then runs its own GEMM + bevops_bias_act_nhwc. */
+size_t bevops_linear_workspace_size(void);
+int bevops_linear_bias_act(int dtype, const void *a, const void *weight, const void *bias,
+                           const void *residual, void *out, long long M, int N, int K, int relu,
+                           void *workspace, size_t workspace_bytes, void *stream);
 int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,
                                  const void *mask, const void *packed_weight, const void *bias,
                                  void *output, void *workspace, size_t workspace_bytes, int B,
