@@ -30,6 +30,7 @@ Differences from the reference that do not change results:
   * frozen BatchNorm is folded into the preceding convolution.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -73,7 +74,7 @@ def _from_rows(y, n, h, w):
     return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
 
-_FUSED_LINEAR = {"enabled": True}
+_FUSED_LINEAR = {"enabled": os.environ.get("BEVOPS_FUSED_LINEAR", "1") != "0"}   # A/B switch
 
 
 def _fused_linear(ops, x, weight, bias, residual, relu):

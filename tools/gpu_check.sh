@@ -1,13 +1,17 @@
 #!/bin/bash
 # Short GPU visit: the whole GPU suite (no -x, every failure listed), the reference-kernel
-# checker on this host, and a kernel-level breakdown of one end-to-end frame.
-# usage: tools/gpu_check.sh <tag>
+# checker on this host, end-to-end frames/s and a kernel-level breakdown of one frame.
+# usage: tools/gpu_check.sh <tag> [skip-trace]
 TAG=${1:-chk}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -60 ) > $OUT/pytest.log
 ( timeout 300 python -m pytest tests/test_ref_kernels_cpu.py -q 2>&1 | tail -5 ) > $OUT/pytest_refk_cpu.log
-( timeout 600 bash tools/model_profile.sh $TAG/trace base 2>&1 | tail -60 ) > $OUT/model_trace.txt
-rm -rf $OUT/trace/prof
-tail -15 $OUT/pytest.log; cat $OUT/pytest_refk_cpu.log; head -30 $OUT/model_trace.txt
+( timeout 600 python tools/model_bench.py base --graph 2>&1 | grep "{" ) > $OUT/model_bench.jsonl
+( BEVOPS_FUSED_LINEAR=0 timeout 600 python tools/model_bench.py base --graph 2>&1 | grep "{" | sed 's/^/two-launch: /' ) >> $OUT/model_bench.jsonl
+if [ -z "$2" ]; then
+  ( timeout 600 bash tools/model_profile.sh $TAG/trace base 2>&1 | tail -60 ) > $OUT/model_trace.txt
+  rm -rf $OUT/trace/prof
+fi
+tail -15 $OUT/pytest.log; cat $OUT/pytest_refk_cpu.log; cat $OUT/model_bench.jsonl; head -40 $OUT/model_trace.txt
