@@ -9,11 +9,15 @@
 // Column-major view used for hipBLASLt: D^T is [N x M] (ld N) = W (stored [N][K] = col-major
 // [K x N], ld K, op T) x A (stored [M][K] = col-major [K x M], ld K, op N); the bias runs along the
 // rows of D^T, i.e. along N.  Not a reference plugin.
+#include <hipblaslt/hipblaslt-ext.hpp>
 #include <hipblaslt/hipblaslt.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "common.h"
 
@@ -25,6 +29,7 @@ struct Plan {
   hipblasLtMatmulAlgo_t algo;
   size_t ws = 0;
   bool ok = false;
+  bool tuned = false;  // algo chosen by timing (first non-capturing call), not by the heuristic
 };
 
 using Key = std::tuple<int, long long, int, int, int, int, int, size_t>;  // dev, M, N, K, relu, bias, res, ws
@@ -86,6 +91,70 @@ bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool rel
   return false;
 }
 
+// One-time selection by measurement, like the framework's TunableOp does for its own GEMMs: every
+// algorithm of the fp16 TN family that supports the problem (bias / ReLU epilogue, beta = 1) is
+// timed once on the caller's stream with the caller's buffers, the best few are re-timed, the
+// winner is cached for the process.  Needs a non-capturing stream; synchronises it (first call
+// per shape only).  `out` is scratch during tuning and is rewritten by the real call afterwards.
+void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const void *a, const void *w,
+               const void *c, void *out, float beta, void *workspace, size_t ws_bytes, hipStream_t st) {
+  std::vector<hipblasLtMatmulHeuristicResult_t> all;
+  if (hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N, HIP_R_16F,
+                                 HIP_R_16F, HIP_R_16F, HIP_R_16F, HIPBLAS_COMPUTE_32F, all) != HIPBLAS_STATUS_SUCCESS)
+    return;
+  const float alpha = 1.f;
+  struct Cand {
+    hipblasLtMatmulAlgo_t algo;
+    size_t ws;
+    float ms;
+  };
+  std::vector<Cand> cands;
+  for (auto &r : all) {
+    size_t need = 0;
+    if (hipblaslt_ext::matmulIsAlgoSupported(h, desc, &alpha, p.a, p.b, &beta, p.c, p.c, r.algo, need) ==
+            HIPBLAS_STATUS_SUCCESS &&
+        need <= ws_bytes)
+      cands.push_back(Cand{r.algo, need, 1e30f});
+  }
+  if (cands.empty()) return;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return;
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return;
+  }
+  auto time_one = [&](Cand &cd, int reps) {
+    float best = 1e30f;
+    for (int i = 0; i < reps; ++i) {
+      (void)hipEventRecord(e0, st);
+      const hipblasStatus_t rc = hipblasLtMatmul(h, desc, &alpha, w, p.a, a, p.b, &beta, c, p.c, out, p.c, &cd.algo,
+                                                 workspace, cd.ws, st);
+      (void)hipEventRecord(e1, st);
+      if (rc != HIPBLAS_STATUS_SUCCESS || hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      best = std::min(best, ms);
+    }
+    return best;
+  };
+  Cand cur{p.algo, p.ws, 1e30f};
+  time_one(cur, 1);  // warm the caches / clocks with the heuristic's choice
+  for (auto &cd : cands) cd.ms = time_one(cd, 1);
+  std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.ms < y.ms; });
+  const size_t top = std::min<size_t>(cands.size(), 8);
+  for (size_t i = 0; i < top; ++i) cands[i].ms = time_one(cands[i], 5);
+  cur.ms = time_one(cur, 5);
+  std::sort(cands.begin(), cands.begin() + top, [](const Cand &x, const Cand &y) { return x.ms < y.ms; });
+  if (cands[0].ms < cur.ms) {
+    p.algo = cands[0].algo;
+    p.ws = cands[0].ws;
+  }
+  p.tuned = true;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipGetLastError();
+}
+
 }  // namespace
 }  // namespace bevops
 
@@ -130,6 +199,22 @@ extern "C" int bevops_linear_bias_act(int dtype, const void *a, const void *weig
   if (!desc) return BEVOPS_FAILURE;
   const float alpha = 1.f, beta = residual ? 1.f : 0.f;
   const void *c = residual ? residual : out;
+  if (!plan.tuned && out != residual) {
+    static const bool tune_on = [] {
+      const char *e = std::getenv("BEVOPS_LINEAR_TUNE");
+      return !(e && e[0] == '0');
+    }();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (tune_on && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) == hipSuccess &&
+        cap == hipStreamCaptureStatusNone) {
+      tune_plan(h, plan, desc, a, weight, c, out, beta, workspace, workspace ? workspace_bytes : 0,
+                static_cast<hipStream_t>(stream));
+      if (plan.tuned) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_plans[Key{dev, M, N, K, relu != 0, bias != nullptr, residual != nullptr, workspace_bytes}] = plan;
+      }
+    }
+  }
   const hipblasStatus_t st =
       hipblasLtMatmul(h, desc, &alpha, weight, plan.a, a, plan.b, &beta, c, plan.c, out, plan.c, &plan.algo,
                       workspace, plan.ws, static_cast<hipStream_t>(stream));

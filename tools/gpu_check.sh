@@ -1,7 +1,7 @@
 #!/bin/bash
 # Short GPU visit: the whole GPU suite (no -x, every failure listed), the reference-kernel
-# checker on this host, end-to-end frames/s and a kernel-level breakdown of one frame.
-# usage: tools/gpu_check.sh <tag> [skip-trace]
+# checker on this host, end-to-end frames/s (fused-linear A/B) and an operator-level profile.
+# usage: tools/gpu_check.sh <tag> [skip-profile]
 TAG=${1:-chk}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,7 +11,6 @@ export TMPDIR=/tmp
 ( timeout 600 python tools/model_bench.py base --graph 2>&1 | grep "{" ) > $OUT/model_bench.jsonl
 ( BEVOPS_FUSED_LINEAR=0 timeout 600 python tools/model_bench.py base --graph 2>&1 | grep "{" | sed 's/^/two-launch: /' ) >> $OUT/model_bench.jsonl
 if [ -z "$2" ]; then
-  ( timeout 600 bash tools/model_profile.sh $TAG/trace base 2>&1 | tail -60 ) > $OUT/model_trace.txt
-  rm -rf $OUT/trace/prof
+  ( timeout 600 python tools/model_ops_profile.py base 80 2>&1 | tail -100 ) > $OUT/model_ops.txt
 fi
-tail -15 $OUT/pytest.log; cat $OUT/pytest_refk_cpu.log; cat $OUT/model_bench.jsonl; head -40 $OUT/model_trace.txt
+tail -15 $OUT/pytest.log; cat $OUT/pytest_refk_cpu.log; cat $OUT/model_bench.jsonl; cat $OUT/model_ops.txt | cut -c1-250
