@@ -93,6 +93,15 @@ def _fused_linear(ops, x, weight, bias, residual, relu):
         return None
 
 
+def _layer_norm(ops, norm, x):
+    """nn.LayerNorm as one streaming pass (ops.layer_norm) when the operator set has it."""
+    fn = getattr(ops, "layer_norm", None)
+    if fn is None or not _FUSED_LINEAR["enabled"] or x.dtype != torch.float16 or not x.is_cuda or \
+            x.shape[-1] not in (64, 128, 256, 512):
+        return norm(x)
+    return fn(x, norm.weight, norm.bias, norm.eps)
+
+
 def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
     s = conv.stride[0]
     if s > 1:
@@ -338,9 +347,10 @@ class BEVFormerLayer(nn.Module):
             prev = torch.where(use_prev_bev.to(torch.bool), prev_bev, query.expand(2, -1, -1))
         else:
             prev = prev_bev if use_prev_bev else query.repeat(2, 1, 1)
-        query = self.norms[0](self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
-        query = self.norms[1](self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather))
-        return self.norms[2](self.ffn(query, self.tsa.ops))
+        ops = self.tsa.ops
+        query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
+        query = _layer_norm(ops, self.norms[1], self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather))
+        return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
 
 
 class CustomMSDeformableAttention(nn.Module):
@@ -372,9 +382,10 @@ class DecoderLayer(nn.Module):
 
     def forward(self, query, value, query_pos, reference_points, spatial_shapes):
         qk = query + query_pos
-        query = self.norms[0](query + self.self_attn(qk, qk, query, need_weights=False)[0])
-        query = self.norms[1](self.cross_attn(query, value, query_pos, reference_points, spatial_shapes))
-        return self.norms[2](self.ffn(query))
+        ops = self.cross_attn.ops
+        query = _layer_norm(ops, self.norms[0], query + self.self_attn(qk, qk, query, need_weights=False)[0])
+        query = _layer_norm(ops, self.norms[1], self.cross_attn(query, value, query_pos, reference_points, spatial_shapes))
+        return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
 
 
 # --------------------------------------------------------------------------- the model

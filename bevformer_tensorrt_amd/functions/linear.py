@@ -56,3 +56,26 @@ def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
             nbytes, _lib.current_stream_ptr(x.device))
     _lib.check(st, "bevops_linear_bias_act")
     return out.view(*x.shape[:-1], N)
+
+
+def layer_norm(x, weight=None, bias=None, eps=1e-5, out=None):
+    """torch.nn.functional.layer_norm over the last dimension (fp16, C in {64,128,256,512}) as one
+    streaming pass (bevops_layer_norm).  Raises BevopsError (status 3) for other widths."""
+    assert x.is_cuda and x.dtype == torch.float16
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    if out is None:
+        out = torch.empty_like(x2)
+    else:
+        assert out.is_contiguous() and out.numel() == x2.numel() and out.dtype == x.dtype
+    w = weight.to(torch.float16).contiguous() if weight is not None else None
+    b = bias.to(torch.float16).contiguous() if bias is not None else None
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_layer_norm(_lib.F16, x2.data_ptr(), w.data_ptr() if w is not None else None,
+                                      b.data_ptr() if b is not None else None, out.data_ptr(), x2.shape[0], C,
+                                      float(eps), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_layer_norm")
+    return out.view(x.shape)

@@ -268,6 +268,12 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+/* out[rows, channels] = (x - mean) * rsqrt(var + eps) * gamma + beta over the last dimension
+ * (biased variance, fp32 statistics; torch.nn.LayerNorm semantics); fp16, channels in
+ * {64, 128, 256, 512}; gamma / beta optional; out may alias x.  The norms between the attention
+ * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
+int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
+                      size_t rows, int channels, float eps, void *stream);
 /* out[M, N] = act(a[M, K] . weight[N, K]^T + bias[N] + residual[M, N]) -- the dense layers around the
  * sampler (value_proj / output_proj / FFN) and the 1x1 convolutions of the
  * channels-last backbone as ONE hipBLASLt GEMM whose epilogue carries shift + identity + ReLU

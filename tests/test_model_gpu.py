@@ -188,3 +188,23 @@ def test_fused_linear_model_path_equals_two_launch_path():
             scale = max(1.0, y.float().abs().max().item())
             assert (x.float() - y.float()).abs().max().item() <= 4e-2 * scale
             assert (x.float() - y.float()).abs().mean().item() <= 4e-3 * scale
+
+
+def test_layer_norm_matches_torch():
+    import torch.nn.functional as F
+    import bevformer_tensorrt_amd.functions as hip_ops
+    g = torch.Generator().manual_seed(0)
+    for rows, C in [(40000, 256), (900, 256), (37, 64), (1001, 128), (513, 512), (1, 256)]:
+        x = (torch.randn(rows, C, generator=g) * 3 + 0.5).half().cuda()
+        w = torch.randn(C, generator=g).half().cuda()
+        b = torch.randn(C, generator=g).half().cuda()
+        want = F.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-5)
+        got = hip_ops.layer_norm(x, w, b, 1e-5)
+        assert (got.float() - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+        got = hip_ops.layer_norm(x.view(1, rows, C), None, None, 1e-5)
+        want = F.layer_norm(x.float(), (C,), None, None, 1e-5)
+        assert got.shape == (1, rows, C)
+        assert (got.float().view(rows, C) - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+        y = x.clone()
+        hip_ops.layer_norm(y, w, b, 1e-5, out=y)     # in place
+        assert torch.equal(y, hip_ops.layer_norm(x, w, b, 1e-5))
