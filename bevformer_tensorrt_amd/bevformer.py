@@ -462,9 +462,15 @@ class BEVFormer(nn.Module):
         # ---- transformer.get_bev_features_trt (:245-341); index/grid math in fp32 (a6)
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / bev_h, (PC_RANGE[3] - PC_RANGE[0]) / bev_w)
         shift = G.bev_shift(can_bus.float(), bev_h, bev_w, grid_length).to(dtype)
-        prev_bev = self.ops.rotate(prev_bev.view(bev_h, bev_w, -1).permute(2, 0, 1), can_bus[-1].float().reshape(1),
-                                   self.rotate_center.float())
-        prev_bev = prev_bev.permute(1, 2, 0).reshape(nq, 1, -1)
+        rot_hwc = getattr(self.ops, "rotate_hwc", None)
+        if rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0:
+            # prev_bev [nq, 1, C] already is [H, W, C]: rotate in place of the permute / copy / permute
+            prev_bev = rot_hwc(prev_bev.view(bev_h, bev_w, -1), can_bus[-1].float().reshape(1),
+                               self.rotate_center.float()).view(nq, 1, -1)
+        else:
+            prev_bev = self.ops.rotate(prev_bev.view(bev_h, bev_w, -1).permute(2, 0, 1),
+                                       can_bus[-1].float().reshape(1), self.rotate_center.float())
+            prev_bev = prev_bev.permute(1, 2, 0).reshape(nq, 1, -1)
         bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
         feats, level_hw = [], []
         cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]

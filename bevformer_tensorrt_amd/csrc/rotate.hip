@@ -24,16 +24,10 @@ template <> __device__ __forceinline__ float scalar_at<__half>(const void *p, in
   return __half2float(static_cast<const __half *>(p)[i]);
 }
 
-template <typename T, typename A>
-__global__ __launch_bounds__(kBlock) void rotate_kernel(const T *__restrict__ img,
-                                                        const void *__restrict__ angle,
-                                                        const void *__restrict__ center,
-                                                        T *__restrict__ out, int C, int H, int W,
-                                                        int interp, float s_in, float s_out) {
-  const int pix = blockIdx.x * kBlock + threadIdx.x;
-  const int HW = H * W;
-  if (pix >= HW) return;
-  const int w = pix % W, h = pix / W;
+// source pixel coordinates of output pixel (w, h): functions/rotate.py:15-48,66
+template <typename A>
+__device__ __forceinline__ void rotate_source(const void *angle, const void *center, int w, int h, int H, int W,
+                                              float &ix, float &iy) {
   float gx, gy;
   {
 #pragma clang fp contract(off)
@@ -52,8 +46,69 @@ __global__ __launch_bounds__(kBlock) void rotate_kernel(const T *__restrict__ im
     gx = (x * ax + y * bx) + cx2;
     gy = (x * ay + y * by) + cy2;
   }
-  const float ix = gs_source_index(gx, W, BEVOPS_PAD_ZEROS, false);
-  const float iy = gs_source_index(gy, H, BEVOPS_PAD_ZEROS, false);
+  ix = gs_source_index(gx, W, BEVOPS_PAD_ZEROS, false);
+  iy = gs_source_index(gy, H, BEVOPS_PAD_ZEROS, false);
+}
+
+// Channels-last variant: img / out are [H, W, C] (the layout prev_bev [H*W, 1, C] already has in the
+// model, transformer.py:296-303 permutes it to [C, H, W] and back around the plugin).  A thread
+// moves one 16-byte channel vector of one pixel, so a pixel's channels are one contiguous run: the
+// nearest mode the model uses is a gather of whole 512-byte rows.  Same arithmetic as above.
+template <typename T, typename A>
+__global__ __launch_bounds__(kBlock) void rotate_hwc_kernel(const T *__restrict__ img,
+                                                            const void *__restrict__ angle,
+                                                            const void *__restrict__ center,
+                                                            T *__restrict__ out, int C, int H, int W,
+                                                            int interp) {
+  constexpr int V = 16 / sizeof(T);
+  const int vpp = C / V;  // vectors per pixel
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (size_t)H * W * vpp) return;
+  const int pix = (int)(idx / vpp), v = (int)(idx - (size_t)pix * vpp);
+  const int w = pix % W, h = pix / W;
+  float ix, iy;
+  rotate_source<A>(angle, center, w, h, H, W, ix, iy);
+  uint4 *op = reinterpret_cast<uint4 *>(out + (size_t)pix * C) + v;
+  if (interp == BEVOPS_NEAREST) {
+    const int o = footprint_nearest(ix, iy, H, W);
+    *op = o >= 0 ? reinterpret_cast<const uint4 *>(img + (size_t)o * C)[v] : make_uint4(0, 0, 0, 0);
+    return;
+  }
+  Footprint2D<4> f;
+  footprint_bilinear(ix, iy, H, W, f);
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (f.off[k] >= 0) {
+      const uint4 raw = reinterpret_cast<const uint4 *>(img + (size_t)f.off[k] * C)[v];
+      const T *e = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+#pragma clang fp contract(off)
+        acc[j] += ld<T>(e + j) * f.w[k];
+      }
+    }
+  uint4 res;
+  T *r = reinterpret_cast<T *>(&res);
+#pragma unroll
+  for (int j = 0; j < V; ++j) st<T>(r + j, acc[j], 1.f);
+  *op = res;
+}
+
+template <typename T, typename A>
+__global__ __launch_bounds__(kBlock) void rotate_kernel(const T *__restrict__ img,
+                                                        const void *__restrict__ angle,
+                                                        const void *__restrict__ center,
+                                                        T *__restrict__ out, int C, int H, int W,
+                                                        int interp, float s_in, float s_out) {
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int w = pix % W, h = pix / W;
+  float ix, iy;
+  rotate_source<A>(angle, center, w, h, H, W, ix, iy);
   const int c0 = blockIdx.y * kCPT;
   const int c1 = min(c0 + kCPT, C);
   const T *ip = img + (size_t)c0 * HW;
@@ -145,4 +200,34 @@ extern "C" int bevops_rotate_forward(int dtype, const void *img, const void *ang
     default:
       return BEVOPS_NOT_SUPPORTED;
   }
+}
+
+extern "C" int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, const void *center,
+                                         int angle_dtype, void *output, int channels, int height, int width,
+                                         int interpolation, void *stream) {
+  if (!img || !angle || !center || !output) return BEVOPS_BAD_PARAM;
+  if (channels <= 0 || height <= 0 || width <= 0) return BEVOPS_BAD_PARAM;
+  if (interpolation != BEVOPS_BILINEAR && interpolation != BEVOPS_NEAREST) return BEVOPS_BAD_PARAM;
+  if (angle_dtype != BEVOPS_F32 && angle_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (dtype != BEVOPS_F32 && dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (dtype == BEVOPS_F32 && angle_dtype != BEVOPS_F32) return BEVOPS_NOT_SUPPORTED;
+  const int V = dtype == BEVOPS_F32 ? 4 : 8;
+  if (channels % V != 0) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(img) || !aligned16(output)) return BEVOPS_BAD_PARAM;
+  if ((long)height * width > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
+  const size_t threads = (size_t)height * width * (channels / V);
+  const size_t blocks = (threads + kBlock - 1) / kBlock;
+  if (blocks > 0x7FFFFFFFull) return BEVOPS_NOT_SUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks), blk(kBlock);
+  if (dtype == BEVOPS_F32)
+    hipLaunchKernelGGL((rotate_hwc_kernel<float, float>), grid, blk, 0, st, (const float *)img, angle, center,
+                       (float *)output, channels, height, width, interpolation);
+  else if (angle_dtype == BEVOPS_F32)
+    hipLaunchKernelGGL((rotate_hwc_kernel<__half, float>), grid, blk, 0, st, (const __half *)img, angle, center,
+                       (__half *)output, channels, height, width, interpolation);
+  else
+    hipLaunchKernelGGL((rotate_hwc_kernel<__half, __half>), grid, blk, 0, st, (const __half *)img, angle, center,
+                       (__half *)output, channels, height, width, interpolation);
+  return launch_status();
 }

@@ -60,3 +60,29 @@ def rotate2(img, angle, center, interpolation="nearest"):
 def rotate_int8(img, angle, center, scale_in, scale_out, interpolation="nearest"):
     """INT8 flavour (rotateKernel.cu:415-706): int8 image + per-tensor scales."""
     return _rotate(img, angle, center, interpolation, (scale_in, scale_out))
+
+
+def rotate_hwc(img, angle, center, interpolation="nearest"):
+    """`rotate` on channels-last data: img [H, W, C] -> [H, W, C] (fp32 / fp16).  Element for element
+    the same result as rotate(img.permute(2, 0, 1), ...).permute(1, 2, 0), without the two layout
+    copies (not a reference plugin: the layout prev_bev already has between frames)."""
+    assert img.is_cuda and img.ndim == 3
+    if interpolation not in _MODE:
+        raise KeyError(interpolation)
+    handle = _lib.load_library()
+    img = img.contiguous()
+    angle = _scalar_dev(angle, img.device, 1)
+    center = _scalar_dev(center, img.device, 2)
+    if center.dtype != angle.dtype:
+        center = center.to(angle.dtype)
+    if img.dtype == torch.float32 and angle.dtype != torch.float32:
+        angle, center = angle.float(), center.float()
+    out = torch.empty_like(img)
+    H, W, C = img.shape
+    with torch.cuda.device(img.device):
+        st = handle.bevops_rotate_forward_hwc(
+            _lib.torch_dtype_code(img), img.data_ptr(), angle.data_ptr(), center.data_ptr(),
+            _lib.torch_dtype_code(angle), out.data_ptr(), C, H, W, _MODE[interpolation],
+            _lib.current_stream_ptr(img.device))
+    _lib.check(st, "bevops_rotate_forward_hwc")
+    return out

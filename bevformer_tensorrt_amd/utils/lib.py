@@ -47,6 +47,8 @@ SIGNATURES = {
     "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                    [c_void_p]),
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "bevops_rotate_forward_hwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_void_p]),
     "bevops_layer_norm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "bevops_linear_workspace_size": (c_size_t, []),
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,

@@ -268,6 +268,13 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+/* bevops_rotate_forward on channels-last data: img / output are [height, width, channels] (fp32 /
+ * fp16, channels a multiple of 4 / 8) -- the layout prev_bev [H*W, 1, C] already has in the model,
+ * so the permute-copy to [C, H, W] and back around the plugin (transformer.py:296-303) disappears.
+ * Same arithmetic, element for element. */
+int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, const void *center,
+                              int angle_dtype, void *output, int channels, int height, int width,
+                              int interpolation, void *stream);
 /* out[rows, channels] = (x - mean) * rsqrt(var + eps) * gamma + beta over the last dimension
  * (biased variance, fp32 statistics; torch.nn.LayerNorm semantics); fp16, channels in
  * {64, 128, 256, 512}; gamma / beta optional; out may alias x.  The norms between the attention

@@ -234,3 +234,18 @@ def test_rotate_int8(bev, oracle_mod, interp):
                                 s_in, s_out).astype(np.int32)
     d = np.abs(out - want)
     assert d.max() <= 1 and (d > 0).mean() <= 0.01
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+def test_rotate_hwc_equals_rotate_on_permuted_data(dtype, interp):
+    """The channels-last entry (prev_bev's own [H, W, C] layout) gives, element for element, what
+    the plugin-layout op gives on the permuted tensor."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(0)
+    for C, H, W, ang, ctr in [(256, 50, 50, 7.3, (25.0, 25.0)), (64, 31, 45, -101.0, (20.0, 11.0)), (8, 5, 7, 45.0, (3.0, 2.0))]:
+        img = torch.randn(C, H, W, generator=g).to(dtype).cuda()
+        a, c = torch.tensor(ang).cuda(), torch.tensor(ctr).cuda()
+        want = bev.rotate(img, a, c, interp)
+        got = bev.rotate_hwc(img.permute(1, 2, 0).contiguous(), a, c, interp).permute(2, 0, 1)
+        assert torch.equal(got, want), (C, H, W, (got.float() - want.float()).abs().max().item())

@@ -9,7 +9,7 @@ import csv, glob, collections, re
 f = glob.glob("$OUT/prof/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # frames are delimited by the rotate kernel (one per frame after the first)
-idx = [i for i, r in enumerate(rows) if "rotate_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "rotate_kernel" in r["Kernel_Name"] or "rotate_hwc_kernel" in r["Kernel_Name"]]
 a, b = (idx[-2], idx[-1]) if len(idx) >= 2 else (0, len(rows))
 fr = rows[a:b]
 span = (int(fr[-1]["End_Timestamp"]) - int(fr[0]["Start_Timestamp"])) / 1e6
