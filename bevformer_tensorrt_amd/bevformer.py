@@ -136,6 +136,7 @@ class DCNv2Pack(nn.Module):
     def __init__(self, cin, cout, ops, stride=1):
         super().__init__()
         self.ops, self.stride = ops, stride
+        self._c32_ok = True
         self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9))
         self.bias = nn.Parameter(torch.zeros(cout))  # carries the folded BN shift
         self.conv_offset = nn.Conv2d(cin, 27, 3, stride, 1)
@@ -152,6 +153,17 @@ class DCNv2Pack(nn.Module):
     def forward_nhwc(self, x, relu):
         # MIOpen's NHWC kernels are 3-8x slower at 27 output channels than at 32 (170 vs 52 us at
         # stage 3): run the offset conv with the filters zero-padded to 32 and drop the extra planes
+        fn = getattr(self.ops, "conv_offset_nhwc", None)
+        if fn is not None and self.stride == 1 and _FUSED_LINEAR["enabled"] and self._c32_ok:
+            # own implicit-GEMM kernel: all 9 x Cin x 32 weights LDS-resident, bias in the epilogue
+            try:
+                out = fn(x, self.conv_offset.weight, self.conv_offset.bias)
+                return self.ops.modulated_deformable_conv2d_nhwc(x, None, None, self.weight, self.bias, self.stride,
+                                                                 1, 1, 1, 1, relu=relu, offset_mask_nhwc=out)
+            except RuntimeError as exc:
+                if "status 3" not in str(exc):
+                    raise
+                self._c32_ok = False   # unsupported channel count: library convolution below
         w = self.conv_offset.weight
         if getattr(self, "_w32", None) is None or self._w32[2] != (w._version, w.dtype, w.device):
             w32 = torch.zeros(32, *w.shape[1:], dtype=w.dtype, device=w.device)

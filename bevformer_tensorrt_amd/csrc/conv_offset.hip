@@ -1,0 +1,198 @@
+// conv3x3_c32: the DCNv2 pack's `conv_offset` (cnn/dcn.py:62-70: a plain 3x3 / stride 1 / pad 1
+// convolution producing the 27 offset + mask channels that feed modulated_deformable_conv2d) on
+// channels-last activations, fp16, with its bias in the epilogue.  The library convolution spends
+// 48 us per stage-3 call on this 32-channel output (+ 10 us for the bias pass + 9 us for its own
+// tensor set-up) -- as much as the deformable convolution it prepares.  As an implicit GEMM it is
+// M = pixels, N = 32, K = 9 * Cin: N is exactly one 32-wide MFMA tile, and ALL weights of a
+// 256-channel phase (9 * 256 * 32 * 2 B = 144 KiB) fit the CU's LDS.
+//
+// MI355X mapping: a 512-thread block fills LDS once with the packed weights of a phase (straight
+// 16-byte copies of a pre-swizzled image, conflict-free ds_read_b128 afterwards); each of its 8 waves
+// owns one tile of 32 consecutive pixels: accumulators = one v_mfma_f32_32x32x16_f16 tile (weights
+// are the A operand, the image is the B operand, so a lane ends up with 4 x 4 consecutive output
+// channels of one pixel = 8-byte stores into the [pixel][32] result).  The image operand never
+// touches LDS: in NHWC the 16 k-values of a lane are 16 contiguous bytes of a pixel's channel row,
+// fetched through a buffer descriptor (out-of-image taps read as zero by the range check, no
+// branches), a ring of DEPTH (tap, 64-channel chunk) steps ahead of the MFMAs.
+// Not a reference plugin by itself: part of ModulatedDeformConv2dPackPlugin.forward.
+#include "common.h"
+
+namespace bevops {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 512;
+constexpr int kTile = 32;                       // pixels per wave
+constexpr int kTilesPerBlock = kThreads / 64;   // 8
+constexpr int kDepth = 6;                       // (tap, chunk) steps in flight per wave
+constexpr unsigned kOob = 0xFFFFFF00u;          // beyond any buffer: reads as zero
+
+// packed weight image, per phase of CP = 64 * CCP channels:
+//   [tap 9][chunk CCP][j 4][hi 2][m 32][8 halves]   (16-byte groups; lane (m, hi) of k-step j reads group
+//   ((tap * CCP + chunk) * 4 + j) * 64 + hi * 32 + m), holding channels chunk*64 + hi*32 + j*8 .. +7
+__global__ __launch_bounds__(256) void pack_conv3x3_c32_kernel(const __half *__restrict__ w, __half *__restrict__ dst,
+                                                                int cout, int Cin, int CP) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one output half each
+  const size_t total = (size_t)9 * Cin * 32;
+  if (idx >= total) return;
+  const int e = (int)(idx & 7);
+  const int m = (int)((idx >> 3) & 31);
+  const int hi = (int)((idx >> 8) & 1);
+  const int j = (int)((idx >> 9) & 3);
+  const size_t rest = idx >> 11;  // (phase * 9 + tap) * CCP + chunk
+  const int CCP = CP / 64;
+  const int chunk = (int)(rest % CCP);
+  const int tap = (int)((rest / CCP) % 9);
+  const int phase = (int)(rest / ((size_t)CCP * 9));
+  const int c = phase * CP + chunk * 64 + hi * 32 + j * 8 + e;
+  dst[idx] = m < cout ? w[((size_t)m * Cin + c) * 9 + tap] : __float2half(0.f);
+}
+
+template <int CCP>  // 64-channel chunks per phase (1, 2 or 4)
+__global__ __launch_bounds__(kThreads) void conv3x3_c32_kernel(const __half *__restrict__ x,
+                                                               const __half *__restrict__ wp,
+                                                               const __half *__restrict__ bias,
+                                                               __half *__restrict__ out, int B, int H, int W, int Cin,
+                                                               int phases) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kSteps = 9 * CCP;
+  constexpr int kGroups = kSteps * 4 * 64;  // 16-byte groups per phase
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const long npix = (long)B * H * W;
+  const long pix = ((long)blockIdx.x * kTilesPerBlock + wave) * kTile + n;
+  const bool live = pix < npix;
+  int pb = 0, ph = 0, pw = 0;
+  if (live) {
+    pb = (int)(pix / ((long)H * W));
+    const int r = (int)(pix - (long)pb * H * W);
+    ph = r / W;
+    pw = r - ph * W;
+  }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(x), 0, (unsigned)((size_t)npix * Cin * 2), 0x00020000);
+  // byte offset of (tap, channel 0) for this lane's pixel, or kOob
+  unsigned toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int hh = ph + t / 3 - 1, ww = pw + t % 3 - 1;
+    const bool ok = live && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    toff[t] = ok ? (unsigned)((((size_t)pb * H + hh) * W + ww) * Cin * 2) + (unsigned)(hi * 64) : kOob;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int phase = 0; phase < phases; ++phase) {
+    if (phase) __syncthreads();  // everyone is done reading the previous phase's weights
+    {
+      const uint4 *src = reinterpret_cast<const uint4 *>(wp) + (size_t)phase * kGroups;
+      uint4 *dst = reinterpret_cast<uint4 *>(smem);
+      for (int i = tid; i < kGroups; i += kThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const unsigned cbase = (unsigned)(phase * CCP * 128);  // byte offset of the phase's first channel
+    u32x4 ring[kDepth][4];
+    auto issue = [&](int s, int slot) {
+      const int tap = s / CCP, chunk = s % CCP;
+      const unsigned vo = toff[tap];
+      const unsigned so = cbase + (unsigned)(chunk * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * j), (int)so, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < kDepth && s < kSteps; ++s) issue(s, s);
+    // keep the ring kDepth steps ahead: the scheduler would otherwise sink the loads next to their use
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      const int slot = s % kDepth;
+      const f16x8 *ag = reinterpret_cast<const f16x8 *>(smem) + (size_t)s * 256 + hi * 32 + n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 a = ag[j * 64];
+        const f16x8 b = __builtin_bit_cast(f16x8, ring[slot][j]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+      }
+      if (s + kDepth < kSteps) issue(s + kDepth, slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!live) return;
+  // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  __half *op = out + (size_t)pix * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = 8 * g + 4 * hi;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[4 * g + k] + (bias ? __half2float(bias[c0 + k]) : 0.f);
+    u32x2 o;
+    o.x = pack_h2(v[0], v[1]);
+    o.y = pack_h2(v[2], v[3]);
+    *reinterpret_cast<u32x2 *>(op + c0) = o;
+  }
+}
+
+template <int CCP>
+int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W, int Cin,
+                int phases, hipStream_t st) {
+  const size_t lds = (size_t)9 * CCP * 4 * 64 * 16;
+  static bool ready = false;  // attribute set once per process (idempotent; benign if raced)
+  if (!ready) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_kernel<CCP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return BEVOPS_FAILURE;
+    ready = true;
+  }
+  const long npix = (long)B * H * W;
+  const long blocks = (npix + kTile * kTilesPerBlock - 1) / (kTile * kTilesPerBlock);
+  if (blocks > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL(conv3x3_c32_kernel<CCP>, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, wp, bias, out, B,
+                     H, W, Cin, phases);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace bevops
+
+using namespace bevops;
+
+extern "C" size_t bevops_conv3x3_c32_packed_weight_size(int dtype, int Cin) {
+  if (dtype != BEVOPS_F16 || Cin <= 0 || Cin % 64 != 0 || Cin == 192 || (Cin > 256 && Cin % 256 != 0)) return 0;
+  return (size_t)9 * Cin * 32 * 2;
+}
+
+extern "C" int bevops_conv3x3_c32_pack_weight(int dtype, const void *weight, void *packed, int Cout, int Cin,
+                                              void *stream) {
+  if (!weight || !packed || Cout <= 0 || Cout > 32) return BEVOPS_BAD_PARAM;
+  if (bevops_conv3x3_c32_packed_weight_size(dtype, Cin) == 0) return BEVOPS_NOT_SUPPORTED;
+  const int CP = Cin < 256 ? Cin : 256;
+  const size_t total = (size_t)9 * Cin * 32;
+  hipLaunchKernelGGL(pack_conv3x3_c32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const __half *)weight, (__half *)packed, Cout, Cin, CP);
+  return launch_status();
+}
+
+extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const void *packed_weight,
+                                               const void *bias32, void *output_nhwc, int B, int H, int W, int Cin,
+                                               void *stream) {
+  if (!input_nhwc || !packed_weight || !output_nhwc || B <= 0 || H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
+  if (bevops_conv3x3_c32_packed_weight_size(dtype, Cin) == 0) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(input_nhwc) || !aligned16(packed_weight) || !aligned16(output_nhwc)) return BEVOPS_BAD_PARAM;
+  if ((size_t)B * H * W * Cin * 2 >= 0xFFFFFF00ull) return BEVOPS_NOT_SUPPORTED;  // 32-bit buffer offsets
+  const int CP = Cin < 256 ? Cin : 256;
+  const int phases = Cin / CP;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const __half *x = (const __half *)input_nhwc, *wp = (const __half *)packed_weight, *b = (const __half *)bias32;
+  __half *o = (__half *)output_nhwc;
+  switch (CP / 64) {
+    case 1: return launch_conv<1>(x, wp, b, o, B, H, W, Cin, phases, st);
+    case 2: return launch_conv<2>(x, wp, b, o, B, H, W, Cin, phases, st);
+    case 3: return BEVOPS_NOT_SUPPORTED;
+    default: return launch_conv<4>(x, wp, b, o, B, H, W, Cin, phases, st);
+  }
+}

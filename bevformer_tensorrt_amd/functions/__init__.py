@@ -10,7 +10,7 @@ from .grid_sampler import grid_sampler, grid_sampler2, grid_sampler_int8
 from .bev_pool_v2 import bev_pool_v2, bev_pool_v2_2, bev_pool_v2_int8
 from .modulated_deformable_conv2d import (modulated_deformable_conv2d, modulated_deformable_conv2d2,
                                           modulated_deformable_conv2d_int8, modulated_deformable_conv2d_nhwc,
-                                          bias_act_nhwc_)
+                                          bias_act_nhwc_, conv_offset_nhwc)
 from .spatial_cross_attention import spatial_cross_attention_sample
 from .linear import linear_bias_act, layer_norm
 from ..utils.register import TRT_FUNCTIONS
@@ -32,5 +32,5 @@ __all__ = [
     "grid_sampler", "grid_sampler2", "grid_sampler_int8",
     "bev_pool_v2", "bev_pool_v2_2", "bev_pool_v2_int8",
     "modulated_deformable_conv2d", "modulated_deformable_conv2d2", "modulated_deformable_conv2d_int8",
-    "spatial_cross_attention_sample", "modulated_deformable_conv2d_nhwc", "bias_act_nhwc_", "linear_bias_act", "layer_norm", "rotate_hwc",
+    "spatial_cross_attention_sample", "modulated_deformable_conv2d_nhwc", "bias_act_nhwc_", "linear_bias_act", "layer_norm", "rotate_hwc", "conv_offset_nhwc",
 ]

@@ -187,3 +187,48 @@ def bias_act_nhwc_(x, bias=None, residual=None, relu=False):
                                          int(relu), _lib.current_stream_ptr(x.device))
     _lib.check(st, "bevops_bias_act_nhwc")
     return x
+
+
+_PACKED_C32 = _TensorCache()
+
+
+def conv_offset_nhwc(input, weight, bias=None):
+    """The DCNv2 pack's offset convolution (cnn/dcn.py:62-70) on a channels-last fp16 activation:
+    3x3 / stride 1 / pad 1, weight [Cout <= 32, Cin, 3, 3], bias [Cout] -> [B, 32, H, W] in
+    channels_last memory format (channels >= Cout are zero), ready to be the `offset_mask_nhwc`
+    operand of modulated_deformable_conv2d_nhwc.  One implicit-GEMM launch with the bias in its
+    epilogue (bevops_conv3x3_c32_forward_nhwc).  Raises BevopsError (status 3) for unsupported Cin."""
+    assert input.is_cuda and input.dtype == torch.float16 and weight.dtype == torch.float16
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[0] > 32:
+        raise ValueError(f"conv_offset_nhwc: weight {tuple(weight.shape)} is not [<=32, Cin, 3, 3]")
+    handle = _lib.load_library()
+    if not input.is_contiguous(memory_format=torch.channels_last):
+        input = input.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = input.shape
+    Cout = weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError("conv_offset_nhwc: weight / input channel mismatch")
+    hit = _PACKED_C32.get(weight)
+    if hit is None:
+        nbytes = handle.bevops_conv3x3_c32_packed_weight_size(_lib.F16, Cin)
+        if nbytes == 0:
+            raise _lib.BevopsError("bevops_conv3x3_c32_pack_weight: dtype/shape combination not supported (status 3)")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        wc = weight.detach().contiguous()
+        b32 = torch.zeros(32, dtype=torch.float16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            st = handle.bevops_conv3x3_c32_pack_weight(_lib.F16, wc.data_ptr(), packed.data_ptr(), Cout, Cin,
+                                                       _lib.current_stream_ptr(weight.device))
+        _lib.check(st, "bevops_conv3x3_c32_pack_weight")
+        hit = _PACKED_C32.put(weight, [packed, b32, None])
+    packed, b32, bias_version = hit
+    if bias is not None and bias_version != (id(bias), bias._version):   # refresh the padded bias only when it changed
+        b32[:Cout].copy_(bias.detach())
+        hit[2] = (id(bias), bias._version)
+    out = torch.empty((B, 32, H, W), dtype=input.dtype, device=input.device, memory_format=torch.channels_last)
+    with torch.cuda.device(input.device):
+        st = handle.bevops_conv3x3_c32_forward_nhwc(_lib.F16, input.data_ptr(), packed.data_ptr(), b32.data_ptr(),
+                                                    out.data_ptr(), B, H, W, Cin,
+                                                    _lib.current_stream_ptr(input.device))
+    _lib.check(st, "bevops_conv3x3_c32_forward_nhwc")
+    return out

@@ -268,6 +268,19 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+/* The DCNv2 pack's offset convolution (cnn/dcn.py:62-70: 3x3, stride 1, pad 1, Cout <= 32) on
+ * channels-last fp16 activations with its bias in the epilogue:
+ *   output_nhwc[B, H, W, 32] = conv3x3(input_nhwc[B, H, W, Cin], weight[Cout, Cin, 3, 3]) + bias32
+ * (channels >= Cout are the bias32 values, normally 0).  Cin in {64, 128, 256} or a multiple of
+ * 256.  The weight is packed once (bevops_conv3x3_c32_pack_weight into a caller buffer of
+ * bevops_conv3x3_c32_packed_weight_size bytes; 0 = unsupported Cin); bias32 has 32 entries or is
+ * NULL.  The result is the `offset` operand of bevops_mdconv_forward_nhwc with
+ * offset_mask_channels = 32. */
+size_t bevops_conv3x3_c32_packed_weight_size(int dtype, int Cin);
+int bevops_conv3x3_c32_pack_weight(int dtype, const void *weight, void *packed, int Cout, int Cin, void *stream);
+int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const void *packed_weight,
+                                    const void *bias32, void *output_nhwc, int B, int H, int W, int Cin,
+                                    void *stream);
 /* bevops_rotate_forward on channels-last data: img / output are [height, width, channels] (fp32 /
  * fp16, channels a multiple of 4 / 8) -- the layout prev_bev [H*W, 1, C] already has in the model,
  * so the permute-copy to [C, H, W] and back around the plugin (transformer.py:296-303) disappears.

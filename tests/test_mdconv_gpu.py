@@ -180,3 +180,24 @@ def test_packed_weight_cache_tracks_weight_updates(bev):
     fresh = bev.modulated_deformable_conv2d(*args(w.clone()))
     assert torch.equal(a3, fresh)
     assert not torch.equal(a3, a1)
+
+
+@pytest.mark.parametrize("shape", [(6, 256, 58, 100), (6, 512, 29, 50), (2, 64, 13, 17), (1, 128, 9, 9), (3, 256, 7, 5)])
+def test_conv_offset_nhwc_matches_conv2d(bev, shape):
+    """The pack's offset convolution as our LDS-resident-weight implicit GEMM (27 channels padded to
+    32, bias in the epilogue) vs the library convolution in fp32."""
+    import torch.nn.functional as F
+    B, Cin, H, W = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(27, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().cuda()
+    b = torch.randn(27, generator=g).half().cuda()
+    out = bev.conv_offset_nhwc(x, w, b)
+    assert out.shape == (B, 32, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    want = F.conv2d(x.float(), w.float(), b.float(), 1, 1)
+    err = (out[:, :27].float() - want).abs().max().item()
+    assert err <= 4e-3 * max(1.0, want.abs().max().item()), err
+    assert not out[:, 27:].any()
+    assert torch.equal(out, bev.conv_offset_nhwc(x, w, b))      # cached packed weights, deterministic
+    out2 = bev.conv_offset_nhwc(x, w, None)                       # bias is optional
+    assert out2.shape == out.shape
