@@ -227,7 +227,8 @@ def conv_offset_nhwc(input, weight, bias=None):
         hit[2] = (id(bias), bias._version)
     out = torch.empty((B, 32, H, W), dtype=input.dtype, device=input.device, memory_format=torch.channels_last)
     with torch.cuda.device(input.device):
-        st = handle.bevops_conv3x3_c32_forward_nhwc(_lib.F16, input.data_ptr(), packed.data_ptr(), b32.data_ptr(),
+        st = handle.bevops_conv3x3_c32_forward_nhwc(_lib.F16, input.data_ptr(), packed.data_ptr(),
+                                                    b32.data_ptr() if bias is not None else None,
                                                     out.data_ptr(), B, H, W, Cin,
                                                     _lib.current_stream_ptr(input.device))
     _lib.check(st, "bevops_conv3x3_c32_forward_nhwc")

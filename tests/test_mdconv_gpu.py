@@ -200,4 +200,5 @@ def test_conv_offset_nhwc_matches_conv2d(bev, shape):
     assert not out[:, 27:].any()
     assert torch.equal(out, bev.conv_offset_nhwc(x, w, b))      # cached packed weights, deterministic
     out2 = bev.conv_offset_nhwc(x, w, None)                       # bias is optional
-    assert out2.shape == out.shape
+    want2 = F.conv2d(x.float(), w.float(), None, 1, 1)
+    assert (out2[:, :27].float() - want2).abs().max().item() <= 4e-3 * max(1.0, want2.abs().max().item())
