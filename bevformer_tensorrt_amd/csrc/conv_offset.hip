@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 512;
 constexpr int kTile = 32;                       // pixels per wave
 constexpr int kTilesPerBlock = kThreads / 64;   // 8
-constexpr int kDepth = 6;                       // (tap, chunk) steps in flight per wave
+constexpr int kDepth = 5;                       // (tap, chunk) steps in flight per wave
 constexpr unsigned kOob = 0xFFFFFF00u;          // beyond any buffer: reads as zero
 
 // packed weight image, per phase of CP = 64 * CCP channels:
@@ -88,9 +88,22 @@ __global__ __launch_bounds__(kThreads) void conv3x3_c32_kernel(const __half *__r
   for (int phase = 0; phase < phases; ++phase) {
     if (phase) __syncthreads();  // everyone is done reading the previous phase's weights
     {
+      // all of a thread's 16-byte groups are requested before the first one is written: one round
+      // trip to L2 for the whole 144 KiB image instead of one per group
       const uint4 *src = reinterpret_cast<const uint4 *>(wp) + (size_t)phase * kGroups;
       uint4 *dst = reinterpret_cast<uint4 *>(smem);
-      for (int i = tid; i < kGroups; i += kThreads) dst[i] = src[i];
+      constexpr int kIters = (kGroups + kThreads - 1) / kThreads;
+      uint4 tmp[kIters];
+#pragma unroll
+      for (int k = 0; k < kIters; ++k) {
+        const int i = tid + k * kThreads;
+        tmp[k] = i < kGroups ? src[i] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < kIters; ++k) {
+        const int i = tid + k * kThreads;
+        if (i < kGroups) dst[i] = tmp[k];
+      }
     }
     __syncthreads();
     const unsigned cbase = (unsigned)(phase * CCP * 128);  // byte offset of the phase's first channel
