@@ -110,6 +110,9 @@ def main():
                          "each rank's camera sum (SURVEY 8e alternative, 6x less data)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-geometry-extra", action="store_true",
+                    help="skip the extra SCA timing on the model's own reference points (profiling runs: keeps "
+                         "the rocprofv3 per-kernel averages to the contract workload)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,7 +277,7 @@ def main():
 
     # the same SCA call on the reference points the model itself produces (BEV pillars projected
     # into a 6-camera rig, geometry.py): extra information, not the contract figure above
-    if roofline is not None and world == 1 and not int8:
+    if roofline is not None and world == 1 and not int8 and not args.no_geometry_extra:
         try:
             from bevformer_tensorrt_amd import geometry as G
             img_hw = (928, 1600)

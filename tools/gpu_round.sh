@@ -12,9 +12,9 @@ if [ -n "$2" ]; then ( VARIANTS=0 timeout 900 python tools/msda_sweep.py 2>&1 ) 
 ( timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -1 ) > $OUT/bench.json
 ( timeout 300 python tools/dcn_time.py 0 2 1 2>&1 | grep shape ) > $OUT/dcn_time.jsonl
 ( timeout 600 python tools/model_bench.py --graph 2>&1 | grep "{" ) > $OUT/model_bench.jsonl
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -5 ) > $OUT/rocprof.log
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -3 ) > $OUT/rocprof_pmc_fetch.log
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end 2>&1 | tail -3 ) > $OUT/rocprof_pmc_write.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-geometry-extra 2>&1 | tail -5 ) > $OUT/rocprof.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-geometry-extra 2>&1 | tail -3 ) > $OUT/rocprof_pmc_fetch.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-geometry-extra 2>&1 | tail -3 ) > $OUT/rocprof_pmc_write.log
 ( timeout 300 bash tools/model_profile.sh $TAG/trace base 2>&1 | tail -45 ) > $OUT/model_trace.txt
 rm -rf $OUT/trace/prof
 find $OUT -name "*.csv" | head -20; du -sh $OUT
