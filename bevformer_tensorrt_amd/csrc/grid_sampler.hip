@@ -151,6 +151,98 @@ __global__ __launch_bounds__(kBlock) void grid_sampler_2d_kernel(
   }
 }
 
+// ---- channels-last staging for the 2-D bilinear / nearest modes ---------------------------------
+// With the NCHW input a thread's 8 channel planes cost 4 two-byte gathers each (32 VMEM instructions
+// per output pixel and 8-channel chunk, + 8 stores): the op is bound by the number of memory
+// instructions, not by bytes (666 us = 0.8 TB/s at the reference test shape).  When the caller
+// lends a workspace, the (small) input is transposed once to [N, H*W, C]; a tap is then ONE
+// 16-byte load of 8 fp16 channels (4 loads + 8 stores per pixel and chunk).  Same arithmetic in
+// the same order: results are bit-identical to the planar kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void gs_nchw_to_nhwc_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                              int C, int HW) {
+  __shared__ T tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const T *src = in + (size_t)n * C * HW;
+  T *dst = out + (size_t)n * C * HW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    if (c < C && p < HW) tile[ty + 8 * i][tx] = src[(size_t)c * HW + p];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    if (c < C && p < HW) dst[(size_t)p * C + c] = tile[tx][ty + 8 * i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_sampler_2d_nhwc_kernel(
+    const T *__restrict__ xt, const T *__restrict__ grid, T *__restrict__ out, Gs2dDims d, int interp,
+    int pad, int align_i) {
+  constexpr int V = 16 / sizeof(T);  // channels per 16-byte vector
+  constexpr int NV = kCPT / V;       // vectors per 8-channel chunk
+  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long plane_o = (long)d.Ho * d.Wo;
+  if (pix >= plane_o * d.N) return;
+  const int n = (int)(pix / plane_o);
+  const long s = pix - (long)n * plane_o;
+  const bool align = align_i != 0;
+  float gx, gy;
+  {
+#pragma clang fp contract(off)
+    gx = ld<T>(grid + ((long)n * 2 + 0) * plane_o + s) / 10;  // grid_sampler.py:28-29
+    gy = ld<T>(grid + ((long)n * 2 + 1) * plane_o + s) / 10;
+  }
+  const int c0 = blockIdx.y * kCPT;
+  const T *ip = xt + (size_t)n * d.H * d.W * d.C + c0;
+  T *op = out + ((size_t)n * d.C + c0) * plane_o + s;
+  const float ix = gs_source_index(gx, d.W, pad, align);
+  const float iy = gs_source_index(gy, d.H, pad, align);
+  float o[kCPT];
+#pragma unroll
+  for (int j = 0; j < kCPT; ++j) o[j] = 0.f;
+  if (interp == BEVOPS_BILINEAR) {
+    Footprint2D<4> f;
+    footprint_bilinear(ix, iy, d.H, d.W, f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (f.off[k] >= 0) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(ip + (size_t)f.off[k] * d.C);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const uint4 raw = row[v];
+          const T *e = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+#pragma clang fp contract(off)
+            o[v * V + j] += ld<T>(e + j) * f.w[k];
+          }
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < kCPT; ++j) st<T>(op + (size_t)j * plane_o, o[j], 1.f);
+  } else {  // nearest: pure copies
+    const int src = footprint_nearest(ix, iy, d.H, d.W);
+    if (src >= 0) {
+      const uint4 *row = reinterpret_cast<const uint4 *>(ip + (size_t)src * d.C);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const uint4 raw = row[v];
+        const T *e = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+        for (int j = 0; j < V; ++j) op[(size_t)(v * V + j) * plane_o] = e[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kCPT; ++j) st<T>(op + (size_t)j * plane_o, 0.f, 1.f);
+    }
+  }
+}
+
 struct Gs3dDims {
   int N, C, D, H, W, Do, Ho, Wo;
 };
@@ -262,6 +354,53 @@ extern "C" int bevops_grid_sampler_2d_forward(int dtype, const void *input, cons
     default:
       return BEVOPS_NOT_SUPPORTED;
   }
+}
+
+extern "C" size_t bevops_grid_sampler_2d_workspace_size(int dtype, int N, int C, int H_in, int W_in) {
+  if ((dtype != BEVOPS_F32 && dtype != BEVOPS_F16) || N <= 0 || C <= 0 || H_in <= 0 || W_in <= 0) return 0;
+  if (C % kCPT != 0) return 0;  // the channels-last path moves whole 8-channel chunks
+  const size_t n = (size_t)N * C * H_in * W_in * (dtype == BEVOPS_F32 ? 4 : 2);
+  return (n + 255) & ~size_t(255);
+}
+
+extern "C" int bevops_grid_sampler_2d_forward_ws(int dtype, const void *input, const void *grid, void *output,
+                                                 int N, int C, int H_in, int W_in, int H_out, int W_out,
+                                                 int interpolation, int padding, int align_corners,
+                                                 float scale_in, float scale_grid, float scale_out,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+  const size_t need = bevops_grid_sampler_2d_workspace_size(dtype, N, C, H_in, W_in);
+  // staging pays when the output is at least a few times the input (the transpose is one extra
+  // read + write of the input) and only for the modes whose taps are plain loads
+  const bool staged = workspace && need && workspace_bytes >= need && aligned16(workspace) &&
+                      (interpolation == BEVOPS_BILINEAR || interpolation == BEVOPS_NEAREST) && H_out > 0 &&
+                      W_out > 0 && (size_t)H_out * W_out >= 2 * (size_t)H_in * W_in;
+  if (!staged)
+    return bevops_grid_sampler_2d_forward(dtype, input, grid, output, N, C, H_in, W_in, H_out, W_out,
+                                          interpolation, padding, align_corners, scale_in, scale_grid, scale_out,
+                                          stream);
+  if (!input || !grid || !output) return BEVOPS_BAD_PARAM;
+  if (!enum_ok(interpolation, padding)) return BEVOPS_BAD_PARAM;
+  const long pixels = (long)N * H_out * W_out;
+  const long blocks = (pixels + kBlock - 1) / kBlock;
+  const long HW = (long)H_in * W_in;
+  if (blocks > 0x7FFFFFFFL || HW > 0x7FFFFFFFL / (C > 0 ? C : 1) || C > 65535 * kCPT || N > 65535)
+    return BEVOPS_NOT_SUPPORTED;
+  const Gs2dDims d{N, C, H_in, W_in, H_out, W_out};
+  const dim3 gt((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+  const dim3 g((unsigned)blocks, (unsigned)(C / kCPT));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == BEVOPS_F32) {
+    hipLaunchKernelGGL((gs_nchw_to_nhwc_kernel<float>), gt, dim3(256), 0, st, (const float *)input,
+                       (float *)workspace, C, (int)HW);
+    hipLaunchKernelGGL((grid_sampler_2d_nhwc_kernel<float>), g, dim3(kBlock), 0, st, (const float *)workspace,
+                       (const float *)grid, (float *)output, d, interpolation, padding, align_corners);
+  } else {
+    hipLaunchKernelGGL((gs_nchw_to_nhwc_kernel<__half>), gt, dim3(256), 0, st, (const __half *)input,
+                       (__half *)workspace, C, (int)HW);
+    hipLaunchKernelGGL((grid_sampler_2d_nhwc_kernel<__half>), g, dim3(kBlock), 0, st, (const __half *)workspace,
+                       (const __half *)grid, (__half *)output, d, interpolation, padding, align_corners);
+  }
+  return launch_status();
 }
 
 extern "C" int bevops_grid_sampler_3d_forward(int dtype, const void *input, const void *grid,

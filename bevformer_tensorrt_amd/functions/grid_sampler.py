@@ -9,6 +9,17 @@ _MODE = {"bilinear": 0, "nearest": 1, "bicubic": 2}
 _PAD = {"zeros": 0, "border": 1, "reflection": 2}
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Scratch buffer per device, grown on demand (the previous one stays alive for launches in flight)."""
+    cur = _WS.get(device.index)
+    if cur is None or cur.numel() < nbytes:
+        cur = _WS[device.index] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return cur
+
+
 def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
                   scales=(1.0, 1.0, 1.0)):
     assert input.is_cuda, "grid_sampler: input must be on the GPU"
@@ -25,12 +36,15 @@ def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
             raise ValueError(f"grid must be [N,2,H_out,W_out], got {tuple(grid.shape)}")
         Ho, Wo = grid.shape[2:]
         out = torch.empty((N, C, Ho, Wo), dtype=input.dtype, device=input.device)
+        # lend a scratch buffer: up-sampling calls stage the input channels-last (same results)
+        nws = handle.bevops_grid_sampler_2d_workspace_size(dt, N, C, H, W) if dt != _lib.I8 else 0
+        ws = _workspace(input.device, nws) if nws and Ho * Wo >= 2 * H * W else None
         with torch.cuda.device(input.device):
-            st = handle.bevops_grid_sampler_2d_forward(
+            st = handle.bevops_grid_sampler_2d_forward_ws(
                 dt, input.data_ptr(), grid.data_ptr(), out.data_ptr(), N, C, H, W, Ho, Wo, mode,
                 pad, int(bool(align_corners)), float(scales[0]), float(scales[1]),
-                float(scales[2]), stream)
-        _lib.check(st, "bevops_grid_sampler_2d_forward")
+                float(scales[2]), ws.data_ptr() if ws is not None else None, nws if ws is not None else 0, stream)
+        _lib.check(st, "bevops_grid_sampler_2d_forward_ws")
         return out
     if grid.dim() == 5:
         N, C, D, H, W = input.shape

@@ -33,6 +33,9 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "bevops_grid_sampler_2d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
                                        [c_float] * 3 + [c_void_p]),
+    "bevops_grid_sampler_2d_workspace_size": (c_size_t, [c_int] * 5),
+    "bevops_grid_sampler_2d_forward_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                                          [c_float] * 3 + [c_void_p, c_size_t, c_void_p]),
     "bevops_bev_pool_v2_forward": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float] * 3 +
                                    [c_void_p]),
     "bevops_mdconv_set_variant": (c_int, [c_int]),

@@ -156,6 +156,17 @@ int bevops_grid_sampler_2d_forward(int dtype, const void *input, const void *gri
                                    int interpolation, int padding, int align_corners,
                                    float scale_in, float scale_grid, float scale_out,
                                    void *stream);
+/* bevops_grid_sampler_2d_forward with a caller-lent scratch buffer (mirrors getWorkspaceSize): fp32 /
+ * fp16 bilinear / nearest calls with C % 8 == 0 whose output is >= 2x the input stage the input
+ * channels-last in the workspace (one 16-byte load per tap and 8-channel chunk instead of 8 two-byte
+ * gathers); every other call runs the planar kernel.  Results are bit-identical either way.
+ * bevops_grid_sampler_2d_workspace_size: bytes to lend (0 = the staged path does not apply). */
+size_t bevops_grid_sampler_2d_workspace_size(int dtype, int N, int C, int H_in, int W_in);
+int bevops_grid_sampler_2d_forward_ws(int dtype, const void *input, const void *grid, void *output,
+                                      int N, int C, int H_in, int W_in, int H_out, int W_out,
+                                      int interpolation, int padding, int align_corners,
+                                      float scale_in, float scale_grid, float scale_out,
+                                      void *workspace, size_t workspace_bytes, void *stream);
 int bevops_grid_sampler_3d_forward(int dtype, const void *input, const void *grid, void *output,
                                    int N, int C, int D_in, int H_in, int W_in, int D_out,
                                    int H_out, int W_out, int interpolation, int padding,

@@ -249,3 +249,28 @@ def test_rotate_hwc_equals_rotate_on_permuted_data(dtype, interp):
         want = bev.rotate(img, a, c, interp)
         got = bev.rotate_hwc(img.permute(1, 2, 0).contiguous(), a, c, interp).permute(2, 0, 1)
         assert torch.equal(got, want), (C, H, W, (got.float() - want.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_grid_sampler_staged_path_is_bit_identical(dtype):
+    """Up-sampling bilinear / nearest calls stage the input channels-last in a lent workspace
+    (bevops_grid_sampler_2d_forward_ws); the planar kernel must give the same bits."""
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.utils import lib as L
+    h = L.load_library()
+    g = torch.Generator().manual_seed(0)
+    for (N, C, H, W, Ho, Wo) in [(2, 16, 9, 11, 40, 37), (1, 32, 20, 20, 101, 99), (3, 8, 5, 7, 13, 6)]:
+        x = torch.randn(N, C, H, W, generator=g).to(dtype).cuda()
+        grid = ((torch.rand(N, 2, Ho, Wo, generator=g) * 2 - 1) * 12).to(dtype).cuda()
+        assert h.bevops_grid_sampler_2d_workspace_size(L.torch_dtype_code(x), N, C, H, W) > 0
+        for mode, mi in (("bilinear", 0), ("nearest", 1)):
+            for pad, pi in (("zeros", 0), ("border", 1), ("reflection", 2)):
+                for align in (False, True):
+                    staged = bev.grid_sampler(x, grid, mode, pad, align)          # workspace lent by the wrapper
+                    planar = torch.empty_like(staged)
+                    st = h.bevops_grid_sampler_2d_forward(L.torch_dtype_code(x), x.data_ptr(), grid.data_ptr(),
+                                                          planar.data_ptr(), N, C, H, W, Ho, Wo, mi, pi, int(align),
+                                                          1.0, 1.0, 1.0, torch.cuda.current_stream().cuda_stream)
+                    assert st == 0
+                    torch.cuda.synchronize()
+                    assert torch.equal(staged, planar), (N, C, H, W, mode, pad, align)
