@@ -6,8 +6,8 @@
 // M = pixels, N = 32, K = 9 * Cin: N is exactly one 32-wide MFMA tile, and ALL weights of a
 // 256-channel phase (9 * 256 * 32 * 2 B = 144 KiB) fit the CU's LDS.
 //
-// MI355X mapping: a 512-thread block fills LDS once with the packed weights of a phase (straight
-// 16-byte copies of a pre-swizzled image, conflict-free ds_read_b128 afterwards); each of its 8 waves
+// MI355X mapping: a block of 2 / 5 / 8 waves fills LDS once with the packed weights of a phase (straight
+// 16-byte copies of a pre-swizzled image, conflict-free ds_read_b128 afterwards); each of its waves
 // owns one tile of 32 consecutive pixels: accumulators = one v_mfma_f32_32x32x16_f16 tile (weights
 // are the A operand, the image is the B operand, so a lane ends up with 4 x 4 consecutive output
 // channels of one pixel = 8-byte stores into the [pixel][32] result).  The image operand never
@@ -23,10 +23,8 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kThreads = 512;
-constexpr int kTile = 32;                       // pixels per wave
-constexpr int kTilesPerBlock = kThreads / 64;   // 8
-constexpr int kDepth = 5;                       // (tap, chunk) steps in flight per wave
+constexpr int kTile = 32;                       // pixels per wave; WPB waves (= tiles) per block
+constexpr int kDepth = 4;                       // (tap, chunk) steps in flight per wave
 constexpr unsigned kOob = 0xFFFFFF00u;          // beyond any buffer: reads as zero
 
 // packed weight image, per phase of CP = 64 * CCP channels:
@@ -50,13 +48,14 @@ __global__ __launch_bounds__(256) void pack_conv3x3_c32_kernel(const __half *__r
   dst[idx] = m < cout ? w[((size_t)m * Cin + c) * 9 + tap] : __float2half(0.f);
 }
 
-template <int CCP>  // 64-channel chunks per phase (1, 2 or 4)
-__global__ __launch_bounds__(kThreads) void conv3x3_c32_kernel(const __half *__restrict__ x,
+template <int CCP, int WPB>  // 64-channel chunks per phase (1, 2 or 4); waves per block
+__global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__restrict__ x,
                                                                const __half *__restrict__ wp,
                                                                const __half *__restrict__ bias,
                                                                __half *__restrict__ out, int B, int H, int W, int Cin,
                                                                int phases) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kThreads = WPB * 64, kTilesPerBlock = WPB;
   constexpr int kSteps = 9 * CCP;
   constexpr int kGroups = kSteps * 4 * 64;  // 16-byte groups per phase
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,16 +92,20 @@ __global__ __launch_bounds__(kThreads) void conv3x3_c32_kernel(const __half *__r
       const uint4 *src = reinterpret_cast<const uint4 *>(wp) + (size_t)phase * kGroups;
       uint4 *dst = reinterpret_cast<uint4 *>(smem);
       constexpr int kIters = (kGroups + kThreads - 1) / kThreads;
-      uint4 tmp[kIters];
+      constexpr int kBatch = 16;  // groups requested together per thread (64 VGPRs)
 #pragma unroll
-      for (int k = 0; k < kIters; ++k) {
-        const int i = tid + k * kThreads;
-        tmp[k] = i < kGroups ? src[i] : make_uint4(0, 0, 0, 0);
-      }
+      for (int k0 = 0; k0 < kIters; k0 += kBatch) {
+        uint4 tmp[kBatch];
 #pragma unroll
-      for (int k = 0; k < kIters; ++k) {
-        const int i = tid + k * kThreads;
-        if (i < kGroups) dst[i] = tmp[k];
+        for (int k = 0; k < kBatch; ++k) {
+          const int i = tid + (k0 + k) * kThreads;
+          tmp[k] = (k0 + k < kIters && i < kGroups) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+          const int i = tid + (k0 + k) * kThreads;
+          if (k0 + k < kIters && i < kGroups) dst[i] = tmp[k];
+        }
       }
     }
     __syncthreads();
@@ -150,23 +153,40 @@ __global__ __launch_bounds__(kThreads) void conv3x3_c32_kernel(const __half *__r
   }
 }
 
-template <int CCP>
+template <int CCP, int WPB>
 int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W, int Cin,
                 int phases, hipStream_t st) {
   const size_t lds = (size_t)9 * CCP * 4 * 64 * 16;
   static bool ready = false;  // attribute set once per process (idempotent; benign if raced)
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_kernel<CCP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_kernel<CCP, WPB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return BEVOPS_FAILURE;
     ready = true;
   }
   const long npix = (long)B * H * W;
-  const long blocks = (npix + kTile * kTilesPerBlock - 1) / (kTile * kTilesPerBlock);
+  const long blocks = (npix + kTile * WPB - 1) / (kTile * WPB);
   if (blocks > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
-  hipLaunchKernelGGL(conv3x3_c32_kernel<CCP>, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, wp, bias, out, B,
-                     H, W, Cin, phases);
+  hipLaunchKernelGGL((conv3x3_c32_kernel<CCP, WPB>), dim3((unsigned)blocks), dim3(WPB * 64), lds, st, x, wp, bias,
+                     out, B, H, W, Cin, phases);
   return launch_status();
+}
+
+// The image operand comes from the fabric (it was written by another XCD a moment ago) at ~11 B/clk
+// per CU whatever the block does, so the launch is as fast as its busiest CU: the LDS image allows
+// one block per CU, hence tiles per block = ceil(tiles / CUs), from {2, 5, 8} waves.
+template <int CCP>
+int launch_conv_any(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W, int Cin,
+                    int phases, hipStream_t st) {
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return BEVOPS_FAILURE;
+  const long tiles = ((long)B * H * W + kTile - 1) / kTile;
+  const long need = (tiles + cus - 1) / cus;
+  if (need <= 2) return launch_conv<CCP, 2>(x, wp, bias, out, B, H, W, Cin, phases, st);
+  if (need <= 5) return launch_conv<CCP, 5>(x, wp, bias, out, B, H, W, Cin, phases, st);
+  return launch_conv<CCP, 8>(x, wp, bias, out, B, H, W, Cin, phases, st);
 }
 
 }  // namespace
@@ -203,9 +223,9 @@ extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc
   const __half *x = (const __half *)input_nhwc, *wp = (const __half *)packed_weight, *b = (const __half *)bias32;
   __half *o = (__half *)output_nhwc;
   switch (CP / 64) {
-    case 1: return launch_conv<1>(x, wp, b, o, B, H, W, Cin, phases, st);
-    case 2: return launch_conv<2>(x, wp, b, o, B, H, W, Cin, phases, st);
+    case 1: return launch_conv_any<1>(x, wp, b, o, B, H, W, Cin, phases, st);
+    case 2: return launch_conv_any<2>(x, wp, b, o, B, H, W, Cin, phases, st);
     case 3: return BEVOPS_NOT_SUPPORTED;
-    default: return launch_conv<4>(x, wp, b, o, B, H, W, Cin, phases, st);
+    default: return launch_conv_any<4>(x, wp, b, o, B, H, W, Cin, phases, st);
   }
 }
