@@ -132,3 +132,104 @@ def get_calibrator(calibrator):
     """Factory with the reference's names (det2trt/quantization/calibrator_trt.py:6-16)."""
     assert calibrator in CALIBRATORS, f"calibrator should be in {sorted(CALIBRATORS)}"
     return CALIBRATORS[calibrator]
+
+
+class Int8PluginOps:
+    """INT8 scale plumbing for the plugin call sites of a model.
+
+    An operator namespace that can be handed to `BEVFormer(ops=...)` in place of
+    `bevformer_tensorrt_amd.functions`.  Two phases, like a TensorRT PTQ build
+    (tools/bevformer/onnx2trt.py:110-241 feeds calibration batches through the network, TensorRT
+    records one scale per plugin tensor, the engine then hands `PluginTensorDesc::scale` to
+    `enqueue`):
+
+      calibrate : every plugin call runs the fp operator while the calibrator collects its boundary
+                  tensors under a stable name  "<op>#<call index within the frame>.<tensor>";
+      int8      : the same call sites quantise their inputs with the recorded scales, run the
+                  INT8 flavour of the operator (`*_int8`) and de-quantise the result.
+
+    Only the sampling operators are quantised (the scope of the custom plugins); dense layers stay
+    in the model's dtype.  `begin_frame()` resets the per-frame call counters (the model's
+    forward pre-hook installed by `attach`).  The fused / channels-last entries are deliberately not
+    exposed, so a model built on this namespace takes the reference op sequence.
+    """
+
+    def __init__(self, calibrator="entropy", fp_ops=None):
+        from . import functions as _f
+        self.fp = fp_ops if fp_ops is not None else _f
+        self.cal = get_calibrator(calibrator)() if isinstance(calibrator, str) else calibrator
+        self.mode = "calibrate"
+        self._scales = {}
+        self._n = {}
+
+    # ---- bookkeeping
+    def begin_frame(self):
+        self._n = {}
+
+    def attach(self, model):
+        model.register_forward_pre_hook(lambda m, args: self.begin_frame())
+        return self
+
+    def freeze(self):
+        """End of calibration: fix the scales and switch the call sites to their INT8 flavours."""
+        self._scales = self.cal.scales()
+        self.mode = "int8"
+        return self._scales
+
+    def _site(self, op):
+        i = self._n.get(op, 0)
+        self._n[op] = i + 1
+        return f"{op}#{i}"
+
+    def _q(self, name, t):
+        s = self._scales[name]
+        return self.cal.quantize(t, s), s
+
+    # ---- call sites
+    def multi_scale_deformable_attn(self, value, shapes, ref, off, w):
+        site = self._site("msda")
+        if self.mode == "calibrate":
+            out = self.fp.multi_scale_deformable_attn(value, shapes, ref, off, w)
+            for k, t in (("value", value), ("offsets", off), ("weights", w), ("out", out)):
+                self.cal.collect(f"{site}.{k}", t)
+            return out
+        (qv, sv), (qo, so), (qw, sw) = (self._q(f"{site}.{k}", t) for k, t in
+                                        (("value", value), ("offsets", off), ("weights", w)))
+        s_out = self._scales[f"{site}.out"]
+        # reference points stay fp16: the <__half2> flavour (multiScaleDeformableAttnPlugin.cpp:118-125)
+        out = self.fp.multi_scale_deformable_attn_int8(qv, shapes, ref.to(torch.float16).contiguous(),
+                                                       qo.contiguous(), qw.contiguous(), sv, so, sw, s_out)
+        return (out.to(value.dtype) * s_out)
+
+    multi_scale_deformable_attn2 = multi_scale_deformable_attn
+
+    def rotate(self, img, angle, center, interpolation="nearest"):
+        site = self._site("rotate")
+        if self.mode == "calibrate":
+            out = self.fp.rotate(img, angle, center, interpolation)
+            self.cal.collect(f"{site}.img", img)
+            return out
+        q, s = self._q(f"{site}.img", img)
+        out = self.fp.rotate_int8(q.contiguous(), angle, center, s, s, interpolation)
+        return out.to(img.dtype) * s
+
+    rotate2 = rotate
+
+    def modulated_deformable_conv2d(self, x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
+                                    groups=1, deform_groups=1):
+        site = self._site("dcn")
+        if self.mode == "calibrate":
+            out = self.fp.modulated_deformable_conv2d(x, offset, mask, weight, bias, stride, padding, dilation,
+                                                      groups, deform_groups)
+            for k, t in (("x", x), ("offset", offset), ("mask", mask), ("weight", weight), ("out", out)):
+                self.cal.collect(f"{site}.{k}", t)
+            return out
+        (qx, sx), (qo, so), (qm, sm), (qw, sw) = (self._q(f"{site}.{k}", t) for k, t in
+                                                  (("x", x), ("offset", offset), ("mask", mask), ("weight", weight)))
+        s_out = self._scales[f"{site}.out"]
+        out = self.fp.modulated_deformable_conv2d_int8(qx, qo, qm, qw, None if bias is None else bias.float(),
+                                                       sx, so, sm, sw, s_out, stride, padding, dilation, groups,
+                                                       deform_groups)
+        return out.to(x.dtype) * s_out
+
+    modulated_deformable_conv2d2 = modulated_deformable_conv2d
