@@ -46,6 +46,16 @@ const Entry kTable[] = {
     {"bevops_mdconv_forward_int8", (void *)&bevops_mdconv_forward_int8},
     {"ModulatedDeformableConv2dTRT", (void *)&bevops_mdconv_forward},
     {"ModulatedDeformableConv2dTRT2", (void *)&bevops_mdconv_forward},
+    // entries that are not reference plugins: workspace-lending / channels-last / fused forms
+    {"bevops_grid_sampler_2d_forward_ws", (void *)&bevops_grid_sampler_2d_forward_ws},
+    {"bevops_grid_sampler_2d_workspace_size", (void *)&bevops_grid_sampler_2d_workspace_size},
+    {"bevops_rotate_forward_hwc", (void *)&bevops_rotate_forward_hwc},
+    {"bevops_sca_forward", (void *)&bevops_sca_forward},
+    {"bevops_mdconv_forward_nhwc", (void *)&bevops_mdconv_forward_nhwc},
+    {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
+    {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
+    {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
+    {"bevops_layer_norm", (void *)&bevops_layer_norm},
 };
 }  // namespace
 
