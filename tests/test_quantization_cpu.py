@@ -65,3 +65,69 @@ def test_entropy_threshold_minimises_kl_against_brute_force():
 
     best = min(range(128, 2049, 16), key=kl_at)
     assert abs(kl_at(i + 1) - kl_at(best)) <= 0.02 * max(kl_at(best), 1e-6) + 1e-4
+
+
+class _FakeOps:
+    """Host-only stand-ins with the operator signatures: enough to drive Int8PluginOps' plumbing."""
+
+    def __init__(self):
+        self.calls = []
+
+    def multi_scale_deformable_attn(self, value, shapes, ref, off, w):
+        self.calls.append("msda")
+        return value[:, : off.shape[1]] * 0.5 + off.mean() + w.mean()
+
+    def multi_scale_deformable_attn_int8(self, value, shapes, ref, off, w, s_v, s_o, s_w, s_out):
+        self.calls.append(("msda_int8", round(s_v, 9), round(s_o, 9), round(s_w, 9), round(s_out, 9)))
+        import torch
+        assert value.dtype == off.dtype == w.dtype == torch.int8 and ref.dtype == torch.float16
+        real = (value[:, : off.shape[1]].float() * s_v) * 0.5 + (off.float() * s_o).mean() + (w.float() * s_w).mean()
+        return torch.clamp(torch.round(real / s_out), -127, 127).to(torch.int8)
+
+    def rotate(self, img, angle, center, interpolation="nearest"):
+        self.calls.append("rotate")
+        return img.flip(-1)
+
+    def rotate_int8(self, img, angle, center, s_in, s_out, interpolation="nearest"):
+        self.calls.append(("rotate_int8", round(s_in, 9), round(s_out, 9)))
+        return img.flip(-1)
+
+
+def test_int8_plugin_ops_plumbing():
+    """calibrate -> freeze -> int8: stable per-frame site names, one scale per boundary tensor, the INT8
+    flavours receive exactly the calibrator's scales, results de-quantise to the fp results."""
+    import torch
+    from bevformer_tensorrt_amd.quantization import Int8PluginOps
+    fake = _FakeOps()
+    q = Int8PluginOps("minmax", fp_ops=fake)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    frames = [[(mk(1, 6, 2, 4), mk(1, 6, 2, 8), mk(1, 6, 2, 4)) for _ in range(2)] for _ in range(3)]
+    img = mk(4, 5, 5)
+    shapes, ref = torch.tensor([[2, 3]]), torch.rand(1, 6, 1, 2, generator=g)
+    fp_out = []
+    for fr in frames:                                   # three calibration frames, two MSDA sites + one rotate each
+        q.begin_frame()
+        outs = [q.multi_scale_deformable_attn(v, shapes, ref, o, w) for v, o, w in fr]
+        outs.append(q.rotate(img, 1.0, (2.0, 2.0)))
+        fp_out.append(outs)
+    scales = q.freeze()
+    assert sorted(scales) == sorted([f"msda#{i}.{k}" for i in (0, 1) for k in ("value", "offsets", "weights", "out")]
+                                    + ["rotate#0.img"])
+    # min-max over ALL calibration frames of a site
+    want = max(float(fr[1][0].abs().max()) for fr in frames) / 127.0
+    assert abs(scales["msda#1.value"] - want) <= 1e-12
+    fake.calls.clear()
+    q.begin_frame()
+    v, o, w = frames[2][0]
+    out = q.multi_scale_deformable_attn(v, shapes, ref, o, w)
+    r = q.rotate(img, 1.0, (2.0, 2.0))
+    kind, s_v, s_o, s_w, s_out = fake.calls[0]
+    assert kind == "msda_int8" and s_v == round(scales["msda#0.value"], 9) and s_out == round(scales["msda#0.out"], 9)
+    assert fake.calls[1][0] == "rotate_int8" and fake.calls[1][1] == fake.calls[1][2] == round(scales["rotate#0.img"], 9)
+    assert out.dtype == v.dtype and (out - fp_out[2][0]).abs().max().item() <= 3 * scales["msda#0.out"] + 0.05
+    assert (r - fp_out[2][2]).abs().max().item() <= scales["rotate#0.img"]
+    # the counters restart with the frame: the same sites are addressed again
+    q.begin_frame()
+    q.multi_scale_deformable_attn(v, shapes, ref, o, w)
+    assert fake.calls[-1][1] == round(scales["msda#0.value"], 9)
