@@ -1,5 +1,8 @@
+#!/bin/bash
+# PMC pass over tools/conv_offset_probe.py (FETCH_SIZE / TCC hit+miss per kernel).  Needs ~3-4 min on a fresh box
+# (first torch import + counter serialisation): the one attempt of round 1 ran out of its 110 s budget.
 OUT=gpurun_out/r01f_pmc; mkdir -p $OUT; export TMPDIR=/tmp
-( cd /tmp && timeout 110 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $GRAFT_REPO_ROOT/$OUT/p -o k -- python $GRAFT_REPO_ROOT/tools/conv_offset_probe.py 2>&1 | tail -3 ) > $OUT/log.txt
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $GRAFT_REPO_ROOT/$OUT/p -o k -- python $GRAFT_REPO_ROOT/tools/conv_offset_probe.py 2>&1 | tail -3 ) > $OUT/log.txt
 python3 - <<PY
 import csv, glob, collections
 fs = glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True)
