@@ -278,7 +278,12 @@ __device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned 
   o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
 }
 
-template <typename RefT, int PPL, int CH, bool U8W>
+// HM = true (experimental, bevops_msda_set_variant(21)): `value` is the head-major re-layout
+// [bs][heads][nk][32] made by msda_i8_repack_kernel and the items are enumerated (batch, head)-major,
+// so that -- with the XCD remap -- an XCD works on few (batch, head) planes (1 MB each at base SCA)
+// that stay in its L2, as msda_hm.hip does for fp16.  Only the addressing differs; the arithmetic of
+// an item is the same code, so the result is bit-identical to HM = false.
+template <typename RefT, int PPL, int CH, bool U8W, bool HM = false>
 __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
     const int8_t *__restrict__ value, unsigned value_bytes, const int32_t *__restrict__ shapes,
     const RefT *__restrict__ ref, const int8_t *__restrict__ off, const int8_t *__restrict__ logit,
@@ -297,15 +302,28 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
   }
   __syncthreads();
   const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned item = vb * (kBlock / 4) + (threadIdx.x >> 2);
-  if (item >= n_item) return;
+  const unsigned slot = vb * (kBlock / 4) + (threadIdx.x >> 2);
+  if (slot >= n_item) return;
   const unsigned sub = threadIdx.x & 3u;
-  const unsigned bq = item / (unsigned)d.heads;
-  const unsigned h = item - bq * (unsigned)d.heads;
-  const unsigned b = bq / (unsigned)d.nq;
+  unsigned item, bq, h, b, row_bytes, lane_base;
+  if constexpr (HM) {  // slot = (b * heads + h) * nq + q
+    const unsigned plane = slot / (unsigned)d.nq;
+    const unsigned q = slot - plane * (unsigned)d.nq;
+    b = plane / (unsigned)d.heads;
+    h = plane - b * (unsigned)d.heads;
+    bq = b * (unsigned)d.nq + q;
+    item = bq * (unsigned)d.heads + h;  // index into logits / offsets / out (reference layout)
+    row_bytes = 32u;
+    lane_base = plane * (unsigned)d.nk * 32u + sub * V;
+  } else {
+    item = slot;
+    bq = item / (unsigned)d.heads;
+    h = item - bq * (unsigned)d.heads;
+    b = bq / (unsigned)d.nq;
+    row_bytes = (unsigned)d.heads * 32u;
+    lane_base = (b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V;
+  }
   constexpr int LP = 4 * PPL;
-  const unsigned row_bytes = (unsigned)d.heads * 32u;
-  const unsigned lane_base = (b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(value), 0, value_bytes, 0x00020000);
 
@@ -577,6 +595,38 @@ int msda_float(const T *value, const int32_t *shapes, const T *ref, const T *off
   return launch_status();
 }
 
+// [bs, nk, heads, 32] int8 -> [bs, heads, nk, 32]; thread = one 16-byte half row
+__global__ __launch_bounds__(256) void msda_i8_repack_kernel(const int8_t *__restrict__ value,
+                                                             int8_t *__restrict__ hm, int bs, int nk, int heads) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)bs * nk * heads * 2;
+  if (idx >= total) return;
+  const unsigned half = (unsigned)(idx & 1);
+  const size_t r = idx >> 1;                        // ((b * heads + h) * nk + k): coalesced WRITES
+  const unsigned k = (unsigned)(r % (size_t)nk);
+  const size_t bh = r / (size_t)nk;
+  const unsigned h = (unsigned)(bh % (size_t)heads);
+  const size_t b = bh / (size_t)heads;
+  const uint4 v = *reinterpret_cast<const uint4 *>(value + ((b * nk + k) * heads + h) * 32 + half * 16);
+  *reinterpret_cast<uint4 *>(hm + r * 32 + half * 16) = v;
+}
+
+template <typename RefT, bool U8W, int PPL, int CH>
+int launch_quad_i8_hm(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
+                      const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o,
+                      float s_w, float s_out, int8_t *hm, hipStream_t st) {
+  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
+  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
+  const size_t rthreads = (size_t)d.bs * d.nk * d.heads * 2;
+  hipLaunchKernelGGL(msda_i8_repack_kernel, dim3((unsigned)((rthreads + 255) / 256)), dim3(256), 0, st, value,
+                     hm, d.bs, d.nk, d.heads);
+  const unsigned grid = (unsigned)((n_item + kBlock / 4 - 1) / (kBlock / 4));
+  hipLaunchKernelGGL((msda_quad_int8_kernel<RefT, PPL, CH, U8W, true>), dim3(grid), dim3(kBlock), 0, st,
+                     (const int8_t *)hm, (unsigned)vbytes, shapes, ref, off, logit, out, d, (unsigned)n_item, s_v,
+                     s_o, s_w, s_out);
+  return launch_status();
+}
+
 template <typename RefT, bool U8W, int PPL, int CH>
 int launch_quad_i8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
                    const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o,
@@ -593,13 +643,25 @@ int launch_quad_i8(const int8_t *value, const int32_t *shapes, const RefT *ref, 
 template <typename RefT, bool U8W>
 int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
               const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o, float s_w,
-              float s_out, hipStream_t st) {
+              float s_out, hipStream_t st, void *workspace = nullptr, size_t workspace_bytes = 0) {
   const size_t n_item = (size_t)d.bs * d.nq * d.heads;
   const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
   const int LP = d.L * d.P;
   const bool quad_ok = d.C == 32 && LP % 4 == 0 && d.L <= kMaxLevels && vbytes < 0xFFFFFF00ull &&
                        n_item < 0x7FFFFFFFull && aligned16(value) && aligned16(off) &&
                        aligned16(logit) && aligned16(out) && aligned16(ref) && g_variant != 99;
+  // experimental head-major INT8 path (variant 21; not the default until validated on the GPU)
+  if (quad_ok && g_variant == 21 && workspace && workspace_bytes >= vbytes && aligned16(workspace)) {
+    int8_t *hm = static_cast<int8_t *>(workspace);
+    switch (LP / 4) {
+      case 1: return launch_quad_i8_hm<RefT, U8W, 1, 1>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
+      case 2: return launch_quad_i8_hm<RefT, U8W, 2, 2>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
+      case 4: return launch_quad_i8_hm<RefT, U8W, 4, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
+      case 8: return launch_quad_i8_hm<RefT, U8W, 8, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
+      case 16: return launch_quad_i8_hm<RefT, U8W, 16, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
+      default: break;
+    }
+  }
   if (quad_ok) {
     switch (LP / 4) {
       case 1: return launch_quad_i8<RefT, U8W, 1, 1>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
@@ -631,10 +693,11 @@ extern "C" int bevops_msda_set_variant(int variant) {
 
 extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
                                              int num_levels, int num_query, int num_point) {
-  if (dtype != BEVOPS_F16 || bs <= 0 || nk <= 0 || heads <= 0 || num_levels <= 0 ||
-      num_query <= 0 || num_point <= 0)
-    return 0;
+  if (bs <= 0 || nk <= 0 || heads <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0) return 0;
   if ((num_levels * num_point) % 4 != 0) return 0;
+  if (dtype == BEVOPS_I8)  // experimental head-major INT8 path only (variant 21)
+    return (g_variant == 21 && channels == 32) ? (((size_t)bs * nk * heads * 32 + 255) & ~size_t(255)) : 0;
+  if (dtype != BEVOPS_F16) return 0;
   return msda_hm_workspace_bytes(bs, nk, heads, channels, num_levels);
 }
 
@@ -643,7 +706,7 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
                                                     int num_levels, int num_query, int num_point) {
   const size_t a = bevops_msda_workspace_size(dtype, bs, nk, heads, channels, num_levels, num_query,
                                               num_point);
-  if (a == 0 || !spatial_shapes_host) return a;
+  if (a == 0 || !spatial_shapes_host || dtype != BEVOPS_F16) return a;
   const size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
                                             num_query, num_point);
   return a > b ? a : b;
@@ -781,13 +844,15 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
                                        (const float *)reference_points,
                                        (const int8_t *)sampling_offsets,
                                        (const int8_t *)attention_weights, (int8_t *)output, d,
-                                       scale_value, scale_offset, scale_weight, scale_out, st);
+                                       scale_value, scale_offset, scale_weight, scale_out, st, workspace,
+                                       workspace_bytes);
       if (ref_dtype == BEVOPS_F16)
         return msda_int8<__half, true>((const int8_t *)value, spatial_shapes,
                                        (const __half *)reference_points,
                                        (const int8_t *)sampling_offsets,
                                        (const int8_t *)attention_weights, (int8_t *)output, d,
-                                       scale_value, scale_offset, scale_weight, scale_out, st);
+                                       scale_value, scale_offset, scale_weight, scale_out, st, workspace,
+                                       workspace_bytes);
       return BEVOPS_NOT_SUPPORTED;
     default:
       return BEVOPS_NOT_SUPPORTED;
