@@ -38,7 +38,7 @@ def _worker(rank, world, port, n_cams, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_cams", [(2, 6), (4, 6), (2, 5)])
+@pytest.mark.parametrize("world,n_cams", [(2, 6), (4, 6), (2, 5), (8, 6)])   # 8: two ranks own no camera
 def test_gather_camera_features_gloo(world, n_cams):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
