@@ -153,6 +153,139 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
   }
 }
 
+// ---- experimental "rows" variant (bevops_conv3x3_c32_set_variant(1); NOT the default: written after
+// the last GPU visit of round 1, not yet run on hardware) -----------------------------------------
+// The default kernel pulls every tap of every pixel from the fabric: 9 x the image bytes, at the
+// ~11 B/clk a CU gets for data another XCD wrote.  The 9 taps of a run of consecutive pixels
+// [P0, P0 + 128) only touch the contiguous flattened range [P0 - W - 1, P0 + 128 + W + 1): this
+// variant stages that range ONCE per 64-channel chunk in LDS (coalesced 128-byte rows, 16-byte
+// chunks XOR-swizzled by the row so the fragment reads are conflict-free) next to the chunk's
+// 36 KiB of weights, and both MFMA operands come from LDS.  <= 80 KiB per block at W <= 100, so two
+// blocks share a CU and one computes while the other loads.
+constexpr int kRowsWaves = 4;                      // 128 pixels per block
+constexpr int kRowsThreads = kRowsWaves * 64;
+constexpr int kWGroups = 9 * 4 * 64;               // weight groups (16 B) of one 64-channel chunk
+
+__global__ __launch_bounds__(kRowsThreads) void conv3x3_c32_rows_kernel(const __half *__restrict__ x,
+                                                                        const __half *__restrict__ wp,
+                                                                        const __half *__restrict__ bias,
+                                                                        __half *__restrict__ out, int B, int H, int W,
+                                                                        int Cin, int CCP) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4 *wl = reinterpret_cast<uint4 *>(smem);                // [tap 9][j 4][hi 2][m 32] x 16 B
+  char *al = smem + (size_t)kWGroups * 16;                     // (R + 1) rows x 128 B; row R stays zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const int R = 32 * kRowsWaves + 2 * W + 2;
+  const long npix = (long)B * H * W;
+  const long P0 = (long)blockIdx.x * (32 * kRowsWaves);
+  const long pix = P0 + wave * 32 + n;
+  const bool live = pix < npix;
+  int ph = 0, pw = 0;
+  if (live) {
+    const int r = (int)(pix % ((long)H * W));
+    ph = r / W;
+    pw = r - ph * W;
+  }
+  // LDS byte offset of the (row, 16-byte chunk 0) a tap reads for this lane, or the zero row
+  unsigned trow[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    const bool ok = live && ph + dy >= 0 && ph + dy < H && pw + dx >= 0 && pw + dx < W;
+    trow[t] = (unsigned)(ok ? wave * 32 + n + dy * W + dx + W + 1 : R);
+  }
+  if (tid < 8) reinterpret_cast<uint4 *>(al + (size_t)R * 128)[tid] = make_uint4(0, 0, 0, 0);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(x), 0, (unsigned)((size_t)npix * Cin * 2), 0x00020000);
+  const unsigned row_bytes = (unsigned)Cin * 2u;
+  const long first = P0 - W - 1;  // flattened pixel of staged row 0 (may be negative / beyond the end)
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int nchunks = Cin / 64;
+  const int stage_items = R * 8;  // 16-byte pieces of the activation range
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // the previous chunk's fragments have been read
+    // weights of this chunk: 9 taps x 256 groups, strided by CCP * 256 in the packed image
+    {
+      const int phase = cc / CCP, chunk = cc - phase * CCP;
+      const uint4 *src = reinterpret_cast<const uint4 *>(wp) + (size_t)phase * (9 * CCP * 256) + (size_t)chunk * 256;
+#pragma unroll
+      for (int k = 0; k < kWGroups / kRowsThreads; ++k) {  // 9 iterations of 256 threads
+        const int i = tid + k * kRowsThreads;              // = tap * 256 + (i & 255)
+        wl[i] = src[(size_t)(i >> 8) * (CCP * 256) + (i & 255)];
+      }
+    }
+    // activation range of this chunk: piece e = row * 8 + chunk16; rows outside the tensor read as zero
+    for (int e0 = 0; e0 < stage_items; e0 += kRowsThreads * 4) {
+      u32x4 tmp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + tid + k * kRowsThreads;
+        const int row = e >> 3, c16 = e & 7;
+        const long p = first + row;
+        const bool ok = e < stage_items && p >= 0 && p < npix;
+        const unsigned vo = ok ? (unsigned)((size_t)p * row_bytes) + (unsigned)(cc * 128 + c16 * 16) : kOob;
+        tmp[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + tid + k * kRowsThreads;
+        if (e < stage_items) {
+          const int row = e >> 3, c16 = e & 7;
+          *reinterpret_cast<u32x4 *>(al + (size_t)row * 128 + (size_t)((c16 ^ (row & 7)) * 16)) = tmp[k];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned row = trow[t];
+      const char *rb = al + (size_t)row * 128;
+      const unsigned sw = row & 7u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 a = reinterpret_cast<const f16x8 *>(wl)[t * 256 + j * 64 + hi * 32 + n];
+        const f16x8 b = *reinterpret_cast<const f16x8 *>(rb + (((unsigned)(hi * 4 + j) ^ sw) * 16));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (!live) return;
+  __half *op = out + (size_t)pix * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = 8 * g + 4 * hi;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[4 * g + k] + (bias ? __half2float(bias[c0 + k]) : 0.f);
+    u32x2 o;
+    o.x = pack_h2(v[0], v[1]);
+    o.y = pack_h2(v[2], v[3]);
+    *reinterpret_cast<u32x2 *>(op + c0) = o;
+  }
+}
+
+int g_conv_variant = 0;
+
+int launch_conv_rows(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W,
+                     int Cin, int CCP, hipStream_t st) {
+  const size_t lds = (size_t)kWGroups * 16 + ((size_t)32 * kRowsWaves + 2 * W + 3) * 128;
+  if (lds > 160 * 1024) return BEVOPS_NOT_SUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_rows_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return BEVOPS_FAILURE;
+  const long npix = (long)B * H * W;
+  const long blocks = (npix + 32 * kRowsWaves - 1) / (32 * kRowsWaves);
+  if (blocks > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL(conv3x3_c32_rows_kernel, dim3((unsigned)blocks), dim3(kRowsThreads), lds, st, x, wp, bias, out,
+                     B, H, W, Cin, CCP);
+  return launch_status();
+}
+
 template <int CCP, int WPB>
 int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W, int Cin,
                 int phases, hipStream_t st) {
@@ -222,10 +355,20 @@ extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __half *x = (const __half *)input_nhwc, *wp = (const __half *)packed_weight, *b = (const __half *)bias32;
   __half *o = (__half *)output_nhwc;
+  if (g_conv_variant == 1) {  // experimental rows-in-LDS variant; falls through when it does not fit
+    const int rc = launch_conv_rows(x, wp, b, o, B, H, W, Cin, CP / 64, st);
+    if (rc != BEVOPS_NOT_SUPPORTED) return rc;
+  }
   switch (CP / 64) {
     case 1: return launch_conv_any<1>(x, wp, b, o, B, H, W, Cin, phases, st);
     case 2: return launch_conv_any<2>(x, wp, b, o, B, H, W, Cin, phases, st);
     case 3: return BEVOPS_NOT_SUPPORTED;
     default: return launch_conv_any<4>(x, wp, b, o, B, H, W, Cin, phases, st);
   }
+}
+
+extern "C" int bevops_conv3x3_c32_set_variant(int variant) {
+  const int prev = g_conv_variant;
+  g_conv_variant = variant;
+  return prev;
 }
