@@ -38,6 +38,7 @@ import torch.nn.functional as F
 
 from . import functions as _hip_ops
 from . import geometry as G
+from .utils import lib as _lib
 
 CONFIGS = {
     # name: backbone depth, DCN stages, FPN inputs/outs, padded image (h, w), BEV size, encoder layers
@@ -52,9 +53,7 @@ PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
 EMBED, HEADS, NUM_QUERY, NUM_CAMS = 256, 8, 900, 6
 
 
-def inverse_sigmoid(x, eps=1e-5):  # decoder.py:24-40
-    x = x.clamp(min=0, max=1)
-    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+inverse_sigmoid = G.inverse_sigmoid   # the head's (mmdet) form; the decoder's is in G.refine_reference_points
 
 
 # --------------------------------------------------------------------------- backbone
@@ -87,8 +86,8 @@ def _fused_linear(ops, x, weight, bias, residual, relu):
         return None
     try:
         return fn(x, weight, bias, residual, relu)
-    except RuntimeError as exc:   # BevopsError: NOT_SUPPORTED for this shape
-        if "status 3" not in str(exc):
+    except _lib.BevopsError as exc:   # only NOT_SUPPORTED (no algorithm for this shape) falls back
+        if exc.status != _lib.NOT_SUPPORTED:
             raise
         return None
 
@@ -160,8 +159,8 @@ class DCNv2Pack(nn.Module):
                 out = fn(x, self.conv_offset.weight, self.conv_offset.bias)
                 return self.ops.modulated_deformable_conv2d_nhwc(x, None, None, self.weight, self.bias, self.stride,
                                                                  1, 1, 1, 1, relu=relu, offset_mask_nhwc=out)
-            except RuntimeError as exc:
-                if "status 3" not in str(exc):
+            except _lib.BevopsError as exc:
+                if exc.status != _lib.NOT_SUPPORTED:
                     raise
                 self._c32_ok = False   # unsupported channel count: library convolution below
         w = self.conv_offset.weight
@@ -463,7 +462,10 @@ class BEVFormer(nn.Module):
         return pos.permute(2, 0, 1).unsqueeze(0).to(dtype)   # [1, 256, h, w]
 
     @torch.no_grad()
-    def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None):
+    def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None, shift=None):
+        """`shift` [1, 2]: optional precomputed G.bev_shift(can_bus) -- the frame loop evaluates it
+        on the host (atan / sin / cos differ in the last ulp between host and device libraries;
+        the host value is the reference's CPU path bit for bit)."""
         dev, dtype = image.device, image.dtype
         image_shape = image.shape[-2:]
         mlvl = self.extract_feat(image, cams)
@@ -473,7 +475,9 @@ class BEVFormer(nn.Module):
 
         # ---- transformer.get_bev_features_trt (:245-341); index/grid math in fp32 (a6)
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / bev_h, (PC_RANGE[3] - PC_RANGE[0]) / bev_w)
-        shift = G.bev_shift(can_bus.float(), bev_h, bev_w, grid_length).to(dtype)
+        if shift is None:
+            shift = G.bev_shift(can_bus.float(), bev_h, bev_w, grid_length)
+        shift = shift.to(dtype)
         rot_hwc = getattr(self.ops, "rotate_hwc", None)
         if rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0:
             # prev_bev [nq, 1, C] already is [H, W, C]: rotate in place of the permute / copy / permute
@@ -501,8 +505,11 @@ class BEVFormer(nn.Module):
 
         # ---- encoder.forward_trt (:261-334)
         if self._static is None or self._static[0].device != dev:   # frame-independent geometry
-            ref_3d = G.reference_points_3d(bev_h, bev_w, PC_RANGE[5] - PC_RANGE[2], 4, device=dev, dtype=torch.float)
-            self._static = (ref_3d, G.reference_points_2d(ref_3d), G.pillar_points(ref_3d, PC_RANGE))
+            # evaluated on the HOST once (linspace / scalar divisions are not bit-stable across
+            # devices) and uploaded: the anchors are then the reference's CPU values bit for bit
+            ref_3d = G.reference_points_3d(bev_h, bev_w, PC_RANGE[5] - PC_RANGE[2], 4, device="cpu", dtype=torch.float)
+            self._static = tuple(t.to(dev) for t in (ref_3d, G.reference_points_2d(ref_3d),
+                                                     G.pillar_points(ref_3d, PC_RANGE)))
         ref_3d, ref_2d, pillars = self._static
         ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
         hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
@@ -524,8 +531,7 @@ class BEVFormer(nn.Module):
         for lid, layer in enumerate(self.decoder):
             out = layer(out, bev_embed, query_pos, reference_points[..., :2].unsqueeze(2).contiguous(), bev_shapes)
             tmp = self.reg_branches[lid](out).view(1, -1, 10)
-            reference_points = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points[..., :2]),
-                                          tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])], dim=-1).sigmoid()
+            reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
             inter.append(out)
             inter_refs.append(reference_points)
 
@@ -585,12 +591,14 @@ class FrameRunner:
         H, W = model.cfg["image"]
         self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
                         can_bus=torch.zeros(18, device=device), lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
-                        use=torch.zeros((), device=device, dtype=dtype))
+                        use=torch.zeros((), device=device, dtype=dtype),
+                        shift=torch.zeros(1, 2, device=device))
         self._out = None
 
     def _forward(self):
         i = self._in
-        return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather)
+        return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,
+                          shift=i["shift"])
 
     def _capture(self):
         s = torch.cuda.Stream()
@@ -620,6 +628,9 @@ class FrameRunner:
         i["image"].copy_(image, non_blocking=True)
         i["can_bus"].copy_(can_bus, non_blocking=True)
         i["lidar2img"].copy_(lidar2img, non_blocking=True)
+        m = self.model
+        grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / m.bev_h, (PC_RANGE[3] - PC_RANGE[0]) / m.bev_w)
+        i["shift"].copy_(G.bev_shift(can_bus.cpu(), m.bev_h, m.bev_w, grid_length), non_blocking=True)
         i["use"].fill_(use_prev)
         if self.use_graph:
             if self._graph is None:
@@ -627,7 +638,9 @@ class FrameRunner:
                 self._capture()
                 self.prev_bev.copy_(saved)   # capture/warm-up ran the model on scratch state
             self._graph.replay()
-            return self._out
+            # the capture's output buffers are overwritten by the next replay: hand out copies
+            # (2 x 54 000 values), as the eager path hands out fresh tensors
+            return tuple(t.clone() for t in self._out)
         bev_embed, cls, crd = self._forward()
         self.prev_bev = bev_embed                                               # stays on device (:144)
         return cls, crd

@@ -51,7 +51,7 @@ def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups
     dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
     ws_bytes = handle.bevops_mdconv_workspace_size(dt, *dims)
     if ws_bytes == 0:
-        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments")
+        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments", _lib.NOT_SUPPORTED)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device)
     # the cache is keyed on the caller's tensor object; a converted / re-laid-out temporary
@@ -105,7 +105,7 @@ def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in
     dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
     ws_bytes = handle.bevops_mdconv_workspace_size(_lib.I8, *dims)
     if ws_bytes == 0:
-        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments")
+        raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments", _lib.NOT_SUPPORTED)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.int8, device=input.device)
     with torch.cuda.device(input.device):
@@ -146,7 +146,7 @@ def modulated_deformable_conv2d_nhwc(input, offset, mask, weight, bias=None, str
     Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) // sw + 1
     dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
     if weight.dtype != torch.float16 or not weight.is_contiguous():
-        raise _lib.BevopsError("modulated_deformable_conv2d_nhwc: weight must be a contiguous fp16 tensor")
+        raise _lib.BevopsError("modulated_deformable_conv2d_nhwc: weight must be a contiguous fp16 tensor", _lib.BAD_PARAM)
     packed = _PACKED.get(weight)
     if packed is None:
         packed = _packed_weight(handle, weight, _lib.F16)
@@ -212,7 +212,7 @@ def conv_offset_nhwc(input, weight, bias=None):
     if hit is None:
         nbytes = handle.bevops_conv3x3_c32_packed_weight_size(_lib.F16, Cin)
         if nbytes == 0:
-            raise _lib.BevopsError("bevops_conv3x3_c32_pack_weight: dtype/shape combination not supported (status 3)")
+            raise _lib.BevopsError("bevops_conv3x3_c32_pack_weight: dtype/shape combination not supported (status 3)", _lib.NOT_SUPPORTED)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         wc = weight.detach().contiguous()
         b32 = torch.zeros(32, dtype=torch.float16, device=weight.device)

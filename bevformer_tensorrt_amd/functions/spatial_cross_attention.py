@@ -54,7 +54,7 @@ def spatial_cross_attention_sample(value, value_spatial_shapes, reference_points
         stream = _lib.current_stream_ptr(value.device)
         ws_bytes = handle.bevops_sca_workspace_size(_lib.F16, shapes_host.data_ptr(), ncam, nk, heads, ch, L, nq, P)
         if ws_bytes == 0:
-            raise _lib.BevopsError("bevops_sca_workspace_size: unsupported arguments (needs 32 channels per head)")
+            raise _lib.BevopsError("bevops_sca_workspace_size: unsupported arguments (needs 32 channels per head)", _lib.NOT_SUPPORTED)
         ws = _workspace(ws_bytes, value.device, stream)
         st = handle.bevops_sca_forward(_lib.F16, value.data_ptr(), shapes_host.data_ptr(), ref.data_ptr(),
                                        off.data_ptr(), w.data_ptr(), mask.data_ptr(), out.data_ptr(), ncam, nk,

@@ -9,6 +9,7 @@ same torch ops in the same order so that they are bit-identical on the same back
   bev_shift                 : ego-motion shift of the TSA grid
                               (det2trt/models/modules/transformer.py:262-294)
   hybrid_ref_2d             : encoder.py:297-307
+  refine_reference_points   : decoder reference-point refinement (decoder.py:24-40,93-103)
   level_layout              : spatial_shapes / level_start_index (transformer.py:313-321,
                               functions/multi_scale_deformable_attn.py:103-106)
   synthetic_lidar2img       : a 6-camera ring rig for synthetic frames (new; the reference
@@ -62,20 +63,28 @@ def pillar_points(reference_points, pc_range):
 
 
 def project_points(pts, lidar2img, image_shape, num_cams=6, projection="matmul"):
-    """Second half of point_sampling_trt (encoder.py:220-259): projection, normalisation, mask."""
+    """Second half of point_sampling_trt (encoder.py:220-259): projection, normalisation, mask.
+    Bit-exactness across devices: projection="fma" spells the 4-term dot product as separately
+    rounded multiplies and adds in ascending k -- what the CPU BLAS does for these 4x4 @ 4x1
+    products (tests/test_geometry_cpu.py holds them equal at the base size) -- and the image
+    size divides as a TENSOR: with a Python scalar the GPU division kernel multiplies by the
+    rounded reciprocal, which is not the reference's CPU result for 1600 or 928."""
     D = pts.shape[0]
     l2i = lidar2img.view(1, 1, num_cams, 1, 4, 4)
     if projection == "matmul":
         cam = torch.matmul(l2i, pts).squeeze(-1)
     else:
-        cam = (l2i * pts.squeeze(-1).unsqueeze(-2)).sum(-1)
+        p = pts.squeeze(-1).unsqueeze(-2)                    # [D,1,1,nq,1,4]
+        cam = l2i[..., 0] * p[..., 0]
+        for k in range(1, 4):
+            cam = cam + l2i[..., k] * p[..., k]
     eps = 1e-5
     zeros = cam.new_zeros(D, 1, num_cams, int(cam.shape[3]), 1, dtype=torch.float32)
     ones = zeros + 1
     bev_mask = torch.where(cam[..., 2:3] > eps, ones, zeros)
     cam = cam[..., 0:2] / torch.max(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
-    cam[..., 0] /= image_shape[1]
-    cam[..., 1] /= image_shape[0]
+    cam[..., 0] /= torch.tensor(float(image_shape[1]), dtype=cam.dtype, device=cam.device)
+    cam[..., 1] /= torch.tensor(float(image_shape[0]), dtype=cam.dtype, device=cam.device)
     bev_mask *= torch.where(cam[..., 1:2] > 0.0, ones, zeros)
     bev_mask *= torch.where(cam[..., 1:2] < 1.0, ones, zeros)
     bev_mask *= torch.where(cam[..., 0:1] < 1.0, ones, zeros)
@@ -84,6 +93,29 @@ def project_points(pts, lidar2img, image_shape, num_cams=6, projection="matmul")
     bev_mask = (1 - (1 - bev_mask).prod(0)).view(num_cams, -1, 1)
     bev_mask = bev_mask / torch.clamp(bev_mask.sum(0, keepdims=True), min=1e-4)
     return cam, bev_mask
+
+
+def refine_reference_points(tmp, reference_points):
+    """Decoder reference-point refinement (det2trt/models/modules/decoder.py:93-103):
+    tmp [1, nq, 10] = reg_branch output, reference_points [1, nq, 3] in (0, 1).  The decoder
+    uses ITS OWN inverse_sigmoid (decoder.py:24-40: one clamp to [eps, 1-eps]); the head uses
+    mmdet's (bevformer_head.py:6,254: clamp to [0, 1], then each factor to >= eps) -- they differ
+    below eps, so both are restated."""
+    return torch.cat([tmp[..., :2] + inverse_sigmoid_decoder(reference_points[..., :2]),
+                      tmp[..., 4:5] + inverse_sigmoid_decoder(reference_points[..., 2:3])], dim=-1).sigmoid()
+
+
+def inverse_sigmoid_decoder(x, eps=1e-5):
+    """det2trt/models/modules/decoder.py:24-40."""
+    x = x.clamp(min=eps, max=1 - eps)
+    return torch.log(x / (1 - x))
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """mmdet.models.utils.transformer.inverse_sigmoid (mmdet 2.25.1, the form
+    third_party/bev_mmdet3d/models/modules/decoder.py:38-54 restates), used by the head."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
 def bev_shift(can_bus, bev_h, bev_w, grid_length=(0.512, 0.512), use_shift=True):

@@ -95,14 +95,21 @@ def load_library():
     return handle
 
 
+SUCCESS, FAILURE, BAD_PARAM, NOT_SUPPORTED, NOT_INITIALIZED = range(5)   # include/bevops.h
+
+
 class BevopsError(RuntimeError):
-    pass
+    """A non-zero pluginStatus_t-style code came back through the C ABI; `.status` holds it."""
+
+    def __init__(self, message, status):
+        super().__init__(message)
+        self.status = status
 
 
 def check(status, what):
     if status != 0:
         msg = load_library().bevops_status_string(status).decode()
-        raise BevopsError(f"{what}: {msg} (status {status})")
+        raise BevopsError(f"{what}: {msg} (status {status})", status)
 
 
 def torch_dtype_code(t):

@@ -27,6 +27,28 @@ def test_reference_points_and_point_sampling_bit_exact(tag):
     assert seen.max() <= 3 and (seen >= 1).float().mean() > 0.6
 
 
+def _digest(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("projection", ["matmul", "fma"])
+def test_base_size_point_sampling_bit_exact(projection):
+    """BEVFormer-base: 200x200 pillars x 4 anchors x 6 cameras of 928x1600 (the addresses the
+    base SCA call samples).  The golden holds SHA-256 digests of the reference's arrays (they are
+    11 MB) plus every 37th query; both projection spellings must reproduce them on the CPU."""
+    g = golden("geometry_base")
+    bh, bw, ih, iw, step = (int(x) for x in g["meta"])
+    ref_3d = G.reference_points_3d(bh, bw, PC_RANGE[5] - PC_RANGE[2], 4, device="cpu")
+    l2i = G.synthetic_lidar2img((ih, iw))
+    assert np.array_equal(l2i.numpy(), g["lidar2img"])
+    cam, mask = G.point_sampling(ref_3d, PC_RANGE, l2i, (ih, iw), projection=projection)
+    assert np.array_equal(ref_3d.numpy()[:, :, ::step], g["ref3d_sample"])
+    assert np.array_equal(cam.numpy()[:, :, ::step], g["cam_sample"])
+    assert np.array_equal(mask.numpy()[:, ::step], g["mask_sample"])
+    assert [_digest(ref_3d.numpy()), _digest(cam.numpy()), _digest(mask.numpy())] == list(g["sha256"])
+
+
 def test_bev_shift_bit_exact():
     g = golden("geometry")
     for can, want in zip(g["can_bus"], g["shift"]):
