@@ -83,8 +83,9 @@ def project_points(pts, lidar2img, image_shape, num_cams=6, projection="matmul")
     ones = zeros + 1
     bev_mask = torch.where(cam[..., 2:3] > eps, ones, zeros)
     cam = cam[..., 0:2] / torch.max(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
-    cam[..., 0] /= torch.tensor(float(image_shape[1]), dtype=cam.dtype, device=cam.device)
-    cam[..., 1] /= torch.tensor(float(image_shape[0]), dtype=cam.dtype, device=cam.device)
+    # (torch.full is a fill kernel: legal under stream capture, unlike a host-to-device copy)
+    cam[..., 0] /= torch.full((), float(image_shape[1]), dtype=cam.dtype, device=cam.device)
+    cam[..., 1] /= torch.full((), float(image_shape[0]), dtype=cam.dtype, device=cam.device)
     bev_mask *= torch.where(cam[..., 1:2] > 0.0, ones, zeros)
     bev_mask *= torch.where(cam[..., 1:2] < 1.0, ones, zeros)
     bev_mask *= torch.where(cam[..., 0:1] < 1.0, ones, zeros)
