@@ -238,16 +238,6 @@ __global__ __launch_bounds__(kBlock) void msda_generic_kernel(
 //                 mixed-sign dot4, so v*a (a in 0..255) = dot4(v, a^0x80) + 128*dot4(v, 1).
 //                 Intermediate math is fp32 here (the reference uses half2).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int t2i8_away(float a) {  // kernel.cu:44-55
-  a = fminf(fmaxf(a, -128.f), 127.f);
-  return (int)(a + (a > 0.f ? 0.5f : -0.5f));
-}
-__device__ __forceinline__ int t2i8_rne(float a) {  // kernel.cu:57-62
-  return (int)fminf(fmaxf(rintf(a), -128.f), 127.f);
-}
-__device__ __forceinline__ unsigned u16_rne(float a) {  // __half2ushort_rn
-  return (unsigned)fminf(fmaxf(rintf(a), 0.f), 65535.f);
-}
 template <int N>
 __device__ __forceinline__ void load_i8(const int8_t *p, float (&d)[N]) {
   int8_t raw[N];
@@ -265,25 +255,7 @@ __device__ __forceinline__ void load_i8(const int8_t *p, float (&d)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) d[i] = (float)raw[i];
 }
-// 4x4 byte transpose: r[k] = 4 channels of corner k  ->  o[c] = channel c of corners 0..3
-__device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned r2, unsigned r3,
-                                             unsigned (&o)[4]) {
-  const unsigned a = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
-  const unsigned b = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
-  const unsigned c = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
-  const unsigned d = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
-  o[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
-  o[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
-  o[2] = __builtin_amdgcn_perm(d, b, 0x05040100u);
-  o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
-}
-
-// HM = true (experimental, bevops_msda_set_variant(21)): `value` is the head-major re-layout
-// [bs][heads][nk][32] made by msda_i8_repack_kernel and the items are enumerated (batch, head)-major,
-// so that -- with the XCD remap -- an XCD works on few (batch, head) planes (1 MB each at base SCA)
-// that stay in its L2, as msda_hm.hip does for fp16.  Only the addressing differs; the arithmetic of
-// an item is the same code, so the result is bit-identical to HM = false.
-template <typename RefT, int PPL, int CH, bool U8W, bool HM = false>
+template <typename RefT, int PPL, int CH, bool U8W>
 __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
     const int8_t *__restrict__ value, unsigned value_bytes, const int32_t *__restrict__ shapes,
     const RefT *__restrict__ ref, const int8_t *__restrict__ off, const int8_t *__restrict__ logit,
@@ -305,24 +277,12 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
   const unsigned slot = vb * (kBlock / 4) + (threadIdx.x >> 2);
   if (slot >= n_item) return;
   const unsigned sub = threadIdx.x & 3u;
-  unsigned item, bq, h, b, row_bytes, lane_base;
-  if constexpr (HM) {  // slot = (b * heads + h) * nq + q
-    const unsigned plane = slot / (unsigned)d.nq;
-    const unsigned q = slot - plane * (unsigned)d.nq;
-    b = plane / (unsigned)d.heads;
-    h = plane - b * (unsigned)d.heads;
-    bq = b * (unsigned)d.nq + q;
-    item = bq * (unsigned)d.heads + h;  // index into logits / offsets / out (reference layout)
-    row_bytes = 32u;
-    lane_base = plane * (unsigned)d.nk * 32u + sub * V;
-  } else {
-    item = slot;
-    bq = item / (unsigned)d.heads;
-    h = item - bq * (unsigned)d.heads;
-    b = bq / (unsigned)d.nq;
-    row_bytes = (unsigned)d.heads * 32u;
-    lane_base = (b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V;
-  }
+  const unsigned item = slot;
+  const unsigned bq = item / (unsigned)d.heads;
+  const unsigned h = item - bq * (unsigned)d.heads;
+  const unsigned b = bq / (unsigned)d.nq;
+  const unsigned row_bytes = (unsigned)d.heads * 32u;
+  const unsigned lane_base = (b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V;
   constexpr int LP = 4 * PPL;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(value), 0, value_bytes, 0x00020000);
@@ -595,38 +555,6 @@ int msda_float(const T *value, const int32_t *shapes, const T *ref, const T *off
   return launch_status();
 }
 
-// [bs, nk, heads, 32] int8 -> [bs, heads, nk, 32]; thread = one 16-byte half row
-__global__ __launch_bounds__(256) void msda_i8_repack_kernel(const int8_t *__restrict__ value,
-                                                             int8_t *__restrict__ hm, int bs, int nk, int heads) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)bs * nk * heads * 2;
-  if (idx >= total) return;
-  const unsigned half = (unsigned)(idx & 1);
-  const size_t r = idx >> 1;                        // ((b * heads + h) * nk + k): coalesced WRITES
-  const unsigned k = (unsigned)(r % (size_t)nk);
-  const size_t bh = r / (size_t)nk;
-  const unsigned h = (unsigned)(bh % (size_t)heads);
-  const size_t b = bh / (size_t)heads;
-  const uint4 v = *reinterpret_cast<const uint4 *>(value + ((b * nk + k) * heads + h) * 32 + half * 16);
-  *reinterpret_cast<uint4 *>(hm + r * 32 + half * 16) = v;
-}
-
-template <typename RefT, bool U8W, int PPL, int CH>
-int launch_quad_i8_hm(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
-                      const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o,
-                      float s_w, float s_out, int8_t *hm, hipStream_t st) {
-  const size_t n_item = (size_t)d.bs * d.nq * d.heads;
-  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
-  const size_t rthreads = (size_t)d.bs * d.nk * d.heads * 2;
-  hipLaunchKernelGGL(msda_i8_repack_kernel, dim3((unsigned)((rthreads + 255) / 256)), dim3(256), 0, st, value,
-                     hm, d.bs, d.nk, d.heads);
-  const unsigned grid = (unsigned)((n_item + kBlock / 4 - 1) / (kBlock / 4));
-  hipLaunchKernelGGL((msda_quad_int8_kernel<RefT, PPL, CH, U8W, true>), dim3(grid), dim3(kBlock), 0, st,
-                     (const int8_t *)hm, (unsigned)vbytes, shapes, ref, off, logit, out, d, (unsigned)n_item, s_v,
-                     s_o, s_w, s_out);
-  return launch_status();
-}
-
 template <typename RefT, bool U8W, int PPL, int CH>
 int launch_quad_i8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
                    const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o,
@@ -643,25 +571,13 @@ int launch_quad_i8(const int8_t *value, const int32_t *shapes, const RefT *ref, 
 template <typename RefT, bool U8W>
 int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const int8_t *off,
               const int8_t *logit, int8_t *out, const MsdaDims &d, float s_v, float s_o, float s_w,
-              float s_out, hipStream_t st, void *workspace = nullptr, size_t workspace_bytes = 0) {
+              float s_out, hipStream_t st) {
   const size_t n_item = (size_t)d.bs * d.nq * d.heads;
   const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C;
   const int LP = d.L * d.P;
   const bool quad_ok = d.C == 32 && LP % 4 == 0 && d.L <= kMaxLevels && vbytes < 0xFFFFFF00ull &&
                        n_item < 0x7FFFFFFFull && aligned16(value) && aligned16(off) &&
                        aligned16(logit) && aligned16(out) && aligned16(ref) && g_variant != 99;
-  // experimental head-major INT8 path (variant 21; not the default until validated on the GPU)
-  if (quad_ok && g_variant == 21 && workspace && workspace_bytes >= vbytes && aligned16(workspace)) {
-    int8_t *hm = static_cast<int8_t *>(workspace);
-    switch (LP / 4) {
-      case 1: return launch_quad_i8_hm<RefT, U8W, 1, 1>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
-      case 2: return launch_quad_i8_hm<RefT, U8W, 2, 2>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
-      case 4: return launch_quad_i8_hm<RefT, U8W, 4, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
-      case 8: return launch_quad_i8_hm<RefT, U8W, 8, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
-      case 16: return launch_quad_i8_hm<RefT, U8W, 16, 4>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, hm, st);
-      default: break;
-    }
-  }
   if (quad_ok) {
     switch (LP / 4) {
       case 1: return launch_quad_i8<RefT, U8W, 1, 1>(value, shapes, ref, off, logit, out, d, s_v, s_o, s_w, s_out, st);
@@ -691,12 +607,28 @@ extern "C" int bevops_msda_set_variant(int variant) {
   return prev;
 }
 
+// A head-major re-layout pays when a batch's maps overflow an XCD's 4 MiB L2 and there are enough
+// samples per pixel to amortise it (profiles/r01: base SCA 1.75x, base TSA 1.1x; small / tiny
+// maps are L2-resident already and stay on the layout-preserving kernels)
+static bool hm_pays(int esize, int bs, int nk, int heads, int channels, int num_levels, int num_query,
+                    int num_point) {
+  const double samples = (double)bs * num_query * heads * num_levels * num_point;
+  const double pixels = (double)bs * nk * heads;
+  const double plane_mb = (double)nk * heads * channels * esize / 1048576.0;
+  return (samples >= 16.0 * pixels && plane_mb >= 4.0) || (samples >= 4.0 * pixels && plane_mb >= 16.0);
+}
+
 extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
                                              int num_levels, int num_query, int num_point) {
   if (bs <= 0 || nk <= 0 || heads <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0) return 0;
   if ((num_levels * num_point) % 4 != 0) return 0;
-  if (dtype == BEVOPS_I8)  // experimental head-major INT8 path only (variant 21)
-    return (g_variant == 21 && channels == 32) ? (((size_t)bs * nk * heads * 32 + 255) & ~size_t(255)) : 0;
+  if (dtype == BEVOPS_I8) {
+    // padded head-major int8 planes (msda_hm4.hip): 128-byte entries, at most (H + 2)(W + 1) <= 3 H W
+    // + 2 of them per level -- an upper bound; bevops_msda_workspace_size_shapes gives the exact size
+    if (channels != 32 || g_variant == 10 || g_variant == 99) return 0;
+    if (g_variant != 17 && !hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point)) return 0;
+    return (size_t)bs * heads * ((size_t)3 * nk + 2 * num_levels + 4) * 128 + 4096;
+  }
   if (dtype != BEVOPS_F16) return 0;
   return msda_hm_workspace_bytes(bs, nk, heads, channels, num_levels);
 }
@@ -706,10 +638,14 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
                                                     int num_levels, int num_query, int num_point) {
   const size_t a = bevops_msda_workspace_size(dtype, bs, nk, heads, channels, num_levels, num_query,
                                               num_point);
-  if (a == 0 || !spatial_shapes_host || dtype != BEVOPS_F16) return a;
+  if (a == 0 || !spatial_shapes_host) return a;
+  const size_t c = msda_hm4_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
+                                            num_query, num_point);
+  if (dtype == BEVOPS_I8) return c;   // exact (0: shape outside the head-major domain)
+  if (dtype != BEVOPS_F16) return a;
   const size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
                                             num_query, num_point);
-  return a > b ? a : b;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 extern "C" size_t bevops_sca_workspace_size(int dtype, const int32_t *spatial_shapes_host, int num_cams,
@@ -803,15 +739,21 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       // head-major path (msda_hm.hip) when the caller lends a workspace and the call is big
       // enough to amortise the re-layout; variants 10 (never) / 11 (no LDS staging) / 12 (force)
       if (workspace && g_variant != 10 && g_variant != 99 && g_variant != 1 && g_variant != 2) {
-        // pays when a batch's maps overflow an XCD's 4 MiB L2 and there are enough samples per
-        // pixel to amortise the re-layout (profiles/r01: base SCA 1.75x, base TSA 1.1x; small /
-        // tiny maps are L2-resident already and stay on the layout-preserving kernel)
-        const double samples = (double)bs * num_query * heads * num_levels * num_point;
-        const double pixels = (double)bs * nk * heads;
-        const double plane_mb = (double)nk * heads * channels * 2 / 1048576.0;
-        const bool pays = (samples >= 16.0 * pixels && plane_mb >= 4.0) ||
-                          (samples >= 4.0 * pixels && plane_mb >= 16.0);
+        const bool pays = hm_pays(2, bs, nk, heads, channels, num_levels, num_query, num_point);
         const int LP = num_levels * num_point;
+        // hm4 (software-pipelined, msda_hm4.hip): default for the many-point calls; variant 17
+        // forces it for every shape it supports, 170 + k picks a chunk size, 16 keeps hm3
+        const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
+                        (g_variant == 0 && pays && LP >= 16);
+        if (spatial_shapes_host && h4) {
+          static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
+          const int rc = msda_hm4_forward(
+              BEVOPS_F16, BEVOPS_F16, value, spatial_shapes_host, reference_points, sampling_offsets,
+              attention_weights, output, bs, nk, heads, channels, num_levels, num_query, num_point,
+              points_per_group, shared_offsets ? 1 : 0, 1.f, 1.f, 1.f, 1.f, workspace, workspace_bytes,
+              g_variant >= 170 ? kChunks[g_variant - 170] : 0, st);
+          if (rc != BEVOPS_NOT_SUPPORTED || g_variant != 0) return rc;
+        }
         if (spatial_shapes_host && (g_variant == 16 || (g_variant == 0 && pays && LP >= 16))) {
           const int rc = msda_hm3_forward_f16(
               (const __half *)value, spatial_shapes_host, (const __half *)reference_points,
@@ -839,20 +781,30 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       if (!(scale_value > 0.f) || !(scale_offset > 0.f) || !(scale_weight > 0.f) ||
           !(scale_out > 0.f))
         return BEVOPS_BAD_PARAM;
+      // head-major int8 path (msda_hm4.hip) when the caller lends a workspace and the call is big
+      // enough (variant 17 forces it, 10 / 99 keep the layout-preserving kernels)
+      if (workspace && spatial_shapes_host && g_variant != 10 && g_variant != 99 &&
+          (ref_dtype == BEVOPS_F32 || ref_dtype == BEVOPS_F16) &&
+          (g_variant == 17 || hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point))) {
+        const int rc = msda_hm4_forward(BEVOPS_I8, ref_dtype, value, spatial_shapes_host, reference_points,
+                                        sampling_offsets, attention_weights, output, bs, nk, heads, channels,
+                                        num_levels, num_query, num_point, points_per_group,
+                                        shared_offsets ? 1 : 0, scale_value, scale_offset, scale_weight,
+                                        scale_out, workspace, workspace_bytes, 0, st);
+        if (rc != BEVOPS_NOT_SUPPORTED) return rc;
+      }
       if (ref_dtype == BEVOPS_F32)
         return msda_int8<float, false>((const int8_t *)value, spatial_shapes,
                                        (const float *)reference_points,
                                        (const int8_t *)sampling_offsets,
                                        (const int8_t *)attention_weights, (int8_t *)output, d,
-                                       scale_value, scale_offset, scale_weight, scale_out, st, workspace,
-                                       workspace_bytes);
+                                       scale_value, scale_offset, scale_weight, scale_out, st);
       if (ref_dtype == BEVOPS_F16)
         return msda_int8<__half, true>((const int8_t *)value, spatial_shapes,
                                        (const __half *)reference_points,
                                        (const int8_t *)sampling_offsets,
                                        (const int8_t *)attention_weights, (int8_t *)output, d,
-                                       scale_value, scale_offset, scale_weight, scale_out, st, workspace,
-                                       workspace_bytes);
+                                       scale_value, scale_offset, scale_weight, scale_out, st);
       return BEVOPS_NOT_SUPPORTED;
     default:
       return BEVOPS_NOT_SUPPORTED;

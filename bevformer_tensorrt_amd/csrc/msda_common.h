@@ -156,6 +156,31 @@ __device__ __forceinline__ void store8(float *p, const float (&a)[8]) {
   reinterpret_cast<float4 *>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
 }
 
+// int8 rounding rules of the reference and the byte transpose of the
+// dot4 operands
+__device__ __forceinline__ int t2i8_away(float a) {  // kernel.cu:44-55
+  a = fminf(fmaxf(a, -128.f), 127.f);
+  return (int)(a + (a > 0.f ? 0.5f : -0.5f));
+}
+__device__ __forceinline__ int t2i8_rne(float a) {  // kernel.cu:57-62
+  return (int)fminf(fmaxf(rintf(a), -128.f), 127.f);
+}
+__device__ __forceinline__ unsigned u16_rne(float a) {  // __half2ushort_rn
+  return (unsigned)fminf(fmaxf(rintf(a), 0.f), 65535.f);
+}
+// 4x4 byte transpose: r[k] = 4 channels of corner k  ->  o[c] = channel c of corners 0..3
+__device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned r2, unsigned r3,
+                                             unsigned (&o)[4]) {
+  const unsigned a = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+  const unsigned b = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+  const unsigned c = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+  const unsigned d = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(d, b, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+}
+
 // location arithmetic kept un-fused so that it rounds exactly like the
 // reference's fp32 kernel (mul, add, sub as separate roundings).
 __device__ __forceinline__ float loc_im(float ref, float size, float off) {
@@ -183,6 +208,13 @@ int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const 
                          const __half *off, const __half *logit, __half *out, int bs, int nk,
                          int heads, int C, int L, int nq, int P, int ppg, int shared,
                          void *workspace, size_t workspace_bytes, hipStream_t st);
+// msda_hm4.hip -- software-pipelined successor of hm3 on the same padded layout idea; fp16 and
+// both int8 flavours (dtype BEVOPS_F16 / BEVOPS_I8, ref_dtype selects the int8 flavour).
+size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
+int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
+                     const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
+                     int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
+                     void *workspace, size_t workspace_bytes, int chunk_override, hipStream_t st);
 size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                     int P);
 int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,

@@ -17,38 +17,10 @@
 //   * the level table is computed on the host and travels as a kernel argument (no per-block
 //     serial global loads), blocks are long (one (camera, head) plane x a chunk of queries).
 #include "msda_common.h"
+#include "msda_pad.h"
 
 namespace bevops {
 namespace {
-
-constexpr int kHm3MaxLevels = 8;
-constexpr int kEntBytes = 128;   // big levels: interleaved pixel pair
-constexpr int kLdsPixBytes = 64; // staged levels: 32 ch x fp16
-constexpr int kLdsLimit = 160 * 1024;
-
-struct Hm3Tab {
-  int L, ls;                    // levels, first LDS-staged level (== L: none)
-  int H[kHm3MaxLevels], W[kHm3MaxLevels];
-  int ent0[kHm3MaxLevels];      // entry index of padded (row 0, col 0) in its set (big / staged)
-  int src0[kHm3MaxLevels];      // first source pixel of the level
-  int g_entries, s_entries;     // entries per (batch, head) plane of each set
-};
-
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-
-// padded-set entry -> source pixel of the level it falls in, or -1 for a pad
-__device__ __forceinline__ int hm3_source(const Hm3Tab &t, int l0, int l1, int f) {
-  int src = -1;
-  for (int l = l0; l < l1; ++l) {
-    const int Wp = t.W[l] + 1;
-    const int rel = f - t.ent0[l];
-    if (rel >= 0 && rel < (t.H[l] + 2) * Wp) {
-      const int yp = rel / Wp, x = rel - yp * Wp;
-      if (yp >= 1 && yp <= t.H[l] && x < t.W[l]) src = t.src0[l] + (yp - 1) * t.W[l] + x;
-    }
-  }
-  return src;
-}
 
 // ---- re-layout: [bs, nk, heads, 32] -> big set [bs][heads][g_entries][128 B] and staged set
 // [bs][heads][s_entries][64 B].  thread = (b, entry, head, 16-byte chunk)
@@ -88,27 +60,6 @@ __global__ __launch_bounds__(256) void msda_hm3_repack_kernel(const __half *__re
   uint4 v = make_uint4(0, 0, 0, 0);
   if (s0 >= 0) v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c4 * 8);
   *reinterpret_cast<uint4 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c4 * 16) = v;
-}
-
-__device__ __forceinline__ float oct_max(float v) {
-  v = quad_max(v);
-  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
-}
-__device__ __forceinline__ float oct_sum(float v) {
-  v = quad_sum(v);
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dot2f(unsigned pair, unsigned w, float acc) {
-  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, pair), __builtin_bit_cast(h2_t, w), acc, false);
-}
-__device__ __forceinline__ h2_t as_h2(unsigned u) { return __builtin_bit_cast(h2_t, u); }
-
-// acc += (float)lo/hi half of a packed fp16 pair -- v_fma_mix_f32 with the constant 1.0 (the
-// compiler emits v_cvt_f32_f16 + v_add_f32 for the plain C++ form)
-__device__ __forceinline__ void add_h2(float &a0, float &a1, h2_t v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(u));
-  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(u));
 }
 
 // N points served by the L1/L2 path: per point two 128-byte entries (bilinear rows), 8 dot2.
@@ -166,11 +117,6 @@ __device__ __forceinline__ void taps_lds(const char *smem, const char *box, unsi
     add_h2(acc[2], acc[3], b);
   }
 }
-
-// level table in LDS, 32 B per level: {float W, float H, u32 byte offset of entry (row 0, col 0),
-// u32 row bytes} {i32 W + 1, u32 log2(bytes per entry), -, -}
-constexpr int kTabEnt = 32;
-constexpr int kTab = kHm3MaxLevels * kTabEnt;
 
 // MASKED (fused SCA, bevops_sca_forward): `qmask` [bs, nq] holds the camera-visibility weight of
 // every (batch = camera, query) pair; pairs with weight 0 are skipped altogether (no loads, no
@@ -443,56 +389,6 @@ __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
   }
 }
 
-// host: padded-set layout.  Set = one leading zero entry, then per level (H+2) rows of (W+1)
-// entries, then one trailing zero entry (the pair partner of the last one).
-struct Hm3Plan {
-  Hm3Tab t;
-  size_t g_bytes, s_bytes;  // whole sets (all batches and heads)
-  int stage_bytes;          // per (batch, head) staged plane
-  int threads;
-};
-
-bool hm3_plan(const int32_t *shapes_host, int bs, int heads, int L, int LP, int nq, Hm3Plan &pl) {
-  if (!shapes_host || L > kHm3MaxLevels) return false;
-  Hm3Tab &t = pl.t;
-  t.L = L;
-  int src = 0;
-  for (int l = 0; l < L; ++l) {
-    t.H[l] = shapes_host[2 * l];
-    t.W[l] = shapes_host[2 * l + 1];
-    if (t.H[l] > 0x7fff || t.W[l] > 0x7fff) return false;
-    t.src0[l] = src;
-    src += t.H[l] * t.W[l];
-  }
-  auto padded = [&](int l) { return (t.H[l] + 2) * (t.W[l] + 1); };
-  // longest tail of levels whose padded planes fit in LDS next to the mailboxes of a
-  // 1024-thread block; staging a plane per block only pays with enough queries per plane
-  const int mb = LP >= 8 ? 8 : LP;
-  const int box1024 = 128 * (mb * 16 + 16);
-  const int budget = kLdsLimit - kTab - box1024;
-  int ls = L;
-  if (nq >= 2048) {
-    long tail = 2;
-    for (int l = L - 1; l >= 0; --l) {
-      tail += padded(l);
-      if (tail * kLdsPixBytes > budget) break;
-      ls = l;
-    }
-  }
-  t.ls = ls;
-  int e = 1;
-  for (int l = 0; l < ls; ++l) { t.ent0[l] = e; e += padded(l); }
-  t.g_entries = e + 1;
-  e = 1;
-  for (int l = ls; l < L; ++l) { t.ent0[l] = e; e += padded(l); }
-  t.s_entries = ls < L ? e + 1 : 0;
-  pl.stage_bytes = t.s_entries * kLdsPixBytes;
-  pl.g_bytes = (size_t)bs * heads * t.g_entries * kEntBytes;
-  pl.s_bytes = (((size_t)bs * heads * pl.stage_bytes) + 127) & ~size_t(127);
-  pl.threads = ls < L ? 1024 : 256;
-  return pl.g_bytes + 128 < 0xFFFFFF00ull;
-}
-
 template <int LP>
 int launch_hm3(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref,
                const __half *off, const __half *logit, __half *out, const MsdaDims &d,
@@ -505,18 +401,21 @@ int launch_hm3(const Hm3Plan &pl, const char *gset, const char *sset, const __ha
   const size_t lds = kTab + pl.stage_bytes + (size_t)octets * (MB * 16 + 16) + (qmask ? chunk * 2 + 64 : 0);
   const dim3 grid((unsigned)(d.bs * d.heads * nchunk));
   const unsigned gb = (unsigned)pl.g_bytes;
-  auto go = [&](auto kern, int threads) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return (int)BEVOPS_FAILURE;
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, gset, gb, sset, ref, off, logit, out, d, pl.t,
-                       chunk, nchunk, pl.threads == 1024 ? pl.stage_bytes : 0, qmask);
-    return launch_status();
-  };
-  if (pl.threads == 1024)
-    return qmask ? go(msda_hm3_kernel<LP, 1024, true>, 1024) : go(msda_hm3_kernel<LP, 1024, false>, 1024);
-  return qmask ? go(msda_hm3_kernel<LP, 256, true>, 256) : go(msda_hm3_kernel<LP, 256, false>, 256);
+  const int stage = pl.threads == 1024 ? pl.stage_bytes : 0;
+#define BEVOPS_HM3_GO(THREADS, MASKED)                                                                   \
+  do {                                                                                                   \
+    if (!ensure_dynamic_lds<msda_hm3_kernel<LP, THREADS, MASKED>>(lds)) return (int)BEVOPS_FAILURE;      \
+    hipLaunchKernelGGL((msda_hm3_kernel<LP, THREADS, MASKED>), grid, dim3(THREADS), lds, st, gset, gb,   \
+                       sset, ref, off, logit, out, d, pl.t, chunk, nchunk, stage, qmask);                \
+    return launch_status();                                                                              \
+  } while (0)
+  if (pl.threads == 1024) {
+    if (qmask) BEVOPS_HM3_GO(1024, true);
+    BEVOPS_HM3_GO(1024, false);
+  }
+  if (qmask) BEVOPS_HM3_GO(256, true);
+  BEVOPS_HM3_GO(256, false);
+#undef BEVOPS_HM3_GO
 }
 
 // fused SCA, second step: slots[q, :] = sum over cameras of mask[b, q] * sampled[b, q, :], reading
@@ -551,7 +450,7 @@ __global__ __launch_bounds__(256) void sca_camera_reduce_kernel(const __half *__
 size_t msda_hm3_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                 int P) {
   Hm3Plan pl;
-  if (C != 32 || !hm3_plan(shapes_host, bs, heads, L, L * P, nq, pl)) return 0;
+  if (C != 32 || !hm3_plan(shapes_host, bs, heads, L, nq, hm3_box_bytes(L * P), pl)) return 0;
   return pl.g_bytes + 128 + pl.s_bytes;
 }
 
@@ -563,7 +462,7 @@ int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const 
   const bool lp_ok = LP == 4 || LP == 8 || LP == 16 || LP == 32 || LP == 64;
   Hm3Plan pl;
   if (C != 32 || !lp_ok || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) ||
-      !hm3_plan(shapes_host, bs, heads, L, LP, nq, pl))
+      !hm3_plan(shapes_host, bs, heads, L, nq, hm3_box_bytes(LP), pl))
     return BEVOPS_NOT_SUPPORTED;
   if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
   const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
@@ -602,7 +501,7 @@ int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, co
   const bool lp_ok = LP == 4 || LP == 8 || LP == 16 || LP == 32 || LP == 64;
   Hm3Plan pl;
   if (C != 32 || !lp_ok || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) ||
-      !hm3_plan(shapes_host, bs, heads, L, LP, nq, pl))
+      !hm3_plan(shapes_host, bs, heads, L, nq, hm3_box_bytes(LP), pl))
     return BEVOPS_NOT_SUPPORTED;
   if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;
   const size_t need = msda_hm3_sca_workspace_bytes(shapes_host, bs, heads, C, L, nq, P);

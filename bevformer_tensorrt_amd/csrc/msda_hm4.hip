@@ -1,0 +1,763 @@
+// MSDA, fourth head-major generation ("hm4"): fp16 and int8 on ONE software-pipelined skeleton.
+//
+// What hm3 left on the table (profiles/r01d-f): its three pipes -- the per-item front
+// end (VALU), the LDS taps of the staged levels and the L1/L2 taps of the big levels -- ran one after
+// the other inside every wave (front end -> 2 phases of L2 taps -> 2 phases of LDS taps, each
+// waiting for its own loads), 16 waves per CU all in the same order, so the call took about the SUM
+// of the pipes (550 us) where the slowest one alone (the L2 line rate, 2 lines per big-level sample)
+// is 240 us.  hm4 keeps hm3's data layout idea (msda_pad.h) and changes the schedule:
+//   * 512-thread blocks = 8 waves per CU with a 256-register budget each (the staged planes still
+//     allow one block per CU): all L*P point records of an item fit one mailbox, and a wave keeps
+//     TWO batches of big-level taps (16 x 16-byte loads per lane) in flight;
+//   * one straight-line loop body per group of 8 items: issue big batch 0 and 1 -> front end of the
+//     NEXT group (softmax, locations, corner weights) -> LDS batch -> consume big 0 -> issue big 2
+//     -> LDS batch -> ... : the L2 round trips hide behind the wave's own VALU / LDS work instead
+//     of behind other waves that are in the same phase;
+//   * streamed operands (logits, offsets, reference points) are requested TWO groups ahead.
+// int8 (the reference's INT8 plugin flavours, multiScaleDeformableAttnKernel.cu:848-1104) rides the
+// same skeleton with its own entries:
+//   * big levels: one 128-byte entry per pixel f = the whole 2x2 footprint (f, f+1, f+W', f+W'+1)
+//     of all 32 channels, bytes pre-transposed so that a lane's 16-byte load IS four v_dot4
+//     operands (channel c: v00, v01, v10, v11) -- ONE cache line per sample instead of two, no
+//     v_perm transposes;
+//   * staged levels: 64-byte pixel-pair entries (channel-interleaved bytes of pixels f and f+1);
+//   * per channel and sample the reference computes T2int8(tsum / 127) (round half away; ties
+//     cannot occur because 127 and 255 are odd) -- evaluated exactly in integers as the top byte
+//     of a saturating v_mad_i32_i24(tsum, round(2^24 / 127), 2^23): 1 instruction instead of 6;
+//     the four samples of a batch are gathered with v_perm_b32 and accumulated with ONE
+//     v_dot4_i32_i8 against their packed softmax weights, as the reference's own dp4a does.
+// Results: fp16 within 1e-2 of the oracle (same arithmetic as hm3); int8 bit-identical to the
+// layout-preserving int8 kernels of msda.hip (tests/test_msda_hm4_gpu.py).
+#include "msda_common.h"
+#include "msda_pad.h"
+
+namespace bevops {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// re-layouts
+// ------------------------------------------------------------------------------------------------
+// fp16: big set = pixel-pair entries 32 x half2(v[f][c], v[f+1][c]); staged set = row-major pixels.
+// thread = (b, entry, head, 16-byte chunk)
+__global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *__restrict__ value,
+                                                                  char *__restrict__ gset,
+                                                                  char *__restrict__ sset, Hm3Tab t,
+                                                                  int bs, int nk, int heads) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
+  if (idx < n_big) {
+    const int c8 = (int)(idx & 7);
+    const int h = (int)((idx >> 3) % heads);
+    const size_t r = (idx >> 3) / heads;
+    const int f = (int)(r % t.g_entries);
+    const size_t b = r / t.g_entries;
+    const int s0 = hm3_source(t, 0, t.ls, f), s1 = hm3_source(t, 0, t.ls, f + 1);
+    uint2 a = make_uint2(0, 0), c = make_uint2(0, 0);
+    if (s0 >= 0) a = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c8 * 4);
+    if (s1 >= 0) c = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s1) * heads + h) * 32 + c8 * 4);
+    uint4 o;
+    o.x = (a.x & 0xffffu) | (c.x << 16);
+    o.y = (a.x >> 16) | (c.x & 0xffff0000u);
+    o.z = (a.y & 0xffffu) | (c.y << 16);
+    o.w = (a.y >> 16) | (c.y & 0xffff0000u);
+    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) = o;
+    return;
+  }
+  const size_t j = idx - n_big;
+  const int c4 = (int)(j & 3);
+  const int h = (int)((j >> 2) % heads);
+  const size_t r = (j >> 2) / heads;
+  if (t.s_entries == 0) return;
+  const int f = (int)(r % t.s_entries);
+  const size_t b = r / t.s_entries;
+  if (b >= (size_t)bs) return;
+  const int s0 = hm3_source(t, t.ls, t.L, f);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (s0 >= 0) v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c4 * 8);
+  *reinterpret_cast<uint4 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c4 * 16) = v;
+}
+
+// int8: big set = 2x2-footprint entries (dword c of 16-byte chunk k = channel 4k+c of pixels
+// f, f+1, f+W', f+W'+1); staged set = pixel-pair entries (bytes c(x0), c(x1) interleaved).
+// thread = (b, entry, head, chunk of 4 channels)
+__global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
+                                                                 char *__restrict__ gset,
+                                                                 char *__restrict__ sset, Hm3Tab t,
+                                                                 int bs, int nk, int heads) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
+  auto px = [&](size_t b, int src, int h, int c8) -> unsigned {
+    return src >= 0 ? *reinterpret_cast<const unsigned *>(value + (((size_t)b * nk + src) * heads + h) * 32 + c8 * 4)
+                    : 0u;
+  };
+  if (idx < n_big) {
+    const int c8 = (int)(idx & 7);
+    const int h = (int)((idx >> 3) % heads);
+    const size_t r = (idx >> 3) / heads;
+    const int f = (int)(r % t.g_entries);
+    const size_t b = r / t.g_entries;
+    // row stride of the level entry f falls in (pads included); entries outside every level
+    // (leading / trailing zero entries) keep their own pixel only
+    int wp = 0;
+    for (int l = 0; l < t.ls; ++l) {
+      const int rel = f - t.ent0[l];
+      if (rel >= -1 && rel < (t.H[l] + 2) * (t.W[l] + 1)) wp = t.W[l] + 1;
+    }
+    unsigned r0 = px(b, hm3_source(t, 0, t.ls, f), h, c8), r1 = px(b, hm3_source(t, 0, t.ls, f + 1), h, c8);
+    unsigned r2 = 0, r3 = 0;
+    if (wp && f + wp + 1 < t.g_entries) {
+      r2 = px(b, hm3_source(t, 0, t.ls, f + wp), h, c8);
+      r3 = px(b, hm3_source(t, 0, t.ls, f + wp + 1), h, c8);
+    }
+    unsigned o[4];
+    transpose4x4(r0, r1, r2, r3, o);
+    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) =
+        make_uint4(o[0], o[1], o[2], o[3]);
+    return;
+  }
+  const size_t j = idx - n_big;
+  const int c8 = (int)(j & 7);
+  const int h = (int)((j >> 3) % heads);
+  const size_t r = (j >> 3) / heads;
+  if (t.s_entries == 0) return;
+  const int f = (int)(r % t.s_entries);
+  const size_t b = r / t.s_entries;
+  if (b >= (size_t)bs) return;
+  const unsigned r0 = px(b, hm3_source(t, t.ls, t.L, f), h, c8);
+  const unsigned r1 = f + 1 < t.s_entries ? px(b, hm3_source(t, t.ls, t.L, f + 1), h, c8) : 0u;
+  uint2 o;
+  o.x = __builtin_amdgcn_perm(r1, r0, 0x05010400u);  // c0(x0), c0(x1), c1(x0), c1(x1)
+  o.y = __builtin_amdgcn_perm(r1, r0, 0x07030602u);  // c2(x0), c2(x1), c3(x0), c3(x1)
+  *reinterpret_cast<uint2 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c8 * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+struct H4Args {
+  const char *gset;
+  unsigned g_bytes;
+  const char *sset;
+  const void *ref, *off, *logit;
+  void *out;
+  MsdaDims d;
+  Hm3Tab t;
+  int chunk, nchunk, stage_bytes;
+  const __half *qmask;
+  float s_v, s_o, s_w, s_out;
+};
+
+// exact T2int8(tsum / DIV) for DIV in {127, 255}: no ties (DIV odd), so round-half-away ==
+// round-half-even == floor(tsum / DIV + 0.5); with M = round(2^24 / DIV) the product error stays
+// 60x below the 1 / (2 DIV) margin for |tsum| <= 2^15, and the mad SATURATES exactly where the
+// reference clamps (|tsum| / DIV >= 127.5 resp. <= -128.5 lands beyond int32): the result sits
+// in bits 31..24
+template <bool U8W>
+__device__ __forceinline__ int requant_hi(int tsum, int magic, int half) {
+  int x;
+  asm("v_mad_i32_i24 %0, %1, %2, %3 clamp" : "=v"(x) : "v"(tsum), "v"(magic), "v"(half));
+  return x;
+}
+// the four samples' top bytes -> one dword (sample 0 in byte 0)
+__device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
+  const unsigned a = __builtin_amdgcn_perm((unsigned)x1, (unsigned)x0, 0x00000703u);
+  const unsigned b = __builtin_amdgcn_perm((unsigned)x3, (unsigned)x2, 0x00000703u);
+  return (int)__builtin_amdgcn_perm(b, a, 0x05040100u);
+}
+
+// I8: int8 tensors (U8W: the <__half2> flavour with unsigned x255 weights and RNE rounding, else the
+// <float> flavour with signed x127 weights); RefT: reference point type (fp16 path: __half).
+// NBIG: batches (of BT points) served by the L1/L2 path, the remaining ones come from LDS.
+// RR: the PP reference points of an owner lane are one contiguous run (BEVFormer SCA: 4 anchors).
+template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR>
+__global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
+  constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
+  constexpr int PP = LP / NOWN;           // points per owner
+  constexpr int BT = LP >= 4 ? 4 : LP;    // points per tap batch
+  constexpr int NB = LP / BT;
+  constexpr int NLDS = NB - NBIG;
+  constexpr int D = NBIG >= 2 ? 2 : 1;    // big batches in flight
+  constexpr int kBox = LP * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
+  constexpr int ESZ = I8 ? 1 : 2;         // bytes per logit / offset component
+  static_assert(NBIG >= 0 && NBIG <= NB, "NBIG");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const MsdaDims &d = a.d;
+  const Hm3Tab &t = a.t;
+  // smem: [level table] [staged planes] [mailboxes] [compaction list]
+  unsigned bh, ck;
+  if (d.heads == 8) {  // XCD x keeps head x; all XCDs walk the same (batch, chunk) sequence
+    const unsigned rest = blockIdx.x >> 3;
+    bh = (rest / (unsigned)a.nchunk) * 8u + (blockIdx.x & 7u);
+    ck = rest % (unsigned)a.nchunk;
+  } else {
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    bh = vb / (unsigned)a.nchunk;
+    ck = vb - bh * (unsigned)a.nchunk;
+  }
+  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  if (threadIdx.x < (unsigned)t.L) {
+    const int l = threadIdx.x;
+    const bool staged = l >= t.ls;
+    const unsigned sh = staged ? 6u : 7u;
+    const unsigned base = staged ? (unsigned)kTab : bh * (unsigned)t.g_entries * kEntBytes;
+    float4 f;
+    f.x = (float)t.W[l];
+    f.y = (float)t.H[l];
+    f.z = __uint_as_float(base + ((unsigned)t.ent0[l] << sh));
+    f.w = __uint_as_float((unsigned)(t.W[l] + 1) << sh);
+    *reinterpret_cast<float4 *>(smem + l * kTabEnt) = f;
+    *reinterpret_cast<int2 *>(smem + l * kTabEnt + 16) = make_int2(t.W[l] + 1, (int)sh);
+  }
+  if (a.stage_bytes) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.sset + (size_t)bh * a.stage_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem + kTab);
+    for (int i = threadIdx.x; i < a.stage_bytes / 16; i += THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.gset), 0, a.g_bytes, 0x00020000);
+  const unsigned n_in = (unsigned)(d.shared ? 1 : d.bs) * (unsigned)d.nq * (unsigned)d.heads * LP;
+  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.logit), 0, n_in * (unsigned)ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_of = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.off), 0, n_in * 2u * (unsigned)ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_rf = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.ref), 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT),
+      0x00020000);
+  const unsigned lane8 = threadIdx.x & 7u;
+  const unsigned lane16 = lane8 * 16u, lane8b = lane8 * 8u;
+  char *box = smem + kTab + a.stage_bytes + (threadIdx.x >> 3) * kBox;
+  const unsigned q_end = min((ck + 1u) * (unsigned)a.chunk, (unsigned)d.nq);
+
+  // per-lane constants of the owner's PP points: level and reference-point group
+  const bool owner = NOWN == 8 || lane8 < (unsigned)NOWN;
+  unsigned lvo[PP], gof[PP];
+  {
+    const int j0 = (int)lane8 * PP;
+    int l = j0 / d.P;
+    int p = j0 - l * d.P;
+    int g = p % d.ppg;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      lvo[k] = owner ? (unsigned)l * kTabEnt : 0u;
+      gof[k] = 2u * (unsigned)sizeof(RefT) * (unsigned)g;
+      ++p; ++g;
+      if (g == d.ppg) g = 0;
+      if (p == d.P) { p = 0; g = 0; ++l; }
+    }
+  }
+  constexpr unsigned kStride = THREADS / 8;
+  const unsigned q0 = ck * (unsigned)a.chunk;
+  unsigned n_items = q_end - q0;
+  const unsigned short *qlist = reinterpret_cast<const unsigned short *>(
+      smem + kTab + a.stage_bytes + (THREADS / 8) * kBox);
+  if constexpr (MASKED) {  // compact the chunk to the (camera, query) pairs with a non-zero weight
+    unsigned short *wl = const_cast<unsigned short *>(qlist);
+    unsigned *wtot = reinterpret_cast<unsigned *>(smem + kTab + a.stage_bytes + (THREADS / 8) * kBox + a.chunk * 2);
+    unsigned base_count = 0;
+    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
+      const unsigned i = t0 + threadIdx.x;
+      const bool vis = i < n_items && __half2float(a.qmask[(size_t)b * d.nq + q0 + i]) != 0.f;
+      const unsigned long long bal = __ballot(vis);
+      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
+      __syncthreads();
+      unsigned before = base_count, all = 0;
+      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
+        const unsigned c = wtot[w2];
+        if (w2 < wv) before += c;
+        all += c;
+      }
+      if (vis) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      base_count += all;
+      __syncthreads();
+    }
+    n_items = base_count;
+  }
+  auto query_of = [&](unsigned i) { return MASKED ? q0 + (unsigned)qlist[i] : q0 + i; };
+
+  // ---- streamed operands: byte offsets into the three descriptors
+  constexpr int NLG = I8 ? 1 + (PP > 4) : (PP + 1) / 2;           // logits dwords per lane
+  constexpr int NOF = I8 ? (PP + 1) / 2 : PP;                      // offsets dwords per lane
+  constexpr int NRF = (int)sizeof(RefT) / 2 * PP;                  // reference dwords per lane
+  struct Pre { unsigned lg[NLG], of[NOF], rf[NRF]; };
+  const unsigned b_in = d.shared ? 0u : b;
+  const unsigned lg_base = ((b_in * (unsigned)d.nq * (unsigned)d.heads + h) * LP + lane8 * PP) * (unsigned)ESZ;
+  const unsigned lg_q = (unsigned)d.heads * LP * (unsigned)ESZ;
+  const unsigned rf_base = b * (unsigned)d.nq * (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
+  const unsigned rf_q = (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
+  static_assert(!RR || PP == 4, "RR");
+  constexpr int aux = LP >= 32 ? 2 : 0;   // long read-once rows: non-temporal, the maps keep the L2
+  auto request = [&](Pre &r, unsigned q) {
+    const unsigned o_lg = lg_base + q * lg_q, o_of = 2u * o_lg, o_rf = rf_base + q * rf_q;
+#pragma unroll
+    for (int k = 0; k < NLG; ++k) r.lg[k] = I8 ? 0x80808080u : 0xfc00fc00u;  // most negative logits
+#pragma unroll
+    for (int k = 0; k < NOF; ++k) r.of[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NRF; ++k) r.rf[k] = 0;
+    if (!owner) return;
+    constexpr int LGB = PP * ESZ;  // logits bytes of this lane; offsets: twice that
+    if constexpr (LGB == 1) {
+      r.lg[0] = 0x80808000u | (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_lg, (int)o_lg, 0, 0);
+      r.of[0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_of, (int)o_of, 0, 0);
+    } else if constexpr (LGB == 2) {
+      r.lg[0] = (I8 ? 0x80800000u : 0xfc000000u) | (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_lg, (int)o_lg, 0, 0);
+      r.of[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_of, (int)o_of, 0, 0);
+    } else if constexpr (LGB == 4) {
+      r.lg[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_lg, (int)o_lg, 0, 0);
+      const u32x2 v = aux ? __builtin_amdgcn_raw_buffer_load_b64(rs_of, (int)o_of, 0, 2)
+                          : __builtin_amdgcn_raw_buffer_load_b64(rs_of, (int)o_of, 0, 0);
+      r.of[0] = v.x; r.of[1] = v.y;
+    } else if constexpr (LGB == 8) {
+      const u32x2 g = aux ? __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 2)
+                          : __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 0);
+      r.lg[0] = g.x; r.lg[1] = g.y;
+      const u32x4 v = aux ? __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)o_of, 0, 2)
+                          : __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)o_of, 0, 0);
+      r.of[0] = v.x; r.of[1] = v.y; r.of[2] = v.z; r.of[3] = v.w;
+    } else {
+      static_assert(LGB == 16, "points per owner");
+      const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rs_lg, (int)o_lg, 0, 2);
+      r.lg[0] = g.x; r.lg[1] = g.y; r.lg[2] = g.z; r.lg[3] = g.w;
+      const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)o_of, 0, 2);
+      const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)o_of + 16, 0, 2);
+      r.of[0] = v0.x; r.of[1] = v0.y; r.of[2] = v0.z; r.of[3] = v0.w;
+      r.of[4] = v1.x; r.of[5] = v1.y; r.of[6] = v1.z; r.of[7] = v1.w;
+    }
+    if constexpr (RR) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_rf, (int)o_rf, 0, 0);
+      r.rf[0] = v.x; r.rf[1] = v.y; r.rf[2] = v.z; r.rf[3] = v.w;
+      if constexpr (sizeof(RefT) == 4) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs_rf, (int)o_rf + 16, 0, 0);
+        r.rf[4] = w.x; r.rf[5] = w.y; r.rf[6] = w.z; r.rf[7] = w.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PP; ++k) {
+        if constexpr (sizeof(RefT) == 4) {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_rf, (int)(o_rf + gof[k]), 0, 0);
+          r.rf[2 * k] = v.x; r.rf[2 * k + 1] = v.y;
+        } else {
+          r.rf[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_rf, (int)(o_rf + gof[k]), 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- front end of one item on its owner lanes: softmax, locations, corner weights, addresses.
+  // Records: fp16 {half2 row-0 weights, half2 row-1 weights, row-0 address, row-1 address};
+  //          int8 {4 packed area weights, softmax weight (0 when out of view), address, row-1 address}
+  auto front = [&](const Pre &r, uint4 (&pl)[PP], float &s_out, bool &any_out) {
+    float e[PP];
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      if constexpr (I8) e[k] = (float)(int)(signed char)((r.lg[k / 4] >> (8 * (k & 3))) & 0xffu) * a.s_w;
+      else e[k] = (k & 1) ? h2f_hi(r.lg[k / 2]) : h2f_lo(r.lg[k / 2]);
+    }
+    float m = e[0];
+#pragma unroll
+    for (int k = 1; k < PP; ++k) m = fmaxf(m, e[k]);
+    m = oct_max(m);
+    float s = 0.f;
+    int wq[PP];
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      const float ex = owner ? __expf(e[k] - m) : 0.f;
+      if constexpr (!I8) {
+        e[k] = ex;
+        s += ex;
+        wq[k] = 0;
+      } else if constexpr (U8W) {  // kernel.cu:1028-1037: S sums the UN-quantised x255 weights
+        const float w255 = ex * 255.f;
+        s += w255;
+        wq[k] = (int)u16_rne(w255);
+      } else {                     // kernel.cu:926-930: S sums the quantised x127 weights
+        wq[k] = owner ? t2i8_away(ex * 127.f) : 0;
+        s += (float)wq[k];
+      }
+    }
+    s_out = oct_sum(s);
+    bool any_valid = false;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      const float4 tf = *reinterpret_cast<const float4 *>(smem + lvo[k]);
+      const int2 ti = *reinterpret_cast<const int2 *>(smem + lvo[k] + 16);
+      float rx, ry, ox, oy;
+      if constexpr (sizeof(RefT) == 4) {
+        rx = __uint_as_float(r.rf[2 * k]); ry = __uint_as_float(r.rf[2 * k + 1]);
+      } else {
+        rx = h2f_lo(r.rf[k]); ry = h2f_hi(r.rf[k]);
+      }
+      float x, y;
+      if constexpr (I8) {
+#pragma clang fp contract(off)
+        const unsigned pr = (r.of[k / 2] >> (16 * (k & 1))) & 0xffffu;
+        ox = (float)(int)(signed char)(pr & 0xffu);
+        oy = (float)(int)(signed char)(pr >> 8);
+        if constexpr (U8W) {  // kernel.cu:1040-1056: ref * size + (off * scale - 0.5)
+          x = rx * tf.x + (ox * a.s_o - 0.5f);
+          y = ry * tf.y + (oy * a.s_o - 0.5f);
+        } else {              // kernel.cu:905-917
+          x = (rx * tf.x + ox * a.s_o) - 0.5f;
+          y = (ry * tf.y + oy * a.s_o) - 0.5f;
+        }
+      } else {
+        ox = h2f_lo(r.of[k]); oy = h2f_hi(r.of[k]);
+        x = fmaf(rx, tf.x, ox) - 0.5f;
+        y = fmaf(ry, tf.y, oy) - 0.5f;
+      }
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const bool valid = owner && (y > -1.f) && (x > -1.f) && (y < tf.y) && (x < tf.x);
+      any_valid |= valid;
+      if constexpr (I8) {
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        unsigned a0, a1, a2, a3;
+        if constexpr (U8W) {
+          a0 = u16_rne(hy * hx * 255.f); a1 = u16_rne(hy * lx * 255.f);
+          a2 = u16_rne(ly * hx * 255.f); a3 = u16_rne(ly * lx * 255.f);
+        } else {
+#pragma clang fp contract(off)
+          const float sa = 1 / 127.f;   // kernel.cu:298-358 divides by the rounded 1/127
+          a0 = (unsigned)t2i8_away((hy * hx) / sa); a1 = (unsigned)t2i8_away((hy * lx) / sa);
+          a2 = (unsigned)t2i8_away((ly * hx) / sa); a3 = (unsigned)t2i8_away((ly * lx) / sa);
+        }
+        pl[k].x = (a0 & 255u) | ((a1 & 255u) << 8) | ((a2 & 255u) << 16) | ((a3 & 255u) << 24);
+        pl[k].y = valid ? (unsigned)wq[k] : 0u;
+      } else {
+        const float ev = valid ? e[k] : 0.f;
+        const float wr1 = ly * ev, wr0 = ev - wr1;
+        const float b0 = wr0 * lx, b1 = wr1 * lx;
+        pl[k].x = pack_h2(wr0 - b0, b0);
+        pl[k].y = pack_h2(wr1 - b1, b1);
+      }
+      // entry (yp, x0), yp = floor(y) + 1 in [0, H], x0 = floor(x) in [-1, W-1]
+      const int rel = __mul24((int)yf + 1, ti.x) + (int)xf;
+      pl[k].z = __float_as_uint(tf.z) + ((valid ? (unsigned)rel : 0u) << ti.y);
+      pl[k].w = pl[k].z + __float_as_uint(tf.w);
+    }
+    any_out = any_valid;
+  };
+  auto post = [&](const uint4 (&pl)[PP]) {  // owner -> mailbox
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (owner) {
+#pragma unroll
+      for (int k = 0; k < PP; ++k) *reinterpret_cast<uint4 *>(box + (lane8 * PP + k) * 16) = pl[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+
+  const int magic = U8W ? 65793 : 132104;  // round(2^24 / 255), round(2^24 / 127)
+  const int half = 1 << 23;
+
+  Pre pre1, pre2;  // operands of the next group and of the one after it
+  unsigned i = threadIdx.x >> 3;
+  uint4 pl[PP];
+  float s_cur = 1.f;
+  bool any_cur = false;
+  {
+    Pre pre0;
+    if (i < n_items) request(pre0, query_of(i));
+    else request(pre0, q0);  // harmless, in range
+    request(pre1, i + kStride < n_items ? query_of(i + kStride) : q0);
+    front(pre0, pl, s_cur, any_cur);
+    post(pl);
+  }
+  for (; i < n_items; i += kStride) {
+    const unsigned q = query_of(i);
+    request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
+    float s_nxt;
+    bool any_nxt;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int ia[4] = {0, 0, 0, 0}, ib[4] = {0, 0, 0, 0};
+    if (__any(any_cur)) {
+      uint4 bp[D][BT];
+      u32x4 r0[D][BT], r1[D][BT];
+      auto issue = [&](int tb) {
+        const int sl = tb % D;
+#pragma unroll
+        for (int j = 0; j < BT; ++j) bp[sl][j] = *reinterpret_cast<const uint4 *>(box + (tb * BT + j) * 16);
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+          r0[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].z + lane16), 0, 0);
+          if constexpr (!I8) r1[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].w + lane16), 0, 0);
+        }
+      };
+      // int8: 4 samples x 4 channels -> requantised samples, gathered per channel, one dot4 each
+      auto i8_batch = [&](const unsigned (&v)[BT][4], const uint4 (&rec)[BT]) {
+        int x[BT][4];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            int tsum;
+            if constexpr (U8W)
+              tsum = __builtin_amdgcn_sdot4((int)v[j][c], (int)(rec[j].x ^ 0x80808080u), 0, false) +
+                     (__builtin_amdgcn_sdot4((int)v[j][c], 0x01010101, 0, false) << 7);
+            else
+              tsum = __builtin_amdgcn_sdot4((int)v[j][c], (int)rec[j].x, 0, false);
+            x[j][c] = requant_hi<U8W>(tsum, magic, half);
+          }
+        }
+        unsigned w4 = rec[0].y & 0xffu;
+        if constexpr (BT > 1) w4 |= (rec[1].y & 0xffu) << 8;
+        if constexpr (BT > 2) w4 |= (rec[2].y & 0xffu) << 16;
+        if constexpr (BT > 3) w4 |= rec[3].y << 24;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int g4 = gather_hi(x[0][c], BT > 1 ? x[1][c] : 0, BT > 2 ? x[2][c] : 0, BT > 3 ? x[3][c] : 0);
+          if constexpr (U8W) {  // unsigned weights: s * w = s * (w - 128) + 128 * s
+            ia[c] = __builtin_amdgcn_sdot4(g4, (int)(w4 ^ 0x80808080u), ia[c], false);
+            ib[c] = __builtin_amdgcn_sdot4(g4, 0x01010101, ib[c], false);
+          } else {
+            ia[c] = __builtin_amdgcn_sdot4(g4, (int)w4, ia[c], false);
+          }
+        }
+      };
+      auto consume = [&](int tb) {
+        const int sl = tb % D;
+        if constexpr (I8) {
+          unsigned v[BT][4];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) { v[j][0] = r0[sl][j].x; v[j][1] = r0[sl][j].y; v[j][2] = r0[sl][j].z; v[j][3] = r0[sl][j].w; }
+          i8_batch(v, bp[sl]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {
+            const unsigned w0 = bp[sl][j].x, w1 = bp[sl][j].y;
+            acc[0] = dot2f(r0[sl][j].x, w0, acc[0]); acc[1] = dot2f(r0[sl][j].y, w0, acc[1]);
+            acc[2] = dot2f(r0[sl][j].z, w0, acc[2]); acc[3] = dot2f(r0[sl][j].w, w0, acc[3]);
+            acc[0] = dot2f(r1[sl][j].x, w1, acc[0]); acc[1] = dot2f(r1[sl][j].y, w1, acc[1]);
+            acc[2] = dot2f(r1[sl][j].z, w1, acc[2]); acc[3] = dot2f(r1[sl][j].w, w1, acc[3]);
+          }
+        }
+      };
+      auto lds_batch = [&](int u) {
+        uint4 rec[BT];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) rec[j] = *reinterpret_cast<const uint4 *>(box + ((NBIG + u) * BT + j) * 16);
+        if constexpr (I8) {
+          uint2 t0[BT], t1[BT];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {
+            t0[j] = *reinterpret_cast<const uint2 *>(smem + rec[j].z + lane8b);
+            t1[j] = *reinterpret_cast<const uint2 *>(smem + rec[j].w + lane8b);
+          }
+          unsigned v[BT][4];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {
+            v[j][0] = __builtin_amdgcn_perm(t1[j].x, t0[j].x, 0x05040100u);
+            v[j][1] = __builtin_amdgcn_perm(t1[j].x, t0[j].x, 0x07060302u);
+            v[j][2] = __builtin_amdgcn_perm(t1[j].y, t0[j].y, 0x05040100u);
+            v[j][3] = __builtin_amdgcn_perm(t1[j].y, t0[j].y, 0x07060302u);
+          }
+          i8_batch(v, rec);
+        } else {
+          uint2 l0[BT], rr0[BT], l1[BT], rr1[BT];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {
+            const char *p0 = smem + rec[j].z + lane8b;
+            const char *p1 = smem + rec[j].w + lane8b;
+            l0[j] = *reinterpret_cast<const uint2 *>(p0);
+            rr0[j] = *reinterpret_cast<const uint2 *>(p0 + kLdsPixBytes);
+            l1[j] = *reinterpret_cast<const uint2 *>(p1);
+            rr1[j] = *reinterpret_cast<const uint2 *>(p1 + kLdsPixBytes);
+          }
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {
+            const h2_t w0 = as_h2(rec[j].x), w1 = as_h2(rec[j].y);
+            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
+            h2_t va = as_h2(l0[j].x) * w00, vb = as_h2(l0[j].y) * w00;
+            va = as_h2(rr0[j].x) * w01 + va; vb = as_h2(rr0[j].y) * w01 + vb;
+            va = as_h2(l1[j].x) * w10 + va; vb = as_h2(l1[j].y) * w10 + vb;
+            va = as_h2(rr1[j].x) * w11 + va; vb = as_h2(rr1[j].y) * w11 + vb;
+            add_h2(acc[0], acc[1], va);
+            add_h2(acc[2], acc[3], vb);
+          }
+        }
+      };
+      // The schedule, pinned step by step (the compiler is free inside a step only):
+      //   issue big 0 .. D-1 | front end of the next group | HEAD LDS batches |
+      //   { consume big t | issue big t+D | one LDS batch } ... | remaining LDS batches
+      // Buffer loads retire in order, so the first consume also waits for the (HBM) operand
+      // request made just before this block: the front end and the LDS head start cover it.
+      constexpr int HEAD = NBIG == 0 ? NLDS : (NLDS > NBIG ? NLDS - NBIG + 1 : (NLDS >= 2 ? 2 : NLDS));
+      uint4 npl[PP];
+#pragma unroll
+      for (int tb = 0; tb < D && tb < NBIG; ++tb) issue(tb);
+      __builtin_amdgcn_sched_barrier(0);
+      front(pre1, npl, s_nxt, any_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < HEAD; ++u) {
+        lds_batch(u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int tb = 0; tb < NBIG; ++tb) {
+        consume(tb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tb + D < NBIG) issue(tb + D);
+        __builtin_amdgcn_sched_barrier(0);
+        if (HEAD + tb < NLDS) {
+          lds_batch(HEAD + tb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int u = HEAD + NBIG; u < NLDS; ++u) lds_batch(u);
+#pragma unroll
+      for (int k = 0; k < PP; ++k) pl[k] = npl[k];
+    } else {
+      front(pre1, pl, s_nxt, any_nxt);
+    }
+    // ---- normalise, store
+    if constexpr (I8) {
+      int8_t *outp = reinterpret_cast<int8_t *>(a.out) + (((size_t)b * d.nq + q) * d.heads + h) * 32u + lane8 * 4u;
+      unsigned res = 0;
+      {
+#pragma clang fp contract(off)
+        const float scale_o = a.s_v * (1.0f / a.s_out);
+        const float f = scale_o * (1.0f / s_cur);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int av = U8W ? ia[c] + (ib[c] << 7) : ia[c];
+          const int rq = U8W ? t2i8_rne((float)av * f) : t2i8_away((float)av * f);
+          res |= ((unsigned)rq & 0xffu) << (8 * c);
+        }
+      }
+      *reinterpret_cast<unsigned *>(outp) = res;
+    } else {
+      __half *outp = reinterpret_cast<__half *>(a.out) + (((size_t)b * d.nq + q) * d.heads + h) * 32u + lane8 * 4u;
+      const float inv = __builtin_amdgcn_rcpf(s_cur);
+      uint2 v;
+      v.x = pack_h2(acc[0] * inv, acc[1] * inv);
+      v.y = pack_h2(acc[2] * inv, acc[3] * inv);
+      if constexpr (LP >= 32)
+        __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x,
+                                    reinterpret_cast<unsigned long long *>(outp));
+      else
+        *reinterpret_cast<uint2 *>(outp) = v;
+    }
+    post(pl);
+    s_cur = s_nxt;
+    any_cur = any_nxt;
+    pre1 = pre2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+constexpr int kH4Threads = 512;
+inline int h4_box_bytes(int LP) { return (kH4Threads / 8) * (LP * 16 + 16); }
+
+struct H4Plan {
+  Hm3Plan p;
+  int nbig;  // tap batches served by L1/L2
+};
+
+bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl) {
+  const int LP = L * P;
+  if (!hm3_plan(shapes_host, bs, heads, L, nq, h4_box_bytes(LP), pl.p)) return false;
+  const int bt = LP >= 4 ? 4 : LP;
+  if ((pl.p.t.ls * P) % bt) return false;  // a batch never straddles the big / staged boundary
+  pl.nbig = pl.p.t.ls * P / bt;
+  return true;
+}
+
+template <int LP, int NBIG, bool I8, bool U8W, typename RefT, bool MASKED, bool RR>
+int h4_go(const H4Args &a, hipStream_t st) {
+  const size_t lds = kTab + a.stage_bytes + (size_t)h4_box_bytes(LP) + (a.qmask ? a.chunk * 2 + 64 : 0);
+  if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
+  if (!ensure_dynamic_lds<msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR>>(lds))
+    return BEVOPS_FAILURE;
+  const dim3 grid((unsigned)(a.d.bs * a.d.heads * a.nchunk));
+  hipLaunchKernelGGL((msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR>), grid, dim3(kH4Threads),
+                     lds, st, a);
+  return launch_status();
+}
+
+// instantiated (L*P, big batches) combinations: the model's calls.  Anything else -> NOT_SUPPORTED
+// (the caller keeps its older kernels for those).
+template <bool I8, bool U8W, typename RefT, bool MASKED>
+int h4_dispatch(int LP, int nbig, const H4Args &a, hipStream_t st) {
+  // points of an owner lane (4 of them when L*P = 32) share ONE run of reference points
+  const bool rr = LP == 32 && a.d.ppg == 4 && a.d.P % 4 == 0;
+#define BEVOPS_H4_CASE(LP_, NBIG_)                                                        \
+  if (LP == LP_ && nbig == NBIG_) {                                                       \
+    if constexpr (LP_ == 32) {                                                            \
+      if (rr) return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, true>(a, st);               \
+    }                                                                                     \
+    return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false>(a, st);                        \
+  }
+  BEVOPS_H4_CASE(32, 4)   // base SCA: 4 levels x 8 points, two levels staged
+  BEVOPS_H4_CASE(32, 8)   //   ... nothing staged (few queries)
+  BEVOPS_H4_CASE(32, 6)   //   ... one level staged
+  BEVOPS_H4_CASE(8, 0)    // tiny / small SCA: 1 level x 8 points, staged
+  BEVOPS_H4_CASE(8, 2)    //   ... not staged
+  BEVOPS_H4_CASE(4, 1)    // TSA / decoder: 1 level x 4 points
+  BEVOPS_H4_CASE(4, 0)
+#undef BEVOPS_H4_CASE
+  return BEVOPS_NOT_SUPPORTED;
+}
+
+int h4_chunk(const Hm3Plan &p, int nq, int variant_chunk) {
+  if (variant_chunk > 0) return variant_chunk;
+  return p.stage_bytes ? 1280 : 512;
+}
+
+}  // namespace
+
+size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
+  H4Plan pl;
+  if (C != 32 || !shapes_host || !h4_plan(shapes_host, bs, heads, L, P, nq, pl)) return 0;
+  return ((pl.p.g_bytes + 127) & ~size_t(127)) + 128 + pl.p.s_bytes;
+}
+
+// dtype: BEVOPS_F16 (ref fp16) or BEVOPS_I8 (ref fp32 -> x127 flavour, ref fp16 -> x255 flavour)
+int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
+                     const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
+                     int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
+                     void *workspace, size_t workspace_bytes, int chunk_override, hipStream_t st) {
+  const int LP = L * P;
+  H4Plan pl;
+  if (C != 32 || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) || !shapes_host ||
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl))
+    return BEVOPS_NOT_SUPPORTED;
+  if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
+  const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
+  if (workspace_bytes < g_room + pl.p.s_bytes) return BEVOPS_NOT_SUPPORTED;
+  char *gset = static_cast<char *>(workspace);
+  char *sset = gset + g_room;
+  const Hm3Tab &t = pl.p.t;
+  H4Args a;
+  a.gset = gset; a.g_bytes = (unsigned)pl.p.g_bytes; a.sset = sset;
+  a.ref = ref; a.off = off; a.logit = logit; a.out = out;
+  a.d = MsdaDims{bs, nk, heads, C, L, nq, P, ppg, shared};
+  a.t = t;
+  a.chunk = h4_chunk(pl.p, nq, chunk_override);
+  if (a.chunk > 0xffff) a.chunk = 0xff00;
+  a.nchunk = (nq + a.chunk - 1) / a.chunk;
+  a.stage_bytes = pl.p.stage_bytes;
+  a.qmask = nullptr;
+  a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
+  const bool i8 = dtype == BEVOPS_I8;
+  {
+    const size_t threads = (size_t)bs * t.g_entries * heads * 8 + (size_t)bs * t.s_entries * heads * (i8 ? 8 : 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (i8)
+      hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t,
+                         bs, nk, heads);
+    else
+      hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t,
+                         bs, nk, heads);
+  }
+  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, a, st);
+  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, a, st);
+  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, a, st);
+  return BEVOPS_NOT_SUPPORTED;
+}
+
+}  // namespace bevops

@@ -4,20 +4,15 @@ scaled to [-10, 10])."""
 import torch
 
 from ..utils import lib as _lib
+from ..utils import workspace as _ws
 
 _MODE = {"bilinear": 0, "nearest": 1, "bicubic": 2}
 _PAD = {"zeros": 0, "border": 1, "reflection": 2}
 
 
-_WS = {}
-
-
-def _workspace(device, nbytes):
-    """Scratch buffer per device, grown on demand (the previous one stays alive for launches in flight)."""
-    cur = _WS.get(device.index)
-    if cur is None or cur.numel() < nbytes:
-        cur = _WS[device.index] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return cur
+def _workspace(device, nbytes, stream):
+    """Scratch per (device, stream); superseded buffers stay alive (utils/workspace.py)."""
+    return _ws.lend("grid_sampler", nbytes, device, stream)
 
 
 def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
@@ -38,7 +33,7 @@ def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
         out = torch.empty((N, C, Ho, Wo), dtype=input.dtype, device=input.device)
         # lend a scratch buffer: up-sampling calls stage the input channels-last (same results)
         nws = handle.bevops_grid_sampler_2d_workspace_size(dt, N, C, H, W) if dt != _lib.I8 else 0
-        ws = _workspace(input.device, nws) if nws and Ho * Wo >= 2 * H * W else None
+        ws = _workspace(input.device, nws, stream) if nws and Ho * Wo >= 2 * H * W else None
         with torch.cuda.device(input.device):
             st = handle.bevops_grid_sampler_2d_forward_ws(
                 dt, input.data_ptr(), grid.data_ptr(), out.data_ptr(), N, C, H, W, Ho, Wo, mode,

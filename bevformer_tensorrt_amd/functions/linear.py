@@ -5,16 +5,11 @@ the reference leaves these layers to cuBLAS / TensorRT."""
 import torch
 
 from ..utils import lib as _lib
+from ..utils import workspace as _ws
 
-_WS = {}
-
-
-def _workspace(device, nbytes):
-    key = (device.index, nbytes)
-    ws = _WS.get(key)
-    if ws is None:
-        ws = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws
+def _workspace(device, nbytes, stream):
+    """hipBLASLt workspace per (device, stream): two streams never share one (utils/workspace.py)."""
+    return _ws.lend("linear", nbytes, device, stream)
 
 
 def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
@@ -48,12 +43,13 @@ def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
     handle = _lib.load_library()
     nbytes = handle.bevops_linear_workspace_size()
-    ws = _workspace(x.device, nbytes)
+    stream = _lib.current_stream_ptr(x.device)
+    ws = _workspace(x.device, nbytes, stream)
     with torch.cuda.device(x.device):
         st = handle.bevops_linear_bias_act(
             _lib.F16, x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
             r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K, int(bool(relu)), ws.data_ptr(),
-            nbytes, _lib.current_stream_ptr(x.device))
+            nbytes, stream)
     _lib.check(st, "bevops_linear_bias_act")
     return out.view(*x.shape[:-1], N)
 

@@ -12,33 +12,38 @@ import weakref
 import torch
 
 from ..utils import lib as _lib
+from ..utils import workspace as _ws
 
-# Caches are keyed by the tensor OBJECT (weakly) + its in-place version counter: a live
-# tensor cannot have its storage recycled, unlike a (data_ptr) key.
+# Caches are keyed by the tensor OBJECT (weakly) and validated by everything that can change
+# under a live object: the in-place version counter, and -- because nn.Module.half() / .to() /
+# `param.data = ...` swap the storage of the SAME Parameter object without bumping the version --
+# dtype, device, data pointer and shape.
 class _TensorCache:
-    """id(tensor) -> value, validated by a weak reference to the tensor and its version
-    (WeakKeyDictionary cannot be used: Tensor.__eq__ is element-wise)."""
+    """id(tensor) -> value (WeakKeyDictionary cannot be used: Tensor.__eq__ is element-wise)."""
 
     def __init__(self):
         self._d = {}
 
+    @staticmethod
+    def _stamp(t):
+        return (t._version, t.dtype, t.device, t.data_ptr(), tuple(t.shape))
+
     def get(self, t):
         hit = self._d.get(id(t))
-        if hit is not None and hit[0]() is t and hit[1] == t._version:
+        if hit is not None and hit[0]() is t and hit[1] == self._stamp(t):
             return hit[2]
         return None
 
     def put(self, t, value):
         if len(self._d) > 256:
             self._d = {k: v for k, v in self._d.items() if v[0]() is not None}
-        self._d[id(t)] = (weakref.ref(t), t._version, value)
+        self._d[id(t)] = (weakref.ref(t), self._stamp(t), value)
         return value
 
 
 _CPU_SHAPES = {}
 _DEV_I32 = _TensorCache()
 _HOST_SHAPES = _TensorCache()
-_WORKSPACES = {}
 
 
 def _shapes_i32(shapes, device):
@@ -69,14 +74,12 @@ def _host_shapes(shapes_dev):
 
 
 def _workspace(nbytes, device, stream_ptr):
-    """Scratch for the head-major re-layout, one buffer per (device, stream): calls on one
-    stream are ordered, so reuse is safe; other streams get their own."""
-    key = (str(device), stream_ptr)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = buf
-    return buf
+    """Scratch for the head-major re-layouts: see utils/workspace.py (per device AND stream,
+    superseded buffers kept alive for captured graphs)."""
+    return _ws.lend("msda", nbytes, device, stream_ptr)
+
+
+release_workspaces = _ws.release
 
 
 def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights,
@@ -112,11 +115,15 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
         out = torch.empty((bs, nq, heads, ch), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = _lib.current_stream_ptr(value.device)
+        # the library validates sum(H*W) == num_keys (and plans the head-major layouts) from the
+        # HOST copy of the shapes: always hand it over (one blocking copy per distinct shapes
+        # tensor, then cached; skipped only for a first sighting under stream capture)
+        if shapes_host is None and (_HOST_SHAPES.get(shapes_dev) is not None
+                                    or not torch.cuda.is_current_stream_capturing()):
+            shapes_host = _host_shapes(shapes_dev)
         ws_bytes = handle.bevops_msda_workspace_size(dt, bs, nk, heads, ch, L, nq, P)
         ws = None
-        if ws_bytes:
-            if shapes_host is None:
-                shapes_host = _host_shapes(shapes_dev)
+        if ws_bytes and shapes_host is not None:
             ws_bytes = handle.bevops_msda_workspace_size_shapes(
                 dt, shapes_host.data_ptr(), bs, nk, heads, ch, L, nq, P)
             ws = _workspace(ws_bytes, value.device, stream)

@@ -1,0 +1,116 @@
+"""hm4 (csrc/msda_hm4.hip): the software-pipelined head-major kernels, fp16 and both int8 flavours.
+  fp16 : vs the oracle, |err| <= 1e-2 (north_star), and vs hm3 (same arithmetic, other schedule);
+  int8 : BIT-IDENTICAL to the layout-preserving int8 kernels of msda.hip -- the exact integer
+         requantisation (saturating v_mad_i32_i24 + top byte) must reproduce the float formula
+         T2int8(tsum / 127) resp. / 255 for every input -- and vs the C oracle with the int8 LSB
+         budget of tests/test_msda_int8_gpu.py.
+Every (L*P, big batches) instantiation is exercised: staged / not staged, 1 level and 4 levels."""
+import numpy as np
+import pytest
+import torch
+
+from test_msda_gpu import gen, oracle_of
+from test_msda_int8_gpu import make, quantize
+
+pytestmark = pytest.mark.gpu
+
+BASE = [[116, 200], [58, 100], [29, 50], [15, 25]]
+# name: (shape, expected kernel instance -- documentation only)
+SHAPES = {
+    "base_sca_q4k": ((6, BASE, 4096, 8, 4), "<32,4> two levels staged"),
+    "base_sca_q1k": ((6, BASE, 1000, 8, 4), "<32,8> nothing staged (few queries)"),
+    "sca_3lvl_q3k": ((2, [[160, 260], [80, 130], [40, 65], [20, 33]], 3000, 8, 4), "<32,6> one level staged"),
+    "small_sca": ((6, [[23, 40]], 22500, 8, 4), "<8,0> whole plane staged"),
+    "sca_1lvl_q1k": ((6, [[23, 40]], 1500, 8, 4), "<8,2> not staged"),
+    "tsa_like": ((2, [[120, 120]], 9000, 4, 1), "<4,1>"),
+    "tsa_staged": ((2, [[40, 40]], 9000, 4, 1), "<4,0>"),
+    "ragged_tail": ((3, BASE, 2049, 8, 4), "<32,4> last chunk of one query"),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bevformer_tensorrt_amd as b
+    from bevformer_tensorrt_amd.utils import load_library
+    return b, load_library()
+
+
+def run(ctx, args, variant, int8_scales=None):
+    bev, lib = ctx
+    lib.bevops_msda_set_variant(variant)
+    try:
+        if int8_scales is None:
+            out = bev.multi_scale_deformable_attn(*args)
+        else:
+            out = bev.multi_scale_deformable_attn_int8(*args, *int8_scales)
+        torch.cuda.synchronize()
+    finally:
+        lib.bevops_msda_set_variant(0)
+    return out
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_fp16_vs_oracle_and_hm3(ctx, oracle_mod, name):
+    args = gen(SHAPES[name][0], dtype=torch.float16)
+    out = run(ctx, args, 17)
+    want = oracle_of(oracle_mod, args)
+    err = np.abs(out.float().cpu().numpy() - want)
+    assert err.max() <= 1e-2, (name, err.max())
+    ref = run(ctx, args, 10)                      # layout-preserving quad kernel
+    assert (out.float() - ref.float()).abs().max().item() <= 6e-3
+    assert torch.equal(out, run(ctx, args, 17))   # deterministic
+
+
+def test_fp16_out_of_view_and_dirty_workspace(ctx):
+    big = gen(SHAPES["small_sca"][0], dtype=torch.float16)
+    run(ctx, big, 17)                              # leaves a large, dirty workspace behind
+    args = gen(SHAPES["base_sca_q4k"][0], dtype=torch.float16)
+    args[2] = args[2] + 7.0                        # every sample out of range
+    assert torch.count_nonzero(run(ctx, args, 17)).item() == 0
+    args = gen(SHAPES["base_sca_q4k"][0], dtype=torch.float16, ref_lo=-0.3, ref_hi=1.3)
+    a, b = run(ctx, args, 17), run(ctx, args, 10)
+    assert torch.isfinite(a).all() and (a.float() - b.float()).abs().max().item() <= 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_fp16_camera_shared_offsets(ctx, dtype):
+    args = gen(SHAPES["base_sca_q4k"][0], dtype=dtype)
+    one = [args[0], args[1], args[2], args[3][:1], args[4][:1]]
+    rep = [args[0], args[1], args[2], one[3].repeat(6, 1, 1, 1), one[4].repeat(6, 1, 1, 1)]
+    shared = [args[0], args[1], args[2], one[3].expand(6, -1, -1, -1), one[4].expand(6, -1, -1, -1)]
+    assert torch.equal(run(ctx, rep, 17), run(ctx, shared, 17))
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("ref_dtype", [torch.float32, torch.float16], ids=["s8w_f32ref", "u8w_f16ref"])
+def test_int8_bit_identical_to_layout_preserving_kernel(ctx, oracle_mod, name, ref_dtype):
+    value, sh, ref, off, logit = make(SHAPES[name][0])
+    if name == "ragged_tail":                      # saturating inputs: the clamp of T2int8 must bite
+        value = value * 3.0
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    if name == "ragged_tail":
+        qv = torch.where(torch.rand(qv.shape) < 0.3, torch.full_like(qv, 127), qv)
+        qv = torch.where(torch.rand(qv.shape) < 0.2, torch.full_like(qv, -128), qv)
+    ref_in = ref.to(ref_dtype)
+    args = (qv.cuda(), sh.cuda(), ref_in.cuda(), qo.cuda(), qw.cuda())
+    scales = (s_v, s_o, s_w, 0.02)
+    a = run(ctx, args, 17, scales)
+    b = run(ctx, args, 10, scales)
+    assert torch.equal(a, b), (name, (a.int() - b.int()).abs().max().item(),
+                               (a != b).float().mean().item())
+    if SHAPES[name][0][2] <= 4096:
+        want = oracle_mod.msda_s8(qv.numpy(), s_v, sh.numpy(), ref_in.float().numpy(), qo.numpy(), s_o,
+                                  qw.numpy(), s_w, 0.02, u8_weights=(ref_dtype == torch.float16)).astype(np.int32)
+        d = np.abs(a.cpu().numpy().astype(np.int32) - want)
+        assert d.max() <= 1 and (d > 0).mean() <= 0.01
+
+
+@pytest.mark.parametrize("ref_dtype", [torch.float32, torch.float16], ids=["s8w_f32ref", "u8w_f16ref"])
+def test_int8_default_choice_at_full_base_size(ctx, ref_dtype):
+    """6 x 40 000 queries: the default dispatch (hm4) against the layout-preserving kernel."""
+    value, sh, ref, off, logit = make((6, BASE, 40000, 8, 4))
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    args = (qv.cuda(), sh.cuda(), ref.to(ref_dtype).cuda(), qo.cuda(), qw.cuda())
+    a = run(ctx, args, 0, (s_v, s_o, s_w, 0.02))
+    b = run(ctx, args, 10, (s_v, s_o, s_w, 0.02))
+    assert torch.equal(a, b)

@@ -93,23 +93,3 @@ def test_int8_requires_p_multiple_of_4(bev):
     with pytest.raises(BevopsError):   # multiScaleDeformableAttnPlugin.cpp:151-156
         bev.multi_scale_deformable_attn_int8(q(value), sh.cuda(), ref.cuda(), q(off), q(logit),
                                              0.1, 0.1, 0.1, 0.1)
-
-
-@pytest.mark.skipif(not __import__("os").environ.get("BEVOPS_TEST_EXPERIMENTAL"),
-                    reason="head-major INT8 path (variant 21) is experimental: not validated on the GPU yet")
-@pytest.mark.parametrize("name", list(SHAPES))
-def test_int8_head_major_variant_is_bit_identical(bev, name):
-    from bevformer_tensorrt_amd.utils import load_library
-    lib = load_library()
-    heads, C = (3, 12) if name == "generic_c12" else (8, 32)
-    value, sh, ref, off, logit = make(SHAPES[name], heads, C)
-    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
-    for rdt in (torch.float32, torch.float16):
-        args = (qv.cuda(), sh.cuda(), ref.to(rdt).cuda(), qo.cuda(), qw.cuda(), s_v, s_o, s_w, 0.02)
-        a = bev.multi_scale_deformable_attn_int8(*args)
-        try:
-            lib.bevops_msda_set_variant(21)
-            b = bev.multi_scale_deformable_attn_int8(*args)
-        finally:
-            lib.bevops_msda_set_variant(0)
-        assert torch.equal(a, b)

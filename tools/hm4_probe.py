@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A/B timing of the head-major MSDA generations on the current GPU (HIP events, median of 30):
+fp16 base SCA (uniform refs of the op test and the model's own camera geometry) on hm3 (16) / hm4 (17,
+chunk sizes 170+k), base / small TSA on the old hm kernel (0) vs hm4 (17), and both int8 flavours
+on the layout-preserving kernel (10) vs hm4.  One JSON line per measurement."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bevformer_tensorrt_amd as bev  # noqa: E402
+from bevformer_tensorrt_amd.utils import load_library  # noqa: E402
+from msda_sweep import SHAPES, gen, time_call  # noqa: E402
+
+
+def main():
+    lib = load_library()
+    plan = [("base_sca", "uniform", [16, 17, 172, 175, 176]), ("base_sca", "rig", [16, 17]),
+            ("base_tsa", "uniform", [0, 10, 17]), ("small_tsa", "uniform", [0, 17]), ("small_sca", "uniform", [0, 17])]
+    for name, dist, variants in plan:
+        args, byt = gen(SHAPES[name], torch.float16, dist)
+        for v in variants:
+            lib.bevops_msda_set_variant(v)
+            try:
+                med, mn = time_call(lambda: bev.multi_scale_deformable_attn(*args))
+                print(json.dumps({"call": name, "dtype": "f16", "refs": dist, "variant": v, "us": round(med, 1),
+                                  "min_us": round(mn, 1), "GBps": round(byt / med / 1e3, 1)}), flush=True)
+            except Exception as exc:  # noqa: BLE001
+                print(json.dumps({"call": name, "variant": v, "error": str(exc)[:120]}), flush=True)
+            finally:
+                lib.bevops_msda_set_variant(0)
+    for name, dist in (("base_sca", "uniform"), ("base_sca", "rig"), ("base_tsa", "uniform")):
+        args, _ = gen(SHAPES[name], torch.float32, dist)
+        value, sh, ref, off, logit = args
+
+        def q(t):
+            s = float(t.abs().max()) / 127.0
+            return torch.clamp(torch.round(t / s), -127, 127).to(torch.int8), s
+        qv, s_v = q(value); qo, s_o = q(off); qw, s_w = q(logit)
+        for rdt in (torch.float32, torch.float16):
+            r = ref.to(rdt)
+            byt = qv.numel() + qo.numel() + qw.numel() + r.numel() * r.element_size() + \
+                value.shape[0] * off.shape[1] * 8 * 32 + 8 * sh.shape[0]
+            for v in (10, 0, 17):
+                lib.bevops_msda_set_variant(v)
+                try:
+                    med, mn = time_call(lambda: bev.multi_scale_deformable_attn_int8(qv, sh, r, qo, qw, s_v, s_o, s_w, 0.02))
+                    print(json.dumps({"call": name, "dtype": "i8", "ref": str(rdt)[6:], "refs": dist, "variant": v,
+                                      "us": round(med, 1), "min_us": round(mn, 1), "GBps": round(byt / med / 1e3, 1)}),
+                          flush=True)
+                except Exception as exc:  # noqa: BLE001
+                    print(json.dumps({"call": name, "dtype": "i8", "variant": v, "error": str(exc)[:120]}), flush=True)
+                finally:
+                    lib.bevops_msda_set_variant(0)
+
+
+if __name__ == "__main__":
+    main()
