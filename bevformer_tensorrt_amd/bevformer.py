@@ -323,8 +323,8 @@ class SpatialCrossAttention(nn.Module):
 
     def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None):
         inp_residual = query
-        ncam, nq = value.shape[0], query.shape[1]
-        value = self.value_proj(value.view(ncam, -1, EMBED)).view(ncam, -1, HEADS, EMBED // HEADS)
+        ncam, nk, nq = value.shape[0], value.shape[1], query.shape[1]   # ncam may be 0 (rank without cameras)
+        value = self.value_proj(value.reshape(ncam, nk, EMBED)).view(ncam, nk, HEADS, EMBED // HEADS)
         # the per-camera copies of `query` are identical: project once, expand (stride 0)
         off = self.sampling_offsets(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
         w = self.attention_weights(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
@@ -332,11 +332,27 @@ class SpatialCrossAttention(nn.Module):
         if cams is not None:  # camera-sharded: this rank's cameras only
             ref = ref[cams]
         fused = getattr(self.ops, "spatial_cross_attention_sample", None)
-        if fused is not None and gather is None and value.dtype == torch.float16:
+        msda = self.ops.multi_scale_deformable_attn
+        if getattr(gather, "mode", None) == "gather":
+            # camera-sharded, pipelined: camera i's all-gather overlaps the sampling of camera i + 1
+            ref = ref.contiguous()
+            queries = gather.gather(
+                lambda i: msda(value[i:i + 1], spatial_shapes, ref[i:i + 1], off[:1], w[:1]).flatten(2),
+                (nq, EMBED), value.dtype, value.device)
+            slots = (queries * bev_mask).sum(0, keepdim=True)
+        elif getattr(gather, "mode", None) == "reduce":
+            # camera-sharded, cheaper exchange: this rank's masked camera sum, then ONE all-reduce
+            if ncam:
+                queries = msda(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
+                slots = (queries * bev_mask[cams]).sum(0, keepdim=True)
+            else:
+                slots = torch.zeros((1, nq, EMBED), dtype=value.dtype, device=value.device)
+            slots = gather.reduce(slots)
+        elif fused is not None and gather is None and value.dtype == torch.float16:
             # one call: camera-shared offsets, invisible (camera, query) pairs skipped, masked sum
             slots = fused(value, spatial_shapes, ref, off[:1], w[:1], bev_mask)
         else:
-            queries = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
+            queries = msda(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
             if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
                 queries = gather(queries)
             slots = (queries * bev_mask).sum(0, keepdim=True)

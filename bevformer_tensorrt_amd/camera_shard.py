@@ -58,3 +58,49 @@ def reduce_camera_slots(local_weighted_sum, dist, group=None):
     In place on `local_weighted_sum`; ranks without cameras pass zeros."""
     dist.all_reduce(local_weighted_sum, op=dist.ReduceOp.SUM, group=group)
     return local_weighted_sum
+
+
+class CameraExchange:
+    """The per-layer exchange of the camera-sharded encoder, as one object the model calls
+    (`BEVFormer.forward(..., cams=..., gather=CameraExchange(...))`).
+
+    mode "gather" (BASELINE config 4): the local cameras are sampled ONE AT A TIME and each
+    camera's [nq, embed] features go out as their own asynchronous all-gather -- the collective
+    of camera i runs (on the process group's stream) while camera i + 1 is being sampled, so only
+    the last camera's exchange is exposed.  Camera c = i * world + rank lands in slot (i, rank) of
+    the receive buffer, which therefore already IS camera-major.  Ranks with fewer cameras than
+    ceil(n_cams / world) still join every collective (with zeros).
+    mode "reduce" (SURVEY.md 8e alternative): each rank reduces its cameras with the bev_mask
+    weights and ONE all-reduce adds the [1, nq, embed] partial sums."""
+
+    def __init__(self, dist, n_cams, mode="gather", group=None):
+        assert mode in ("gather", "reduce")
+        self.dist, self.n_cams, self.mode, self.group = dist, n_cams, mode, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.cams = camera_shards(n_cams, self.world)[self.rank]
+        self.max_local = -(-n_cams // self.world)
+        self._recv = {}
+
+    def gather(self, sample, tail, dtype, device):
+        """sample(i) -> [1, *tail] features of the i-th LOCAL camera.  Returns [n_cams, *tail]."""
+        key = (tuple(tail), dtype, str(device))
+        recv = self._recv.get(key)
+        if recv is None:
+            recv = self._recv[key] = torch.empty((self.max_local, self.world) + tuple(tail), dtype=dtype, device=device)
+        works, keep = [], []
+        for i in range(self.max_local):
+            if i < len(self.cams):
+                out = sample(i).reshape(-1)
+                if not out.is_contiguous():
+                    out = out.contiguous()
+            else:
+                out = torch.zeros(recv[i, 0].numel(), dtype=dtype, device=device)
+            keep.append(out)   # alive until its collective has run
+            works.append(self.dist.all_gather_into_tensor(recv[i].view(-1), out, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        return recv.view((self.max_local * self.world,) + tuple(tail))[: self.n_cams]
+
+    def reduce(self, local_weighted_sum):
+        return reduce_camera_slots(local_weighted_sum, self.dist, self.group)

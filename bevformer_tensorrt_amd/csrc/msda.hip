@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    e[k] *= s_w;
+    e[k] = mul_rn(e[k], s_w);
     m = fmaxf(m, e[k]);
   }
   m = quad_max(m);
@@ -302,11 +302,11 @@ __global__ __launch_bounds__(kBlock) void msda_quad_int8_kernel(
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     if constexpr (U8W) {
-      const float w255 = __expf(e[k] - m) * 255.f;
-      s += w255;
+      const float w255 = mul_rn(__expf(sub_rn(e[k], m)), 255.f);
+      s = add_rn(s, w255);
       wq[k] = (int)u16_rne(w255);
     } else {
-      wq[k] = t2i8_away(__expf(e[k] - m) * 127.f);
+      wq[k] = t2i8_away(mul_rn(__expf(sub_rn(e[k], m)), 127.f));
       s += (float)wq[k];
     }
   }
@@ -626,7 +626,7 @@ extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int head
     // padded head-major int8 planes (msda_hm4.hip): 128-byte entries, at most (H + 2)(W + 1) <= 3 H W
     // + 2 of them per level -- an upper bound; bevops_msda_workspace_size_shapes gives the exact size
     if (channels != 32 || g_variant == 10 || g_variant == 99) return 0;
-    if (g_variant != 17 && !hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point)) return 0;
+    if (g_variant != 17 && g_variant < 200 && !hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point)) return 0;
     return (size_t)bs * heads * ((size_t)3 * nk + 2 * num_levels + 4) * 128 + 4096;
   }
   if (dtype != BEVOPS_F16) return 0;
@@ -744,14 +744,15 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         // hm4 (software-pipelined, msda_hm4.hip): default for the many-point calls; variant 17
         // forces it for every shape it supports, 170 + k picks a chunk size, 16 keeps hm3
         const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant == 0 && pays && LP >= 16);
+                        (g_variant >= 200 && g_variant < 232) || (g_variant == 0 && pays && LP >= 16);
         if (spatial_shapes_host && h4) {
           static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(
               BEVOPS_F16, BEVOPS_F16, value, spatial_shapes_host, reference_points, sampling_offsets,
               attention_weights, output, bs, nk, heads, channels, num_levels, num_query, num_point,
               points_per_group, shared_offsets ? 1 : 0, 1.f, 1.f, 1.f, 1.f, workspace, workspace_bytes,
-              g_variant >= 170 ? kChunks[g_variant - 170] : 0, st);
+              g_variant >= 170 && g_variant <= 179 ? kChunks[g_variant - 170] : 0,
+              g_variant >= 200 ? g_variant - 200 : 0, st);
           if (rc != BEVOPS_NOT_SUPPORTED || g_variant != 0) return rc;
         }
         if (spatial_shapes_host && (g_variant == 16 || (g_variant == 0 && pays && LP >= 16))) {
@@ -785,12 +786,14 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       // enough (variant 17 forces it, 10 / 99 keep the layout-preserving kernels)
       if (workspace && spatial_shapes_host && g_variant != 10 && g_variant != 99 &&
           (ref_dtype == BEVOPS_F32 || ref_dtype == BEVOPS_F16) &&
-          (g_variant == 17 || hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point))) {
+          (g_variant == 17 || g_variant >= 200 ||
+           hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point))) {
         const int rc = msda_hm4_forward(BEVOPS_I8, ref_dtype, value, spatial_shapes_host, reference_points,
                                         sampling_offsets, attention_weights, output, bs, nk, heads, channels,
                                         num_levels, num_query, num_point, points_per_group,
                                         shared_offsets ? 1 : 0, scale_value, scale_offset, scale_weight,
-                                        scale_out, workspace, workspace_bytes, 0, st);
+                                        scale_out, workspace, workspace_bytes, 0,
+                                        g_variant >= 200 ? g_variant - 200 : 0, st);
         if (rc != BEVOPS_NOT_SUPPORTED) return rc;
       }
       if (ref_dtype == BEVOPS_F32)

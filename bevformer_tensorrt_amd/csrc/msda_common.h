@@ -181,6 +181,21 @@ __device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned 
   o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
 }
 
+// single roundings that must not be contracted into an fma with a neighbouring multiply (the
+// int8 softmax: logit * scale - max; the oracle and the reference's host build round each step)
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // location arithmetic kept un-fused so that it rounds exactly like the
 // reference's fp32 kernel (mul, add, sub as separate roundings).
 __device__ __forceinline__ float loc_im(float ref, float size, float off) {
@@ -214,7 +229,7 @@ size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
 int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
                      const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
                      int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
-                     void *workspace, size_t workspace_bytes, int chunk_override, hipStream_t st);
+                     void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st);
 size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                     int P);
 int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,

@@ -15,8 +15,37 @@ from bevformer_tensorrt_amd.utils import load_library  # noqa: E402
 from msda_sweep import SHAPES, gen, time_call  # noqa: E402
 
 
+def ablations(lib):
+    """Time the base SCA call with parts of the hm4 kernel compiled out (variants 200 + mask; results
+    are wrong by construction): 1 no L1/L2 taps, 2 no LDS taps, 4 no operand requests in the loop,
+    8 no front end in the loop, 16 no store."""
+    args, byt = gen(SHAPES["base_sca"], torch.float16, "uniform")
+    value, sh, ref, off, logit = gen(SHAPES["base_sca"], torch.float32, "uniform")[0]
+
+    def q(t):
+        s = float(t.abs().max()) / 127.0
+        return torch.clamp(torch.round(t / s), -127, 127).to(torch.int8), s
+    qv, s_v = q(value); qo, s_o = q(off); qw, s_w = q(logit)
+    for mask in (0, 1, 2, 3, 4, 8, 12, 15, 16, 19, 31, 11, 7):
+        for dt in ("f16", "i8"):
+            lib.bevops_msda_set_variant(200 + mask if mask else 17)
+            try:
+                if dt == "f16":
+                    med, mn = time_call(lambda: bev.multi_scale_deformable_attn(*args), iters=12, warm=3)
+                else:
+                    med, mn = time_call(lambda: bev.multi_scale_deformable_attn_int8(qv, sh, ref, qo, qw, s_v, s_o, s_w,
+                                                                                     0.02), iters=12, warm=3)
+                print(json.dumps({"ablate": mask, "dtype": dt, "us": round(med, 1), "min_us": round(mn, 1)}), flush=True)
+            except Exception as exc:  # noqa: BLE001
+                print(json.dumps({"ablate": mask, "dtype": dt, "error": str(exc)[:100]}), flush=True)
+            finally:
+                lib.bevops_msda_set_variant(0)
+
+
 def main():
     lib = load_library()
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+        return ablations(lib)
     plan = [("base_sca", "uniform", [16, 17, 172, 175, 176]), ("base_sca", "rig", [16, 17]),
             ("base_tsa", "uniform", [0, 10, 17]), ("small_tsa", "uniform", [0, 17]), ("small_sca", "uniform", [0, 17])]
     for name, dist, variants in plan:
