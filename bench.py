@@ -98,52 +98,45 @@ def cpu_baseline(max_seconds=30.0):
         t_frame += dt * (BASE["enc_layers"] if name != "dec" else BASE["dec_layers"])
     return 1.0 / t_frame, " ".join(parts)
 
+def cpu_full_model(frames=2):
+    """BASELINE config 1: the WHOLE BEVFormer-tiny (R50 + FPN level, 3 encoder + 6 decoder layers,
+    heads) in fp32 on the host cores, bs=1, synthetic 6-camera 480x800 frames -- the reference's
+    `*TRT` (non-plugin) wrappers' CPU branch (configs/bevformer/bevformer_tiny_trt.py:3-56): torch
+    dense layers + the torch statement of the samplers (oracle/ref_ops.py).  Frame protocol of
+    evaluate_pth.py: prev_bev carried, 1 warm-up frame untimed."""
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    from oracle.ref_ops import RefOps
+    model = B.BEVFormer("tiny", ops=RefOps, seed=0)
+    runner = B.FrameRunner(model, torch.device("cpu"), torch.float32)
+    H, W = B.CONFIGS["tiny"]["image"]
+    g = torch.Generator().manual_seed(0)
+    l2i = G.synthetic_lidar2img((H, W))
+    ts = []
+    for i in range(frames + 1):
+        img = torch.randn(1, 6, 3, H, W, generator=g)
+        can = torch.zeros(18)
+        can[0], can[1], can[-2], can[-1] = 0.5 * i, 0.1 * i, 0.01 * i, 0.8 * i
+        t0 = time.perf_counter()
+        runner.step(img, can, l2i, "scene")
+        ts.append(time.perf_counter() - t0)
+    core = ts[1:]
+    return {"config": "BEVFormer-tiny fp32, whole model, PyTorch CPU path (BASELINE config 1)",
+            "frames_per_s": round(len(core) / sum(core), 3), "ms_per_frame": round(sum(core) / len(core) * 1e3, 1),
+            "cores": torch.get_num_threads(), "frames": len(core)}
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "int8"])
-    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
-                    help="N>1: all-gather of per-camera features (BASELINE config 4) or all-reduce of "
-                         "each rank's camera sum (SURVEY 8e alternative, 6x less data)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--no-geometry-extra", action="store_true",
-                    help="skip the extra SCA timing on the model's own reference points (profiling runs: keeps "
-                         "the rocprofv3 per-kernel averages to the contract workload)")
-    args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    import bevformer_tensorrt_amd as bev
-    from bevformer_tensorrt_amd.camera_shard import camera_shards, gather_camera_features, reduce_camera_slots
-
-    int8 = args.dtype == "int8"
-    dtype = torch.float32 if args.dtype == "fp32" else torch.float16
-    esize = 1 if int8 else (2 if dtype == torch.float16 else 4)
+def build_workload(bev, kind, dev, my_cams):
+    """The per-frame hot-path operands of one flavour ("fp16" | "fp32" | "int8"), resident in HBM."""
+    int8 = kind == "int8"
+    dtype = torch.float32 if kind == "fp32" else torch.float16
     gen = torch.Generator().manual_seed(0)
-    my_cams = camera_shards(BASE["sca"]["bs"], world)[rank]
     sca, sca_bs = msda_inputs(BASE["sca"], dtype, dev, gen, cams=my_cams)
     tsa, _ = msda_inputs(BASE["tsa"], dtype, dev, gen)
     dec, _ = msda_inputs(BASE["dec"], dtype, dev, gen)
-    extra = ["26x DCNv2", "rotate"]
     prev_bev = torch.randn(BASE["embed"], *BASE["bev"], generator=gen).to(dtype).to(dev)
     rot = (prev_bev, torch.tensor(1.5, device=dev), torch.tensor([100.0, 100.0], device=dev))
     dcn = []
-    ncam = max(len(my_cams), 0)
+    ncam = len(my_cams)
     for count, C, H, W in BASE["dcn"]:
         if ncam == 0:
             continue
@@ -153,7 +146,7 @@ def main():
         w = (torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5).to(dtype).to(dev)
         b = torch.randn(C, generator=gen).to(dtype).to(dev)
         dcn.append((count, (x, off, mask, w, b, 1, 1, 1, 1, 1)))
-
+    ops = (bev.multi_scale_deformable_attn, bev.modulated_deformable_conv2d, bev.rotate)
     if int8:
         # INT8 flavour of the same step: every plugin-boundary tensor quantised per tensor with the
         # scale the native entropy (KL) calibrator gives for it (quantization.py; the reference
@@ -181,16 +174,28 @@ def main():
             x, sx = q("dcn.x", a[0]); o, so = q("dcn.off", a[1]); m, sm = q("dcn.mask", a[2]); w, sw = q("dcn.w", a[3])
             dcn_q.append((count, (x, o, m, w, a[4].float(), sx, so, sm, sw, 4.0 / 127, 1, 1, 1, 1, 1)))
         dcn = dcn_q
-        op_msda, op_dcn, op_rot = (bev.multi_scale_deformable_attn_int8, bev.modulated_deformable_conv2d_int8,
-                                   bev.rotate_int8)
-    else:
-        op_msda, op_dcn, op_rot = bev.multi_scale_deformable_attn, bev.modulated_deformable_conv2d, bev.rotate
+        ops = (bev.multi_scale_deformable_attn_int8, bev.modulated_deformable_conv2d_int8, bev.rotate_int8)
+    return dict(sca=sca, sca_bs=sca_bs, tsa=tsa, dec=dec, rot=rot, dcn=dcn, ops=ops, dtype=dtype, int8=int8,
+                esize=1 if int8 else (2 if dtype == torch.float16 else 4))
 
+
+def run_hot_path(wl, steps, warmup, dev, dist, exchange, world):
+    """W untimed + K timed frames of the hot path, barrier + synchronize on both sides, MAX over
+    ranks.  Returns (elapsed seconds, [HIP-event pairs around every base SCA call])."""
+    op_msda, op_dcn, op_rot = wl["ops"]
     nq, embed = BASE["sca"]["nq"], BASE["embed"]
-    sca_out = torch.empty((max(sca_bs, 1), nq, BASE["heads"], BASE["C"]), dtype=torch.int8 if int8 else dtype,
-                          device=dev)
-    gathered = None
+    sca, tsa, dec, rot, dcn, sca_bs = wl["sca"], wl["tsa"], wl["dec"], wl["rot"], wl["dcn"], wl["sca_bs"]
+    out_dtype = torch.int8 if wl["int8"] else wl["dtype"]
+    empty = torch.empty((0, nq, BASE["heads"], BASE["C"]), dtype=out_dtype, device=dev)
     sca_events = []
+    ex = None
+    if world > 1:
+        from bevformer_tensorrt_amd.camera_shard import CameraExchange
+        ex = CameraExchange(dist, BASE["sca"]["bs"], exchange)
+
+    def sca_call(i=None):
+        a = sca if i is None else tuple(t[i:i + 1] if k in (0, 2, 3, 4) else t for k, t in enumerate(sca))
+        return op_msda(*a)
 
     def step(record):
         for count, a in dcn:
@@ -199,22 +204,21 @@ def main():
         op_rot(*rot)
         for _ in range(BASE["enc_layers"]):
             op_msda(*tsa)
-            if sca_bs:
-                if record:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                out = op_msda(*sca)
-                if record:
-                    e1.record()
-                    sca_events.append((e0, e1))
+            if record and sca_bs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if ex is not None and exchange == "gather":
+                # camera i's all-gather (RCCL, the process group's stream) overlaps the sampling of camera i + 1
+                ex.gather(lambda i: sca_call(i).view(1, nq, embed), (nq, embed), out_dtype, dev)
             else:
-                out = sca_out[:0]
-            if world > 1 and args.exchange == "gather":
-                gather_camera_features(out.view(out.shape[0], nq, embed), BASE["sca"]["bs"], dist)
-            elif world > 1:
-                part = out.view(out.shape[0], nq, embed).sum(0, keepdim=True) if out.shape[0] else \
-                    torch.zeros((1, nq, embed), dtype=out.dtype, device=dev)
-                reduce_camera_slots(part, dist)
+                out = sca_call() if sca_bs else empty
+                if ex is not None:
+                    part = out.view(out.shape[0], nq, embed).sum(0, keepdim=True) if out.shape[0] else \
+                        torch.zeros((1, nq, embed), dtype=out.dtype, device=dev)
+                    ex.reduce(part)
+            if record and sca_bs:
+                e1.record()
+                sca_events.append((e0, e1))
         for _ in range(BASE["dec_layers"]):
             op_msda(*dec)
 
@@ -224,11 +228,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
@@ -236,97 +240,208 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed, sca_events
 
+
+def pmc_traffic(int8):
+    """HBM/fabric bytes per base-SCA call from the newest committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
+    correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM").  The call is two
+    launches (re-layout + gather); both are summed."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel*.json")))
+        f = [x for x in f if ("int8" in os.path.basename(x)) == int8][-1]
+        total = 0.0
+        for k, v in json.load(open(f)).items():
+            hit = ("msda_hm4_kernel<32" in k or "msda_hm4_repack" in k or "msda_hm3_kernel<32" in k or
+                   "msda_hm3_repack_kernel" in k)
+            if hit and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
+                total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
+        return (int(total) if total else None), os.path.relpath(f, ROOT)
+    except Exception:
+        return None, None
+
+
+def sca_roofline(wl, sca_events):
+    if not sca_events:
+        return None
+    ms = [a.elapsed_time(b) for a, b in sca_events]
+    avg_ms = sum(ms) / len(ms)
+    byt = msda_bytes(BASE["sca"], wl["esize"], bs=wl["sca_bs"])
+    if wl["int8"]:   # reference points stay fp16 in the INT8 flavour (SURVEY.md 8d: 296.9 MB)
+        byt += wl["sca_bs"] * BASE["sca"]["nq"] * 2 * BASE["sca"]["ppg"] * (2 - wl["esize"])
+    achieved = byt / (avg_ms * 1e-3) / 1e9
+    kern = ("base SCA MSDA call = msda_hm4_repack_i8_kernel + msda_hm4_kernel<32,4,int8 x255 flavour>" if wl["int8"]
+            else "base SCA MSDA call = msda_hm4_repack_f16_kernel + msda_hm4_kernel<32,4,fp16>")
+    r = {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
+         "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": len(ms)}
+    if wl["sca_bs"] == BASE["sca"]["bs"]:
+        r["traffic"], r["traffic_src"] = pmc_traffic(wl["int8"])
+    return r
+
+
+def time_us(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
+
+
+def geometry_rooflines(bev, wl, dev):
+    """The same SCA call on the reference points the MODEL produces (BEV pillars projected into a
+    6-camera rig, geometry.py: 81 % of the (camera, pillar) pairs out of view), as the drop-in op and
+    as the fused SCA op (camera-shared offsets / logits read once, invisible pairs skipped, masked
+    camera sum inside; SURVEY.md 8d: its own byte count, 282.9 MB)."""
+    from bevformer_tensorrt_amd import geometry as G
+    img_hw = (928, 1600)
+    nq = BASE["sca"]["nq"]
+    ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
+    cam, mask = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img(img_hw), img_hw)
+    sca = wl["sca"]
+    dtype = wl["dtype"]
+    rig = list(sca)
+    rig[2] = torch.nan_to_num(cam.reshape(6, nq, 1, 8), nan=-5.0, posinf=5.0, neginf=-5.0).to(dtype).to(dev)
+    us = time_us(lambda: bev.multi_scale_deformable_attn(*rig))
+    byt = msda_bytes(BASE["sca"], wl["esize"])
+    out = {"model_geometry": {"what": "drop-in op, reference points of the 6-camera rig", "bytes_per_launch": byt,
+                              "avg_launch_us": round(us, 2), "achieved": round(byt / us / 1e3, 1),
+                              "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}}
+    heads, C, LP = BASE["heads"], BASE["C"], 32
+    nk = sum(h * w for h, w in BASE["sca"]["levels"])
+    fused_bytes = (6 * nk * heads * C + nq * heads * LP * 3 + 6 * nq * 8 + 6 * nq + nq * heads * C) * 2 + 8 * 4
+    bm = mask.to(dtype).to(dev)
+    us = time_us(lambda: bev.spatial_cross_attention_sample(rig[0], rig[1], rig[2], rig[3][:1], rig[4][:1], bm))
+    out["fused_sca"] = {"what": "bevops_sca_forward on the same inputs (SURVEY 8f-3)", "bytes_per_launch": fused_bytes,
+                        "avg_launch_us": round(us, 2), "achieved": round(fused_bytes / us / 1e3, 1),
+                        "frac": round(fused_bytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def end_to_end_model(dev, dtype, gen):
+    """The whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random weights,
+    synthetic 6-camera frames), frame loop replayed from a HIP graph; protocol of
+    det2trt/utils/tensorrt.py:72-76 (device time of a frame between syncs, first/last dropped)."""
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    torch.cuda.empty_cache()
+    model = B.BEVFormer("base").to(dev, dtype)
+    runner = B.FrameRunner(model, dev, dtype, graph=True)
+    H, W = B.CONFIGS["base"]["image"]
+    img = torch.randn(1, 6, 3, H, W, generator=gen).to(dev, dtype)
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    ts = []
+    for i in range(10):
+        can = torch.zeros(18)
+        can[0], can[1], can[-2], can[-1] = 0.5 * i, 0.1 * i, 0.01 * i, 0.8 * i
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        runner.step(img, can, l2i, "scene")
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+    core = ts[1:-1]
+    return {"model": "BEVFormer-base (re-hosted, random weights)", "dtype": "f16",
+            "frames_per_s": round(len(core) / sum(core), 2),
+            "ms_per_frame": round(sum(core) / len(core) * 1e3, 3), "hip_graph": True}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks here (one process per GPU,
+    RCCL rendezvous on 127.0.0.1) -- the driver's torch.distributed.run launch sets WORLD_SIZE itself
+    and never comes through this path."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    raise SystemExit(rc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "int8"])
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
+                    help="N>1: per-camera all-gathers of the camera features (BASELINE config 4) or all-reduce of "
+                         "each rank's masked camera sum (SURVEY 8e alternative, 6x less data)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-int8", action="store_true", help="skip the INT8 sub-record of the default fp16 run")
+    ap.add_argument("--no-geometry-extra", action="store_true",
+                    help="skip the extra SCA timings on the model's own reference points (profiling runs: keeps "
+                         "the rocprofv3 per-kernel averages to the contract workload)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.camera_shard import camera_shards
+
+    my_cams = camera_shards(BASE["sca"]["bs"], world)[rank]
+    wl = build_workload(bev, args.dtype, dev, my_cams)
+    elapsed, sca_events = run_hot_path(wl, args.steps, args.warmup, dev, dist, args.exchange, world)
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
+    roofline = sca_roofline(wl, sca_events) if world == 1 or args.exchange == "reduce" else None
+    if roofline is not None and world > 1:
+        roofline["note"] = "N>1: this rank's cameras only, exchange inside the bracket"
 
-    def pmc_traffic():
-        """HBM/fabric bytes per base-SCA call from the newest committed rocprofv3 PMC passes
-        (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
-        correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM").  The call is two
-        launches since round 1b (re-layout + gather); both are summed."""
+    # extra rooflines (N=1, fp16): the model's own geometry, as the drop-in op and as the fused op
+    if roofline is not None and world == 1 and args.dtype == "fp16" and not args.no_geometry_extra:
         try:
-            import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel.json")))[-1]
-            total = 0.0
-            for k, v in json.load(open(f)).items():
-                sca = ("msda_hm3_kernel<32" in k or "msda_hm3_repack_kernel" in k or
-                       "msda_hm2_kernel<32>" in k or "msda_hm2_repack_kernel" in k or
-                       ("msda_quad_kernel<__half, 8" in k))
-                if sca and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
-                    total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
-            return (int(total) if total else None), os.path.relpath(f, ROOT)
-        except Exception:
-            return None, None
+            roofline.update(geometry_rooflines(bev, wl, dev))
+        except Exception as exc:  # the contract line must still be printed
+            roofline["model_geometry"] = {"error": repr(exc)[:160]}
 
-    roofline = None
-    if sca_events:
-        ms = [a.elapsed_time(b) for a, b in sca_events]
-        avg_ms = sum(ms) / len(ms)
-        byt = msda_bytes(BASE["sca"], esize, bs=sca_bs)
-        achieved = byt / (avg_ms * 1e-3) / 1e9
-        kern = ("base SCA MSDA call = msda_int8_quad_kernel (u8 x255 weights)" if int8 else
-                "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>")
-        roofline = {"kernel": kern, "bound": "hbm",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
-                    "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "launches": len(ms)}
-        if sca_bs == BASE["sca"]["bs"] and not int8:
-            roofline["traffic"], roofline["traffic_src"] = pmc_traffic()
-
-    # the same SCA call on the reference points the model itself produces (BEV pillars projected
-    # into a 6-camera rig, geometry.py): extra information, not the contract figure above
-    if roofline is not None and world == 1 and not int8 and not args.no_geometry_extra:
+    # INT8 flavour of the same step, measured in the SAME default run (the metric is "fp16/INT8")
+    int8_rec = None
+    if world == 1 and args.dtype == "fp16" and not args.no_int8:
         try:
-            from bevformer_tensorrt_amd import geometry as G
-            img_hw = (928, 1600)
-            ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
-            cam, _ = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img(img_hw), img_hw)
-            rig = list(sca)
-            rig[2] = torch.nan_to_num(cam.reshape(6, BASE["sca"]["nq"], 1, 8), nan=-5.0, posinf=5.0, neginf=-5.0).to(dtype).to(dev)
-            for _ in range(3):
-                bev.multi_scale_deformable_attn(*rig)
-            evs = []
-            for _ in range(10):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); bev.multi_scale_deformable_attn(*rig); e1.record()
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
-            byt = roofline["bytes_per_launch"]
-            roofline["model_geometry_refs"] = {"avg_launch_us": round(us, 2), "achieved": round(byt / us / 1e3, 1),
-                                               "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}
+            wl8 = build_workload(bev, "int8", dev, my_cams)
+            el8, ev8 = run_hot_path(wl8, args.steps, args.warmup, dev, None, args.exchange, 1)
+            int8_rec = {"value": round(args.steps / el8, 3), "unit": "frames/s", "ms_per_step": round(el8 / args.steps * 1e3, 4),
+                        "steps": args.steps, "warmup": args.warmup, "dtype": "i8",
+                        "scales": "entropy (KL) calibrator per plugin-boundary tensor; fp16 reference points "
+                                  "(the reference's <__half2> x255-weight flavour); fp32 DCN bias",
+                        "roofline": sca_roofline(wl8, ev8)}
+            del wl8
         except Exception as exc:
-            roofline["model_geometry_refs"] = {"error": repr(exc)[:120]}
+            int8_rec = {"error": repr(exc)[:200]}
 
     end_to_end = None
-    if world == 1 and not args.no_end_to_end and not int8:
-        # the whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random
-        # weights, synthetic 6-camera frames), frame loop replayed from a HIP graph; protocol of
-        # det2trt/utils/tensorrt.py:72-76 (device time of a frame between syncs, first/last dropped)
+    if world == 1 and not args.no_end_to_end and args.dtype == "fp16":
         try:
-            from bevformer_tensorrt_amd import bevformer as B, geometry as G
-            del sca, tsa, dec, dcn
-            torch.cuda.empty_cache()
-            model = B.BEVFormer("base").to(dev, dtype)
-            runner = B.FrameRunner(model, dev, dtype, graph=True)
-            H, W = B.CONFIGS["base"]["image"]
-            img = torch.randn(1, 6, 3, H, W, generator=gen).to(dev, dtype)
-            l2i = G.synthetic_lidar2img((H, W)).to(dev)
-            ts = []
-            for i in range(10):
-                can = torch.zeros(18)
-                can[0], can[1], can[-2], can[-1] = 0.5 * i, 0.1 * i, 0.01 * i, 0.8 * i
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                runner.step(img, can, l2i, "scene")
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t1)
-            core = ts[1:-1]
-            end_to_end = {"model": "BEVFormer-base (re-hosted, random weights)", "dtype": "f16",
-                          "frames_per_s": round(len(core) / sum(core), 2),
-                          "ms_per_frame": round(sum(core) / len(core) * 1e3, 3), "hip_graph": True}
+            del wl
+            end_to_end = end_to_end_model(dev, torch.float16, torch.Generator().manual_seed(0))
         except Exception as exc:  # the contract line must still be printed
             end_to_end = {"error": repr(exc)[:200]}
 
@@ -338,18 +453,23 @@ def main():
                    "kind": "port",
                    "sample": "reference PyTorch CPU MSDA path (oracle/torch_ref.py), fp32, base "
                              "TSA + decoder calls in full and 1/8 of the SCA queries, scaled to "
-                             "6+6+6 calls per frame; per-call " + sample}
+                             "6+6+6 calls per frame (the MSDA part of the step only); per-call " + sample}
+            try:
+                cpu["full_model"] = cpu_full_model()
+            except Exception as exc:
+                cpu["full_model"] = {"error": repr(exc)[:200]}
+        int8 = args.dtype == "int8"
         line = {
             "metric": f"frames/sec BEVFormer-base bs=1 {'int8' if int8 else args.dtype} sampling hot path (synthetic)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "i8" if int8 else ("f16" if dtype == torch.float16 else "f32"), "data": "synthetic",
-            "config": {"workload": "BEVFormer-base hot path per frame: "
-                                   + "+".join(extra + ["6x(TSA+SCA) MSDA", "6x decoder MSDA"]),
+            "dtype": "i8" if int8 else ("f16" if args.dtype == "fp16" else "f32"), "data": "synthetic",
+            "config": {"workload": "BEVFormer-base hot path per frame: 26x DCNv2+rotate+6x(TSA+SCA) MSDA+6x decoder MSDA",
                        "shapes": "SCA(6,30825,40000,4x8) TSA(2,40000,40000,1x4) dec(1,40000,900,1x4)",
                        "parallelism": f"cameras/{world}+all-{args.exchange}" if world > 1 else "single"},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end,
+            "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "roofline": roofline, "cpu_baseline": cpu, "int8": int8_rec, "end_to_end": end_to_end,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -196,6 +196,20 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
   return a * b;
 }
 
+// t2i8_away for a >= 0 (area weights, softmax weights): the clamp from below and the sign select
+// drop out ((int)(0 + 0.5) == (int)(0 - 0.5) == 0)
+__device__ __forceinline__ int t2i8_away_nonneg(float a) { return (int)add_rn(fminf(a, 127.f), 0.5f); }
+// RN(p / sa) for sa = fl(1/127), p >= 0, WITHOUT the 10-instruction IEEE division: 127.0f is the
+// correctly rounded reciprocal of sa, so one residual correction of q0 = RN(127 p) gives the
+// correctly rounded quotient (Markstein; checked against the division over 40 M products on the
+// host and on every tested input against the dividing kernels, tests/test_msda_hm4_gpu.py)
+__device__ __forceinline__ float div_by_inv127(float p) {
+  const float sa = 1 / 127.f;
+  const float q0 = mul_rn(p, 127.f);
+  const float r = __builtin_fmaf(-q0, sa, p);
+  return __builtin_fmaf(r, 127.f, q0);
+}
+
 // location arithmetic kept un-fused so that it rounds exactly like the
 // reference's fp32 kernel (mul, add, sub as separate roundings).
 __device__ __forceinline__ float loc_im(float ref, float size, float off) {

@@ -38,97 +38,118 @@ namespace {
 // re-layouts
 // ------------------------------------------------------------------------------------------------
 // fp16: big set = pixel-pair entries 32 x half2(v[f][c], v[f+1][c]); staged set = row-major pixels.
-// thread = (b, entry, head, 16-byte chunk)
+// thread = (b, entry, head, 16-byte chunk of the entry); the entry is decomposed into (level,
+// padded row, column) once.
 __global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *__restrict__ value,
                                                                   char *__restrict__ gset,
                                                                   char *__restrict__ sset, Hm3Tab t,
                                                                   int bs, int nk, int heads) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
-  if (idx < n_big) {
-    const int c8 = (int)(idx & 7);
-    const int h = (int)((idx >> 3) % heads);
-    const size_t r = (idx >> 3) / heads;
-    const int f = (int)(r % t.g_entries);
-    const size_t b = r / t.g_entries;
-    const int s0 = hm3_source(t, 0, t.ls, f), s1 = hm3_source(t, 0, t.ls, f + 1);
-    uint2 a = make_uint2(0, 0), c = make_uint2(0, 0);
-    if (s0 >= 0) a = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c8 * 4);
-    if (s1 >= 0) c = *reinterpret_cast<const uint2 *>(value + (((size_t)b * nk + s1) * heads + h) * 32 + c8 * 4);
-    uint4 o;
-    o.x = (a.x & 0xffffu) | (c.x << 16);
-    o.y = (a.x >> 16) | (c.x & 0xffff0000u);
-    o.z = (a.y & 0xffffu) | (c.y << 16);
-    o.w = (a.y >> 16) | (c.y & 0xffff0000u);
-    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) = o;
-    return;
-  }
-  const size_t j = idx - n_big;
-  const int c4 = (int)(j & 3);
-  const int h = (int)((j >> 2) % heads);
-  const size_t r = (j >> 2) / heads;
-  if (t.s_entries == 0) return;
-  const int f = (int)(r % t.s_entries);
-  const size_t b = r / t.s_entries;
+  const bool big = idx < n_big;
+  const size_t j = big ? idx : idx - n_big;
+  const int chunks = big ? 8 : 4;
+  const int ck = (int)(j % chunks);
+  const int h = (int)((j / chunks) % heads);
+  const size_t r = (j / chunks) / heads;
+  const int entries = big ? t.g_entries : t.s_entries;
+  if (entries == 0) return;
+  const int f = (int)(r % entries);
+  const size_t b = r / entries;
   if (b >= (size_t)bs) return;
-  const int s0 = hm3_source(t, t.ls, t.L, f);
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (s0 >= 0) v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + s0) * heads + h) * 32 + c4 * 8);
-  *reinterpret_cast<uint4 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c4 * 16) = v;
+  const int l0 = big ? 0 : t.ls, l1 = big ? t.ls : t.L;
+  int lv = -1;
+  for (int l = l0; l < l1; ++l)
+    if (f >= t.ent0[l] - 1) lv = l;
+  uint2 p0 = make_uint2(0, 0), p1 = make_uint2(0, 0);  // big: 4 channels of pixels f, f+1
+  uint4 q = make_uint4(0, 0, 0, 0);                    // staged: 8 channels of pixel f
+  if (lv >= 0) {
+    const int W = t.W[lv], H = t.H[lv], wp = W + 1;
+    const int rel = f - t.ent0[lv];
+    const int yp = rel < 0 ? -1 : rel / wp;
+    const int x = rel - yp * wp;
+    const __half *base = value + (((size_t)b * nk + t.src0[lv]) * heads + h) * 32;
+    auto src = [&](int yy, int xx) -> const __half * {   // padded (row, column) -> pixel or null
+      if (xx >= wp) { xx -= wp; ++yy; }
+      if (yy < 1 || yy > H || xx >= W) return nullptr;
+      return base + ((size_t)(yy - 1) * W + xx) * heads * 32;
+    };
+    if (yp <= H + 1) {
+      if (big) {
+        if (const __half *s0 = src(yp, x)) p0 = *reinterpret_cast<const uint2 *>(s0 + ck * 4);
+        if (const __half *s1 = src(yp, x + 1)) p1 = *reinterpret_cast<const uint2 *>(s1 + ck * 4);
+      } else if (const __half *s0 = src(yp, x)) {
+        q = *reinterpret_cast<const uint4 *>(s0 + ck * 8);
+      }
+    }
+  }
+  if (big) {
+    uint4 o;
+    o.x = (p0.x & 0xffffu) | (p1.x << 16);
+    o.y = (p0.x >> 16) | (p1.x & 0xffff0000u);
+    o.z = (p0.y & 0xffffu) | (p1.y << 16);
+    o.w = (p0.y >> 16) | (p1.y & 0xffff0000u);
+    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + ck * 16) = o;
+  } else {
+    *reinterpret_cast<uint4 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + ck * 16) = q;
+  }
 }
 
 // int8: big set = 2x2-footprint entries (dword c of 16-byte chunk k = channel 4k+c of pixels
 // f, f+1, f+W', f+W'+1); staged set = pixel-pair entries (bytes c(x0), c(x1) interleaved).
-// thread = (b, entry, head, chunk of 4 channels)
+// thread = (b, entry, head, chunk of 4 channels).  The entry is decomposed into (level, padded
+// row, column) ONCE; its neighbours follow by stepping, wrapping at the end of a padded row.
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
                                                                  int bs, int nk, int heads) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
-  auto px = [&](size_t b, int src, int h, int c8) -> unsigned {
-    return src >= 0 ? *reinterpret_cast<const unsigned *>(value + (((size_t)b * nk + src) * heads + h) * 32 + c8 * 4)
-                    : 0u;
-  };
-  if (idx < n_big) {
-    const int c8 = (int)(idx & 7);
-    const int h = (int)((idx >> 3) % heads);
-    const size_t r = (idx >> 3) / heads;
-    const int f = (int)(r % t.g_entries);
-    const size_t b = r / t.g_entries;
-    // row stride of the level entry f falls in (pads included); entries outside every level
-    // (leading / trailing zero entries) keep their own pixel only
-    int wp = 0;
-    for (int l = 0; l < t.ls; ++l) {
-      const int rel = f - t.ent0[l];
-      if (rel >= -1 && rel < (t.H[l] + 2) * (t.W[l] + 1)) wp = t.W[l] + 1;
-    }
-    unsigned r0 = px(b, hm3_source(t, 0, t.ls, f), h, c8), r1 = px(b, hm3_source(t, 0, t.ls, f + 1), h, c8);
-    unsigned r2 = 0, r3 = 0;
-    if (wp && f + wp + 1 < t.g_entries) {
-      r2 = px(b, hm3_source(t, 0, t.ls, f + wp), h, c8);
-      r3 = px(b, hm3_source(t, 0, t.ls, f + wp + 1), h, c8);
-    }
-    unsigned o[4];
-    transpose4x4(r0, r1, r2, r3, o);
-    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) =
-        make_uint4(o[0], o[1], o[2], o[3]);
-    return;
-  }
-  const size_t j = idx - n_big;
+  const bool big = idx < n_big;
+  const size_t j = big ? idx : idx - n_big;
   const int c8 = (int)(j & 7);
   const int h = (int)((j >> 3) % heads);
   const size_t r = (j >> 3) / heads;
-  if (t.s_entries == 0) return;
-  const int f = (int)(r % t.s_entries);
-  const size_t b = r / t.s_entries;
+  const int entries = big ? t.g_entries : t.s_entries;
+  if (entries == 0) return;
+  const int f = (int)(r % entries);
+  const size_t b = r / entries;
   if (b >= (size_t)bs) return;
-  const unsigned r0 = px(b, hm3_source(t, t.ls, t.L, f), h, c8);
-  const unsigned r1 = f + 1 < t.s_entries ? px(b, hm3_source(t, t.ls, t.L, f + 1), h, c8) : 0u;
-  uint2 o;
-  o.x = __builtin_amdgcn_perm(r1, r0, 0x05010400u);  // c0(x0), c0(x1), c1(x0), c1(x1)
-  o.y = __builtin_amdgcn_perm(r1, r0, 0x07030602u);  // c2(x0), c2(x1), c3(x0), c3(x1)
-  *reinterpret_cast<uint2 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c8 * 8) = o;
+  // level whose padded block [ent0 - 1, ent0 + (H + 2) W') holds f (the entry before a level's
+  // first one is the base of the samples left of and above its first pixel)
+  const int l0 = big ? 0 : t.ls, l1 = big ? t.ls : t.L;
+  int lv = -1;
+  for (int l = l0; l < l1; ++l)
+    if (f >= t.ent0[l] - 1) lv = l;
+  unsigned px[4] = {0u, 0u, 0u, 0u};  // pixels f, f+1, f+W', f+W'+1 (4 channels each)
+  if (lv >= 0) {
+    const int W = t.W[lv], H = t.H[lv], wp = W + 1;
+    const int rel = f - t.ent0[lv];
+    int yp = rel < 0 ? -1 : rel / wp;
+    int x = rel - yp * wp;
+    const int8_t *base = value + (((size_t)b * nk + t.src0[lv]) * heads + h) * 32 + c8 * 4;
+    auto at = [&](int yy, int xx) -> unsigned {   // padded (row, column) -> 4 channels or zeros
+      if (xx >= wp) { xx -= wp; ++yy; }
+      if (yy < 1 || yy > H || xx >= W) return 0u;
+      return *reinterpret_cast<const unsigned *>(base + ((size_t)(yy - 1) * W + xx) * heads * 32);
+    };
+    if (yp <= H + 1) {
+      px[0] = at(yp, x);
+      px[1] = at(yp, x + 1);
+      if (big) { px[2] = at(yp + 1, x); px[3] = at(yp + 1, x + 1); }
+    }
+  }
+  if (big) {
+    unsigned o[4];
+    transpose4x4(px[0], px[1], px[2], px[3], o);
+    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) =
+        make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(px[1], px[0], 0x05010400u);  // c0(x0), c0(x1), c1(x0), c1(x1)
+    o.y = __builtin_amdgcn_perm(px[1], px[0], 0x07030602u);  // c2(x0), c2(x1), c3(x0), c3(x1)
+    *reinterpret_cast<uint2 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c8 * 8) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -147,16 +168,50 @@ struct H4Args {
   float s_v, s_o, s_w, s_out;
 };
 
-// exact T2int8(tsum / DIV) for DIV in {127, 255}: no ties (DIV odd), so round-half-away ==
-// round-half-even == floor(tsum / DIV + 0.5); with M = round(2^24 / DIV) the product error stays
-// 60x below the 1 / (2 DIV) margin for |tsum| <= 2^15, and the mad SATURATES exactly where the
-// reference clamps (|tsum| / DIV >= 127.5 resp. <= -128.5 lands beyond int32): the result sits
-// in bits 31..24
-template <bool U8W>
-__device__ __forceinline__ int requant_hi(int tsum, int magic, int half) {
-  int x;
-  asm("v_mad_i32_i24 %0, %1, %2, %3 clamp" : "=v"(x) : "v"(tsum), "v"(magic), "v"(half));
-  return x;
+// One sample, four channels: tsum[c] = dot4(corners of channel c, area weights), then the exact
+// T2int8(tsum / DIV) for DIV in {127, 255}: no ties (DIV odd), so round-half-away == round-half-even
+// == floor(tsum / DIV + 0.5); with M = round(2^24 / DIV) the product error stays 60x below the
+// 1 / (2 DIV) margin for |tsum| <= 2^15, and the mad SATURATES exactly where the reference clamps
+// (|tsum| / DIV >= 127.5 resp. <= -128.5 lands beyond int32): the result sits in bits 31..24.
+// Hand-placed because gfx950 needs 3 wait states between a DOT write and a different VALU opcode
+// reading it, and the compiler's hazard recogniser does not look inside an asm statement: the four
+// dots run first, then the four mads (a mad directly behind its dot read a stale register).
+__device__ __forceinline__ void i8_sample_s(const unsigned (&v)[4], unsigned aw, int magic, int half,
+                                            int (&x)[4]) {
+  asm("v_dot4_i32_i8 %0, %4, %8, 0\n\t"
+      "v_dot4_i32_i8 %1, %5, %8, 0\n\t"
+      "v_dot4_i32_i8 %2, %6, %8, 0\n\t"
+      "v_dot4_i32_i8 %3, %7, %8, 0\n\t"
+      "v_mad_i32_i24 %0, %0, %9, %10 clamp\n\t"
+      "v_mad_i32_i24 %1, %1, %9, %10 clamp\n\t"
+      "v_mad_i32_i24 %2, %2, %9, %10 clamp\n\t"
+      "v_mad_i32_i24 %3, %3, %9, %10 clamp"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(aw), "v"(magic), "v"(half));
+}
+// unsigned x255 area weights (gfx950 has no mixed-sign dot4): v * a = dot4(v, a ^ 0x80) + 128 * dot4(v, 1)
+__device__ __forceinline__ void i8_sample_u(const unsigned (&v)[4], unsigned awx, int magic, int half,
+                                            int (&x)[4]) {
+  int t0, t1, t2, t3;
+  const int ones = 0x01010101;
+  asm("v_dot4_i32_i8 %0, %8, %12, 0\n\t"
+      "v_dot4_i32_i8 %4, %8, %13, 0\n\t"
+      "v_dot4_i32_i8 %1, %9, %12, 0\n\t"
+      "v_dot4_i32_i8 %5, %9, %13, 0\n\t"
+      "v_dot4_i32_i8 %2, %10, %12, 0\n\t"
+      "v_dot4_i32_i8 %6, %10, %13, 0\n\t"
+      "v_dot4_i32_i8 %3, %11, %12, 0\n\t"
+      "v_dot4_i32_i8 %7, %11, %13, 0\n\t"
+      "v_lshl_add_u32 %0, %4, 7, %0\n\t"
+      "v_lshl_add_u32 %1, %5, 7, %1\n\t"
+      "v_lshl_add_u32 %2, %6, 7, %2\n\t"
+      "v_lshl_add_u32 %3, %7, 7, %3\n\t"
+      "v_mad_i32_i24 %0, %0, %14, %15 clamp\n\t"
+      "v_mad_i32_i24 %1, %1, %14, %15 clamp\n\t"
+      "v_mad_i32_i24 %2, %2, %14, %15 clamp\n\t"
+      "v_mad_i32_i24 %3, %3, %14, %15 clamp"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(awx), "v"(ones), "v"(magic), "v"(half));
 }
 // the four samples' top bytes -> one dword (sample 0 in byte 0)
 __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
@@ -373,9 +428,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
       } else if constexpr (U8W) {  // kernel.cu:1028-1037: S sums the UN-quantised x255 weights
         const float w255 = mul_rn(ex, 255.f);
         s = add_rn(s, w255);
-        wq[k] = (int)u16_rne(w255);
+        wq[k] = (int)rintf(w255);   // in [0, 255]: u16_rne's clamps cannot bite
       } else {                     // kernel.cu:926-930: S sums the quantised x127 weights
-        wq[k] = owner ? t2i8_away(mul_rn(ex, 127.f)) : 0;
+        wq[k] = owner ? t2i8_away_nonneg(mul_rn(ex, 127.f)) : 0;
         s += (float)wq[k];
       }
     }
@@ -417,13 +472,14 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         const float hx = 1.f - lx, hy = 1.f - ly;
         unsigned a0, a1, a2, a3;
         if constexpr (U8W) {
-          a0 = u16_rne(mul_rn(mul_rn(hy, hx), 255.f)); a1 = u16_rne(mul_rn(mul_rn(hy, lx), 255.f));
-          a2 = u16_rne(mul_rn(mul_rn(ly, hx), 255.f)); a3 = u16_rne(mul_rn(mul_rn(ly, lx), 255.f));
-        } else {
-#pragma clang fp contract(off)
-          const float sa = 1 / 127.f;   // kernel.cu:298-358 divides by the rounded 1/127
-          a0 = (unsigned)t2i8_away((hy * hx) / sa); a1 = (unsigned)t2i8_away((hy * lx) / sa);
-          a2 = (unsigned)t2i8_away((ly * hx) / sa); a3 = (unsigned)t2i8_away((ly * lx) / sa);
+          // (products of two numbers in [0, 1] times 255: u16_rne's clamps cannot bite)
+          a0 = (unsigned)rintf(mul_rn(mul_rn(hy, hx), 255.f)); a1 = (unsigned)rintf(mul_rn(mul_rn(hy, lx), 255.f));
+          a2 = (unsigned)rintf(mul_rn(mul_rn(ly, hx), 255.f)); a3 = (unsigned)rintf(mul_rn(mul_rn(ly, lx), 255.f));
+        } else {   // kernel.cu:298-358 divides by the rounded 1/127: div_by_inv127 is that quotient
+          a0 = (unsigned)t2i8_away_nonneg(div_by_inv127(mul_rn(hy, hx)));
+          a1 = (unsigned)t2i8_away_nonneg(div_by_inv127(mul_rn(hy, lx)));
+          a2 = (unsigned)t2i8_away_nonneg(div_by_inv127(mul_rn(ly, hx)));
+          a3 = (unsigned)t2i8_away_nonneg(div_by_inv127(mul_rn(ly, lx)));
         }
         pl[k].x = (a0 & 255u) | ((a1 & 255u) << 8) | ((a2 & 255u) << 16) | ((a3 & 255u) << 24);
         pl[k].y = valid ? (unsigned)wq[k] : 0u;
@@ -492,16 +548,8 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         int x[BT][4];
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            int tsum;
-            if constexpr (U8W)
-              tsum = __builtin_amdgcn_sdot4((int)v[j][c], (int)(rec[j].x ^ 0x80808080u), 0, false) +
-                     (__builtin_amdgcn_sdot4((int)v[j][c], 0x01010101, 0, false) << 7);
-            else
-              tsum = __builtin_amdgcn_sdot4((int)v[j][c], (int)rec[j].x, 0, false);
-            x[j][c] = requant_hi<U8W>(tsum, magic, half);
-          }
+          if constexpr (U8W) i8_sample_u(v[j], rec[j].x ^ 0x80808080u, magic, half, x[j]);
+          else i8_sample_s(v[j], rec[j].x, magic, half, x[j]);
         }
         unsigned w4 = rec[0].y & 0xffu;
         if constexpr (BT > 1) w4 |= (rec[1].y & 0xffu) << 8;
