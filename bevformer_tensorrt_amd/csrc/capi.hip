@@ -55,6 +55,15 @@ const Entry kTable[] = {
     {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
+    {"bevops_linear_tune", (void *)&bevops_linear_tune},
+    {"bevops_linear_workspace_size", (void *)&bevops_linear_workspace_size},
+    {"bevops_msda_workspace_size_shapes", (void *)&bevops_msda_workspace_size_shapes},
+    {"bevops_sca_workspace_size", (void *)&bevops_sca_workspace_size},
+    {"bevops_mdconv_forward_packed", (void *)&bevops_mdconv_forward_packed},
+    {"bevops_mdconv_pack_weight", (void *)&bevops_mdconv_pack_weight},
+    {"bevops_mdconv_packed_weight_size", (void *)&bevops_mdconv_packed_weight_size},
+    {"bevops_conv3x3_c32_pack_weight", (void *)&bevops_conv3x3_c32_pack_weight},
+    {"bevops_conv3x3_c32_packed_weight_size", (void *)&bevops_conv3x3_c32_packed_weight_size},
     {"bevops_layer_norm", (void *)&bevops_layer_norm},
 };
 }  // namespace

@@ -29,7 +29,7 @@ struct Plan {
   hipblasLtMatmulAlgo_t algo;
   size_t ws = 0;
   bool ok = false;
-  bool tuned = false;  // algo chosen by timing (first non-capturing call), not by the heuristic
+  bool tuned = false;  // algo chosen by bevops_linear_tune, not by the heuristic
 };
 
 using Key = std::tuple<int, long long, int, int, int, int, int, size_t>;  // dev, M, N, K, relu, bias, res, ws
@@ -91,11 +91,10 @@ bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool rel
   return false;
 }
 
-// One-time selection by measurement, like the framework's TunableOp does for its own GEMMs: every
-// algorithm of the fp16 TN family that supports the problem (bias / ReLU epilogue, beta = 1) is
-// timed once on the caller's stream with the caller's buffers, the best few are re-timed, the
-// winner is cached for the process.  Needs a non-capturing stream; synchronises it (first call
-// per shape only).  `out` is scratch during tuning and is rewritten by the real call afterwards.
+// Selection by measurement (bevops_linear_tune), like the framework's TunableOp does for its own
+// GEMMs: every algorithm of the fp16 TN family that supports the problem (bias / ReLU epilogue,
+// beta = 1) is timed once on the caller's stream with the caller's buffers, the best few are
+// re-timed, the winner is cached for the process.  Synchronises; `out` is scratch.
 void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const void *a, const void *w,
                const void *c, void *out, float beta, void *workspace, size_t ws_bytes, hipStream_t st) {
   std::vector<hipblasLtMatmulHeuristicResult_t> all;
@@ -162,59 +161,89 @@ using namespace bevops;
 
 extern "C" size_t bevops_linear_workspace_size(void) { return (size_t)32 << 20; }
 
-extern "C" int bevops_linear_bias_act(int dtype, const void *a, const void *weight, const void *bias,
-                                      const void *residual, void *out, long long M, int N, int K, int relu,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+
+// shared front half of the two entries: argument checks, per-device handle, cached plan
+int linear_prepare(int dtype, const void *a, const void *weight, const void *bias, const void *residual,
+                   void *out, long long M, int N, int K, int relu, void *workspace, size_t workspace_bytes,
+                   int &dev, hipblasLtHandle_t &h, Plan &plan) {
   if (!a || !weight || !out || M < 0 || N <= 0 || K <= 0) return BEVOPS_BAD_PARAM;
   if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
-  if (M == 0) return BEVOPS_SUCCESS;
   if (!aligned16(a) || !aligned16(weight) || !aligned16(out) || (residual && !aligned16(residual)) ||
       (workspace_bytes && !aligned16(workspace)))
     return BEVOPS_BAD_PARAM;
-  int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return BEVOPS_FAILURE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto hit = g_handles.find(dev);
+  if (hit == g_handles.end()) {
+    if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) return BEVOPS_NOT_INITIALIZED;
+    g_handles[dev] = h;
+  } else {
+    h = hit->second;
+  }
+  const Key key{dev, M, N, K, relu != 0, bias != nullptr, residual != nullptr, workspace_bytes};
+  auto pit = g_plans.find(key);
+  if (pit == g_plans.end()) {
+    Plan p;
+    make_plan(h, p, M, N, K, relu != 0, bias != nullptr, workspace ? workspace_bytes : 0);
+    pit = g_plans.emplace(key, p).first;  // failures are cached too: the caller falls back once, not per call
+  }
+  plan = pit->second;
+  return plan.ok ? BEVOPS_SUCCESS : BEVOPS_NOT_SUPPORTED;
+}
+
+}  // namespace
+
+// Algorithm selection by measurement for ONE problem (shape + epilogue), kept apart from the
+// operator so that `bevops_linear_bias_act` itself never synchronises: this entry times every
+// supporting algorithm on `stream` with the caller's buffers (`out` is scratch here and must not
+// alias `residual`), BLOCKS the host until done, and caches the winner for the process.  Not legal
+// under stream capture (returns BEVOPS_BAD_PARAM there).  Optional: without it the operator runs
+// the library heuristic's choice.
+extern "C" int bevops_linear_tune(int dtype, const void *a, const void *weight, const void *bias,
+                                  const void *residual, void *out, long long M, int N, int K, int relu,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (M == 0) return BEVOPS_SUCCESS;
+  if (out == residual) return BEVOPS_BAD_PARAM;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return BEVOPS_BAD_PARAM;
+  int dev = 0;
   hipblasLtHandle_t h = nullptr;
   Plan plan;
-  {
+  const int rc = linear_prepare(dtype, a, weight, bias, residual, out, M, N, K, relu, workspace, workspace_bytes,
+                                dev, h, plan);
+  if (rc != BEVOPS_SUCCESS) return rc;
+  if (plan.tuned) return BEVOPS_SUCCESS;
+  hipblasLtMatmulDesc_t desc = make_desc(relu != 0, bias, bias != nullptr);
+  if (!desc) return BEVOPS_FAILURE;
+  const float beta = residual ? 1.f : 0.f;
+  tune_plan(h, plan, desc, a, weight, residual ? residual : out, out, beta, workspace, workspace ? workspace_bytes : 0,
+            static_cast<hipStream_t>(stream));
+  hipblasLtMatmulDescDestroy(desc);
+  if (plan.tuned) {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto hit = g_handles.find(dev);
-    if (hit == g_handles.end()) {
-      if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) return BEVOPS_NOT_INITIALIZED;
-      g_handles[dev] = h;
-    } else {
-      h = hit->second;
-    }
-    const Key key{dev, M, N, K, relu != 0, bias != nullptr, residual != nullptr, workspace_bytes};
-    auto pit = g_plans.find(key);
-    if (pit == g_plans.end()) {
-      Plan p;
-      make_plan(h, p, M, N, K, relu != 0, bias != nullptr, workspace ? workspace_bytes : 0);
-      pit = g_plans.emplace(key, p).first;  // failures are cached too: the caller falls back once, not per call
-    }
-    plan = pit->second;
+    g_plans[Key{dev, M, N, K, relu != 0, bias != nullptr, residual != nullptr, workspace_bytes}] = plan;
   }
-  if (!plan.ok) return BEVOPS_NOT_SUPPORTED;
+  return BEVOPS_SUCCESS;
+}
+
+// Asynchronous on `stream`, no host synchronisation, legal under stream capture.
+extern "C" int bevops_linear_bias_act(int dtype, const void *a, const void *weight, const void *bias,
+                                      const void *residual, void *out, long long M, int N, int K, int relu,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+  if (M == 0 && a && weight && out && N > 0 && K > 0 && dtype == BEVOPS_F16) return BEVOPS_SUCCESS;
+  int dev = 0;
+  hipblasLtHandle_t h = nullptr;
+  Plan plan;
+  const int rc = linear_prepare(dtype, a, weight, bias, residual, out, M, N, K, relu, workspace, workspace_bytes,
+                                dev, h, plan);
+  if (rc != BEVOPS_SUCCESS) return rc;
   // the bias pointer lives in the matmul descriptor: a fresh one per call keeps the entry re-entrant
   hipblasLtMatmulDesc_t desc = make_desc(relu != 0, bias, bias != nullptr);
   if (!desc) return BEVOPS_FAILURE;
   const float alpha = 1.f, beta = residual ? 1.f : 0.f;
   const void *c = residual ? residual : out;
-  if (!plan.tuned && out != residual) {
-    static const bool tune_on = [] {
-      const char *e = std::getenv("BEVOPS_LINEAR_TUNE");
-      return !(e && e[0] == '0');
-    }();
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (tune_on && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) == hipSuccess &&
-        cap == hipStreamCaptureStatusNone) {
-      tune_plan(h, plan, desc, a, weight, c, out, beta, workspace, workspace ? workspace_bytes : 0,
-                static_cast<hipStream_t>(stream));
-      if (plan.tuned) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        g_plans[Key{dev, M, N, K, relu != 0, bias != nullptr, residual != nullptr, workspace_bytes}] = plan;
-      }
-    }
-  }
   const hipblasStatus_t st =
       hipblasLtMatmul(h, desc, &alpha, weight, plan.a, a, plan.b, &beta, c, plan.c, out, plan.c, &plan.algo,
                       workspace, plan.ws, static_cast<hipStream_t>(stream));

@@ -12,6 +12,23 @@ def _workspace(device, nbytes, stream):
     return _ws.lend("linear", nbytes, device, stream)
 
 
+_TUNED = set()   # problems whose algorithm has been chosen by bevops_linear_tune in this process
+
+
+def _tune_once(handle, key, args, x2, out_shape):
+    """The library never synchronises inside the operator; algorithm selection by measurement is
+    its own BLOCKING entry (bevops_linear_tune), called here once per problem, outside stream
+    capture, with a scratch output (BEVOPS_LINEAR_TUNE=0 switches it off)."""
+    import os
+    _TUNED.add(key)
+    if os.environ.get("BEVOPS_LINEAR_TUNE", "1") == "0":
+        return
+    scratch = torch.empty(out_shape, dtype=x2.dtype, device=x2.device)
+    a = list(args)
+    a[5] = scratch.data_ptr()
+    handle.bevops_linear_tune(*a)       # status ignored: the heuristic's choice stays on failure
+
+
 def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
     """x [..., K] fp16 (contiguous rows), weight [N, K], bias [N] or None, residual [..., N] or None
     -> [..., N].  `out` may be given (and may be `residual` itself).  Raises BevopsError with status
@@ -45,11 +62,14 @@ def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
     nbytes = handle.bevops_linear_workspace_size()
     stream = _lib.current_stream_ptr(x.device)
     ws = _workspace(x.device, nbytes, stream)
-    with torch.cuda.device(x.device):
-        st = handle.bevops_linear_bias_act(
-            _lib.F16, x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+    args = (_lib.F16, x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
             r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K, int(bool(relu)), ws.data_ptr(),
             nbytes, stream)
+    with torch.cuda.device(x.device):
+        key = (str(x.device), M, N, K, bool(relu), bias is not None, r2 is not None)
+        if key not in _TUNED and not torch.cuda.is_current_stream_capturing():
+            _tune_once(handle, key, args, x2, (M, N))
+        st = handle.bevops_linear_bias_act(*args)
     _lib.check(st, "bevops_linear_bias_act")
     return out.view(*x.shape[:-1], N)
 

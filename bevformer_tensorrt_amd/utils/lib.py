@@ -61,6 +61,8 @@ SIGNATURES = {
     "bevops_linear_workspace_size": (c_size_t, []),
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                                   c_void_p, c_size_t, c_void_p]),
+    "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
+                                                              c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),
     "bevops_mdconv_pack_weight": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "bevops_grid_sampler_3d_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +

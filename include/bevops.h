@@ -15,9 +15,18 @@
  *     throws across the ABI; launch errors are returned, not printed.
  *   - all pointers are DEVICE pointers unless the name ends in `_host`.
  *   - the caller owns every buffer (inputs, outputs, workspace); the library
- *     allocates nothing and keeps no mutable global state.
+ *     allocates no device memory.  Process state it DOES keep, all of it
+ *     invisible in results: (1) per kernel instance, the dynamic-LDS limit it
+ *     has already raised on a device; (2) bevops_linear_*: one hipBLASLt handle
+ *     per device and the algorithm chosen per problem, under a mutex (as the
+ *     reference keeps the cuBLAS handle TensorRT attaches,
+ *     modulatedDeformableConv2dPlugin.cpp:286-290); (3) the `*_set_variant`
+ *     A/B hooks (thread-local, default 0 = automatic choice; tests and probes
+ *     only).  Every operator entry is re-entrant from several host threads.
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
- *     void*; NULL = the default stream).  No host synchronisation inside.
+ *     void*; NULL = the default stream).  No operator synchronises the host or
+ *     is illegal under stream capture; the ONE blocking entry is the optional
+ *     tuning call bevops_linear_tune, which says so.
  *   - tensors are dense, row-major ("kLINEAR"), 16-byte aligned.
  *   - dtype enums: BEVOPS_F32 / BEVOPS_F16 / BEVOPS_I8.  INT8 tensors carry a
  *     per-tensor scale (real = int8 * scale), as TensorRT's
@@ -318,6 +327,14 @@ size_t bevops_linear_workspace_size(void);
 int bevops_linear_bias_act(int dtype, const void *a, const void *weight, const void *bias,
                            const void *residual, void *out, long long M, int N, int K, int relu,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* OPTIONAL, BLOCKING: pick the hipBLASLt algorithm for one bevops_linear_bias_act problem (same
+ * arguments) by timing every supporting algorithm on `stream` with the caller's buffers, and cache
+ * it for the process.  `out` is scratch and must not alias `residual`.  Synchronises the host;
+ * BAD_PARAM under stream capture.  Without it the operator runs the library heuristic's choice
+ * (measured 1.5-3x slower at the backbone's shapes). */
+int bevops_linear_tune(int dtype, const void *a, const void *weight, const void *bias,
+                       const void *residual, void *out, long long M, int N, int K, int relu,
+                       void *workspace, size_t workspace_bytes, void *stream);
 int bevops_mdconv_forward_packed(int dtype, const void *input, const void *offset,
                                  const void *mask, const void *packed_weight, const void *bias,
                                  void *output, void *workspace, size_t workspace_bytes, int B,

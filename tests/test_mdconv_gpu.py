@@ -225,3 +225,27 @@ def test_conv_offset_rows_variant_matches_default(bev, shape):
     want = F.conv2d(x.float(), w.float(), b.float(), 1, 1)
     assert (got[:, :27].float() - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
     assert (got.float() - ref.float()).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())  # same products, other sum order
+
+
+def test_packed_weight_cache_survives_dtype_conversion():
+    """nn.Module.half() swaps the storage of the SAME Parameter object without bumping its
+    version counter: the packed-weight cache must notice (dtype / data pointer are part of its
+    stamp) instead of handing the fp32-packed image to the fp16 kernel."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(2, 64, 20, 24, generator=g).cuda()
+    off = (torch.randn(2, 18, 20, 24, generator=g) * 1.5).cuda()
+    mask = torch.rand(2, 9, 20, 24, generator=g).cuda()
+    y32 = bev.modulated_deformable_conv2d(x, off, mask, conv.weight, conv.bias, 1, 1, 1, 1, 1)
+    w_obj = conv.weight
+    conv.half()
+    assert conv.weight is w_obj and conv.weight.dtype == torch.float16
+    y16 = bev.modulated_deformable_conv2d(x.half(), off.half(), mask.half(), conv.weight, conv.bias, 1, 1, 1, 1, 1)
+    y16b = bev.modulated_deformable_conv2d(x.half(), off.half(), mask.half(), conv.weight, conv.bias, 1, 1, 1, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y16).all() and torch.equal(y16, y16b)
+    assert (y16.float() - y32).abs().max().item() <= 3e-2 * max(1.0, y32.abs().max().item())
+    conv.float()
+    y32b = bev.modulated_deformable_conv2d(x, off, mask, conv.weight, conv.bias, 1, 1, 1, 1, 1)
+    assert (y32b - y32).abs().max().item() <= 1e-2   # weights went through fp16 once
