@@ -744,7 +744,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         // hm4 (software-pipelined, msda_hm4.hip): default for the many-point calls; variant 17
         // forces it for every shape it supports, 170 + k picks a chunk size, 16 keeps hm3
         const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant >= 200 && g_variant < 232) || (g_variant == 0 && pays && LP >= 16);
+                        (g_variant >= 200 && g_variant < 456) || (g_variant == 0 && pays && LP >= 16);
         if (spatial_shapes_host && h4) {
           static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(

@@ -37,118 +37,112 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // re-layouts
 // ------------------------------------------------------------------------------------------------
-// fp16: big set = pixel-pair entries 32 x half2(v[f][c], v[f+1][c]); staged set = row-major pixels.
-// thread = (b, entry, head, 16-byte chunk of the entry); the entry is decomposed into (level,
-// padded row, column) once.
+// Grid of both re-layout kernels: x = 32-entry slabs of a plane (big set first, then staged set),
+// y = (batch, head) plane; 256 threads = 32 entries x 8 chunks.  Only ONE division per thread (the
+// padded row of its entry, in floating point -- exact, see `row_of`); batch / head come from
+// blockIdx.y.
+__device__ __forceinline__ int row_of(int rel, int wp) {
+  // floor(rel / wp) for 0 <= rel < 2^22: (rel + 0.5) / wp is never closer than 0.5 / wp to an integer
+  return (int)(((float)rel + 0.5f) / (float)wp);
+}
+struct RepackPos {
+  bool big;
+  int f, lv, yp, x;   // entry, level (-1: none), padded row, column
+};
+__device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int lane_entry) {
+  RepackPos p;
+  const int big_slabs = (t.g_entries + 31) >> 5;
+  p.big = slab < big_slabs;
+  p.f = ((p.big ? slab : slab - big_slabs) << 5) + lane_entry;
+  const int entries = p.big ? t.g_entries : t.s_entries;
+  p.lv = -1;
+  p.yp = p.x = 0;
+  if (p.f >= entries) { p.f = -1; return p; }
+  const int l0 = p.big ? 0 : t.ls, l1 = p.big ? t.ls : t.L;
+  for (int l = l0; l < l1; ++l)
+    if (p.f >= t.ent0[l] - 1) p.lv = l;   // the entry before a level's first one is a base too
+  if (p.lv >= 0) {
+    const int wp = t.W[p.lv] + 1, rel = p.f - t.ent0[p.lv];
+    p.yp = rel < 0 ? -1 : row_of(rel, wp);
+    p.x = rel - p.yp * wp;
+    if (p.yp > t.H[p.lv] + 1) p.lv = -1;  // trailing entry of the set
+  }
+  return p;
+}
+
+// fp16: big set = pixel-pair entries 32 x half2(v[f][c], v[f+1][c]); staged set = row-major pixels
 __global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *__restrict__ value,
                                                                   char *__restrict__ gset,
                                                                   char *__restrict__ sset, Hm3Tab t,
-                                                                  int bs, int nk, int heads) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
-  const bool big = idx < n_big;
-  const size_t j = big ? idx : idx - n_big;
-  const int chunks = big ? 8 : 4;
-  const int ck = (int)(j % chunks);
-  const int h = (int)((j / chunks) % heads);
-  const size_t r = (j / chunks) / heads;
-  const int entries = big ? t.g_entries : t.s_entries;
-  if (entries == 0) return;
-  const int f = (int)(r % entries);
-  const size_t b = r / entries;
-  if (b >= (size_t)bs) return;
-  const int l0 = big ? 0 : t.ls, l1 = big ? t.ls : t.L;
-  int lv = -1;
-  for (int l = l0; l < l1; ++l)
-    if (f >= t.ent0[l] - 1) lv = l;
-  uint2 p0 = make_uint2(0, 0), p1 = make_uint2(0, 0);  // big: 4 channels of pixels f, f+1
-  uint4 q = make_uint4(0, 0, 0, 0);                    // staged: 8 channels of pixel f
-  if (lv >= 0) {
-    const int W = t.W[lv], H = t.H[lv], wp = W + 1;
-    const int rel = f - t.ent0[lv];
-    const int yp = rel < 0 ? -1 : rel / wp;
-    const int x = rel - yp * wp;
-    const __half *base = value + (((size_t)b * nk + t.src0[lv]) * heads + h) * 32;
+                                                                  int nk, int heads) {
+  const int ck = threadIdx.x & 7;
+  const RepackPos p = repack_pos(t, blockIdx.x, threadIdx.x >> 3);
+  if (p.f < 0) return;
+  const unsigned bh = blockIdx.y, b = bh / (unsigned)heads, h = bh - b * (unsigned)heads;
+  uint2 p0 = make_uint2(0, 0), p1 = make_uint2(0, 0);
+  uint4 q = make_uint4(0, 0, 0, 0);
+  if (p.lv >= 0) {
+    const int W = t.W[p.lv], H = t.H[p.lv], wp = W + 1;
+    const __half *base = value + (((size_t)b * nk + t.src0[p.lv]) * heads + h) * 32;
     auto src = [&](int yy, int xx) -> const __half * {   // padded (row, column) -> pixel or null
       if (xx >= wp) { xx -= wp; ++yy; }
       if (yy < 1 || yy > H || xx >= W) return nullptr;
       return base + ((size_t)(yy - 1) * W + xx) * heads * 32;
     };
-    if (yp <= H + 1) {
-      if (big) {
-        if (const __half *s0 = src(yp, x)) p0 = *reinterpret_cast<const uint2 *>(s0 + ck * 4);
-        if (const __half *s1 = src(yp, x + 1)) p1 = *reinterpret_cast<const uint2 *>(s1 + ck * 4);
-      } else if (const __half *s0 = src(yp, x)) {
-        q = *reinterpret_cast<const uint4 *>(s0 + ck * 8);
-      }
+    if (p.big) {
+      if (const __half *s0 = src(p.yp, p.x)) p0 = *reinterpret_cast<const uint2 *>(s0 + ck * 4);
+      if (const __half *s1 = src(p.yp, p.x + 1)) p1 = *reinterpret_cast<const uint2 *>(s1 + ck * 4);
+    } else if (ck < 4) {
+      if (const __half *s0 = src(p.yp, p.x)) q = *reinterpret_cast<const uint4 *>(s0 + ck * 8);
     }
   }
-  if (big) {
+  if (p.big) {
     uint4 o;
     o.x = (p0.x & 0xffffu) | (p1.x << 16);
     o.y = (p0.x >> 16) | (p1.x & 0xffff0000u);
     o.z = (p0.y & 0xffffu) | (p1.y << 16);
     o.w = (p0.y >> 16) | (p1.y & 0xffff0000u);
-    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + ck * 16) = o;
-  } else {
-    *reinterpret_cast<uint4 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + ck * 16) = q;
+    *reinterpret_cast<uint4 *>(gset + ((size_t)bh * t.g_entries + p.f) * kEntBytes + ck * 16) = o;
+  } else if (ck < 4) {
+    *reinterpret_cast<uint4 *>(sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes + ck * 16) = q;
   }
 }
 
 // int8: big set = 2x2-footprint entries (dword c of 16-byte chunk k = channel 4k+c of pixels
-// f, f+1, f+W', f+W'+1); staged set = pixel-pair entries (bytes c(x0), c(x1) interleaved).
-// thread = (b, entry, head, chunk of 4 channels).  The entry is decomposed into (level, padded
-// row, column) ONCE; its neighbours follow by stepping, wrapping at the end of a padded row.
+// f, f+1, f+W', f+W'+1); staged set = pixel-pair entries (bytes c(x0), c(x1) interleaved)
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                 int bs, int nk, int heads) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t n_big = (size_t)bs * t.g_entries * heads * 8;
-  const bool big = idx < n_big;
-  const size_t j = big ? idx : idx - n_big;
-  const int c8 = (int)(j & 7);
-  const int h = (int)((j >> 3) % heads);
-  const size_t r = (j >> 3) / heads;
-  const int entries = big ? t.g_entries : t.s_entries;
-  if (entries == 0) return;
-  const int f = (int)(r % entries);
-  const size_t b = r / entries;
-  if (b >= (size_t)bs) return;
-  // level whose padded block [ent0 - 1, ent0 + (H + 2) W') holds f (the entry before a level's
-  // first one is the base of the samples left of and above its first pixel)
-  const int l0 = big ? 0 : t.ls, l1 = big ? t.ls : t.L;
-  int lv = -1;
-  for (int l = l0; l < l1; ++l)
-    if (f >= t.ent0[l] - 1) lv = l;
+                                                                 int nk, int heads, unsigned bias) {
+  // `bias` = 0x80808080 for the x255 flavour: its planes hold v + 128 as u8 (pads included: they
+  // stand for the value 0), see i8_sample_u
+  const int c8 = threadIdx.x & 7;
+  const RepackPos p = repack_pos(t, blockIdx.x, threadIdx.x >> 3);
+  if (p.f < 0) return;
+  const unsigned bh = blockIdx.y, b = bh / (unsigned)heads, h = bh - b * (unsigned)heads;
   unsigned px[4] = {0u, 0u, 0u, 0u};  // pixels f, f+1, f+W', f+W'+1 (4 channels each)
-  if (lv >= 0) {
-    const int W = t.W[lv], H = t.H[lv], wp = W + 1;
-    const int rel = f - t.ent0[lv];
-    int yp = rel < 0 ? -1 : rel / wp;
-    int x = rel - yp * wp;
-    const int8_t *base = value + (((size_t)b * nk + t.src0[lv]) * heads + h) * 32 + c8 * 4;
+  if (p.lv >= 0) {
+    const int W = t.W[p.lv], H = t.H[p.lv], wp = W + 1;
+    const int8_t *base = value + (((size_t)b * nk + t.src0[p.lv]) * heads + h) * 32 + c8 * 4;
     auto at = [&](int yy, int xx) -> unsigned {   // padded (row, column) -> 4 channels or zeros
       if (xx >= wp) { xx -= wp; ++yy; }
       if (yy < 1 || yy > H || xx >= W) return 0u;
       return *reinterpret_cast<const unsigned *>(base + ((size_t)(yy - 1) * W + xx) * heads * 32);
     };
-    if (yp <= H + 1) {
-      px[0] = at(yp, x);
-      px[1] = at(yp, x + 1);
-      if (big) { px[2] = at(yp + 1, x); px[3] = at(yp + 1, x + 1); }
-    }
+    px[0] = at(p.yp, p.x);
+    px[1] = at(p.yp, p.x + 1);
+    if (p.big) { px[2] = at(p.yp + 1, p.x); px[3] = at(p.yp + 1, p.x + 1); }
   }
-  if (big) {
+  if (p.big) {
     unsigned o[4];
     transpose4x4(px[0], px[1], px[2], px[3], o);
-    *reinterpret_cast<uint4 *>(gset + (((size_t)b * heads + h) * t.g_entries + f) * kEntBytes + c8 * 16) =
-        make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4 *>(gset + ((size_t)bh * t.g_entries + p.f) * kEntBytes + c8 * 16) =
+        make_uint4(o[0] ^ bias, o[1] ^ bias, o[2] ^ bias, o[3] ^ bias);
   } else {
     uint2 o;
-    o.x = __builtin_amdgcn_perm(px[1], px[0], 0x05010400u);  // c0(x0), c0(x1), c1(x0), c1(x1)
-    o.y = __builtin_amdgcn_perm(px[1], px[0], 0x07030602u);  // c2(x0), c2(x1), c3(x0), c3(x1)
-    *reinterpret_cast<uint2 *>(sset + (((size_t)b * heads + h) * t.s_entries + f) * kLdsPixBytes + c8 * 8) = o;
+    o.x = __builtin_amdgcn_perm(px[1], px[0], 0x05010400u) ^ bias;  // c0(x0), c0(x1), c1(x0), c1(x1)
+    o.y = __builtin_amdgcn_perm(px[1], px[0], 0x07030602u) ^ bias;  // c2(x0), c2(x1), c3(x0), c3(x1)
+    *reinterpret_cast<uint2 *>(sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes + c8 * 8) = o;
   }
 }
 
@@ -189,29 +183,21 @@ __device__ __forceinline__ void i8_sample_s(const unsigned (&v)[4], unsigned aw,
       : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(aw), "v"(magic), "v"(half));
 }
-// unsigned x255 area weights (gfx950 has no mixed-sign dot4): v * a = dot4(v, a ^ 0x80) + 128 * dot4(v, 1)
-__device__ __forceinline__ void i8_sample_u(const unsigned (&v)[4], unsigned awx, int magic, int half,
+// unsigned x255 area weights (gfx950 has no mixed-sign dot4): the x255 flavour's planes hold the
+// values BIASED by +128 (u8), so sum (v + 128) a - 128 sum(a) is ONE unsigned dot4 whose addend
+// `neg` = -128 (a0 + a1 + a2 + a3) rides in the record
+__device__ __forceinline__ void i8_sample_u(const unsigned (&v)[4], unsigned aw, int neg, int magic, int half,
                                             int (&x)[4]) {
-  int t0, t1, t2, t3;
-  const int ones = 0x01010101;
-  asm("v_dot4_i32_i8 %0, %8, %12, 0\n\t"
-      "v_dot4_i32_i8 %4, %8, %13, 0\n\t"
-      "v_dot4_i32_i8 %1, %9, %12, 0\n\t"
-      "v_dot4_i32_i8 %5, %9, %13, 0\n\t"
-      "v_dot4_i32_i8 %2, %10, %12, 0\n\t"
-      "v_dot4_i32_i8 %6, %10, %13, 0\n\t"
-      "v_dot4_i32_i8 %3, %11, %12, 0\n\t"
-      "v_dot4_i32_i8 %7, %11, %13, 0\n\t"
-      "v_lshl_add_u32 %0, %4, 7, %0\n\t"
-      "v_lshl_add_u32 %1, %5, 7, %1\n\t"
-      "v_lshl_add_u32 %2, %6, 7, %2\n\t"
-      "v_lshl_add_u32 %3, %7, 7, %3\n\t"
-      "v_mad_i32_i24 %0, %0, %14, %15 clamp\n\t"
-      "v_mad_i32_i24 %1, %1, %14, %15 clamp\n\t"
-      "v_mad_i32_i24 %2, %2, %14, %15 clamp\n\t"
-      "v_mad_i32_i24 %3, %3, %14, %15 clamp"
-      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(awx), "v"(ones), "v"(magic), "v"(half));
+  asm("v_dot4_u32_u8 %0, %4, %8, %9\n\t"
+      "v_dot4_u32_u8 %1, %5, %8, %9\n\t"
+      "v_dot4_u32_u8 %2, %6, %8, %9\n\t"
+      "v_dot4_u32_u8 %3, %7, %8, %9\n\t"
+      "v_mad_i32_i24 %0, %0, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %1, %1, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %2, %2, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %3, %3, %10, %11 clamp"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(aw), "v"(neg), "v"(magic), "v"(half));
 }
 // the four samples' top bytes -> one dword (sample 0 in byte 0)
 __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
@@ -224,8 +210,10 @@ __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
 // <float> flavour with signed x127 weights); RefT: reference point type (fp16 path: __half).
 // NBIG: batches (of BT points) served by the L1/L2 path, the remaining ones come from LDS.
 // RR: the PP reference points of an owner lane are one contiguous run (BEVFormer SCA: 4 anchors).
-// ABL: timing ablations for tools/hm4_probe.py (results are WRONG when non-zero): 1 no L1/L2 taps,
+// ABL: timing ablations for tools/hm4_probe.py (results are WRONG with bits 0-4): 1 no L1/L2 taps,
 // 2 no LDS taps, 4 no operand requests inside the loop, 8 no front end inside the loop, 16 no store.
+// Schedule variants with correct results: 32 operand request at the END of the loop body, 64 one
+// big batch in flight instead of two, 128 default cache policy for the streamed operands / output.
 template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
@@ -233,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   constexpr int BT = LP >= 4 ? 4 : LP;    // points per tap batch
   constexpr int NB = LP / BT;
   constexpr int NLDS = NB - NBIG;
-  constexpr int D = NBIG >= 2 ? 2 : 1;    // big batches in flight
+  constexpr int D = (NBIG >= 2 && !(ABL & 64)) ? 2 : 1;    // big batches in flight
   constexpr int kBox = LP * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
   constexpr int ESZ = I8 ? 1 : 2;         // bytes per logit / offset component
   static_assert(NBIG >= 0 && NBIG <= NB, "NBIG");
@@ -344,7 +332,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   const unsigned rf_base = b * (unsigned)d.nq * (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
   const unsigned rf_q = (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
   static_assert(!RR || PP == 4, "RR");
-  constexpr int aux = LP >= 32 ? 2 : 0;   // long read-once rows: non-temporal, the maps keep the L2
+  constexpr int aux = (LP >= 32 && !(ABL & 128)) ? 2 : 0;   // long read-once rows: non-temporal, the maps keep the L2
   auto request = [&](Pre &r, unsigned q) {
     const unsigned o_lg = lg_base + q * lg_q, o_of = 2u * o_lg, o_rf = rf_base + q * rf_q;
 #pragma unroll
@@ -483,6 +471,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         }
         pl[k].x = (a0 & 255u) | ((a1 & 255u) << 8) | ((a2 & 255u) << 16) | ((a3 & 255u) << 24);
         pl[k].y = valid ? (unsigned)wq[k] : 0u;
+        if constexpr (U8W) pl[k].y |= (a0 + a1 + a2 + a3) << 8;   // <= 1020
       } else {
         const float ev = valid ? e[k] : 0.f;
         const float wr1 = ly * ev, wr0 = ev - wr1;
@@ -524,12 +513,12 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   }
   for (; i < n_items; i += kStride) {
     const unsigned q = query_of(i);
-    if constexpr (!(ABL & 4)) request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
-    else pre2 = pre1;
+    if constexpr (ABL & 4) pre2 = pre1;
+    else if constexpr (!(ABL & 32)) request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
     float s_nxt;
     bool any_nxt;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int ia[4] = {0, 0, 0, 0}, ib[4] = {0, 0, 0, 0};
+    int ia[4] = {0, 0, 0, 0}, wsum = 0;
     if (__any(any_cur)) {
       uint4 bp[D][BT];
       u32x4 r0[D][BT], r1[D][BT];
@@ -548,22 +537,24 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         int x[BT][4];
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
-          if constexpr (U8W) i8_sample_u(v[j], rec[j].x ^ 0x80808080u, magic, half, x[j]);
+          if constexpr (U8W) i8_sample_u(v[j], rec[j].x, -(int)((rec[j].y >> 8) << 7), magic, half, x[j]);
           else i8_sample_s(v[j], rec[j].x, magic, half, x[j]);
         }
         unsigned w4 = rec[0].y & 0xffu;
         if constexpr (BT > 1) w4 |= (rec[1].y & 0xffu) << 8;
         if constexpr (BT > 2) w4 |= (rec[2].y & 0xffu) << 16;
-        if constexpr (BT > 3) w4 |= rec[3].y << 24;
+        if constexpr (BT > 3) w4 |= (rec[3].y & 0xffu) << 24;
+        if constexpr (U8W) {
+          // unsigned softmax weights: s w = (s + 128) w - 128 w; the second term once per batch
+          wsum += (int)__builtin_amdgcn_udot4(w4, 0x01010101u, 0u, false);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int g4 = gather_hi(x[0][c], BT > 1 ? x[1][c] : 0, BT > 2 ? x[2][c] : 0, BT > 3 ? x[3][c] : 0);
-          if constexpr (U8W) {  // unsigned weights: s * w = s * (w - 128) + 128 * s
-            ia[c] = __builtin_amdgcn_sdot4(g4, (int)(w4 ^ 0x80808080u), ia[c], false);
-            ib[c] = __builtin_amdgcn_sdot4(g4, 0x01010101, ib[c], false);
-          } else {
+          if constexpr (U8W)
+            ia[c] = (int)__builtin_amdgcn_udot4((unsigned)g4 ^ 0x80808080u, w4, (unsigned)ia[c], false);
+          else
             ia[c] = __builtin_amdgcn_sdot4(g4, (int)w4, ia[c], false);
-          }
         }
       };
       auto consume = [&](int tb) {
@@ -684,7 +675,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         const float f = scale_o * (1.0f / s_cur);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int av = U8W ? ia[c] + (ib[c] << 7) : ia[c];
+          const int av = U8W ? ia[c] - (wsum << 7) : ia[c];
           const int rq = U8W ? t2i8_rne((float)av * f) : t2i8_away((float)av * f);
           res |= ((unsigned)rq & 0xffu) << (8 * c);
         }
@@ -699,13 +690,14 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
       v.y = pack_h2(acc[2] * inv, acc[3] * inv);
       if constexpr (ABL & 16) {
         if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<uint2 *>(outp) = v;  // keeps the math alive
-      } else if constexpr (LP >= 32) {
+      } else if constexpr (LP >= 32 && !(ABL & 128)) {
         __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x,
                                     reinterpret_cast<unsigned long long *>(outp));
       } else {
         *reinterpret_cast<uint2 *>(outp) = v;
       }
     }
+    if constexpr ((ABL & 32) && !(ABL & 4)) request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
     if constexpr (!(ABL & 8)) post(pl);
     s_cur = s_nxt;
     any_cur = any_nxt;
@@ -755,6 +747,7 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
 #define BEVOPS_H4_ABL(A) if (ablate == A) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, A>(a, st);
         BEVOPS_H4_ABL(1) BEVOPS_H4_ABL(2) BEVOPS_H4_ABL(3) BEVOPS_H4_ABL(4) BEVOPS_H4_ABL(8) BEVOPS_H4_ABL(12)
         BEVOPS_H4_ABL(15) BEVOPS_H4_ABL(16) BEVOPS_H4_ABL(19) BEVOPS_H4_ABL(31) BEVOPS_H4_ABL(11) BEVOPS_H4_ABL(7)
+        BEVOPS_H4_ABL(32) BEVOPS_H4_ABL(64) BEVOPS_H4_ABL(96) BEVOPS_H4_ABL(128) BEVOPS_H4_ABL(160) BEVOPS_H4_ABL(224)
 #undef BEVOPS_H4_ABL
       }
     }
@@ -822,14 +815,13 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
   a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
   const bool i8 = dtype == BEVOPS_I8;
   {
-    const size_t threads = (size_t)bs * t.g_entries * heads * 8 + (size_t)bs * t.s_entries * heads * (i8 ? 8 : 4);
-    const dim3 grid((unsigned)((threads + 255) / 256));
+    const dim3 grid((unsigned)(((t.g_entries + 31) >> 5) + ((t.s_entries + 31) >> 5)), (unsigned)(bs * heads));
     if (i8)
-      hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t,
-                         bs, nk, heads);
+      hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
+                         heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
     else
-      hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t,
-                         bs, nk, heads);
+      hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t, nk,
+                         heads);
   }
   if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, a, ablate, st);
   if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, a, ablate, st);

@@ -26,7 +26,7 @@ def ablations(lib):
         s = float(t.abs().max()) / 127.0
         return torch.clamp(torch.round(t / s), -127, 127).to(torch.int8), s
     qv, s_v = q(value); qo, s_o = q(off); qw, s_w = q(logit)
-    for mask in (0, 1, 2, 3, 4, 8, 12, 15, 16, 19, 31, 11, 7):
+    for mask in [int(m) for m in os.environ.get("MASKS", "0,1,2,3,4,8,12,15,16,19,31,11,7").split(",")]:
         for dt in ("f16", "i8"):
             lib.bevops_msda_set_variant(200 + mask if mask else 17)
             try:
@@ -42,10 +42,32 @@ def ablations(lib):
                 lib.bevops_msda_set_variant(0)
 
 
+def kernels(lib):
+    """A few launches of each base-SCA flavour for `rocprofv3 --kernel-trace --stats` (per-kernel times)."""
+    args, _ = gen(SHAPES["base_sca"], torch.float16, "uniform")
+    value, sh, ref, off, logit = gen(SHAPES["base_sca"], torch.float32, "uniform")[0]
+
+    def q(t):
+        s = float(t.abs().max()) / 127.0
+        return torch.clamp(torch.round(t / s), -127, 127).to(torch.int8), s
+    qv, s_v = q(value); qo, s_o = q(off); qw, s_w = q(logit)
+    for v in (16, 17):
+        lib.bevops_msda_set_variant(v)
+        for _ in range(6):
+            bev.multi_scale_deformable_attn(*args)
+    lib.bevops_msda_set_variant(0)
+    for r in (ref, ref.half()):
+        for _ in range(6):
+            bev.multi_scale_deformable_attn_int8(qv, sh, r, qo, qw, s_v, s_o, s_w, 0.02)
+    torch.cuda.synchronize()
+
+
 def main():
     lib = load_library()
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         return ablations(lib)
+    if len(sys.argv) > 1 and sys.argv[1] == "kernels":
+        return kernels(lib)
     plan = [("base_sca", "uniform", [16, 17, 172, 175, 176]), ("base_sca", "rig", [16, 17]),
             ("base_tsa", "uniform", [0, 10, 17]), ("small_tsa", "uniform", [0, 17]), ("small_sca", "uniform", [0, 17])]
     for name, dist, variants in plan:
