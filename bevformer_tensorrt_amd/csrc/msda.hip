@@ -648,6 +648,57 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
+extern "C" size_t bevops_msda_packed_size(int dtype, const int32_t *spatial_shapes_host, int bs, int nk,
+                                          int heads, int channels, int num_levels, int num_query,
+                                          int num_point) {
+  if ((dtype != BEVOPS_F16 && dtype != BEVOPS_I8) || !spatial_shapes_host || bs <= 0 || nk <= 0 || heads <= 0 ||
+      num_levels <= 0 || num_query <= 0 || num_point <= 0)
+    return 0;
+  return msda_hm4_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels, num_query, num_point);
+}
+
+extern "C" int bevops_msda_pack_value(int dtype, int ref_dtype, const void *value,
+                                      const int32_t *spatial_shapes_host, void *packed, size_t packed_bytes,
+                                      int bs, int nk, int heads, int channels, int num_levels, int num_query,
+                                      int num_point, void *stream) {
+  if (!value || !spatial_shapes_host || !packed) return BEVOPS_BAD_PARAM;
+  if (bs <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0)
+    return BEVOPS_BAD_PARAM;
+  long total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const long H = spatial_shapes_host[2 * l], W = spatial_shapes_host[2 * l + 1];
+    if (H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
+    total += H * W;
+  }
+  if (total != nk) return BEVOPS_BAD_PARAM;
+  return msda_hm4_pack(dtype, ref_dtype, value, spatial_shapes_host, bs, nk, heads, channels, num_levels,
+                       num_query, num_point, packed, packed_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bevops_msda_forward_prepacked(int dtype, const void *packed, size_t packed_bytes,
+                                             const int32_t *spatial_shapes_host, const void *reference_points,
+                                             int ref_dtype, const void *sampling_offsets,
+                                             const void *attention_weights, void *output, int bs, int nk,
+                                             int heads, int channels, int num_levels, int num_query,
+                                             int num_point, int points_per_group, float scale_value,
+                                             float scale_offset, float scale_weight, float scale_out,
+                                             int shared_offsets, void *stream) {
+  if (!packed || !spatial_shapes_host || !reference_points || !sampling_offsets || !attention_weights || !output)
+    return BEVOPS_BAD_PARAM;
+  if (bs <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0 || points_per_group <= 0)
+    return BEVOPS_BAD_PARAM;
+  if (dtype == BEVOPS_F16 && ref_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (dtype == BEVOPS_I8 && (!(scale_value > 0.f) || !(scale_offset > 0.f) || !(scale_weight > 0.f) ||
+                             !(scale_out > 0.f)))
+    return BEVOPS_BAD_PARAM;
+  return msda_hm4_forward_prepacked(dtype, ref_dtype, packed, packed_bytes, spatial_shapes_host, reference_points,
+                                    sampling_offsets, attention_weights, output, bs, nk, heads, channels,
+                                    num_levels, num_query, num_point, points_per_group, shared_offsets ? 1 : 0,
+                                    scale_value, scale_offset, scale_weight, scale_out, 0, 0,
+                                    static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t bevops_sca_workspace_size(int dtype, const int32_t *spatial_shapes_host, int num_cams,
                                             int nk, int heads, int channels, int num_levels,
                                             int num_query, int num_point) {
@@ -744,7 +795,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         // hm4 (software-pipelined, msda_hm4.hip): default for the many-point calls; variant 17
         // forces it for every shape it supports, 170 + k picks a chunk size, 16 keeps hm3
         const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant >= 200 && g_variant < 456) || (g_variant == 0 && pays && LP >= 16);
+                        (g_variant >= 200 && g_variant <= 456) || (g_variant == 0 && pays && LP >= 16);
         if (spatial_shapes_host && h4) {
           static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(

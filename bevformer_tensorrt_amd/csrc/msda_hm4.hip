@@ -37,10 +37,11 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // re-layouts
 // ------------------------------------------------------------------------------------------------
-// Grid of both re-layout kernels: x = 32-entry slabs of a plane (big set first, then staged set),
-// y = (batch, head) plane; 256 threads = 32 entries x 8 chunks.  Only ONE division per thread (the
-// padded row of its entry, in floating point -- exact, see `row_of`); batch / head come from
-// blockIdx.y.
+// Grid of both re-layout kernels: x = slabs of kSlab entries (big set first, then staged set),
+// y = batch; a block's 256 threads = (entry of the slab, head, 16-byte chunk of the head's 64 / 32
+// bytes) with the head and chunk FASTEST, so a wave reads whole source pixels (all heads of a
+// pixel are contiguous in the reference layout) and writes whole 128-byte entries.  One division
+// per thread for the padded row (floating point, exact -- `row_of`).
 __device__ __forceinline__ int row_of(int rel, int wp) {
   // floor(rel / wp) for 0 <= rel < 2^22: (rel + 0.5) / wp is never closer than 0.5 / wp to an integer
   return (int)(((float)rel + 0.5f) / (float)wp);
@@ -49,11 +50,11 @@ struct RepackPos {
   bool big;
   int f, lv, yp, x;   // entry, level (-1: none), padded row, column
 };
-__device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int lane_entry) {
+__device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int per_slab, int lane_entry) {
   RepackPos p;
-  const int big_slabs = (t.g_entries + 31) >> 5;
+  const int big_slabs = (t.g_entries + per_slab - 1) / per_slab;
   p.big = slab < big_slabs;
-  p.f = ((p.big ? slab : slab - big_slabs) << 5) + lane_entry;
+  p.f = (p.big ? slab : slab - big_slabs) * per_slab + lane_entry;
   const int entries = p.big ? t.g_entries : t.s_entries;
   p.lv = -1;
   p.yp = p.x = 0;
@@ -74,11 +75,13 @@ __device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int l
 __global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *__restrict__ value,
                                                                   char *__restrict__ gset,
                                                                   char *__restrict__ sset, Hm3Tab t,
-                                                                  int nk, int heads) {
+                                                                  int nk, int heads, int per_slab) {
   const int ck = threadIdx.x & 7;
-  const RepackPos p = repack_pos(t, blockIdx.x, threadIdx.x >> 3);
+  const unsigned hq = threadIdx.x >> 3, le = hq / (unsigned)heads, h = hq - le * (unsigned)heads;
+  if ((int)le >= per_slab) return;
+  const RepackPos p = repack_pos(t, blockIdx.x, per_slab, (int)le);
   if (p.f < 0) return;
-  const unsigned bh = blockIdx.y, b = bh / (unsigned)heads, h = bh - b * (unsigned)heads;
+  const unsigned b = blockIdx.y, bh = b * (unsigned)heads + h;
   uint2 p0 = make_uint2(0, 0), p1 = make_uint2(0, 0);
   uint4 q = make_uint4(0, 0, 0, 0);
   if (p.lv >= 0) {
@@ -113,13 +116,15 @@ __global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                 int nk, int heads, unsigned bias) {
+                                                                 int nk, int heads, int per_slab, unsigned bias) {
   // `bias` = 0x80808080 for the x255 flavour: its planes hold v + 128 as u8 (pads included: they
   // stand for the value 0), see i8_sample_u
   const int c8 = threadIdx.x & 7;
-  const RepackPos p = repack_pos(t, blockIdx.x, threadIdx.x >> 3);
+  const unsigned hq = threadIdx.x >> 3, le = hq / (unsigned)heads, h = hq - le * (unsigned)heads;
+  if ((int)le >= per_slab) return;
+  const RepackPos p = repack_pos(t, blockIdx.x, per_slab, (int)le);
   if (p.f < 0) return;
-  const unsigned bh = blockIdx.y, b = bh / (unsigned)heads, h = bh - b * (unsigned)heads;
+  const unsigned b = blockIdx.y, bh = b * (unsigned)heads + h;
   unsigned px[4] = {0u, 0u, 0u, 0u};  // pixels f, f+1, f+W', f+W'+1 (4 channels each)
   if (p.lv >= 0) {
     const int W = t.W[p.lv], H = t.H[p.lv], wp = W + 1;
@@ -747,6 +752,7 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
 #define BEVOPS_H4_ABL(A) if (ablate == A) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, A>(a, st);
         BEVOPS_H4_ABL(1) BEVOPS_H4_ABL(2) BEVOPS_H4_ABL(3) BEVOPS_H4_ABL(4) BEVOPS_H4_ABL(8) BEVOPS_H4_ABL(12)
         BEVOPS_H4_ABL(15) BEVOPS_H4_ABL(16) BEVOPS_H4_ABL(19) BEVOPS_H4_ABL(31) BEVOPS_H4_ABL(11) BEVOPS_H4_ABL(7)
+        if (ablate == 256) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, 0>(a, st);
         BEVOPS_H4_ABL(32) BEVOPS_H4_ABL(64) BEVOPS_H4_ABL(96) BEVOPS_H4_ABL(128) BEVOPS_H4_ABL(160) BEVOPS_H4_ABL(224)
 #undef BEVOPS_H4_ABL
       }
@@ -755,12 +761,15 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
   }
   // points of an owner lane (4 of them when L*P = 32) share ONE run of reference points
   const bool rr = LP == 32 && a.d.ppg == 4 && a.d.P % 4 == 0;
+  // production schedule (profiles/r02/hm4_variants.jsonl): fp16 requests the next operands at
+  // the END of the loop body (32); int8 streams them with the default cache policy (128)
+  constexpr int PROD = I8 ? 128 : 32;
 #define BEVOPS_H4_CASE(LP_, NBIG_)                                                        \
   if (LP == LP_ && nbig == NBIG_) {                                                       \
     if constexpr (LP_ == 32) {                                                            \
-      if (rr) return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, true>(a, st);               \
+      if (rr) return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, true, PROD>(a, st);         \
     }                                                                                     \
-    return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false>(a, st);                        \
+    return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false, PROD>(a, st);                  \
   }
   BEVOPS_H4_CASE(32, 4)   // base SCA: 4 levels x 8 points, two levels staged
   BEVOPS_H4_CASE(32, 8)   //   ... nothing staged (few queries)
@@ -771,6 +780,11 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
   BEVOPS_H4_CASE(4, 0)
 #undef BEVOPS_H4_CASE
   return BEVOPS_NOT_SUPPORTED;
+}
+
+bool h4_instantiated(int LP, int nbig) {
+  return (LP == 32 && (nbig == 4 || nbig == 8 || nbig == 6)) || (LP == 8 && (nbig == 0 || nbig == 2)) ||
+         (LP == 4 && (nbig == 1 || nbig == 0));
 }
 
 int h4_chunk(const Hm3Plan &p, int nq, int variant_chunk) {
@@ -786,27 +800,55 @@ size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
   return ((pl.p.g_bytes + 127) & ~size_t(127)) + 128 + pl.p.s_bytes;
 }
 
-// dtype: BEVOPS_F16 (ref fp16) or BEVOPS_I8 (ref fp32 -> x127 flavour, ref fp16 -> x255 flavour)
-int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
-                     const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
-                     int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
-                     void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st) {
+// The call in two halves (bevops_msda_pack_value / bevops_msda_forward_prepacked): the re-layout
+// of `value` into the padded head-major sets, and the sampling kernel on those sets -- for callers
+// that sample one value tensor several times, or produce the packed form themselves.
+// dtype: BEVOPS_F16 (ref fp16) or BEVOPS_I8 (ref fp32 -> x127 flavour, ref fp16 -> x255 flavour:
+// its planes are biased, so the packed form is flavour-specific).
+int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, int bs, int nk,
+                  int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st) {
+  H4Plan pl;
+  if (C != 32 || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) || !shapes_host ||
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl))
+    return BEVOPS_NOT_SUPPORTED;
+  if (dtype != BEVOPS_F16 && dtype != BEVOPS_I8) return BEVOPS_NOT_SUPPORTED;
+  const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
+  if (packed_bytes < g_room + pl.p.s_bytes) return BEVOPS_BAD_PARAM;
+  if (heads > 32) return BEVOPS_NOT_SUPPORTED;
+  char *gset = static_cast<char *>(packed);
+  char *sset = gset + g_room;
+  const Hm3Tab &t = pl.p.t;
+  const int per_slab = 32 / heads > 0 ? 32 / heads : 1;   // entries of a 256-thread block
+  const dim3 grid((unsigned)((t.g_entries + per_slab - 1) / per_slab + (t.s_entries + per_slab - 1) / per_slab),
+                  (unsigned)bs);
+  if (dtype == BEVOPS_I8)
+    hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
+                       heads, per_slab, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
+  else
+    hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t, nk,
+                       heads, per_slab);
+  return launch_status();
+}
+
+int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, size_t packed_bytes,
+                               const int32_t *shapes_host, const void *ref, const void *off, const void *logit,
+                               void *out, int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
+                               int shared, float s_v, float s_o, float s_w, float s_out, int chunk_override,
+                               int ablate, hipStream_t st) {
   const int LP = L * P;
   H4Plan pl;
-  if (C != 32 || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) || !shapes_host ||
+  if (C != 32 || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) || !shapes_host ||
       !h4_plan(shapes_host, bs, heads, L, P, nq, pl))
     return BEVOPS_NOT_SUPPORTED;
   if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
   const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
-  if (workspace_bytes < g_room + pl.p.s_bytes) return BEVOPS_NOT_SUPPORTED;
-  char *gset = static_cast<char *>(workspace);
-  char *sset = gset + g_room;
-  const Hm3Tab &t = pl.p.t;
+  if (packed_bytes < g_room + pl.p.s_bytes) return BEVOPS_NOT_SUPPORTED;
+  const char *gset = static_cast<const char *>(packed);
   H4Args a;
-  a.gset = gset; a.g_bytes = (unsigned)pl.p.g_bytes; a.sset = sset;
+  a.gset = gset; a.g_bytes = (unsigned)pl.p.g_bytes; a.sset = gset + g_room;
   a.ref = ref; a.off = off; a.logit = logit; a.out = out;
   a.d = MsdaDims{bs, nk, heads, C, L, nq, P, ppg, shared};
-  a.t = t;
+  a.t = pl.p.t;
   a.chunk = h4_chunk(pl.p, nq, chunk_override);
   if (a.chunk > 0xffff) a.chunk = 0xff00;
   a.nchunk = (nq + a.chunk - 1) / a.chunk;
@@ -814,19 +856,27 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
   a.qmask = nullptr;
   a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
   const bool i8 = dtype == BEVOPS_I8;
-  {
-    const dim3 grid((unsigned)(((t.g_entries + 31) >> 5) + ((t.s_entries + 31) >> 5)), (unsigned)(bs * heads));
-    if (i8)
-      hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
-                         heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
-    else
-      hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t, nk,
-                         heads);
-  }
   if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, a, ablate, st);
   if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, a, ablate, st);
   if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, a, ablate, st);
   return BEVOPS_NOT_SUPPORTED;
+}
+
+int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
+                     const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
+                     int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
+                     void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st) {
+  H4Plan pl;   // (checked first so that an unsupported shape costs no launch)
+  if (C != 32 || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) || !shapes_host ||
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl) || !h4_instantiated(L * P, pl.nbig))
+    return BEVOPS_NOT_SUPPORTED;
+  const int rc = msda_hm4_pack(dtype, ref_dtype, value, shapes_host, bs, nk, heads, C, L, nq, P, workspace,
+                               workspace_bytes, st);
+  if (rc == BEVOPS_BAD_PARAM) return BEVOPS_NOT_SUPPORTED;   // workspace too small: the caller's other kernels
+  if (rc != BEVOPS_SUCCESS) return rc;
+  return msda_hm4_forward_prepacked(dtype, ref_dtype, workspace, workspace_bytes, shapes_host, ref, off, logit, out,
+                                    bs, nk, heads, C, L, nq, P, ppg, shared, s_v, s_o, s_w, s_out, chunk_override,
+                                    ablate, st);
 }
 
 }  // namespace bevops

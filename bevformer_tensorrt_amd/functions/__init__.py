@@ -4,6 +4,8 @@ from .multi_scale_deformable_attn import (
     multi_scale_deformable_attn,
     multi_scale_deformable_attn2,
     multi_scale_deformable_attn_int8,
+    msda_pack_value,
+    multi_scale_deformable_attn_prepacked,
 )
 from .rotate import rotate, rotate2, rotate_int8, rotate_hwc
 from .grid_sampler import grid_sampler, grid_sampler2, grid_sampler_int8
@@ -33,4 +35,5 @@ __all__ = [
     "bev_pool_v2", "bev_pool_v2_2", "bev_pool_v2_int8",
     "modulated_deformable_conv2d", "modulated_deformable_conv2d2", "modulated_deformable_conv2d_int8",
     "spatial_cross_attention_sample", "modulated_deformable_conv2d_nhwc", "bias_act_nhwc_", "linear_bias_act", "layer_norm", "rotate_hwc", "conv_offset_nhwc",
+    "msda_pack_value", "multi_scale_deformable_attn_prepacked",
 ]

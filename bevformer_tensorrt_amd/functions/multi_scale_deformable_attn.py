@@ -169,3 +169,71 @@ def multi_scale_deformable_attn_int8(value, value_spatial_shapes, reference_poin
     fp32 (signed x127 weights) or fp16 (unsigned x255 weights)."""
     return _msda(value, value_spatial_shapes, reference_points, sampling_offsets,
                  attention_weights, (scale_value, scale_offset, scale_weight, scale_out))
+
+
+class PackedValue:
+    """`value` in the padded head-major form of the library (bevops_msda_pack_value): opaque bytes
+    plus the call geometry they were packed for."""
+
+    def __init__(self, data, dtype, ref_dtype, shapes_host, shapes_dev, dims):
+        self.data, self.dtype, self.ref_dtype = data, dtype, ref_dtype
+        self.shapes_host, self.shapes_dev, self.dims = shapes_host, shapes_dev, dims
+
+
+def msda_pack_value(value, value_spatial_shapes, num_query, num_point, reference_dtype=None, out=None):
+    """Re-lay `value` [bs, nk, heads, 32] (fp16 or int8) once for several
+    `multi_scale_deformable_attn_prepacked` calls with the same (num_query, num_point).  For int8 the
+    packed form depends on the flavour: pass the dtype of the reference points (float32 -> x127
+    weights, float16 -> x255 weights)."""
+    assert value.is_cuda and value.dim() == 4
+    handle = _lib.load_library()
+    bs, nk, heads, ch = value.shape
+    L = value_spatial_shapes.shape[0]
+    dt = _lib.torch_dtype_code(value)
+    rdt = _lib.F16 if reference_dtype in (None, torch.float16) else _lib.F32
+    if dt == _lib.F16:
+        rdt = _lib.F16
+    shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, value.device)
+    if shapes_host is None:
+        shapes_host = _host_shapes(shapes_dev)
+    nbytes = handle.bevops_msda_packed_size(dt, shapes_host.data_ptr(), bs, nk, heads, ch, L, num_query, num_point)
+    if nbytes == 0:
+        raise _lib.BevopsError("bevops_msda_packed_size: shape outside the head-major domain", _lib.NOT_SUPPORTED)
+    if out is None or out.numel() < nbytes:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+    value = value.contiguous()
+    with torch.cuda.device(value.device):
+        st = handle.bevops_msda_pack_value(dt, rdt, value.data_ptr(), shapes_host.data_ptr(), out.data_ptr(),
+                                           out.numel(), bs, nk, heads, ch, L, num_query, num_point,
+                                           _lib.current_stream_ptr(value.device))
+    _lib.check(st, "bevops_msda_pack_value")
+    return PackedValue(out, value.dtype, rdt, shapes_host, shapes_dev, (bs, nk, heads, ch, L, num_query, num_point))
+
+
+def multi_scale_deformable_attn_prepacked(packed, reference_points, sampling_offsets, attention_weights,
+                                          scales=(1.0, 1.0, 1.0, 1.0), out=None):
+    """The sampling half of the op on a `PackedValue` (bevops_msda_forward_prepacked); same arguments
+    and result as `multi_scale_deformable_attn[_int8]` otherwise."""
+    handle = _lib.load_library()
+    bs, nk, heads, ch, L, nq, P = packed.dims
+    ppg = reference_points.shape[-1] // 2
+    if sampling_offsets.shape[1] != nq or attention_weights.numel() // (attention_weights.shape[0] * nq * heads * L) != P:
+        raise ValueError("offsets / weights do not match the geometry the value was packed for")
+    if _lib.torch_dtype_code(reference_points) != packed.ref_dtype:
+        raise TypeError("reference_points dtype differs from the flavour the value was packed for")
+    shared = (bs > 1 and sampling_offsets.stride(0) == 0 and attention_weights.stride(0) == 0)
+    if shared:
+        sampling_offsets, attention_weights = sampling_offsets[:1], attention_weights[:1]
+    reference_points, sampling_offsets, attention_weights = (
+        t.contiguous() for t in (reference_points, sampling_offsets, attention_weights))
+    dev = packed.data.device
+    if out is None:
+        out = torch.empty((bs, nq, heads, ch), dtype=packed.dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = handle.bevops_msda_forward_prepacked(
+            _lib.torch_dtype_code(out), packed.data.data_ptr(), packed.data.numel(), packed.shapes_host.data_ptr(),
+            reference_points.data_ptr(), packed.ref_dtype, sampling_offsets.data_ptr(), attention_weights.data_ptr(),
+            out.data_ptr(), bs, nk, heads, ch, L, nq, P, ppg, float(scales[0]), float(scales[1]), float(scales[2]),
+            float(scales[3]), int(shared), _lib.current_stream_ptr(dev))
+    _lib.check(st, "bevops_msda_forward_prepacked")
+    return out

@@ -27,6 +27,10 @@ SIGNATURES = {
     "bevops_msda_forward_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                                [c_float] * 4 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "bevops_msda_packed_size": (c_size_t, [c_int, c_void_p] + [c_int] * 7),
+    "bevops_msda_pack_value": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
+    "bevops_msda_forward_prepacked": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_void_p] + [c_int] * 8 + [c_float] * 4 + [c_int, c_void_p]),
     "bevops_sca_workspace_size": (c_size_t, [c_int, c_void_p] + [c_int] * 7),
     "bevops_sca_forward": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "bevops_rotate_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

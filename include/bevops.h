@@ -316,6 +316,25 @@ int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, con
  * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
 int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                       size_t rows, int channels, float eps, void *stream);
+/* The MSDA call in two halves, for callers that sample ONE value tensor several times or want the
+ * re-layout off their critical path (not a reference plugin: the plugin's enqueue is
+ * bevops_msda_forward[_ws], which does both).  `packed` = the padded head-major form of `value`
+ * (csrc/msda_pad.h, msda_hm4.hip), bevops_msda_packed_size() bytes, 128-byte aligned, caller-owned;
+ * it depends on (dtype, shapes, bs, heads, num_query, num_point) and, for int8, on the flavour
+ * (ref_dtype).  packed_size == 0 / NOT_SUPPORTED: shape outside the head-major domain (32 channels
+ * per head, the instantiated (levels x points) combinations) -- use bevops_msda_forward. */
+size_t bevops_msda_packed_size(int dtype, const int32_t *spatial_shapes_host, int bs, int nk, int heads,
+                               int channels, int num_levels, int num_query, int num_point);
+int bevops_msda_pack_value(int dtype, int ref_dtype, const void *value, const int32_t *spatial_shapes_host,
+                           void *packed, size_t packed_bytes, int bs, int nk, int heads, int channels,
+                           int num_levels, int num_query, int num_point, void *stream);
+int bevops_msda_forward_prepacked(int dtype, const void *packed, size_t packed_bytes,
+                                  const int32_t *spatial_shapes_host, const void *reference_points,
+                                  int ref_dtype, const void *sampling_offsets, const void *attention_weights,
+                                  void *output, int bs, int nk, int heads, int channels, int num_levels,
+                                  int num_query, int num_point, int points_per_group, float scale_value,
+                                  float scale_offset, float scale_weight, float scale_out, int shared_offsets,
+                                  void *stream);
 /* out[M, N] = act(a[M, K] . weight[N, K]^T + bias[N] + residual[M, N]) -- the dense layers around the
  * sampler (value_proj / output_proj / FFN) and the 1x1 convolutions of the
  * channels-last backbone as ONE hipBLASLt GEMM whose epilogue carries shift + identity + ReLU

@@ -127,3 +127,31 @@ def test_int8_default_choice_at_full_base_size(ctx, ref_dtype):
     a = run(ctx, args, 0, (s_v, s_o, s_w, 0.02))
     b = run(ctx, args, 10, (s_v, s_o, s_w, 0.02))
     same_as_quad(a, b, ref_dtype, "base_sca")
+
+
+@pytest.mark.parametrize("flavour", ["fp16", "s8w_f32ref", "u8w_f16ref"])
+def test_prepacked_equals_one_call(ctx, flavour):
+    """bevops_msda_pack_value + bevops_msda_forward_prepacked == the forced-hm4 single call, bit for
+    bit; one packed value serves several sampling calls."""
+    bev, lib = ctx
+    shape = SHAPES["base_sca_q4k"][0]
+    if flavour == "fp16":
+        args = gen(shape, dtype=torch.float16)
+        packed = bev.msda_pack_value(args[0], args[1], shape[2], shape[3])
+        for seed in (0, 1):
+            other = gen(shape, seed=seed, dtype=torch.float16)
+            a = bev.multi_scale_deformable_attn_prepacked(packed, other[2], other[3], other[4])
+            b = run(ctx, [args[0], args[1], other[2], other[3], other[4]], 17)
+            assert torch.equal(a, b)
+        return
+    rdt = torch.float32 if flavour.startswith("s8w") else torch.float16
+    value, sh, ref, off, logit = make(shape)
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    packed = bev.msda_pack_value(qv.cuda(), sh.cuda(), shape[2], shape[3], reference_dtype=rdt)
+    scales = (s_v, s_o, s_w, 0.02)
+    a = bev.multi_scale_deformable_attn_prepacked(packed, ref.to(rdt).cuda(), qo.cuda(), qw.cuda(), scales)
+    b = run(ctx, (qv.cuda(), sh.cuda(), ref.to(rdt).cuda(), qo.cuda(), qw.cuda()), 17, scales)
+    assert torch.equal(a, b)
+    with pytest.raises(TypeError):   # packed for one flavour, sampled with the other
+        bev.multi_scale_deformable_attn_prepacked(packed, ref.to(torch.float16 if rdt == torch.float32 else torch.float32).cuda(),
+                                                  qo.cuda(), qw.cuda(), scales)

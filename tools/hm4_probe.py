@@ -59,6 +59,16 @@ def kernels(lib):
     for r in (ref, ref.half()):
         for _ in range(6):
             bev.multi_scale_deformable_attn_int8(qv, sh, r, qo, qw, s_v, s_o, s_w, 0.02)
+    # int8 DCNv2 at the two ResNet-101 shapes (kernel breakdown of bevops_mdconv_forward_int8)
+    g = torch.Generator().manual_seed(0)
+    for (B, C, H, W) in ((6, 256, 58, 100), (6, 512, 29, 50)):
+        x = torch.randint(-127, 128, (B, C, H, W), generator=g, dtype=torch.int8).cuda()
+        off = torch.randint(-127, 128, (B, 18, H, W), generator=g, dtype=torch.int8).cuda()
+        mask = torch.randint(0, 128, (B, 9, H, W), generator=g, dtype=torch.int8).cuda()
+        w = torch.randint(-127, 128, (C, C, 3, 3), generator=g, dtype=torch.int8).cuda()
+        b = torch.zeros(C).cuda()
+        for _ in range(6):
+            bev.modulated_deformable_conv2d_int8(x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.01, 0.05, 1, 1, 1, 1, 1)
     torch.cuda.synchronize()
 
 
