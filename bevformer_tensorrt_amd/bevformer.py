@@ -629,6 +629,18 @@ class FrameRunner:
             self.prev_bev.copy_(bev)     # state update is part of the graph
         self._out = (cls, crd)
 
+    def step_raw(self, raw_images, can_bus, lidar2img, scene_token):
+        """Frame from RAW camera images [6, H0, W0, 3] (uint8 or fp32, BGR, on the device): the
+        reference's NormalizeMultiviewImage + PadMultiViewImage(32) + format bundle
+        (configs/bevformer/bevformer_base.py:11,228-231) run as one HIP pass straight into the frame's
+        static input buffer, then `step`."""
+        fn = getattr(self.model.ops, "image_normalize_pad", None)
+        if fn is None:
+            raise RuntimeError("the operator set has no image_normalize_pad")
+        buf = self._in["image"][0]
+        fn(raw_images, dtype=buf.dtype, out=buf)
+        return self.step(buf[None], can_bus, lidar2img, scene_token)
+
     def step(self, image, can_bus, lidar2img, scene_token):
         can_bus = can_bus.clone().float()
         use_prev = 0.0 if scene_token != self.prev["scene"] else 1.0          # evaluate_trt.py:86-88

@@ -65,6 +65,8 @@ SIGNATURES = {
     "bevops_linear_workspace_size": (c_size_t, []),
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                                   c_void_p, c_size_t, c_void_p]),
+    "bevops_image_normalize_pad": (c_int, [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 +
+                                   [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int, c_void_p]),
     "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                               c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),
@@ -73,7 +75,7 @@ SIGNATURES = {
                                        [c_void_p]),
 }
 
-F32, F16, I8 = 0, 1, 2
+F32, F16, I8, U8 = 0, 1, 2, 3
 
 
 def lib_path():

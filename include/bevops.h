@@ -50,7 +50,7 @@ typedef enum {
   BEVOPS_NOT_INITIALIZED = 4  /* STATUS_NOT_INITIALIZED  helper.h:24 */
 } bevops_status_t;
 
-typedef enum { BEVOPS_F32 = 0, BEVOPS_F16 = 1, BEVOPS_I8 = 2 } bevops_dtype_t;
+typedef enum { BEVOPS_F32 = 0, BEVOPS_F16 = 1, BEVOPS_I8 = 2, BEVOPS_U8 = 3 /* raw camera images only */ } bevops_dtype_t;
 
 /* interpolation / padding enums: functions/grid_sampler.py:134-136,
  * gridSamplerKernel.h:9-12 */
@@ -316,6 +316,16 @@ int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, con
  * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
 int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                       size_t rows, int channels, float eps, void *stream);
+/* Camera-image front end of the frame loop (not a plugin): the reference's test
+ * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
+ * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/
+ * transform_3d.py:99-150; mmcv.imnormalize) in one pass.  `images` [N, H0, W0, 3] BEVOPS_U8 or
+ * BEVOPS_F32 (BGR as loaded) -> `output` [N, 3, Hp, Wp] (channels_last: [N, Hp, Wp, 3]) BEVOPS_F16
+ * or BEVOPS_F32 = ((x [swapped to RGB if to_rgb] - mean[c]) * (1 / std[c])), zeros in the padding
+ * rows / columns (Hp >= H0, Wp >= W0).  mean_host / std_host: 3 floats on the HOST. */
+int bevops_image_normalize_pad(int in_dtype, const void *images, int out_dtype, void *output, int N,
+                               int H0, int W0, int Hp, int Wp, const float *mean_host,
+                               const float *std_host, int to_rgb, int channels_last, void *stream);
 /* The MSDA call in two halves, for callers that sample ONE value tensor several times or want the
  * re-layout off their critical path (not a reference plugin: the plugin's enqueue is
  * bevops_msda_forward[_ws], which does both).  `packed` = the padded head-major form of `value`

@@ -234,7 +234,69 @@ def make_geometry_base():
     print("geometry base", cam.shape, mask.shape, res["sha256"])
 
 
+def reference_test_calibration():
+    """The 6-camera nuScenes calibration hard-coded in the reference's bev_pool test
+    (det2trt/models/utils/test_trt_ops/test_bev_pool_v2.py:56-...): run its `bev_pool_prepare()` with
+    `get_lidar_coor` replaced by a recorder and keep the five tensors it is called with."""
+    src = open(os.path.join(REF, "det2trt/models/utils/test_trt_ops/test_bev_pool_v2.py")).read()
+    src = src.split("class ")[0].replace("from .base_test_case import BaseTestCase", "")
+    src = src.replace('device="cuda"', 'device="cpu"').replace(".cuda()", "")
+    ns = {}
+    exec(compile(src, "ref_test_bev_pool_v2", "exec"), ns)
+
+    class _Got(Exception):
+        pass
+
+    def recorder(*args):
+        raise _Got(args)
+
+    ns["get_lidar_coor"] = recorder
+    try:
+        ns["bev_pool_prepare"]()
+    except _Got as g:
+        return [t.clone() for t in g.args[0]]
+    raise RuntimeError("bev_pool_prepare did not call get_lidar_coor")
+
+
+def make_bevdet_geometry():
+    """LSSViewTransformer's own geometry methods (third_party/bev_mmdet3d/models/necks/
+    view_transformer.py:66-168,239-312) lifted and run on CPU at the BEVDet-R50 config
+    (configs/bevdet/bevdet-r50-cbgs.py:44-104) with the reference test's calibration."""
+    path = "third_party/bev_mmdet3d/models/necks/view_transformer.py"
+    names = ["create_grid_infos", "create_frustum", "get_lidar_coor", "voxel_pooling_prepare_v2"]
+    fns = {n: lift(path, "LSSViewTransformer", n) for n in names}
+    cfg = dict(x=[-51.2, 51.2, 0.8], y=[-51.2, 51.2, 0.8], z=[-5, 3, 8], depth=[1.0, 60.0, 1.0])
+    me = Stub(sid=False)
+    fns["create_grid_infos"](me, **cfg)
+    me.frustum = fns["create_frustum"](me, cfg["depth"], (256, 704), 16)
+    sensor2ego, cam2imgs, post_rots, post_trans, bda = reference_test_calibration()
+    # the test's rig is calibrated for 512x1408 inputs; BEVDet-R50 runs the same cameras at 256x704:
+    # the image-view augmentation (post_rots / post_trans) scales by one half
+    post_rots = post_rots.clone()
+    post_rots[..., :2, :2] *= 0.5
+    post_trans = post_trans.clone() * 0.5
+    coor = fns["get_lidar_coor"](me, sensor2ego, None, cam2imgs, post_rots, post_trans, bda)
+    ranks = fns["voxel_pooling_prepare_v2"](me, coor)
+    names5 = ["ranks_bev", "ranks_depth", "ranks_feat", "interval_starts", "interval_lengths"]
+    res = {"sensor2ego": sensor2ego.numpy(), "cam2imgs": cam2imgs.numpy(), "post_rots": post_rots.numpy(),
+           "post_trans": post_trans.numpy(), "bda": bda.numpy(), "D": np.int32(me.D),
+           "frustum_sha256": np.array(digest(me.frustum.contiguous().numpy())),
+           "coor_sha256": np.array(digest(coor.contiguous().numpy())),
+           "coor_sample": coor[0, :, ::7, ::3, ::5].contiguous().numpy()}
+    for n, t in zip(names5, ranks):
+        a = t.numpy().astype(np.int32)
+        res[n + "_sha256"] = np.array(digest(a))
+        res[n + "_len"] = np.int64(a.size)
+        res[n + "_head"] = a[:64]
+    np.savez_compressed(os.path.join(HERE, "bevdet_geometry.npz"), **res)
+    print("bevdet geometry: points", int(res["ranks_bev_len"]), "intervals", int(res["interval_starts_len"]), "D", me.D)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "bevdet":
+        make_bevdet_geometry()
+        raise SystemExit(0)
     make_wrappers()
     make_geometry_base()
+    make_bevdet_geometry()
