@@ -56,6 +56,8 @@ const Entry kTable[] = {
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},
+    {"bevops_quantize_rows", (void *)&bevops_quantize_rows},
+    {"bevops_linear_int8", (void *)&bevops_linear_int8},
     {"bevops_image_normalize_pad", (void *)&bevops_image_normalize_pad},
     {"bevops_msda_packed_size", (void *)&bevops_msda_packed_size},
     {"bevops_msda_pack_value", (void *)&bevops_msda_pack_value},

@@ -95,3 +95,45 @@ def layer_norm(x, weight=None, bias=None, eps=1e-5, out=None):
                                       float(eps), _lib.current_stream_ptr(x.device))
     _lib.check(st, "bevops_layer_norm")
     return out.view(x.shape)
+
+
+def quantize_rows(x, scale, out=None):
+    """fp16 tensor -> int8 with one per-tensor scale: clamp(rne(x / scale), -127, 127) (bevops_quantize_rows)."""
+    assert x.is_cuda and x.dtype == torch.float16
+    x = x.contiguous()
+    if x.numel() % 8:
+        raise ValueError("element count must be a multiple of 8")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_quantize_rows(_lib.F16, x.data_ptr(), out.data_ptr(), x.numel(), float(scale),
+                                         _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_quantize_rows")
+    return out
+
+
+def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False, out_dtype=torch.float16,
+                scale_out=1.0):
+    """INT8 GEMM with de-quantising epilogue (bevops_linear_int8): a_q [..., K] int8, w_q [N, K] int8,
+    scale_w a float (per tensor) or an fp32 [N] tensor (per output channel), bias fp32 [N], residual fp16
+    [..., N] -> fp16 (or int8 requantised with scale_out)."""
+    assert a_q.is_cuda and a_q.dtype == torch.int8 and w_q.dtype == torch.int8
+    K, N = a_q.shape[-1], w_q.shape[0]
+    a2 = a_q.reshape(-1, K).contiguous()
+    w_q = w_q.contiguous()
+    M = a2.shape[0]
+    per_channel = torch.is_tensor(scale_w)
+    ws = scale_w.float().contiguous() if per_channel else None
+    b = bias.float().contiguous() if bias is not None else None
+    r = residual.reshape(M, N).contiguous() if residual is not None else None
+    out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(a_q.device):
+        st = handle.bevops_linear_int8(
+            a2.data_ptr(), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,
+            1.0 if per_channel else float(scale_w), b.data_ptr() if b is not None else None,
+            r.data_ptr() if r is not None else None, _lib.torch_dtype_code(out), out.data_ptr(), float(scale_out),
+            M, N, K, int(bool(relu)), _lib.current_stream_ptr(a_q.device))
+    _lib.check(st, "bevops_linear_int8")
+    return out.view(*a_q.shape[:-1], N)

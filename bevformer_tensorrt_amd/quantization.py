@@ -233,3 +233,118 @@ class Int8PluginOps:
         return out.to(x.dtype) * s_out
 
     modulated_deformable_conv2d2 = modulated_deformable_conv2d
+
+
+class LinearQ(torch.nn.Linear):
+    """`LinearQ` of the reference (det2trt/models/utils/register.py:83: pytorch_quantization's
+    QuantLinear, selected through LINEAR_LAYERS at modules/spatial_cross_attention.py:58,329): a
+    Linear whose input and weight are quantised per tensor (symmetric, amax / 127, round half even,
+    clamp to +-127).  Three phases, like the reference's calibrator_qdq flow
+    (det2trt/quantization/calibrator_qdq.py:29-80):
+
+      "float"     plain Linear (what a freshly built or un-calibrated module does);
+      "calibrate" plain Linear while the calibrator collects the input under `self.site`;
+      "int8"      after `freeze()`: the input is quantised (bevops_quantize_rows), the product runs
+                  as an int8 x int8 -> int32 GEMM on the matrix cores with the de-quantising epilogue
+                  (bevops_linear_int8), output in the input's dtype.
+
+    `fake_quant_reference(x)` is the QuantLinear formula itself -- F.linear(dq(q(x)), dq(q(w))) + b --
+    which the int8 path must reproduce up to the fp32 summation order."""
+
+    def __init__(self, in_features, out_features, bias=True, calibrator=None, site=None):
+        super().__init__(in_features, out_features, bias)
+        self.cal = calibrator
+        self.site = site or f"linear@{id(self):x}"
+        self.mode = "float"
+        self.scale_in = None
+        self.register_buffer("weight_q", None, persistent=False)
+        self.scale_w = None
+
+    @classmethod
+    def from_linear(cls, lin, calibrator, site):
+        m = cls(lin.in_features, lin.out_features, lin.bias is not None, calibrator, site)
+        m.weight, m.bias = lin.weight, lin.bias
+        return m.to(lin.weight.device, lin.weight.dtype)
+
+    def calibrate(self):
+        self.mode = "calibrate"
+        return self
+
+    def freeze(self, weight_calibrator=None):
+        """Fix the input scale from the collected statistics, quantise the weight (per tensor;
+        max calibration unless a calibrator class is given, as QuantDescriptor's weight default)."""
+        self.scale_in = float(self.cal.scale(self.site))
+        wc = (weight_calibrator or MinMaxCalibrator)()
+        wc.collect("w", self.weight.detach())
+        self.scale_w = float(wc.scale("w"))
+        self.weight_q = _Base.quantize(self.weight.detach(), self.scale_w).contiguous()
+        self.mode = "int8"
+        return self
+
+    def fake_quant_reference(self, x):
+        xq = torch.clamp(torch.round(x.float() / self.scale_in), -127, 127) * self.scale_in
+        wq = self.weight_q.float() * self.scale_w
+        return torch.nn.functional.linear(xq, wq, None if self.bias is None else self.bias.float())
+
+    def forward(self, x, residual=None, relu=False):
+        if self.mode != "int8":
+            if self.mode == "calibrate":
+                self.cal.collect(self.site, x)
+            y = super().forward(x)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
+        from . import functions as _f
+        xh = x if x.dtype == torch.float16 else x.to(torch.float16)
+        q = _f.quantize_rows(xh, self.scale_in)
+        res = None if residual is None else residual.to(torch.float16)
+        y = _f.linear_int8(q, self.scale_in, self.weight_q, self.scale_w, self.bias, res, relu)
+        return y.to(x.dtype)
+
+
+class Conv2dQ(torch.nn.Conv2d):
+    """`Conv2dQ` (register.py:79: QuantConv2d) for the 1x1 convolutions of the channels-last backbone:
+    a 1x1 convolution on NHWC activations is the LinearQ GEMM over the [N*H*W, C] rows.  Other kernel
+    sizes stay on the library convolution in the model's dtype (TensorRT is free to do the same)."""
+
+    def __init__(self, conv, calibrator, site):
+        assert conv.kernel_size == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
+        super().__init__(conv.in_channels, conv.out_channels, 1, conv.stride, bias=conv.bias is not None)
+        self.weight, self.bias = conv.weight, conv.bias
+        lin = torch.nn.Linear(conv.in_channels, conv.out_channels, conv.bias is not None)
+        lin.weight = torch.nn.Parameter(conv.weight.detach().view(conv.out_channels, conv.in_channels))
+        lin.bias = conv.bias
+        self.lin = LinearQ.from_linear(lin, calibrator, site)
+
+    def calibrate(self):
+        self.lin.calibrate()
+        return self
+
+    def freeze(self):
+        self.lin.freeze()
+        return self
+
+    def forward(self, x):
+        s = self.stride[0]
+        if s > 1:
+            x = x[:, :, ::s, ::s]
+        n, c, h, w = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(-1, c)
+        y = self.lin(rows.contiguous())
+        return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def quantize_dense_layers(model, calibrator, select=lambda name, mod: True):
+    """Swap every nn.Linear of `model` accepted by `select(name, module)` (K % 16 == 0, N % 4 == 0)
+    for a LinearQ sharing its parameters and calibrator.  Returns the list of swapped modules; call
+    `.calibrate()` on them, run calibration frames, then `.freeze()`."""
+    swapped = []
+    for name, mod in list(model.named_modules()):
+        for child_name, child in list(mod.named_children()):
+            full = f"{name}.{child_name}" if name else child_name
+            if type(child) is torch.nn.Linear and child.in_features % 16 == 0 and child.out_features % 4 == 0 \
+                    and select(full, child):
+                q = LinearQ.from_linear(child, calibrator, "linear:" + full)
+                setattr(mod, child_name, q)
+                swapped.append(q)
+    return swapped

@@ -316,6 +316,19 @@ int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, con
  * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
 int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                       size_t rows, int channels, float eps, void *stream);
+/* INT8 dense layers: what TensorRT builds from the reference's `LinearQ` /
+ * `Conv2dQ` (= pytorch_quantization QuantLinear / QuantConv2d, det2trt/models/utils/register.py:78-84):
+ * per-tensor symmetric quantisation of the layer input, int8 x int8 -> int32 GEMM on the matrix cores,
+ * de-quantising epilogue.  Not plugins.
+ *   bevops_quantize_rows: q = clamp(rne(x / scale), -127, 127), x fp16, count % 8 == 0.
+ *   bevops_linear_int8:   out[M, N] = act((a_q[M, K] . w_q[N, K]^T) * scale_a * w_scale[n] + bias[n]
+ *                         + residual[M, N]); w_scales (device, fp32 [N]) per output channel, or NULL
+ *                         for the per-tensor scale_w; bias fp32 (device) optional; residual fp16
+ *                         optional; out fp16, or int8 requantised with scale_out.  K % 16 == 0, N % 4 == 0. */
+int bevops_quantize_rows(int dtype, const void *x, void *q, size_t count, float scale, void *stream);
+int bevops_linear_int8(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
+                       float scale_w, const float *bias, const void *residual, int out_dtype,
+                       void *out, float scale_out, long long M, int N, int K, int relu, void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

@@ -1,0 +1,68 @@
+"""INT8 dense layers: bevops_quantize_rows / bevops_linear_int8 and the LinearQ module
+against the QuantLinear formula they stand for -- F.linear(dq(q(x)), dq(q(w))) + bias with per-tensor
+symmetric scales (pytorch_quantization semantics, det2trt/models/utils/register.py:78-84).  The integer
+GEMM is exact, the fake-quant reference sums fp32 products: bar 2e-3 relative to the output scale
+(fp16 output rounding), and bit-equality against an int64 evaluation of the same integers."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(40000, 256, 256), (40000, 512, 256), (900, 256, 256), (333, 64, 100), (184950, 256, 256)]
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_linear_int8_vs_integer_reference(M, K, N, per_channel):
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).half().cuda()
+    s_x = float(x.abs().max()) / 127
+    q = bev.quantize_rows(x, s_x)
+    want_q = torch.clamp(torch.round(x.float() / s_x), -127, 127).to(torch.int8)
+    assert torch.equal(q, want_q)
+    if per_channel:
+        s_w = (w.abs().amax(1) / 127).clamp_min(1e-12)
+        wq = torch.clamp(torch.round(w / s_w[:, None]), -127, 127).to(torch.int8)
+        sw_arg = s_w.cuda()
+    else:
+        s_w = float(w.abs().max()) / 127
+        wq = torch.clamp(torch.round(w / s_w), -127, 127).to(torch.int8)
+        sw_arg = s_w
+    out = bev.linear_int8(q, s_x, wq.cuda(), sw_arg, b.cuda(), r, relu=True)
+    rows = slice(0, min(M, 2048))
+    acc = q[rows].cpu().long() @ wq.long().t()                      # exact integers
+    scale = (s_x * s_w)[None, :] if per_channel else s_x * s_w
+    want = torch.relu(acc.double() * scale + b.double() + r[rows].cpu().double())
+    err = (out[rows].cpu().double() - want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
+    # int8 output for a following int8 layer
+    o8 = bev.linear_int8(q, s_x, wq.cuda(), sw_arg, b.cuda(), None, relu=False, out_dtype=torch.int8, scale_out=0.05)
+    want8 = torch.clamp(torch.round((acc.double() * scale + b.double()).float() / 0.05), -127, 127)
+    d = (o8[rows].cpu().float() - want8).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3
+
+
+def test_linearq_module_three_phases():
+    from bevformer_tensorrt_amd.quantization import EntropyCalibrator, LinearQ, MinMaxCalibrator
+    g = torch.Generator().manual_seed(1)
+    lin = torch.nn.Linear(256, 512).cuda().half()
+    for cal_cls, tol in ((MinMaxCalibrator, 3e-2), (EntropyCalibrator, 8e-2)):
+        cal = cal_cls()
+        m = LinearQ.from_linear(lin, cal, "site")
+        x = torch.randn(4096, 256, generator=g).half().cuda()
+        y0 = m(x)
+        assert torch.equal(y0, lin(x))
+        m.calibrate()
+        for _ in range(3):
+            m(torch.randn(4096, 256, generator=g).half().cuda())
+        m.freeze()
+        y = m(x)
+        ref = m.fake_quant_reference(x)
+        assert (y.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+        rel = (y.float() - lin(x).float()).abs().mean().item() / lin(x).float().abs().mean().item()
+        assert rel <= tol, rel      # 8-bit per-tensor quantisation noise of a 256-deep dot product
