@@ -273,7 +273,7 @@ def sca_roofline(wl, sca_events):
         byt += wl["sca_bs"] * BASE["sca"]["nq"] * 2 * BASE["sca"]["ppg"] * (2 - wl["esize"])
     achieved = byt / (avg_ms * 1e-3) / 1e9
     kern = ("base SCA MSDA call = msda_hm4_repack_i8_kernel + msda_hm4_kernel<32,4,int8 x255 flavour>" if wl["int8"]
-            else "base SCA MSDA call = msda_hm4_repack_f16_kernel + msda_hm4_kernel<32,4,fp16>")
+            else "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>")
     r = {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,
          "bytes_per_launch": byt, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": len(ms)}

@@ -63,24 +63,25 @@ int launch(const void *img, void *out, int N, int H0, int W0, int Hp, int Wp, co
 using namespace bevops;
 
 extern "C" int bevops_image_normalize_pad(int in_dtype, const void *images, int out_dtype, void *output, int N,
-                                          int H0, int W0, int Hp, int Wp, const float *mean_host,
-                                          const float *std_host, int to_rgb, int channels_last, void *stream) {
+                                          int H0, int W0, int Hp, int Wp, const double *mean_host,
+                                          const double *std_host, int to_rgb, int channels_last, void *stream) {
   if (!images || !output || !mean_host || !std_host) return BEVOPS_BAD_PARAM;
   if (N <= 0 || H0 <= 0 || W0 <= 0 || Hp < H0 || Wp < W0) return BEVOPS_BAD_PARAM;
   if ((size_t)N * Hp * Wp / 256 >= 0x7fffffffull) return BEVOPS_NOT_SUPPORTED;
-  float inv[3];
+  float inv[3], mean[3];
   for (int c = 0; c < 3; ++c) {
-    if (!(std_host[c] > 0.f)) return BEVOPS_BAD_PARAM;
-    inv[c] = (float)(1.0 / (double)std_host[c]);   // mmcv.imnormalize: stdinv = 1 / float64(std)
+    if (!(std_host[c] > 0.0)) return BEVOPS_BAD_PARAM;
+    inv[c] = (float)(1.0 / std_host[c]);   // mmcv.imnormalize: stdinv = 1 / float64(std), applied in float32
+    mean[c] = (float)mean_host[c];
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool u8 = in_dtype == BEVOPS_U8, f32in = in_dtype == BEVOPS_F32;
   if (!u8 && !f32in) return BEVOPS_NOT_SUPPORTED;
   if (out_dtype == BEVOPS_F16)
-    return u8 ? launch<uint8_t, __half>(images, output, N, H0, W0, Hp, Wp, mean_host, inv, to_rgb, channels_last, st)
-              : launch<float, __half>(images, output, N, H0, W0, Hp, Wp, mean_host, inv, to_rgb, channels_last, st);
+    return u8 ? launch<uint8_t, __half>(images, output, N, H0, W0, Hp, Wp, mean, inv, to_rgb, channels_last, st)
+              : launch<float, __half>(images, output, N, H0, W0, Hp, Wp, mean, inv, to_rgb, channels_last, st);
   if (out_dtype == BEVOPS_F32)
-    return u8 ? launch<uint8_t, float>(images, output, N, H0, W0, Hp, Wp, mean_host, inv, to_rgb, channels_last, st)
-              : launch<float, float>(images, output, N, H0, W0, Hp, Wp, mean_host, inv, to_rgb, channels_last, st);
+    return u8 ? launch<uint8_t, float>(images, output, N, H0, W0, Hp, Wp, mean, inv, to_rgb, channels_last, st)
+              : launch<float, float>(images, output, N, H0, W0, Hp, Wp, mean, inv, to_rgb, channels_last, st);
   return BEVOPS_NOT_SUPPORTED;
 }

@@ -792,10 +792,15 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       if (workspace && g_variant != 10 && g_variant != 99 && g_variant != 1 && g_variant != 2) {
         const bool pays = hm_pays(2, bs, nk, heads, channels, num_levels, num_query, num_point);
         const int LP = num_levels * num_point;
-        // hm4 (software-pipelined, msda_hm4.hip): default for the many-point calls; variant 17
-        // forces it for every shape it supports, 170 + k picks a chunk size, 16 keeps hm3
+        // hm4 (software-pipelined, msda_hm4.hip): fp16 default where every pyramid level is
+        // LDS-resident (tiny / small SCA: 106 vs 142 us at small SCA); for the base SCA call hm3 and
+        // hm4 are level (571 vs 579 us kernel, profiles/r02) and hm3 stays.  Variant 17 forces hm4 for
+        // every shape it supports, 170 + k picks a chunk size, 200 + m a schedule / ablation, 16 hm3
+        const bool staged_all = spatial_shapes_host && g_variant == 0 && num_query >= 8192 &&
+                                msda_hm4_all_staged(spatial_shapes_host, bs, heads, channels, num_levels,
+                                                    num_query, num_point);
         const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant >= 200 && g_variant <= 456) || (g_variant == 0 && pays && LP >= 16);
+                        (g_variant >= 200 && g_variant <= 456) || staged_all;
         if (spatial_shapes_host && h4) {
           static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(

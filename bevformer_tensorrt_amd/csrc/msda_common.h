@@ -244,6 +244,7 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
                      const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
                      int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
                      void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st);
+bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
 int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, int bs, int nk,
                   int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st);
 int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, size_t packed_bytes,
@@ -251,6 +252,8 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
                                void *out, int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
                                int shared, float s_v, float s_o, float s_w, float s_out, int chunk_override,
                                int ablate, hipStream_t st);
+void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const void *tab, int bs, int nk, int heads,
+                            hipStream_t st);
 size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                     int P);
 int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref,

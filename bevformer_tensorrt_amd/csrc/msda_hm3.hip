@@ -447,6 +447,17 @@ __global__ __launch_bounds__(256) void sca_camera_reduce_kernel(const __half *__
 
 }  // namespace
 
+// fp16 re-layout into the padded sets (shared with msda_hm4.hip, whose fp16 planes have the same
+// layout; `tab` points at an Hm3Tab -- passed untyped because the struct lives in each
+// translation unit's unnamed namespace)
+void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const void *tab, int bs, int nk, int heads,
+                            hipStream_t st) {
+  const Hm3Tab &t = *static_cast<const Hm3Tab *>(tab);
+  const size_t threads = (size_t)bs * t.g_entries * heads * 8 + (size_t)bs * t.s_entries * heads * 4;
+  hipLaunchKernelGGL(msda_hm3_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                     static_cast<const __half *>(value), gset, sset, t, bs, nk, heads);
+}
+
 size_t msda_hm3_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                 int P) {
   Hm3Plan pl;

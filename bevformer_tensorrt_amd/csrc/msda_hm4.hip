@@ -37,11 +37,12 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // re-layouts
 // ------------------------------------------------------------------------------------------------
-// Grid of both re-layout kernels: x = slabs of kSlab entries (big set first, then staged set),
-// y = batch; a block's 256 threads = (entry of the slab, head, 16-byte chunk of the head's 64 / 32
-// bytes) with the head and chunk FASTEST, so a wave reads whole source pixels (all heads of a
-// pixel are contiguous in the reference layout) and writes whole 128-byte entries.  One division
-// per thread for the padded row (floating point, exact -- `row_of`).
+// Re-layouts.  fp16 planes have hm3's layout and use its kernel (msda_hm3_repack_launch).  int8:
+// grid x = slabs of 32 entries (big set first, then staged set), y = (batch, head) plane; 256
+// threads = 32 entries x 8 chunks of 4 channels; one division per thread for the padded row
+// (floating point, exact -- `row_of`).  (Measured alternatives, profiles/r02: one thread per
+// (entry, head, chunk) with the head fastest 97 us, a 1-D grid with integer divisions 108 us, this
+// mapping 78 us for the base SCA planes.)
 __device__ __forceinline__ int row_of(int rel, int wp) {
   // floor(rel / wp) for 0 <= rel < 2^22: (rel + 0.5) / wp is never closer than 0.5 / wp to an integer
   return (int)(((float)rel + 0.5f) / (float)wp);
@@ -71,60 +72,18 @@ __device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int p
   return p;
 }
 
-// fp16: big set = pixel-pair entries 32 x half2(v[f][c], v[f+1][c]); staged set = row-major pixels
-__global__ __launch_bounds__(256) void msda_hm4_repack_f16_kernel(const __half *__restrict__ value,
-                                                                  char *__restrict__ gset,
-                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                  int nk, int heads, int per_slab) {
-  const int ck = threadIdx.x & 7;
-  const unsigned hq = threadIdx.x >> 3, le = hq / (unsigned)heads, h = hq - le * (unsigned)heads;
-  if ((int)le >= per_slab) return;
-  const RepackPos p = repack_pos(t, blockIdx.x, per_slab, (int)le);
-  if (p.f < 0) return;
-  const unsigned b = blockIdx.y, bh = b * (unsigned)heads + h;
-  uint2 p0 = make_uint2(0, 0), p1 = make_uint2(0, 0);
-  uint4 q = make_uint4(0, 0, 0, 0);
-  if (p.lv >= 0) {
-    const int W = t.W[p.lv], H = t.H[p.lv], wp = W + 1;
-    const __half *base = value + (((size_t)b * nk + t.src0[p.lv]) * heads + h) * 32;
-    auto src = [&](int yy, int xx) -> const __half * {   // padded (row, column) -> pixel or null
-      if (xx >= wp) { xx -= wp; ++yy; }
-      if (yy < 1 || yy > H || xx >= W) return nullptr;
-      return base + ((size_t)(yy - 1) * W + xx) * heads * 32;
-    };
-    if (p.big) {
-      if (const __half *s0 = src(p.yp, p.x)) p0 = *reinterpret_cast<const uint2 *>(s0 + ck * 4);
-      if (const __half *s1 = src(p.yp, p.x + 1)) p1 = *reinterpret_cast<const uint2 *>(s1 + ck * 4);
-    } else if (ck < 4) {
-      if (const __half *s0 = src(p.yp, p.x)) q = *reinterpret_cast<const uint4 *>(s0 + ck * 8);
-    }
-  }
-  if (p.big) {
-    uint4 o;
-    o.x = (p0.x & 0xffffu) | (p1.x << 16);
-    o.y = (p0.x >> 16) | (p1.x & 0xffff0000u);
-    o.z = (p0.y & 0xffffu) | (p1.y << 16);
-    o.w = (p0.y >> 16) | (p1.y & 0xffff0000u);
-    *reinterpret_cast<uint4 *>(gset + ((size_t)bh * t.g_entries + p.f) * kEntBytes + ck * 16) = o;
-  } else if (ck < 4) {
-    *reinterpret_cast<uint4 *>(sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes + ck * 16) = q;
-  }
-}
-
 // int8: big set = 2x2-footprint entries (dword c of 16-byte chunk k = channel 4k+c of pixels
 // f, f+1, f+W', f+W'+1); staged set = pixel-pair entries (bytes c(x0), c(x1) interleaved)
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                 int nk, int heads, int per_slab, unsigned bias) {
+                                                                 int nk, int heads, unsigned bias) {
   // `bias` = 0x80808080 for the x255 flavour: its planes hold v + 128 as u8 (pads included: they
   // stand for the value 0), see i8_sample_u
   const int c8 = threadIdx.x & 7;
-  const unsigned hq = threadIdx.x >> 3, le = hq / (unsigned)heads, h = hq - le * (unsigned)heads;
-  if ((int)le >= per_slab) return;
-  const RepackPos p = repack_pos(t, blockIdx.x, per_slab, (int)le);
+  const RepackPos p = repack_pos(t, blockIdx.x, 32, (int)(threadIdx.x >> 3));
   if (p.f < 0) return;
-  const unsigned b = blockIdx.y, bh = b * (unsigned)heads + h;
+  const unsigned bh = blockIdx.y, b = bh / (unsigned)heads, h = bh - b * (unsigned)heads;
   unsigned px[4] = {0u, 0u, 0u, 0u};  // pixels f, f+1, f+W', f+W'+1 (4 channels each)
   if (p.lv >= 0) {
     const int W = t.W[p.lv], H = t.H[p.lv], wp = W + 1;
@@ -800,6 +759,13 @@ size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
   return ((pl.p.g_bytes + 127) & ~size_t(127)) + 128 + pl.p.s_bytes;
 }
 
+// every level LDS-resident and an instantiated kernel: the shapes where hm4 is the fp16 default
+bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
+  H4Plan pl;
+  return C == 32 && shapes_host && h4_plan(shapes_host, bs, heads, L, P, nq, pl) && pl.nbig == 0 &&
+         h4_instantiated(L * P, 0);
+}
+
 // The call in two halves (bevops_msda_pack_value / bevops_msda_forward_prepacked): the re-layout
 // of `value` into the padded head-major sets, and the sampling kernel on those sets -- for callers
 // that sample one value tensor several times, or produce the packed form themselves.
@@ -814,19 +780,17 @@ int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *sh
   if (dtype != BEVOPS_F16 && dtype != BEVOPS_I8) return BEVOPS_NOT_SUPPORTED;
   const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
   if (packed_bytes < g_room + pl.p.s_bytes) return BEVOPS_BAD_PARAM;
-  if (heads > 32) return BEVOPS_NOT_SUPPORTED;
   char *gset = static_cast<char *>(packed);
   char *sset = gset + g_room;
   const Hm3Tab &t = pl.p.t;
-  const int per_slab = 32 / heads > 0 ? 32 / heads : 1;   // entries of a 256-thread block
-  const dim3 grid((unsigned)((t.g_entries + per_slab - 1) / per_slab + (t.s_entries + per_slab - 1) / per_slab),
-                  (unsigned)bs);
-  if (dtype == BEVOPS_I8)
+  if (dtype == BEVOPS_I8) {
+    if (bs * heads > 65535) return BEVOPS_NOT_SUPPORTED;
+    const dim3 grid((unsigned)(((t.g_entries + 31) >> 5) + ((t.s_entries + 31) >> 5)), (unsigned)(bs * heads));
     hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
-                       heads, per_slab, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
-  else
-    hipLaunchKernelGGL(msda_hm4_repack_f16_kernel, grid, dim3(256), 0, st, (const __half *)value, gset, sset, t, nk,
-                       heads, per_slab);
+                       heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
+  } else {
+    msda_hm3_repack_launch(value, gset, sset, &t, bs, nk, heads, st);
+  }
   return launch_status();
 }
 

@@ -33,8 +33,8 @@ def image_normalize_pad(images, mean=None, std=None, to_rgb=False, size_divisor=
     if out is None:
         out = torch.empty((N, 3, Hp, Wp), dtype=dtype, device=images.device,
                           memory_format=torch.channels_last if channels_last else torch.contiguous_format)
-    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
-    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    m = (ctypes.c_double * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_double * 3)(*[float(v) for v in std])
     handle = _lib.load_library()
     with torch.cuda.device(images.device):
         st = handle.bevops_image_normalize_pad(

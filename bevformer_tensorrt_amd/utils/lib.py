@@ -66,7 +66,7 @@ SIGNATURES = {
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                                   c_void_p, c_size_t, c_void_p]),
     "bevops_image_normalize_pad": (c_int, [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 +
-                                   [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int, c_void_p]),
+                                   [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_int, c_int, c_void_p]),
     "bevops_quantize_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "bevops_linear_int8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                    c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),

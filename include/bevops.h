@@ -335,10 +335,11 @@ int bevops_linear_int8(const void *a_q, float scale_a, const void *w_q, const fl
  * transform_3d.py:99-150; mmcv.imnormalize) in one pass.  `images` [N, H0, W0, 3] BEVOPS_U8 or
  * BEVOPS_F32 (BGR as loaded) -> `output` [N, 3, Hp, Wp] (channels_last: [N, Hp, Wp, 3]) BEVOPS_F16
  * or BEVOPS_F32 = ((x [swapped to RGB if to_rgb] - mean[c]) * (1 / std[c])), zeros in the padding
- * rows / columns (Hp >= H0, Wp >= W0).  mean_host / std_host: 3 floats on the HOST. */
+ * rows / columns (Hp >= H0, Wp >= W0).  mean_host / std_host: 3 doubles on the HOST (mmcv keeps them
+ * as float64: x - float32(mean), times float32(1 / float64(std))). */
 int bevops_image_normalize_pad(int in_dtype, const void *images, int out_dtype, void *output, int N,
-                               int H0, int W0, int Hp, int Wp, const float *mean_host,
-                               const float *std_host, int to_rgb, int channels_last, void *stream);
+                               int H0, int W0, int Hp, int Wp, const double *mean_host,
+                               const double *std_host, int to_rgb, int channels_last, void *stream);
 /* The MSDA call in two halves, for callers that sample ONE value tensor several times or want the
  * re-layout off their critical path (not a reference plugin: the plugin's enqueue is
  * bevops_msda_forward[_ws], which does both).  `packed` = the padded head-major form of `value`

@@ -3,7 +3,10 @@
 which needs nuScenes + checkpoints): the re-hosted BEVFormer with its plugin call sites (MSDA,
 rotate, DCNv2) on the INT8 operators -- scales from the native PTQ calibrators over K calibration
 frames -- against the same weights on the fp16 operators, on frames NOT used for calibration.
-usage: int8_model_delta.py [tiny|small ...] [--calib K] [--frames N] [--calibrator entropy|minmax|percentile]"""
+With --dense the dense layers of the encoder / decoder blocks (value_proj, sampling_offsets,
+attention_weights, output_proj, FFN) additionally run as LinearQ (int8 x int8 GEMM, per-tensor scales from
+the same calibrator; det2trt/models/utils/register.py:78-84), reported next to the plugin-only figure.
+usage: int8_model_delta.py [tiny|small ...] [--calib K] [--frames N] [--calibrator entropy|minmax|percentile] [--dense]"""
 import argparse
 import json
 import os
@@ -13,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
-from bevformer_tensorrt_amd.quantization import Int8PluginOps  # noqa: E402
+from bevformer_tensorrt_amd.quantization import Int8PluginOps, quantize_dense_layers  # noqa: E402
 
 
 def frame(i, H, W, dev, dtype, gen):
@@ -23,13 +26,18 @@ def frame(i, H, W, dev, dtype, gen):
     return img, can
 
 
-def run(name, calib, frames, calibrator):
+def run(name, calib, frames, calibrator, dense=False):
     dev, dtype = torch.device("cuda"), torch.float16
     H, W = B.CONFIGS[name]["image"]
     l2i = G.synthetic_lidar2img((H, W)).to(dev)
     qops = Int8PluginOps(calibrator)
     model_q = B.BEVFormer(name, ops=qops, seed=0).to(dev, dtype)
     qops.attach(model_q)
+    dense_q = []
+    if dense:   # encoder / decoder blocks only (the backbone's 1x1 convolutions stay in fp16 here)
+        dense_q = quantize_dense_layers(model_q, qops.cal, lambda n, m: n.startswith(("encoder.", "decoder.")))
+        for m in dense_q:
+            m.calibrate()
     model_f = B.BEVFormer(name, seed=0).to(dev, dtype)                 # fp16 operators (fused paths on)
     run_q, run_f = B.FrameRunner(model_q, dev, dtype), B.FrameRunner(model_f, dev, dtype)
     gen = torch.Generator().manual_seed(1)
@@ -37,6 +45,8 @@ def run(name, calib, frames, calibrator):
         img, can = frame(i, H, W, dev, dtype, gen)
         run_q.step(img, can, l2i, "calib")
     scales = qops.freeze()
+    for m in dense_q:
+        m.freeze()
     run_q = B.FrameRunner(model_q, dev, dtype)   # fresh temporal state for the evaluation sequence
     rel, cls_err, crd_err, top1 = [], [], [], []
     for i in range(frames):
@@ -50,6 +60,7 @@ def run(name, calib, frames, calibrator):
         top1.append((cq[-1].argmax(-1) == cf[-1].argmax(-1)).float().mean().item())
     m = lambda v: round(sum(v) / len(v), 5)
     return dict(model=name, calibrator=calibrator, calib_frames=calib, eval_frames=frames, int8_sites=len(scales),
+                int8_dense_layers=len(dense_q),
                 bev_embed_rel_err=m(rel), bev_embed_rel_err_last=round(rel[-1], 5), cls_logit_mae=m(cls_err),
                 box_coord_mae=m(crd_err), top1_class_agreement=m(top1))
 
@@ -60,6 +71,9 @@ if __name__ == "__main__":
     ap.add_argument("--calib", type=int, default=3)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--calibrator", default="entropy")
+    ap.add_argument("--dense", action="store_true")
     a = ap.parse_args()
     for mname in a.models:
         print(json.dumps(run(mname, a.calib, a.frames, a.calibrator)), flush=True)
+        if a.dense:
+            print(json.dumps(run(mname, a.calib, a.frames, a.calibrator, dense=True)), flush=True)
