@@ -38,9 +38,11 @@ template <> __device__ __forceinline__ float fromf<float>(float v) { return v; }
 template <> __device__ __forceinline__ __half fromf<__half>(float v) { return __float2half_rn(v); }
 
 // ---- 1. NCHW -> NHWC ------------------------------------------------------------
+// `flip` (int8 only): XOR applied to every byte -- 0x80 makes the copy hold v + 128 as u8 (the
+// fused int8 kernel's operand form, dcn_fused_s8_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T *__restrict__ in,
-                                                           T *__restrict__ out, int C, int HW) {
+                                                           T *__restrict__ out, int C, int HW, int flip = 0) {
   __shared__ T tile[32][33];
   const int b = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T *__restrict__
 #pragma unroll
   for (int r = 0; r < 32; r += 8) {
     const int c = c0 + ty + r, p = p0 + tx;
-    if (c < C && p < HW) tile[ty + r][tx] = ib[(size_t)c * HW + p];
+    if (c < C && p < HW) {
+      if constexpr (sizeof(T) == 1) tile[ty + r][tx] = (T)(ib[(size_t)c * HW + p] ^ (T)flip);
+      else tile[ty + r][tx] = ib[(size_t)c * HW + p];
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -1053,6 +1058,239 @@ __global__ __launch_bounds__(256) void gemm_tn_s8_kernel(const int8_t *__restric
   }
 }
 
+// ---- 6b. fused deformable implicit GEMM, int8 ------------------------------------------------
+// The int8 flavour of section 5: the column element T2int8(T2int8(sum_corners v a / 255) * mask)
+// (modulatedDeformableConv2dKernel.cu:463-548) is produced by the B-tile loader straight into
+// LDS and consumed by v_mfma_i32_32x32x32_i8 -- no 80 MB column buffer written and re-read per
+// stage-3 call.  Block tile 256 (Cout) x 64 pixels x 64 (one tap, 64 input channels); 4 waves of
+// 64 x 64 outputs.  Producer thread = (pixel, 16-channel quarter): four 16-byte corner loads from
+// the u8-BIASED channels-last copy (v + 128), 4x4 byte transposes, per channel ONE unsigned dot4
+// whose addend -128 * sum(a) removes the bias, the exact integer T2int8(. / 255) of msda_hm4.hip
+// (saturating v_mad_i32_i24, result in the top byte; hand-placed: DOT -> other VALU hazard), then
+// the reference's float multiply by the mask and round-half-away, 16 result bytes = one
+// ds_write_b128.  Out-of-range corners get area weight 0 (so they leave the dot and the bias sum).
+// Bit-identical to im2col_nhwc_s8_kernel + gemm_tn_s8_kernel (tests/test_mdconv_gpu.py).
+constexpr int kSM = 256, kSN = 64, kSK = 64, kSLd = kSK + 16;
+
+__device__ __forceinline__ void s8_quad(const unsigned (&v)[4], unsigned aw, int neg, int magic, int half,
+                                        int (&x)[4]) {
+  asm("v_dot4_u32_u8 %0, %4, %8, %9\n\t"
+      "v_dot4_u32_u8 %1, %5, %8, %9\n\t"
+      "v_dot4_u32_u8 %2, %6, %8, %9\n\t"
+      "v_dot4_u32_u8 %3, %7, %8, %9\n\t"
+      "v_mad_i32_i24 %0, %0, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %1, %1, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %2, %2, %10, %11 clamp\n\t"
+      "v_mad_i32_i24 %3, %3, %10, %11 clamp"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(aw), "v"(neg), "v"(magic), "v"(half));
+}
+// 4x4 byte transpose: r[k] = 4 channels of corner k  ->  o[c] = channel c of corners 0..3
+__device__ __forceinline__ void s8_transpose(unsigned r0, unsigned r1, unsigned r2, unsigned r3, unsigned (&o)[4]) {
+  const unsigned a = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+  const unsigned b = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+  const unsigned c = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+  const unsigned e = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(e, b, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
+    const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
+    const int8_t *__restrict__ wt, const float *__restrict__ bias, int8_t *__restrict__ out, ConvDims d, int g,
+    int Kp, float s_off, float s_mask, float s_iw, float s_out) {
+  __shared__ __attribute__((aligned(16))) int8_t As[kSM][kSLd];
+  __shared__ __attribute__((aligned(16))) int8_t Bs[kSN][kSLd];
+  constexpr int kOmMax = 64;
+  __shared__ int8_t Om[kOmMax][kSN];
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
+  const int HoWo = d.Ho * d.Wo;
+  const int N = d.B * HoWo;
+  const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * kSN, m0 = blockIdx.y * kSM;
+  const int8_t *A = wt + (size_t)g * cout_g * Kp;
+  // B-producer role: pixel n0 + tid / 4, channels [cq * 16, +16) of the 64-channel chunk
+  const int pn = n0 + (tid >> 2), cq = tid & 3;
+  const bool pvalid = pn < N;
+  const int pb = pvalid ? pn / HoWo : 0;
+  const int ppix = pvalid ? pn - pb * HoWo : 0;
+  const int pho = ppix / d.Wo, pwo = ppix - pho * d.Wo;
+  // A-loader role: rows (tid >> 2) + 64 i, 16-byte chunk (tid & 3)
+  const int ar = tid >> 2, ac = (tid & 3) * 16;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(xt), 0, (unsigned)((size_t)d.B * d.H * d.W * d.Cin), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(A), 0, (unsigned)((size_t)cout_g * Kp), 0x00020000);
+  const unsigned ximg_off = (unsigned)((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 16);
+  unsigned a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = m0 + ar + 64 * i;
+    a_off[i] = r < cout_g ? (unsigned)((size_t)r * Kp + ac) : 0xFFFFFFF0u;
+  }
+  i32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  const int chunks = cin_g / kSK;
+  const int nsteps = KK * chunks;
+  int fidx[4];
+  unsigned faw = 0;   // 4 packed u8 area weights (0 for out-of-range corners)
+  int fneg = 0;       // -128 * their sum
+  float fm = 0.f;     // mask value
+  int cur_tap = -1, cur_dg = -1;
+  uint4 ra[4], rb[4];
+
+  const int om_per_dg = 3 * KK;
+  const bool om_ok = d.DG * om_per_dg <= kOmMax;
+  if (om_ok) {
+    for (int idx = tid; idx < d.DG * om_per_dg * kSN; idx += 256) {
+      const int p = idx % kSN, t = idx / kSN;
+      const int dgi = t / om_per_dg, tt = t - dgi * om_per_dg;
+      const int n = n0 + p;
+      int8_t v = 0;
+      if (n < N) {
+        const int b = n / HoWo, pix = n - b * HoWo;
+        v = tt < 2 * KK ? offset[(((size_t)b * d.DG + dgi) * 2 * KK + tt) * HoWo + pix]
+                        : mask[(((size_t)b * d.DG + dgi) * KK + (tt - 2 * KK)) * HoWo + pix];
+      }
+      Om[t][p] = v;
+    }
+    __syncthreads();
+  }
+
+  auto prefetch = [&](int step) {
+    const int tap = step / chunks, c0 = (step - tap * chunks) * kSK;
+    const int dg = (g * cin_g + c0) / (d.Cin / d.DG);
+    if (tap != cur_tap || dg != cur_dg) {
+      cur_tap = tap;
+      cur_dg = dg;
+      const int i = tap / d.Kw, j = tap - i * d.Kw;
+      int qoh, qow, qm;
+      if (om_ok) {
+        const int p = tid >> 2;
+        qoh = Om[dg * om_per_dg + 2 * tap][p];
+        qow = Om[dg * om_per_dg + 2 * tap + 1][p];
+        qm = Om[dg * om_per_dg + 2 * KK + tap][p];
+      } else {
+        const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
+        qoh = offset[ob + (size_t)(2 * tap) * HoWo];
+        qow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
+        qm = mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix];
+      }
+      float h_im, w_im;
+      {
+#pragma clang fp contract(off)
+        const float off_h = (float)qoh * s_off, off_w = (float)qow * s_off;
+        fm = (float)qm * s_mask;
+        h_im = off_h + (float)(pho * d.sh - d.ph + i * d.dh);
+        w_im = off_w + (float)(pwo * d.sw - d.pw + j * d.dw);
+      }
+      const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
+      unsigned aw[4] = {0u, 0u, 0u, 0u};
+      int hs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
+      if (in) {
+#pragma clang fp contract(off)
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h0 = (int)hf, w0 = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 < d.W, h0 + 1 < d.H && w0 >= 0,
+                            h0 + 1 < d.H && w0 + 1 < d.W};
+        const int a4[4] = {u8w(hh * hw), u8w(hh * lw), u8w(lh * hw), u8w(lh * lw)};
+        const int hq[4] = {h0, h0, h0 + 1, h0 + 1}, wq[4] = {w0, w0 + 1, w0, w0 + 1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          aw[q] = ok[q] ? (unsigned)a4[q] : 0u;
+          hs[q] = ok[q] ? hq[q] : 0;
+          ws[q] = ok[q] ? wq[q] : 0;
+        }
+      }
+      faw = aw[0] | (aw[1] << 8) | (aw[2] << 16) | (aw[3] << 24);
+      fneg = -(int)((aw[0] + aw[1] + aw[2] + aw[3]) << 7);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fidx[q] = (int)(ximg_off + (unsigned)(hs[q] * d.W + ws[q]) * (unsigned)d.Cin);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0, 0));
+    const int a_s = tap * cin_g + c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
+  };
+
+  const int magic = 65793, half = 1 << 23;   // round(2^24 / 255): exact T2int8(t / 255), see msda_hm4.hip
+  prefetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    // 16 channels of this thread's pixel: transpose, dot, requantise, mask, pack
+    unsigned res[4];
+    const unsigned c0w[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, c1w[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+    const unsigned c2w[4] = {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, c3w[4] = {rb[3].x, rb[3].y, rb[3].z, rb[3].w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      unsigned tr[4];
+      s8_transpose(c0w[v], c1w[v], c2w[v], c3w[v], tr);
+      int x[4];
+      s8_quad(tr, faw, fneg, magic, half, x);
+      int rq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma clang fp contract(off)
+        const float val = (float)(x[c] >> 24);          // T2int8(sum / 255)
+        rq[c] = q_away(val * fm);                       // T2int8(val * mask)
+      }
+      res[v] = ((unsigned)rq[0] & 0xffu) | (((unsigned)rq[1] & 0xffu) << 8) | (((unsigned)rq[2] & 0xffu) << 16) |
+               ((unsigned)rq[3] << 24);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&As[ar + 64 * i][ac]) = ra[i];
+    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16]) = make_uint4(res[0], res[1], res[2], res[3]);
+    __syncthreads();
+    if (step + 1 < nsteps) prefetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 32 + (lane >> 5) * 16;
+      i32x4_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const i32x4_t *>(&As[wm * 64 + i * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const i32x4_t *>(&Bs[j * 32 + (lane & 31)][kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    const int b = n / HoWo, pix = n - b * HoWo;
+    int8_t *ob = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < cout_g) {
+#pragma clang fp contract(off)
+          const float v = ((float)acc[i][j][r] * s_iw + (bias ? bias[g * cout_g + m] : 0.f)) / s_out;
+          ob[(size_t)m * HoWo] = (int8_t)q_away(v);
+        }
+      }
+  }
+}
+
 int run_s8(const void *input, const void *offset, const void *mask, const void *weight,
            const void *bias, void *output, void *workspace, const ConvDims &d, float s_in, float s_off,
            float s_mask, float s_w, float s_out, hipStream_t st);
@@ -1267,11 +1505,22 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
   if (Kp != Kg) {  // zero the padding columns once (packed weights + column buffer)
     if (hipMemsetAsync(ws + w.wt, 0, w.total - w.wt, st) != hipSuccess) return BEVOPS_FAILURE;
   }
+  // fused implicit GEMM (no column buffer) when a 64-channel chunk stays inside one group and one
+  // deform group; variant 6 keeps the im2col + GEMM pair (A/B reference)
+  const bool fused = g_mdconv_variant != 6 && cin_g % kSK == 0 && (d.Cin / d.DG) % kSK == 0 &&
+                     (size_t)d.B * d.H * d.W * d.Cin < 0xFFFFFF00ull && (size_t)cout_g * Kp < 0xFFFFFF00ull;
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
-                     0, st, (const int8_t *)input, xt, d.Cin, HW);
+                     0, st, (const int8_t *)input, xt, d.Cin, HW, fused ? 0x80 : 0);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   hipLaunchKernelGGL((repack_weight_kernel<int8_t>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
                      (const int8_t *)weight, wt, d.Cout, cin_g, KK, Kp);
+  if (fused) {
+    for (int g = 0; g < d.G; ++g)
+      hipLaunchKernelGGL(dcn_fused_s8_kernel, dim3((unsigned)((N + kSN - 1) / kSN), (cout_g + kSM - 1) / kSM), dim3(256),
+                         0, st, xt, (const int8_t *)offset, (const int8_t *)mask, wt, (const float *)bias,
+                         (int8_t *)output, d, g, Kp, s_off, s_mask, s_in * s_w, s_out);
+    return launch_status();
+  }
   const bool v16 = cin_g % 16 == 0 && (d.Cin / d.DG) % 16 == 0;
   const bool v4 = cin_g % 4 == 0 && (d.Cin / d.DG) % 4 == 0;
   const int V = v16 ? 16 : (v4 ? 4 : 1);

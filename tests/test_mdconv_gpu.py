@@ -249,3 +249,30 @@ def test_packed_weight_cache_survives_dtype_conversion():
     conv.float()
     y32b = bev.modulated_deformable_conv2d(x, off, mask, conv.weight, conv.bias, 1, 1, 1, 1, 1)
     assert (y32b - y32).abs().max().item() <= 1e-2   # weights went through fp16 once
+
+
+@pytest.mark.parametrize("shape", [(6, 256, 256, 58, 100), (6, 512, 512, 29, 50), (2, 64, 96, 33, 47), (3, 128, 64, 9, 140)])
+def test_int8_fused_kernel_is_bit_identical_to_im2col_gemm(bev, shape):
+    """dcn_fused_s8_kernel (column elements produced into LDS, exact integer T2int8(t / 255), u8-biased
+    image copy) against the im2col + GEMM pair it replaces (variant 6): same integers everywhere ->
+    bit-identical, at the two ResNet-101 DCN shapes and two ragged ones; saturated inputs included."""
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-128, 128, (B, Cin, H, W), generator=g, dtype=torch.int8)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.1, torch.full_like(x, 127), x).cuda()
+    off = torch.randint(-127, 128, (B, 18, H, W), generator=g, dtype=torch.int8).cuda()
+    mask = torch.randint(0, 128, (B, 9, H, W), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-127, 128, (Cout, Cin, 3, 3), generator=g, dtype=torch.int8).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    args = (x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.004, 0.6, 1, 1, 1, 1, 1)
+    a = bev.modulated_deformable_conv2d_int8(*args)
+    try:
+        lib.bevops_mdconv_set_variant(6)
+        ref = bev.modulated_deformable_conv2d_int8(*args)
+    finally:
+        lib.bevops_mdconv_set_variant(0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref), ((a.int() - ref.int()).abs().max().item(), (a != ref).float().mean().item())
+    assert a.float().abs().mean().item() > 1.0      # the output scale leaves real signal
