@@ -21,14 +21,14 @@ typedef int i32x16_t __attribute__((ext_vector_type(16)));
 constexpr int kQM = 128, kQN = 128, kQK = 64, kQLd = kQK + 16;  // +16 bytes: conflict-free b128 reads
 
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const __half *__restrict__ x, int8_t *__restrict__ q,
-                                                            size_t nvec, float inv_scale) {
+                                                            size_t nvec, float scale) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
   const uint4 v = reinterpret_cast<const uint4 *>(x)[i];
   const float f[8] = {h2f_lo(v.x), h2f_hi(v.x), h2f_lo(v.y), h2f_hi(v.y), h2f_lo(v.z), h2f_hi(v.z), h2f_lo(v.w), h2f_hi(v.w)};
   int8_t r[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r[k] = (int8_t)(int)fminf(fmaxf(rintf(f[k] * inv_scale), -127.f), 127.f);
+  for (int k = 0; k < 8; ++k) r[k] = (int8_t)(int)fminf(fmaxf(rintf(f[k] / scale), -127.f), 127.f);   // x / s as the host calibrators quantise
   reinterpret_cast<uint2 *>(q)[i] = *reinterpret_cast<const uint2 *>(r);
 }
 
@@ -146,7 +146,7 @@ extern "C" int bevops_quantize_rows(int dtype, const void *x, void *q, size_t co
   if (count == 0) return BEVOPS_SUCCESS;
   const size_t nvec = count / 8;
   hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const __half *)x, (int8_t *)q, nvec, 1.0f / scale);
+                     static_cast<hipStream_t>(stream), (const __half *)x, (int8_t *)q, nvec, scale);
   return launch_status();
 }
 

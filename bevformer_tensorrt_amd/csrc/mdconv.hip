@@ -18,6 +18,8 @@
 //      kernel -- exact fp32, parity path.)
 // Workspace (caller-owned, bevops_mdconv_workspace_size): NHWC copy + packed weights +
 // columns [G][N][K*K*Cin/g].
+#include <type_traits>
+
 #include "common.h"
 
 namespace bevops {
@@ -1097,7 +1099,8 @@ __device__ __forceinline__ void s8_transpose(unsigned r0, unsigned r1, unsigned 
   o[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
 }
 
-__global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
+template <int OCC>   // blocks per CU the register allocation aims at (2: no spills; 3: one round for 544 tiles)
+__global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
     const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
     const int8_t *__restrict__ wt, const float *__restrict__ bias, int8_t *__restrict__ out, ConvDims d, int g,
     int Kp, float s_off, float s_mask, float s_iw, float s_out) {
@@ -1145,7 +1148,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
   int fneg = 0;       // -128 * their sum
   float fm = 0.f;     // mask value
   int cur_tap = -1, cur_dg = -1;
-  uint4 ra[4], rb[4];
+  // two register sets: the loads of step + 1 are issued before the blend of step, so a gather's
+  // round trip hides behind ~250 VALU instructions + the MFMAs instead of behind the MFMAs alone
+  uint4 ra[2][4], rb[2][4];
+  unsigned saw[2];
+  int sneg[2];
+  float sm[2];
 
   const int om_per_dg = 3 * KK;
   const bool om_ok = d.DG * om_per_dg <= kOmMax;
@@ -1165,7 +1173,8 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
     __syncthreads();
   }
 
-  auto prefetch = [&](int step) {
+  auto prefetch = [&](auto buf, int step) {
+    constexpr int S = decltype(buf)::value;
     const int tap = step / chunks, c0 = (step - tap * chunks) * kSK;
     const int dg = (g * cin_g + c0) / (d.Cin / d.DG);
     if (tap != cur_tap || dg != cur_dg) {
@@ -1216,44 +1225,47 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) fidx[q] = (int)(ximg_off + (unsigned)(hs[q] * d.W + ws[q]) * (unsigned)d.Cin);
     }
+    saw[S] = faw; sneg[S] = fneg; sm[S] = fm;   // the footprint this set's corners were loaded with
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0, 0));
+      rb[S][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0, 0));
     const int a_s = tap * cin_g + c0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
+      ra[S][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
   };
 
   const int magic = 65793, half = 1 << 23;   // round(2^24 / 255): exact T2int8(t / 255), see msda_hm4.hip
-  prefetch(0);
-  for (int step = 0; step < nsteps; ++step) {
+  auto body = [&](auto cur, auto nxt, int step) {
+    constexpr int S = decltype(cur)::value;
+    if (step + 1 < nsteps) prefetch(nxt, step + 1);
     // 16 channels of this thread's pixel: transpose, dot, requantise, mask, pack
     unsigned res[4];
-    const unsigned c0w[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, c1w[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
-    const unsigned c2w[4] = {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, c3w[4] = {rb[3].x, rb[3].y, rb[3].z, rb[3].w};
+    const unsigned c0w[4] = {rb[S][0].x, rb[S][0].y, rb[S][0].z, rb[S][0].w};
+    const unsigned c1w[4] = {rb[S][1].x, rb[S][1].y, rb[S][1].z, rb[S][1].w};
+    const unsigned c2w[4] = {rb[S][2].x, rb[S][2].y, rb[S][2].z, rb[S][2].w};
+    const unsigned c3w[4] = {rb[S][3].x, rb[S][3].y, rb[S][3].z, rb[S][3].w};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       unsigned tr[4];
       s8_transpose(c0w[v], c1w[v], c2w[v], c3w[v], tr);
       int x[4];
-      s8_quad(tr, faw, fneg, magic, half, x);
+      s8_quad(tr, saw[S], sneg[S], magic, half, x);
       int rq[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma clang fp contract(off)
         const float val = (float)(x[c] >> 24);          // T2int8(sum / 255)
-        rq[c] = q_away(val * fm);                       // T2int8(val * mask)
+        rq[c] = q_away(val * sm[S]);                    // T2int8(val * mask)
       }
       res[v] = ((unsigned)rq[0] & 0xffu) | (((unsigned)rq[1] & 0xffu) << 8) | (((unsigned)rq[2] & 0xffu) << 16) |
                ((unsigned)rq[3] << 24);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&As[ar + 64 * i][ac]) = ra[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&As[ar + 64 * i][ac]) = ra[S][i];
     *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16]) = make_uint4(res[0], res[1], res[2], res[3]);
     __syncthreads();
-    if (step + 1 < nsteps) prefetch(step + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 32 + (lane >> 5) * 16;
@@ -1270,6 +1282,13 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_s8_kernel(
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  prefetch(B0{}, 0);
+  for (int step = 0; step < nsteps; step += 2) {
+    body(B0{}, B1{}, step);
+    if (step + 1 < nsteps) body(B1{}, B0{}, step + 1);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1516,9 +1535,24 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
                      (const int8_t *)weight, wt, d.Cout, cin_g, KK, Kp);
   if (fused) {
     for (int g = 0; g < d.G; ++g)
-      hipLaunchKernelGGL(dcn_fused_s8_kernel, dim3((unsigned)((N + kSN - 1) / kSN), (cout_g + kSM - 1) / kSM), dim3(256),
-                         0, st, xt, (const int8_t *)offset, (const int8_t *)mask, wt, (const float *)bias,
-                         (int8_t *)output, d, g, Kp, s_off, s_mask, s_in * s_w, s_out);
+    {
+      const dim3 grid((unsigned)((N + kSN - 1) / kSN), (cout_g + kSM - 1) / kSM);
+      // three resident blocks per CU when two would leave a sparse second round (base stage 3: 544
+      // tiles on 512 slots); variants 7 / 8 force 2 / 3
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const size_t blocks = (size_t)grid.x * grid.y;
+      const bool three = g_mdconv_variant == 8 ||
+                         (g_mdconv_variant != 7 && blocks > (size_t)2 * cus && blocks <= (size_t)3 * cus);
+      if (three)
+        hipLaunchKernelGGL(dcn_fused_s8_kernel<3>, grid, dim3(256), 0, st, xt, (const int8_t *)offset,
+                           (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g, Kp, s_off, s_mask,
+                           s_in * s_w, s_out);
+      else
+        hipLaunchKernelGGL(dcn_fused_s8_kernel<2>, grid, dim3(256), 0, st, xt, (const int8_t *)offset,
+                           (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g, Kp, s_off, s_mask,
+                           s_in * s_w, s_out);
+    }
     return launch_status();
   }
   const bool v16 = cin_g % 16 == 0 && (d.Cin / d.DG) % 16 == 0;

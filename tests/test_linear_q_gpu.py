@@ -23,8 +23,9 @@ def test_linear_int8_vs_integer_reference(M, K, N, per_channel):
     r = torch.randn(M, N, generator=g).half().cuda()
     s_x = float(x.abs().max()) / 127
     q = bev.quantize_rows(x, s_x)
-    want_q = torch.clamp(torch.round(x.float() / s_x), -127, 127).to(torch.int8)
-    assert torch.equal(q, want_q)
+    # (on the HOST: the device's tensor / python-scalar division multiplies by the rounded reciprocal)
+    want_q = torch.clamp(torch.round(x.float().cpu() / s_x), -127, 127).to(torch.int8)
+    assert torch.equal(q.cpu(), want_q)
     if per_channel:
         s_w = (w.abs().amax(1) / 127).clamp_min(1e-12)
         wq = torch.clamp(torch.round(w / s_w[:, None]), -127, 127).to(torch.int8)
