@@ -11,6 +11,16 @@
 namespace bevops {
 namespace {
 
+// float -> output type as its OWN rounding step: a plain cast lets the compiler fold the multiply and
+// the conversion into one v_fma_mixlo_f16 (single rounding of the exact product), while the
+// reference multiplies in float32 and converts afterwards
+__device__ __forceinline__ float to_out(float v, float *) { return v; }
+__device__ __forceinline__ __half to_out(float v, __half *) {
+  unsigned r;
+  asm("v_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(v));
+  return __ushort_as_half((unsigned short)r);
+}
+
 template <typename In, typename Out, bool NHWC>
 __global__ __launch_bounds__(256) void image_normalize_pad_kernel(const In *__restrict__ img, Out *__restrict__ out,
                                                                   int N, int H0, int W0, int Hp, int Wp, float m0,
@@ -36,10 +46,10 @@ __global__ __launch_bounds__(256) void image_normalize_pad_kernel(const In *__re
   }
   if constexpr (NHWC) {
     Out *o = out + idx * 3;
-    o[0] = (Out)v[0]; o[1] = (Out)v[1]; o[2] = (Out)v[2];
+    o[0] = to_out(v[0], (Out *)nullptr); o[1] = to_out(v[1], (Out *)nullptr); o[2] = to_out(v[2], (Out *)nullptr);
   } else {
     Out *o = out + (size_t)n * 3 * plane + r;
-    o[0] = (Out)v[0]; o[plane] = (Out)v[1]; o[2 * plane] = (Out)v[2];
+    o[0] = to_out(v[0], (Out *)nullptr); o[plane] = to_out(v[1], (Out *)nullptr); o[2 * plane] = to_out(v[2], (Out *)nullptr);
   }
 }
 

@@ -1099,8 +1099,16 @@ __device__ __forceinline__ void s8_transpose(unsigned r0, unsigned r1, unsigned 
   o[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
 }
 
-template <int OCC>   // blocks per CU the register allocation aims at (2: no spills; 3: one round for 544 tiles)
-__global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
+// Schedule of a k-step (one set of operand registers, 168 VGPRs = 3 blocks per CU, so the 544 tiles
+// of the base stage-3 call run in ONE round; with double-buffered operands the kernel needs 200
+// VGPRs = 512 slots and the 32 left-over tiles cost a second round -- measured 124 us, no better
+// than the im2col + GEMM pair, profiles/r02):
+//   corners of this step arrive -> 4 x (byte transpose + dot / requantise)      [corner registers free]
+//   -> gathers of the NEXT step issued -> mask multiply + rounding of the 16 values (~100 VALU)
+//   -> barrier, weight + pixel tile to LDS, barrier -> weight loads of the next step issued -> MFMAs.
+// A gather's round trip hides behind ~100 VALU instructions, two barriers and the 8 MFMAs; the
+// weight loads (L2 hits, coalesced) behind the MFMAs and the next step's front half.
+__global__ __launch_bounds__(256, 3) void dcn_fused_s8_kernel(
     const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
     const int8_t *__restrict__ wt, const float *__restrict__ bias, int8_t *__restrict__ out, ConvDims d, int g,
     int Kp, float s_off, float s_mask, float s_iw, float s_out) {
@@ -1115,7 +1123,8 @@ __global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
   const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * kSN, m0 = blockIdx.y * kSM;
   const int8_t *A = wt + (size_t)g * cout_g * Kp;
   // B-producer role: pixel n0 + tid / 4, channels [cq * 16, +16) of the 64-channel chunk
-  const int pn = n0 + (tid >> 2), cq = tid & 3;
+  const int pp = tid >> 2, cq = tid & 3;
+  const int pn = n0 + pp;
   const bool pvalid = pn < N;
   const int pb = pvalid ? pn / HoWo : 0;
   const int ppix = pvalid ? pn - pb * HoWo : 0;
@@ -1148,12 +1157,7 @@ __global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
   int fneg = 0;       // -128 * their sum
   float fm = 0.f;     // mask value
   int cur_tap = -1, cur_dg = -1;
-  // two register sets: the loads of step + 1 are issued before the blend of step, so a gather's
-  // round trip hides behind ~250 VALU instructions + the MFMAs instead of behind the MFMAs alone
-  uint4 ra[2][4], rb[2][4];
-  unsigned saw[2];
-  int sneg[2];
-  float sm[2];
+  uint4 ra[4], rb[4];
 
   const int om_per_dg = 3 * KK;
   const bool om_ok = d.DG * om_per_dg <= kOmMax;
@@ -1173,99 +1177,120 @@ __global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
     __syncthreads();
   }
 
-  auto prefetch = [&](auto buf, int step) {
-    constexpr int S = decltype(buf)::value;
+  // footprint of (pixel, tap): corner offsets, packed area weights, mask -- recomputed when the tap
+  // (or the deform group) of `step` differs from the current one
+  auto footprint = [&](int step) {
     const int tap = step / chunks, c0 = (step - tap * chunks) * kSK;
     const int dg = (g * cin_g + c0) / (d.Cin / d.DG);
-    if (tap != cur_tap || dg != cur_dg) {
-      cur_tap = tap;
-      cur_dg = dg;
-      const int i = tap / d.Kw, j = tap - i * d.Kw;
-      int qoh, qow, qm;
-      if (om_ok) {
-        const int p = tid >> 2;
-        qoh = Om[dg * om_per_dg + 2 * tap][p];
-        qow = Om[dg * om_per_dg + 2 * tap + 1][p];
-        qm = Om[dg * om_per_dg + 2 * KK + tap][p];
-      } else {
-        const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
-        qoh = offset[ob + (size_t)(2 * tap) * HoWo];
-        qow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
-        qm = mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix];
-      }
-      float h_im, w_im;
-      {
-#pragma clang fp contract(off)
-        const float off_h = (float)qoh * s_off, off_w = (float)qow * s_off;
-        fm = (float)qm * s_mask;
-        h_im = off_h + (float)(pho * d.sh - d.ph + i * d.dh);
-        w_im = off_w + (float)(pwo * d.sw - d.pw + j * d.dw);
-      }
-      const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
-      unsigned aw[4] = {0u, 0u, 0u, 0u};
-      int hs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
-      if (in) {
-#pragma clang fp contract(off)
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h0 = (int)hf, w0 = (int)wf;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 < d.W, h0 + 1 < d.H && w0 >= 0,
-                            h0 + 1 < d.H && w0 + 1 < d.W};
-        const int a4[4] = {u8w(hh * hw), u8w(hh * lw), u8w(lh * hw), u8w(lh * lw)};
-        const int hq[4] = {h0, h0, h0 + 1, h0 + 1}, wq[4] = {w0, w0 + 1, w0, w0 + 1};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          aw[q] = ok[q] ? (unsigned)a4[q] : 0u;
-          hs[q] = ok[q] ? hq[q] : 0;
-          ws[q] = ok[q] ? wq[q] : 0;
-        }
-      }
-      faw = aw[0] | (aw[1] << 8) | (aw[2] << 16) | (aw[3] << 24);
-      fneg = -(int)((aw[0] + aw[1] + aw[2] + aw[3]) << 7);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) fidx[q] = (int)(ximg_off + (unsigned)(hs[q] * d.W + ws[q]) * (unsigned)d.Cin);
+    if (tap == cur_tap && dg == cur_dg) return;
+    cur_tap = tap;
+    cur_dg = dg;
+    const int i = tap / d.Kw, j = tap - i * d.Kw;
+    int qoh, qow, qm;
+    if (om_ok) {
+      qoh = Om[dg * om_per_dg + 2 * tap][pp];
+      qow = Om[dg * om_per_dg + 2 * tap + 1][pp];
+      qm = Om[dg * om_per_dg + 2 * KK + tap][pp];
+    } else {
+      const size_t ob = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
+      qoh = offset[ob + (size_t)(2 * tap) * HoWo];
+      qow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
+      qm = mask[(((size_t)pb * d.DG + dg) * KK + tap) * HoWo + ppix];
     }
-    saw[S] = faw; sneg[S] = fneg; sm[S] = fm;   // the footprint this set's corners were loaded with
+    float h_im, w_im;
+    {
+#pragma clang fp contract(off)
+      const float off_h = (float)qoh * s_off, off_w = (float)qow * s_off;
+      fm = (float)qm * s_mask;
+      h_im = off_h + (float)(pho * d.sh - d.ph + i * d.dh);
+      w_im = off_w + (float)(pwo * d.sw - d.pw + j * d.dw);
+    }
+    const bool in = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
+    unsigned aw[4] = {0u, 0u, 0u, 0u};
+    int hs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
+    if (in) {
+#pragma clang fp contract(off)
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h0 = (int)hf, w0 = (int)wf;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 < d.W, h0 + 1 < d.H && w0 >= 0,
+                          h0 + 1 < d.H && w0 + 1 < d.W};
+      const int a4[4] = {u8w(hh * hw), u8w(hh * lw), u8w(lh * hw), u8w(lh * lw)};
+      const int hq[4] = {h0, h0, h0 + 1, h0 + 1}, wq[4] = {w0, w0 + 1, w0, w0 + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        aw[q] = ok[q] ? (unsigned)a4[q] : 0u;
+        hs[q] = ok[q] ? hq[q] : 0;
+        ws[q] = ok[q] ? wq[q] : 0;
+      }
+    }
+    faw = aw[0] | (aw[1] << 8) | (aw[2] << 16) | (aw[3] << 24);
+    fneg = -(int)((aw[0] + aw[1] + aw[2] + aw[3]) << 7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fidx[q] = (int)(ximg_off + (unsigned)(hs[q] * d.W + ws[q]) * (unsigned)d.Cin);
+  };
+  auto gather = [&](int step) {
+    const int tap = step / chunks, c0 = (step - tap * chunks) * kSK;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      rb[S][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0, 0));
+      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0, 0));
+  };
+  auto weights = [&](int step) {
+    const int tap = step / chunks, c0 = (step - tap * chunks) * kSK;
     const int a_s = tap * cin_g + c0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[S][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_off[i], a_s, 0));
   };
 
   const int magic = 65793, half = 1 << 23;   // round(2^24 / 255): exact T2int8(t / 255), see msda_hm4.hip
-  auto body = [&](auto cur, auto nxt, int step) {
-    constexpr int S = decltype(cur)::value;
-    if (step + 1 < nsteps) prefetch(nxt, step + 1);
-    // 16 channels of this thread's pixel: transpose, dot, requantise, mask, pack
+  footprint(0);
+  gather(0);
+  weights(0);
+  for (int step = 0; step < nsteps; ++step) {
+    // 1. corners -> requantised bilinear sums of this thread's 16 channels (top bytes of x)
+    int x[16];
+    {
+      const unsigned c0w[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, c1w[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+      const unsigned c2w[4] = {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, c3w[4] = {rb[3].x, rb[3].y, rb[3].z, rb[3].w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        unsigned tr[4];
+        s8_transpose(c0w[v], c1w[v], c2w[v], c3w[v], tr);
+        int xq[4];
+        s8_quad(tr, faw, fneg, magic, half, xq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[4 * v + c] = xq[c];
+      }
+    }
+    const float m_cur = fm;
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. the next step's gathers go out now (corner registers are free)
+    if (step + 1 < nsteps) {
+      footprint(step + 1);
+      gather(step + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. mask multiply + round half away, pack 16 bytes
     unsigned res[4];
-    const unsigned c0w[4] = {rb[S][0].x, rb[S][0].y, rb[S][0].z, rb[S][0].w};
-    const unsigned c1w[4] = {rb[S][1].x, rb[S][1].y, rb[S][1].z, rb[S][1].w};
-    const unsigned c2w[4] = {rb[S][2].x, rb[S][2].y, rb[S][2].z, rb[S][2].w};
-    const unsigned c3w[4] = {rb[S][3].x, rb[S][3].y, rb[S][3].z, rb[S][3].w};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      unsigned tr[4];
-      s8_transpose(c0w[v], c1w[v], c2w[v], c3w[v], tr);
-      int x[4];
-      s8_quad(tr, saw[S], sneg[S], magic, half, x);
       int rq[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma clang fp contract(off)
-        const float val = (float)(x[c] >> 24);          // T2int8(sum / 255)
-        rq[c] = q_away(val * sm[S]);                    // T2int8(val * mask)
+        const float val = (float)(x[4 * v + c] >> 24);   // T2int8(sum / 255)
+        rq[c] = q_away(val * m_cur);                     // T2int8(val * mask)
       }
       res[v] = ((unsigned)rq[0] & 0xffu) | (((unsigned)rq[1] & 0xffu) << 8) | (((unsigned)rq[2] & 0xffu) << 16) |
                ((unsigned)rq[3] << 24);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&As[ar + 64 * i][ac]) = ra[S][i];
-    *reinterpret_cast<uint4 *>(&Bs[tid >> 2][cq * 16]) = make_uint4(res[0], res[1], res[2], res[3]);
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&As[ar + 64 * i][ac]) = ra[i];
+    *reinterpret_cast<uint4 *>(&Bs[pp][cq * 16]) = make_uint4(res[0], res[1], res[2], res[3]);
     __syncthreads();
+    if (step + 1 < nsteps) weights(step + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 32 + (lane >> 5) * 16;
@@ -1282,13 +1307,6 @@ __global__ __launch_bounds__(256, OCC) void dcn_fused_s8_kernel(
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-  };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  prefetch(B0{}, 0);
-  for (int step = 0; step < nsteps; step += 2) {
-    body(B0{}, B1{}, step);
-    if (step + 1 < nsteps) body(B1{}, B0{}, step + 1);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1535,24 +1553,9 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
                      (const int8_t *)weight, wt, d.Cout, cin_g, KK, Kp);
   if (fused) {
     for (int g = 0; g < d.G; ++g)
-    {
-      const dim3 grid((unsigned)((N + kSN - 1) / kSN), (cout_g + kSM - 1) / kSM);
-      // three resident blocks per CU when two would leave a sparse second round (base stage 3: 544
-      // tiles on 512 slots); variants 7 / 8 force 2 / 3
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      const size_t blocks = (size_t)grid.x * grid.y;
-      const bool three = g_mdconv_variant == 8 ||
-                         (g_mdconv_variant != 7 && blocks > (size_t)2 * cus && blocks <= (size_t)3 * cus);
-      if (three)
-        hipLaunchKernelGGL(dcn_fused_s8_kernel<3>, grid, dim3(256), 0, st, xt, (const int8_t *)offset,
-                           (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g, Kp, s_off, s_mask,
-                           s_in * s_w, s_out);
-      else
-        hipLaunchKernelGGL(dcn_fused_s8_kernel<2>, grid, dim3(256), 0, st, xt, (const int8_t *)offset,
-                           (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g, Kp, s_off, s_mask,
-                           s_in * s_w, s_out);
-    }
+      hipLaunchKernelGGL(dcn_fused_s8_kernel, dim3((unsigned)((N + kSN - 1) / kSN), (cout_g + kSM - 1) / kSM), dim3(256),
+                         0, st, xt, (const int8_t *)offset, (const int8_t *)mask, wt, (const float *)bias,
+                         (int8_t *)output, d, g, Kp, s_off, s_mask, s_in * s_w, s_out);
     return launch_status();
   }
   const bool v16 = cin_g % 16 == 0 && (d.Cin / d.DG) % 16 == 0;

@@ -67,7 +67,7 @@ def kernels(lib):
         mask = torch.randint(0, 128, (B, 9, H, W), generator=g, dtype=torch.int8).cuda()
         w = torch.randint(-127, 128, (C, C, 3, 3), generator=g, dtype=torch.int8).cuda()
         b = torch.zeros(C).cuda()
-        for v in (7, 8, 6):     # fused kernel at 2 / 3 blocks per CU, im2col + GEMM
+        for v in (0, 6):     # fused implicit GEMM, im2col + GEMM
             lib.bevops_mdconv_set_variant(v)
             for _ in range(4):
                 bev.modulated_deformable_conv2d_int8(x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.01, 0.05, 1, 1, 1, 1, 1)
