@@ -1544,8 +1544,15 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
   }
   // fused implicit GEMM (no column buffer) when a 64-channel chunk stays inside one group and one
   // deform group; variant 6 keeps the im2col + GEMM pair (A/B reference)
+  // ... and when there are enough 256 x 64 tiles to give every CU two blocks: the base stage-3 call
+  // (544 tiles) 117 vs 170 us; stage 4 (272 tiles, one 4-wave block per CU) 138 vs 130 us keeps the pair
+  // (profiles/r02).  Variant 8 forces the fused kernel.
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t tiles = ((N + kSN - 1) / kSN) * (size_t)((cout_g + kSM - 1) / kSM);
   const bool fused = g_mdconv_variant != 6 && cin_g % kSK == 0 && (d.Cin / d.DG) % kSK == 0 &&
-                     (size_t)d.B * d.H * d.W * d.Cin < 0xFFFFFF00ull && (size_t)cout_g * Kp < 0xFFFFFF00ull;
+                     (size_t)d.B * d.H * d.W * d.Cin < 0xFFFFFF00ull && (size_t)cout_g * Kp < 0xFFFFFF00ull &&
+                     (g_mdconv_variant == 8 || tiles >= (size_t)2 * cus);
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
                      0, st, (const int8_t *)input, xt, d.Cin, HW, fused ? 0x80 : 0);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;

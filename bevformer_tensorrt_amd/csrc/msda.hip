@@ -800,7 +800,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
                                 msda_hm4_all_staged(spatial_shapes_host, bs, heads, channels, num_levels,
                                                     num_query, num_point);
         const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant >= 200 && g_variant <= 456) || staged_all;
+                        (g_variant >= 200 && g_variant <= 712) || staged_all;
         if (spatial_shapes_host && h4) {
           static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(

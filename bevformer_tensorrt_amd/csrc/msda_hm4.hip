@@ -177,7 +177,10 @@ __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
 // ABL: timing ablations for tools/hm4_probe.py (results are WRONG with bits 0-4): 1 no L1/L2 taps,
 // 2 no LDS taps, 4 no operand requests inside the loop, 8 no front end inside the loop, 16 no store.
 // Schedule variants with correct results: 32 operand request at the END of the loop body, 64 one
-// big batch in flight instead of two, 128 default cache policy for the streamed operands / output.
+// big batch in flight instead of two, 128 default cache policy for the streamed operands / output,
+// 256 operand request BEHIND the first big batches (buffer loads retire in order: requested first,
+// the HBM round trip of the operands gates every tap of the iteration; requested behind batches
+// 0 .. D-1, only the later batches wait for it, after most of the iteration's own work).
 template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
@@ -477,8 +480,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
   }
   for (; i < n_items; i += kStride) {
     const unsigned q = query_of(i);
+    const unsigned q_pre = i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0;
     if constexpr (ABL & 4) pre2 = pre1;
-    else if constexpr (!(ABL & 32)) request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
+    else if constexpr (!(ABL & 32) && !(ABL & 256)) request(pre2, q_pre);
     float s_nxt;
     bool any_nxt;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -595,6 +599,10 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
       for (int tb = 0; tb < D && tb < NBIG; ++tb)
         if constexpr (kBig) issue(tb);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((ABL & 256) && !(ABL & 4)) {
+        request(pre2, q_pre);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (kFront) {
         front(pre1, npl, s_nxt, any_nxt);
       } else {
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
 #pragma unroll
       for (int k = 0; k < PP; ++k) pl[k] = npl[k];
     } else {
+      if constexpr ((ABL & 256) && !(ABL & 4)) request(pre2, q_pre);
       front(pre1, pl, s_nxt, any_nxt);
     }
     // ---- normalise, store
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         *reinterpret_cast<uint2 *>(outp) = v;
       }
     }
-    if constexpr ((ABL & 32) && !(ABL & 4)) request(pre2, i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0);
+    if constexpr ((ABL & 32) && !(ABL & 4)) request(pre2, q_pre);
     if constexpr (!(ABL & 8)) post(pl);
     s_cur = s_nxt;
     any_cur = any_nxt;
@@ -711,7 +720,8 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
 #define BEVOPS_H4_ABL(A) if (ablate == A) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, A>(a, st);
         BEVOPS_H4_ABL(1) BEVOPS_H4_ABL(2) BEVOPS_H4_ABL(3) BEVOPS_H4_ABL(4) BEVOPS_H4_ABL(8) BEVOPS_H4_ABL(12)
         BEVOPS_H4_ABL(15) BEVOPS_H4_ABL(16) BEVOPS_H4_ABL(19) BEVOPS_H4_ABL(31) BEVOPS_H4_ABL(11) BEVOPS_H4_ABL(7)
-        if (ablate == 256) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, 0>(a, st);
+        if (ablate == 512) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, 0>(a, st);
+        BEVOPS_H4_ABL(256) BEVOPS_H4_ABL(384) BEVOPS_H4_ABL(320)
         BEVOPS_H4_ABL(32) BEVOPS_H4_ABL(64) BEVOPS_H4_ABL(96) BEVOPS_H4_ABL(128) BEVOPS_H4_ABL(160) BEVOPS_H4_ABL(224)
 #undef BEVOPS_H4_ABL
       }

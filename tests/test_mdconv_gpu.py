@@ -267,8 +267,9 @@ def test_int8_fused_kernel_is_bit_identical_to_im2col_gemm(bev, shape):
     w = torch.randint(-127, 128, (Cout, Cin, 3, 3), generator=g, dtype=torch.int8).cuda()
     b = torch.randn(Cout, generator=g).cuda()
     args = (x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.004, 0.6, 1, 1, 1, 1, 1)
-    a = bev.modulated_deformable_conv2d_int8(*args)
     try:
+        lib.bevops_mdconv_set_variant(8)        # force the fused kernel (small calls default to the pair)
+        a = bev.modulated_deformable_conv2d_int8(*args)
         lib.bevops_mdconv_set_variant(6)
         ref = bev.modulated_deformable_conv2d_int8(*args)
     finally:
