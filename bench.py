@@ -247,15 +247,16 @@ def pmc_traffic(int8):
     """HBM/fabric bytes per base-SCA call from the newest committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
     correction for 16-byte-per-lane loads, MI355X_MICROARCH.md "HBM").  The call is two
-    launches (re-layout + gather); both are summed."""
+    launches (re-layout + gather); both are summed.  fp16: msda_hm3_*; int8: msda_hm4_*<.., true, ..>."""
     try:
         import glob
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel*.json")))
-        f = [x for x in f if ("int8" in os.path.basename(x)) == int8][-1]
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprofv3_pmc_fetch_write_per_kernel.json")))[-1]
         total = 0.0
         for k, v in json.load(open(f)).items():
-            hit = ("msda_hm4_kernel<32" in k or "msda_hm4_repack" in k or "msda_hm3_kernel<32" in k or
-                   "msda_hm3_repack_kernel" in k)
+            if int8:
+                hit = "msda_hm4_repack_i8" in k or ("msda_hm4_kernel<32" in k and ", true," in k)
+            else:
+                hit = "msda_hm3_kernel<32" in k or "msda_hm3_repack_kernel" in k
             if hit and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
                 total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
         return (int(total) if total else None), os.path.relpath(f, ROOT)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the judged evidence of one tools/gpu_round.sh visit into profiles/<round>/.
+"""Copy the judged evidence of one tools/gpu_round.sh / gpu_round2.sh visit into profiles/<round>/.
 usage: tools/collect_profiles.py gpurun_out/<tag> profiles/<round>"""
 import collections, csv, glob, json, os, re, shutil, sys
 
@@ -31,7 +31,9 @@ if per:
     json.dump(per, open(os.path.join(dst, "rocprofv3_pmc_fetch_write_per_kernel.json"), "w"), indent=1)
 for name, out in (("bench.json", "bench_n1.json"), ("sweep.jsonl", "msda_sweep.jsonl"),
                   ("model_bench.jsonl", "model_bench.jsonl"), ("dcn_time.jsonl", "dcn_time.jsonl"),
-                  ("pytest.log", "pytest_gpu_tail.log")):
+                  ("pytest.log", "pytest_gpu_tail.log"), ("smoke.log", "smoke.log"),
+                  ("ops_timing.jsonl", "ops_timing.jsonl"), ("bevdet_slice.jsonl", "bevdet_slice.jsonl"),
+                  ("hm4_probe.jsonl", "hm4_probe.jsonl"), ("rocminfo.txt", "rocminfo.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         lines = [l for l in open(p) if "amdgpu.ids" not in l]
