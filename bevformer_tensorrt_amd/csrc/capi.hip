@@ -44,6 +44,7 @@ const Entry kTable[] = {
     {"bevops_mdconv_forward", (void *)&bevops_mdconv_forward},
     {"bevops_mdconv_workspace_size", (void *)&bevops_mdconv_workspace_size},
     {"bevops_mdconv_forward_int8", (void *)&bevops_mdconv_forward_int8},
+    {"bevops_mdconv_forward_int8_packed", (void *)&bevops_mdconv_forward_int8_packed},
     {"ModulatedDeformableConv2dTRT", (void *)&bevops_mdconv_forward},
     {"ModulatedDeformableConv2dTRT2", (void *)&bevops_mdconv_forward},
     // entries that are not reference plugins: workspace-lending / channels-last / fused forms

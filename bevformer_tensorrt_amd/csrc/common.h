@@ -17,6 +17,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// single roundings that must not be contracted into an fma with a neighbouring multiply (the
+// int8 softmax: logit * scale - max; the oracle and the reference's host build round each step)
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8
 // (MI355X_MICROARCH.md "Workgroup dispatch"); give every XCD one contiguous
 // chunk of the logical grid so neighbouring work shares that XCD's 4 MiB L2.

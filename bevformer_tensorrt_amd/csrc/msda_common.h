@@ -181,21 +181,6 @@ __device__ __forceinline__ void transpose4x4(unsigned r0, unsigned r1, unsigned 
   o[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
 }
 
-// single roundings that must not be contracted into an fma with a neighbouring multiply (the
-// int8 softmax: logit * scale - max; the oracle and the reference's host build round each step)
-__device__ __forceinline__ float sub_rn(float a, float b) {
-#pragma clang fp contract(off)
-  return a - b;
-}
-__device__ __forceinline__ float add_rn(float a, float b) {
-#pragma clang fp contract(off)
-  return a + b;
-}
-__device__ __forceinline__ float mul_rn(float a, float b) {
-#pragma clang fp contract(off)
-  return a * b;
-}
-
 // t2i8_away for a >= 0 (area weights, softmax weights): the clamp from below and the sign select
 // drop out ((int)(0 + 0.5) == (int)(0 - 0.5) == 0)
 __device__ __forceinline__ int t2i8_away_nonneg(float a) { return (int)add_rn(fminf(a, 127.f), 0.5f); }

@@ -108,13 +108,14 @@ def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in
         raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments", _lib.NOT_SUPPORTED)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.int8, device=input.device)
+    packed = _packed_weight(handle, weight, _lib.I8)     # re-laid-out once per weight tensor (version)
     with torch.cuda.device(input.device):
-        st = handle.bevops_mdconv_forward_int8(
+        st = handle.bevops_mdconv_forward_int8_packed(
             input.data_ptr(), float(scale_in), offset.data_ptr(), float(scale_offset), mask.data_ptr(),
-            float(scale_mask), weight.data_ptr(), float(scale_weight),
+            float(scale_mask), packed.data_ptr(), float(scale_weight),
             bias.data_ptr() if bias is not None else None, out.data_ptr(), float(scale_out),
             ws.data_ptr(), ws_bytes, *dims, _lib.current_stream_ptr(input.device))
-    _lib.check(st, "bevops_mdconv_forward_int8")
+    _lib.check(st, "bevops_mdconv_forward_int8_packed")
     return out
 
 

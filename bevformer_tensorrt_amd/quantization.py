@@ -24,6 +24,8 @@ import math
 
 import torch
 
+from .functions.multi_scale_deformable_attn import _TensorCache
+
 _NUM_BINS = 2048
 _NUM_LEVELS = 128
 
@@ -161,6 +163,7 @@ class Int8PluginOps:
         self.mode = "calibrate"
         self._scales = {}
         self._n = {}
+        self._wq = _TensorCache()      # float weight tensor -> (int8 weight, scale)
 
     # ---- bookkeeping
     def begin_frame(self):
@@ -173,6 +176,7 @@ class Int8PluginOps:
     def freeze(self):
         """End of calibration: fix the scales and switch the call sites to their INT8 flavours."""
         self._scales = self.cal.scales()
+        self._wq = _TensorCache()
         self.mode = "int8"
         return self._scales
 
@@ -224,8 +228,12 @@ class Int8PluginOps:
             for k, t in (("x", x), ("offset", offset), ("mask", mask), ("weight", weight), ("out", out)):
                 self.cal.collect(f"{site}.{k}", t)
             return out
-        (qx, sx), (qo, so), (qm, sm), (qw, sw) = (self._q(f"{site}.{k}", t) for k, t in
-                                                  (("x", x), ("offset", offset), ("mask", mask), ("weight", weight)))
+        (qx, sx), (qo, so), (qm, sm) = (self._q(f"{site}.{k}", t) for k, t in
+                                        (("x", x), ("offset", offset), ("mask", mask)))
+        hit = self._wq.get(weight)           # the weights of a deployed model are quantised (and packed) once
+        if hit is None:
+            hit = self._wq.put(weight, self._q(f"{site}.weight", weight))
+        qw, sw = hit
         s_out = self._scales[f"{site}.out"]
         out = self.fp.modulated_deformable_conv2d_int8(qx, qo, qm, qw, None if bias is None else bias.float(),
                                                        sx, so, sm, sw, s_out, stride, padding, dilation, groups,

@@ -47,6 +47,9 @@ SIGNATURES = {
     "bevops_mdconv_forward_int8": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
                                            c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
                                            c_size_t] + [c_int] * 15 + [c_void_p]),
+    "bevops_mdconv_forward_int8_packed": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
+                                           c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_size_t] + [c_int] * 15 + [c_void_p]),
     "bevops_mdconv_forward": (c_int, [c_int] + [c_void_p] * 7 + [c_size_t] + [c_int] * 15 +
                               [c_void_p]),
     "bevops_mdconv_forward_packed": (c_int, [c_int] + [c_void_p] * 7 + [c_size_t] + [c_int] * 15 +

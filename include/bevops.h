@@ -245,7 +245,9 @@ int bevops_sca_forward(int dtype, const void *value, const int32_t *spatial_shap
 /* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
  * channel counts allow), 1 = force the im2col + GEMM pipeline, 2 / 3 = the register-staged
  * fused kernels (256 / 512 threads), 4 = LDS-DMA kernel with 64-pixel tiles and no split-K
- * tail, 5 = LDS-DMA kernel with 128-pixel tiles.  Returns the previous value. */
+ * tail, 5 = LDS-DMA kernel with 128-pixel tiles; INT8: 6 = im2col + GEMM pair, 8 = register-staged
+ * fused kernel, 9 = LDS-DMA kernel whatever the tile count, 20 + mask = timing experiments (wrong
+ * results).  Returns the previous value. */
 int bevops_mdconv_set_variant(int variant);
 size_t bevops_mdconv_workspace_size(int dtype, int B, int Cin, int H, int W, int Cout, int Kh,
                                     int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
@@ -257,6 +259,14 @@ int bevops_mdconv_forward_int8(const void *input, float scale_in, const void *of
                                size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
                                int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                                int dil_w, int groups, int deform_groups, void *stream);
+/* the same with the weights already re-laid-out by bevops_mdconv_pack_weight(BEVOPS_I8, ...) */
+int bevops_mdconv_forward_int8_packed(const void *input, float scale_in, const void *offset,
+                                      float scale_offset, const void *mask, float scale_mask,
+                                      const void *packed_weight, float scale_weight, const float *bias,
+                                      void *output, float scale_out, void *workspace,
+                                      size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
+                                      int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                                      int dil_w, int groups, int deform_groups, void *stream);
 int bevops_mdconv_forward(int dtype, const void *input, const void *offset, const void *mask,
                           const void *weight, const void *bias, void *output, void *workspace,
                           size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
@@ -265,8 +275,8 @@ int bevops_mdconv_forward(int dtype, const void *input, const void *offset, cons
 /* Inference keeps the same weights call after call: the [Cout][tap][Cin/groups] re-layout that
  * bevops_mdconv_forward makes inside its workspace on every call can be made once
  * (the reference builds its weight tensors once in the plugin constructor,
- * modulatedDeformableConv2dPlugin.cpp:33-71).  F32 / F16; `packed` holds
- * bevops_mdconv_packed_weight_size bytes, 16-byte aligned. */
+ * modulatedDeformableConv2dPlugin.cpp:33-71).  F32 / F16 / I8 (I8: rows zero-padded to 16 bytes, for
+ * bevops_mdconv_forward_int8_packed); `packed` holds bevops_mdconv_packed_weight_size bytes, 16-byte aligned. */
 size_t bevops_mdconv_packed_weight_size(int dtype, int Cout, int Cin_per_group, int Kh, int Kw);
 int bevops_mdconv_pack_weight(int dtype, const void *weight, void *packed, int Cout,
                               int Cin_per_group, int Kh, int Kw, void *stream);

@@ -277,3 +277,41 @@ def test_int8_fused_kernel_is_bit_identical_to_im2col_gemm(bev, shape):
     torch.cuda.synchronize()
     assert torch.equal(a, ref), ((a.int() - ref.int()).abs().max().item(), (a != ref).float().mean().item())
     assert a.float().abs().mean().item() > 1.0      # the output scale leaves real signal
+
+
+@pytest.mark.parametrize("shape", [
+    # B, Cin, Cout, H, W, stride, groups, deform_groups
+    (6, 256, 256, 58, 100, 1, 1, 1),     # base stage 3: 128-pixel tiles + split-K tail (272 tiles on 256 CUs)
+    (6, 512, 512, 29, 50, 1, 1, 1),      # base stage 4: 64-pixel tiles, two Cout tiles, 4 chunks per tap
+    (2, 128, 192, 33, 47, 1, 1, 1),      # one chunk per tap, ragged pixel count, Cout below one tile
+    (3, 256, 320, 19, 23, 2, 2, 2),      # stride 2, two groups of 128 channels with their own deform group
+    (1, 256, 64, 5, 7, 1, 1, 1),         # less than one pixel tile
+])
+@pytest.mark.parametrize("variant", [0, 4])
+def test_int8_lds_dma_kernel_is_bit_identical_to_im2col_gemm(bev, shape, variant):
+    """dcn_glds_s8_kernel (weights by LDS-DMA, two LDS buffers, gathers a step ahead, split-K tail with int32
+    partials; variant 4: without the tail split) against the im2col + GEMM pair (variant 6)."""
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    B, Cin, Cout, H, W, stride, G, DG = shape
+    g = torch.Generator().manual_seed(7)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = torch.randint(-128, 128, (B, Cin, H, W), generator=g, dtype=torch.int8)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.1, torch.full_like(x, 127), x).cuda()
+    off = torch.randint(-127, 128, (B, DG * 18, Ho, Wo), generator=g, dtype=torch.int8).cuda()
+    mask = torch.randint(-8, 128, (B, DG * 9, Ho, Wo), generator=g, dtype=torch.int8).cuda()   # a few negative masks too
+    w = torch.randint(-127, 128, (Cout, Cin // G, 3, 3), generator=g, dtype=torch.int8).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    args = (x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.004, 0.6, stride, 1, 1, G, DG)
+    try:
+        lib.bevops_mdconv_set_variant(variant)
+        a = bev.modulated_deformable_conv2d_int8(*args)
+        a2 = bev.modulated_deformable_conv2d_int8(*args)
+        lib.bevops_mdconv_set_variant(6)
+        ref = bev.modulated_deformable_conv2d_int8(*args)
+    finally:
+        lib.bevops_mdconv_set_variant(0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2)
+    assert torch.equal(a, ref), ((a.int() - ref.int()).abs().max().item(), (a != ref).float().mean().item())
+    assert a.float().abs().mean().item() > 1.0

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: tools/pmc_dcn.sh <tag> <variant>  -> gpurun_out/<tag>/
-TAG=$1; VAR=$2
+# usage: tools/pmc_dcn.sh <tag> <variant> [int8]  -> gpurun_out/<tag>/
+TAG=$1; VAR=$2; KIND=$3
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" 
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
            "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_INSTS_WAVE32_LDS"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o x -- python $GRAFT_REPO_ROOT/tools/dcn_one.py $VAR 3 > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o x -- python $GRAFT_REPO_ROOT/tools/dcn_one.py $VAR 3 $KIND > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections
@@ -20,7 +20,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    if "dcn" not in k: continue
+    if "dcn_glds" not in k and "dcn_fused" not in k: continue
     print(k)
     for c,vals in sorted(v.items()): print("   %-36s %.4g  (n=%d)"%(c,sum(vals)/len(vals),len(vals)))
 PY
