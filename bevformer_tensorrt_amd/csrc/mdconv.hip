@@ -623,6 +623,7 @@ template <int WN> struct Glds {
   static constexpr int kPieces = 32 / (4 * WN);  // 1 KB weight DMA pieces per wave
 };
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned swz8(unsigned r) { return (r ^ (r >> 3)) & 7u; }
 
 // Tail handling: when the tile count leaves a sparsely filled last round (base stage 3: 544 tiles
@@ -636,6 +637,8 @@ struct TailPlan {
   int out_nhwc, relu;                 // epilogue: output layout [B,Ho,Wo,Cout], fused ReLU
   int om_channels;                    // > 0: `offset` is the raw [B,Ho,Wo,om_channels] output of the pack's
                                       // offset convolution (2*KK offsets, then KK mask logits): sigmoid here
+  int rotate;                         // fp16 kernel: wave halves in opposite phase order (A/B switch, variant 7;
+                                      // measured 4-6 % slower at both ResNet-101 shapes, profiles/r02)
 };
 
 // 4 consecutive output channels m..m+3 of pixel (b, pix): bias, optional ReLU, NCHW or NHWC store
@@ -740,8 +743,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       const unsigned o2 = *reinterpret_cast<const unsigned *>(offset + omb + 2 * tap);
       oh = __ushort_as_half((unsigned short)(o2 & 0xffffu));
       ow = __ushort_as_half((unsigned short)(o2 >> 16));
-      const float z = __half2float(offset[omb + 2 * KK + tap]);
-      mm = __float2half_rn(1.f / (1.f + __expf(-z)));
+      mm = offset[omb + 2 * KK + tap];   // raw mask logit: the sigmoid is applied where the value is consumed
     } else {
       oh = offset[ob + (size_t)(2 * tap) * HoWo];
       ow = offset[ob + (size_t)(2 * tap + 1) * HoWo];
@@ -762,7 +764,8 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   unsigned fw[4];
   uint4 rb[4];
   auto footprint = [&](int tap) {
-    const float off_h = __half2float(n_oh), off_w = __half2float(n_ow), m = __half2float(n_mm);
+    const float off_h = __half2float(n_oh), off_w = __half2float(n_ow);
+    const float m = tp.om_channels ? __half2float(__float2half_rn(1.f / (1.f + __expf(-__half2float(n_mm))))) : __half2float(n_mm);
     load_om(tap + 1 < KK ? tap + 1 : 0, n_oh, n_ow, n_mm);
     const int i = tap / d.Kw, j = tap - i * d.Kw;
     const float h_im = (float)(pho * d.sh - d.ph + i * d.dh) + off_h;
@@ -782,48 +785,59 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     }
   };
   typedef __attribute__((address_space(3))) void lds_void;
-  // stage k-step (tap, chunk) into buffer `buf`: weight DMA + gather loads (into rb)
-  auto stage_issue = [&](int tap, int chunk, int buf) {
-    const int c0 = chunk * kFK;
-    const int a_s = (tap * cin_g + c0) * 2;
+  // The gathers run TWO steps ahead of the MFMAs (their corners are blended one step ahead), the weight
+  // DMA one step ahead; each pipeline walks (tap, chunk) with its own counters.  Iteration `step` (tiles of
+  // `step` in buffer step & 1, raw corners of step + 1 in rb, a step old):
+  //   blend + ds_write of the step + 1 pixel row [rb free] | weight DMA of step + 1 | footprint + gathers
+  //   of step + 2 | 8 MFMAs | s_waitcnt vmcnt(4): the DMA is older than the 4 gathers, which stay in flight
+  //   across the barrier (r01: gathers issued and consumed inside one step, their round trip exposed).
+  int g_tap = tap_begin, g_chunk = 0, w_tap = tap_begin, w_chunk = 0;
+  unsigned c_fw[4] = {0u, 0u, 0u, 0u};   // blend weights of the corners held in rb
+  auto gather_next = [&]() {
+    if (g_chunk == 0) footprint(g_tap);   // (also requests the offsets / mask of the tap after it: younger than the
+                                          // step's weight DMA, older than the gathers -- retired by the same vmcnt(4))
+    const int c0 = g_chunk * kFK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+      c_fw[q] = fw[q];
+    }
+    if (++g_chunk == chunks) { g_chunk = 0; g_tap = g_tap + 1 < KK ? g_tap + 1 : 0; }
+  };
+  auto weights_next = [&](int buf) {
+    const int a_s = (w_tap * cin_g + w_chunk * kFK) * 2;
     char *adst = smem + buf * kGA + wave * (kPc * 1024);
 #pragma unroll
     for (int j = 0; j < kPc; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+    if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
   };
-  auto blend_write = [&](int buf) {
-    uint4 bl;
-    bl.x = pk_mul(rb[0].x, fw[0]); bl.y = pk_mul(rb[0].y, fw[0]);
-    bl.z = pk_mul(rb[0].z, fw[0]); bl.w = pk_mul(rb[0].w, fw[0]);
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned b_lds = (unsigned)(size_t)((lds_char *)smem) + (unsigned)(2 * kGA) + b_dst;
+  auto blend_store = [&](int buf) {
+    u32x4_t bl;
+    bl.x = pk_mul(rb[0].x, c_fw[0]); bl.y = pk_mul(rb[0].y, c_fw[0]);
+    bl.z = pk_mul(rb[0].z, c_fw[0]); bl.w = pk_mul(rb[0].w, c_fw[0]);
 #pragma unroll
     for (int q = 1; q < 4; ++q) {
-      bl.x = pk_fma(rb[q].x, fw[q], bl.x); bl.y = pk_fma(rb[q].y, fw[q], bl.y);
-      bl.z = pk_fma(rb[q].z, fw[q], bl.z); bl.w = pk_fma(rb[q].w, fw[q], bl.w);
+      bl.x = pk_fma(rb[q].x, c_fw[q], bl.x); bl.y = pk_fma(rb[q].y, c_fw[q], bl.y);
+      bl.z = pk_fma(rb[q].z, c_fw[q], bl.z); bl.w = pk_fma(rb[q].w, c_fw[q], bl.w);
     }
-    *reinterpret_cast<uint4 *>(smem + 2 * kGA + buf * kGB + b_dst) = bl;
+    // hand-written store (see dcn_glds_s8_kernel): a compiler-visible LDS store would drain vmcnt to 0
+    asm volatile("ds_write_b128 %0, %1" ::"v"(b_lds + (unsigned)(buf * kGB)), "v"(bl) : "memory");
   };
 
-  // prologue: first step -> buffer 0
-  footprint(tap_begin);
-  stage_issue(tap_begin, 0, 0);
-  blend_write(0);  // (the compiler waits for rb here)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // prologue: step 0 -> buffer 0, corners of step 1 in flight
+  gather_next();
+  blend_store(0);
+  __builtin_amdgcn_sched_barrier(0);
+  weights_next(0);
+  if (n_my_steps > 1) gather_next();
+  if (n_my_steps > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  int tap = tap_begin, chunk = 0;
-  for (int step = 0; step < n_my_steps; ++step) {
-    const int buf = step & 1;
-    // next step's coordinates
-    int ntap = tap, nchunk = chunk + 1;
-    if (nchunk == chunks) { nchunk = 0; ntap = tap + 1 < KK ? tap + 1 : 0; }
-    const bool more = step + 1 < n_my_steps;
-    if (more) {
-      if (ntap != tap) footprint(ntap);
-      stage_issue(ntap, nchunk, buf ^ 1);
-    }
+  auto mfma_step = [&](int buf) {
     const char *Ab = smem + buf * kGA;
     const char *Bb = smem + 2 * kGA + buf * kGB;
 #pragma unroll
@@ -837,11 +851,32 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b, acc[i], 0, 0, 0);
     }
-    if (more) blend_write(buf ^ 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    tap = ntap;
-    chunk = nchunk;
+  };
+  // tp.rotate: the upper half of the waves runs the same loop rotated by half an iteration (its barrier sits
+  // between the blend and the MFMAs, MFMA(0) is peeled): between two barriers one half issues its loads while
+  // the other half reads fragments and feeds the matrix cores (see dcn_glds_s8_kernel)
+  const bool late = tp.rotate && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  if (late) {
+    if (n_my_steps > 1) weights_next(1);
+    mfma_step(0);
+  }
+  for (int step = 0; step < n_my_steps; ++step) {
+    const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+    if (more1) blend_store((step + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (late ? more2 : more1) weights_next(late ? (step & 1) : ((step + 1) & 1));
+    if (more2) gather_next();
+    __builtin_amdgcn_sched_barrier(0);
+    if (late ? more1 : true) mfma_step(late ? ((step + 1) & 1) : (step & 1));
+    if (!late) {
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
   if (is_tail) {  // fp32 partials, thread-private order (the finish kernel uses the same mapping)
     float4 *pp = reinterpret_cast<float4 *>(tp.partial) +
@@ -1341,7 +1376,6 @@ __global__ __launch_bounds__(256, 3) void dcn_fused_s8_kernel(
 //   barrier -- the upper half of the waves runs the MFMAs first and the producer work after them.
 // The int32 partial sums of the split-K tail are exact in any order.  Bit-identical to the im2col + GEMM pair.
 constexpr int kSOmRows = 32;   // 3 * Kh * Kw int8 rows of offsets / mask per pixel tile
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int WN> struct GldsS8 {
   static constexpr int kLds = Glds<WN>::kLds + kSOmRows * Glds<WN>::kN;
 };
@@ -1349,10 +1383,11 @@ template <int WN> struct GldsS8 {
 // T2int8(T2int8(sum / 255) * mask) of 4 channels whose first requantisation sits in the top byte of x[c]
 __device__ __forceinline__ unsigned s8_mask4(const int (&x)[4], float m) {
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  // (no SDWA byte-select convert here: hand-placed directly behind the v_mad_i32_i24 of s8_quad it read stale
+  // registers -- the hazard recogniser does not see inline asm -- and it measured no faster where it was legal)
   float val[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)   // sign-extended top byte -> float in one SDWA convert
-    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(val[c]) : "v"(x[c]));
+  for (int c = 0; c < 4; ++c) val[c] = (float)(x[c] >> 24);
   int q[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {   // two channels per packed fp32 multiply / add (separate roundings, as the reference)
@@ -1361,19 +1396,14 @@ __device__ __forceinline__ unsigned s8_mask4(const int (&x)[4], float m) {
 #pragma clang fp contract(off)
       a = f32x2_t{val[2 * h], val[2 * h + 1]} * f32x2_t{m, m};
     }
-    a.x = __builtin_amdgcn_fmed3f(a.x, -128.f, 127.f);
-    a.y = __builtin_amdgcn_fmed3f(a.y, -128.f, 127.f);
-    // + copysign(0.5, a): a == 0 rounds to 0 with either sign, as (a > 0 ? 0.5 : -0.5) does
-    f32x2_t hh;
-    hh.x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a.x) & 0x80000000u) | 0x3f000000u);
-    hh.y = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a.y) & 0x80000000u) | 0x3f000000u);
-    f32x2_t r;
-    {
-#pragma clang fp contract(off)
-      r = a + hh;
-    }
-    q[2 * h] = (int)r.x;
-    q[2 * h + 1] = (int)r.y;
+    const float ax = __builtin_amdgcn_fmed3f(a.x, -128.f, 127.f), ay = __builtin_amdgcn_fmed3f(a.y, -128.f, 127.f);
+    // + copysign(0.5, a): a == 0 rounds to 0 with either sign, as (a > 0 ? 0.5 : -0.5) does.  (Scalars on
+    // purpose: with the clamped values written back into the 2-vector, hipcc 7.2 emitted ONE v_bfi for the
+    // pair and gave both lanes the first lane's sign -- caught by the bit-identity test.)
+    const float hx = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, ax) & 0x80000000u) | 0x3f000000u);
+    const float hy = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, ay) & 0x80000000u) | 0x3f000000u);
+    q[2 * h] = (int)add_rn(ax, hx);
+    q[2 * h + 1] = (int)add_rn(ay, hy);
   }
   const unsigned lo = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);   // bytes: q0, q1, 0, 0
   const unsigned hi = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x04000c0cu);   // bytes: 0, 0, q2, q3
@@ -1381,7 +1411,7 @@ __device__ __forceinline__ unsigned s8_mask4(const int (&x)[4], float m) {
 }
 
 // ABL (timing experiments; 1..8 give wrong results): 1 no gathers, 2 no producer VALU, 4 no weight DMA, 8 no MFMA,
-// 16 all waves in the same phase order
+// 16 wave halves in opposite phase order (correct results; measured no faster: the kernel is VALU-bound)
 template <int WN, int ABL>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
     const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
@@ -1572,12 +1602,11 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   // iteration `step`: tiles of `step` in buffer step & 1, raw corners of step + 1 in rb (a step old).  The
   // weight DMA of step + 1 is always issued BEFORE the gathers of step + 2, so vmcnt(4) in front of the
   // barrier retires it and leaves the gathers in flight.
-  // The two halves of the block's waves run the step's phases in opposite order (every SIMD holds two waves
-  // of each half): while the early half does its VALU work (transposes, dots, mask multiply, rounding) the
-  // late half runs the MFMAs + fragment reads, and vice versa -- with all 16 waves in the same order the
-  // barrier keeps them in lockstep and the VALU, MFMA / LDS and gather phases add up (measured: removing any
-  // one of them shortened the kernel by its full length, profiles/r02).
-  const bool late = !(ABL & 16) && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  // ABL & 16: the two halves of the block's waves run the step's phases in opposite order (every SIMD holds
+  // two waves of each half): while the early half does its VALU work the late half runs the MFMAs + fragment
+  // reads.  Measured no faster (68.6 vs 67.6 us): the producer VALU work is ~70 % of the SIMD time whatever
+  // the order (profiles/r02/int8_dcn_pmc.txt), so the default keeps all waves in the same order.
+  const bool late = (ABL & 16) && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
   auto mfma_step = [&](int buf) {
     if constexpr (ABL & 8) return;
     const char *Ab = smem + buf * kGA;
@@ -1687,6 +1716,7 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
 
 thread_local int g_mdconv_variant = 0;
 thread_local bool g_mdconv_no_tail = false;
+thread_local bool g_mdconv_rotate = false;   // variant 7: fp16 LDS-DMA kernel with the wave halves in opposite phase order
 thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles  // variant 4: LDS-DMA kernel without the split-K tail
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -1751,7 +1781,7 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
   const int slots = glds_resident_blocks<WN>();
   if (slots <= 0) return BEVOPS_FAILURE;
   // tail plan: leftover tiles of a sparsely filled last round are split along K
-  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0, om_channels};
+  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0, om_channels, g_mdconv_rotate ? 1 : 0};
   const int blocks = (int)(grid.x * grid.y);
   if (allow_tail && blocks > slots && grid.y == 1) {
     const int left = blocks % slots;
@@ -1804,7 +1834,7 @@ int launch_glds_s8(const int8_t *xt, const void *offset, const void *mask, const
   const dim3 grid((unsigned)((N + Glds<WN>::kN - 1) / Glds<WN>::kN), (cout_g + kFM - 1) / kFM);
   const int slots = glds_s8_resident_blocks<WN, ABL>();
   if (slots <= 0) return BEVOPS_FAILURE;
-  TailPlan tp{0, 1, (int)grid.x, nullptr, 0, 0, 0};
+  TailPlan tp{0, 1, (int)grid.x, nullptr, 0, 0, 0, 0};
   const int blocks = (int)(grid.x * grid.y);
   if (allow_tail && blocks > slots && grid.y == 1) {
     const int left = blocks % slots;
@@ -2049,7 +2079,8 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_variant = (variant == 4 || variant == 5) ? 0 : variant;
+  g_mdconv_rotate = variant == 7;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7) ? 0 : variant;
   return prev;
 }
 

@@ -48,8 +48,13 @@ def main():
         mh = torch.rand(B, 9, H, W, generator=g).half().cuda()
         wh = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().cuda()
         bh = torch.zeros(C).half().cuda()
-        m, mn = med(lambda: bev.modulated_deformable_conv2d(xh, oh, mh, wh, bh, 1, 1, 1, 1, 1))
-        print(json.dumps({"op": "dcn_f16", "shape": [B, C, H, W], "us": m, "min_us": mn}), flush=True)
+        for v in (0, 7):      # 7: wave halves in opposite phase order
+            lib.bevops_mdconv_set_variant(v)
+            try:
+                m, mn = med(lambda: bev.modulated_deformable_conv2d(xh, oh, mh, wh, bh, 1, 1, 1, 1, 1))
+                print(json.dumps({"op": "dcn_f16", "shape": [B, C, H, W], "variant": v, "us": m, "min_us": mn}), flush=True)
+            finally:
+                lib.bevops_mdconv_set_variant(0)
         xc = xh.contiguous(memory_format=torch.channels_last)
         w27 = (torch.randn(27, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().cuda()
         b27 = torch.zeros(27).half().cuda()
