@@ -153,9 +153,9 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
   }
 }
 
-// ---- experimental "rows" variant (bevops_conv3x3_c32_set_variant(1); NOT the default: written after
-// the last GPU visit of round 1, not yet run on hardware) -----------------------------------------
-// The default kernel pulls every tap of every pixel from the fabric: 9 x the image bytes, at the
+// ---- "rows" variant (default for large maps since round 2; bevops_conv3x3_c32_set_variant(1 / 2)
+// forces it on / off) ------------------------------------------------------------------------------
+// The tile kernel pulls every tap of every pixel from the fabric: 9 x the image bytes, at the
 // ~11 B/clk a CU gets for data another XCD wrote.  The 9 taps of a run of consecutive pixels
 // [P0, P0 + 128) only touch the contiguous flattened range [P0 - W - 1, P0 + 128 + W + 1): this
 // variant stages that range ONCE per 64-channel chunk in LDS (coalesced 128-byte rows, 16-byte
@@ -355,7 +355,10 @@ extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __half *x = (const __half *)input_nhwc, *wp = (const __half *)packed_weight, *b = (const __half *)bias32;
   __half *o = (__half *)output_nhwc;
-  if (g_conv_variant == 1) {  // experimental rows-in-LDS variant; falls through when it does not fit
+  // rows-in-LDS variant: measured on hardware in round 2 (profiles/r02/int8_dcn_time.jsonl: 27.2 vs 29.6 us at the
+  // base stage-3 shape, 26.8 vs 26.3 at stage 4) -- the default where it wins (many pixel runs), variant 1 forces
+  // it, variant 2 forces the tile kernel; falls through when a row range does not fit the LDS
+  if (g_conv_variant == 1 || (g_conv_variant == 0 && (size_t)B * H * W >= 16384)) {
     const int rc = launch_conv_rows(x, wp, b, o, B, H, W, Cin, CP / 64, st);
     if (rc != BEVOPS_NOT_SUPPORTED) return rc;
   }

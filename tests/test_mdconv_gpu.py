@@ -204,8 +204,6 @@ def test_conv_offset_nhwc_matches_conv2d(bev, shape):
     assert (out2[:, :27].float() - want2).abs().max().item() <= 4e-3 * max(1.0, want2.abs().max().item())
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("BEVOPS_TEST_EXPERIMENTAL"),
-                    reason="rows-in-LDS offset convolution (variant 1) is experimental: not run on hardware yet")
 @pytest.mark.parametrize("shape", [(6, 256, 58, 100), (6, 512, 29, 50), (2, 64, 13, 17), (1, 128, 9, 9), (3, 256, 7, 5)])
 def test_conv_offset_rows_variant_matches_default(bev, shape):
     import torch.nn.functional as F
@@ -216,9 +214,10 @@ def test_conv_offset_rows_variant_matches_default(bev, shape):
     x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(27, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().cuda()
     b = torch.randn(27, generator=g).half().cuda()
-    ref = bev.conv_offset_nhwc(x, w, b)
     try:
-        lib.bevops_conv3x3_c32_set_variant(1)
+        lib.bevops_conv3x3_c32_set_variant(2)     # tile kernel
+        ref = bev.conv_offset_nhwc(x, w, b)
+        lib.bevops_conv3x3_c32_set_variant(1)     # rows-in-LDS kernel (the default for large maps)
         got = bev.conv_offset_nhwc(x, w, b)
     finally:
         lib.bevops_conv3x3_c32_set_variant(0)
