@@ -1,0 +1,68 @@
+"""The RCCL code path of the camera-sharded encoder on hardware.  The GPU box has ONE device, so the
+process group has one rank: backend "nccl" (= RCCL), device tensors, the asynchronous per-camera
+all_gather_into_tensor / all_reduce of CameraExchange enqueued on RCCL's stream and waited for from the
+compute stream -- everything a multi-GPU run does except the wire.  (World > 1 is covered on gloo:
+tests/test_camera_shard_cpu.py, tests/test_model_shard_cpu.py.)"""
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["gather", "reduce"])
+def test_exchange_primitives_on_rccl(nccl_group, mode):
+    from bevformer_tensorrt_amd.camera_shard import CameraExchange, gather_camera_features, reduce_camera_slots
+    dist = nccl_group
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(6, 2500, 256, generator=g).half().cuda()
+    got = gather_camera_features(feats, 6, dist)
+    assert torch.equal(got, feats)
+    part = feats.float().sum(0, keepdim=True)
+    assert torch.equal(reduce_camera_slots(part.clone(), dist), part)
+    ex = CameraExchange(dist, 6, mode)
+    assert list(ex.cams) == list(range(6)) and ex.world == 1
+
+
+@pytest.mark.parametrize("mode", ["gather", "reduce"])
+def test_model_with_exchange_equals_plain_model(nccl_group, mode):
+    """BEVFormer-tiny (fp16, HIP operators) with cams / CameraExchange wired in -- the sharded code path of
+    bevformer.py with its per-camera sampler calls and collectives -- against the plain single-GPU path
+    (which uses the fused SCA op): same network, two dataflows."""
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    from bevformer_tensorrt_amd.camera_shard import CameraExchange
+    dev, dtype = torch.device("cuda"), torch.float16
+    model = B.BEVFormer("tiny", seed=0).to(dev, dtype)
+    ex = CameraExchange(nccl_group, 6, mode)
+    H, W = B.CONFIGS["tiny"]["image"]
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    g = torch.Generator().manual_seed(0)
+    run_s = B.FrameRunner(model, dev, dtype, cams=list(ex.cams), gather=ex)
+    run_p = B.FrameRunner(model, dev, dtype)
+    for i in range(2):
+        img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+        can = torch.zeros(18)
+        can[0], can[-1] = 0.3 * i, 0.5 * i
+        cs, bs = run_s.step(img, can, l2i, "s")
+        cp, bp = run_p.step(img, can, l2i, "s")
+        torch.cuda.synchronize()
+        scale = run_p.prev_bev.float().std().item()
+        assert (run_s.prev_bev.float() - run_p.prev_bev.float()).abs().max().item() <= 3e-2 * max(1.0, scale)
+        assert (cs.float() - cp.float()).abs().max().item() <= 5e-2
+        # box parameters are unbounded regressions (|values| up to ~25 here): relative bar
+        assert (bs.float() - bp.float()).abs().max().item() <= 2e-2 * max(1.0, bp.float().abs().max().item())
