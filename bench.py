@@ -77,9 +77,15 @@ def msda_bytes(cfg, esize, bs=None):
 
 
 def cpu_baseline(max_seconds=30.0):
-    """Reference PyTorch CPU path (port), fp32, on a bounded sample: one base TSA
-    call + one base decoder call + a query-slice of the base SCA call, scaled to a
-    frame (6 x each).  Returns frames/s."""
+    """The WHOLE hot-path step on the host cores (port), fp32, on a bounded sample scaled to a frame:
+      * MSDA: the reference's PyTorch CPU path (oracle/torch_ref.py) -- one base TSA call + one base
+        decoder call + 1/8 of the queries of the base SCA call (6 x each per frame);
+      * DCNv2: the C restatement of the reference's im2col + GEMM launcher (oracle/mdconv_ref.c,
+        OpenMP) on ONE camera image per ResNet stage (6 images x 23 resp. 3 convolutions per frame);
+      * rotate: oracle/sampler_ref.c at 256 x 200 x 200, once per frame.
+    Returns frames/s and the per-part seconds."""
+    import numpy as np
+    import oracle
     from oracle import torch_ref
     gen = torch.Generator().manual_seed(0)
     t_frame = 0.0
@@ -96,6 +102,23 @@ def cpu_baseline(max_seconds=30.0):
         dt = (time.perf_counter() - t0) / frac
         parts.append(f"{name}:{dt:.3f}s")
         t_frame += dt * (BASE["enc_layers"] if name != "dec" else BASE["dec_layers"])
+    rng = np.random.default_rng(0)
+    for count, C, H, W in BASE["dcn"]:
+        x = rng.standard_normal((1, C, H, W), dtype=np.float32)
+        off = rng.standard_normal((1, 18, H, W), dtype=np.float32)
+        m = rng.random((1, 9, H, W), dtype=np.float32)
+        w = rng.standard_normal((C, C, 3, 3), dtype=np.float32) * 0.02
+        t0 = time.perf_counter()
+        oracle.mdconv(x, off, m, w, np.zeros(C, np.float32), (1, 1), (1, 1), (1, 1), 1, 1)
+        dt = (time.perf_counter() - t0) * 6          # six camera images per call
+        parts.append(f"dcn{C}:{dt:.3f}s")
+        t_frame += dt * count
+    img = rng.standard_normal((BASE["embed"],) + BASE["bev"], dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.rotate(img, 3.0, (100.0, 100.0), 1)
+    dt = time.perf_counter() - t0
+    parts.append(f"rotate:{dt:.3f}s")
+    t_frame += dt
     return 1.0 / t_frame, " ".join(parts)
 
 def cpu_full_model(frames=2):
@@ -452,9 +475,11 @@ def main():
             v, sample = cpu_baseline()
             cpu = {"value": round(v, 5), "unit": "frames/s", "cores": torch.get_num_threads(),
                    "kind": "port",
-                   "sample": "reference PyTorch CPU MSDA path (oracle/torch_ref.py), fp32, base "
-                             "TSA + decoder calls in full and 1/8 of the SCA queries, scaled to "
-                             "6+6+6 calls per frame (the MSDA part of the step only); per-call " + sample}
+                   "sample": "the whole hot-path step in fp32 on the host: MSDA = reference PyTorch CPU path "
+                             "(oracle/torch_ref.py), base TSA + decoder calls in full and 1/8 of the SCA queries, "
+                             "x 6+6+6 calls; DCNv2 = C restatement of the reference launcher (oracle/mdconv_ref.c, "
+                             "OpenMP) on one camera image per stage, x 6 images x 23+3 convolutions; rotate = "
+                             "oracle/sampler_ref.c once; per-call seconds " + sample}
             try:
                 cpu["full_model"] = cpu_full_model()
             except Exception as exc:
