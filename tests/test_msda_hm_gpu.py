@@ -109,14 +109,12 @@ def test_hm_out_of_view_and_zero_pads(ctx):
         assert (d.float() - run(ctx, args, 10).float()).abs().max().item() <= 6e-3
 
 
-@pytest.mark.parametrize("variant", [0, 10, 11, 15, 16, 99])
-@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("variant,dtype", [(v, torch.float16) for v in (0, 10, 11, 15, 16, 17, 99)] +
+                         [(v, torch.float32) for v in (0, 10, 99)])     # the head-major kernels are fp16-only
 def test_camera_shared_offsets_equal_repeated(ctx, variant, dtype):
     """sampling_offsets / attention_weights passed as stride-0 expanded views (the SCA query is
     the same for every camera, spatial_cross_attention.py:254) must give exactly what the
     materialised repeat gives, on every kernel family."""
-    if dtype == torch.float32 and variant in (11, 15, 16):
-        pytest.skip("head-major path is fp16-only")
     bev, lib = ctx
     args = gen((6, [[20, 32], [10, 16], [5, 8], [3, 4]], 2500, 8, 4), ref_lo=-0.2, ref_hi=1.2)
     args = [a.to(dtype) if a.is_floating_point() else a for a in args]
