@@ -438,7 +438,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         }
         pl[k].x = (a0 & 255u) | ((a1 & 255u) << 8) | ((a2 & 255u) << 16) | ((a3 & 255u) << 24);
         pl[k].y = valid ? (unsigned)wq[k] : 0u;
-        if constexpr (U8W) pl[k].y |= (a0 + a1 + a2 + a3) << 8;   // <= 1020
+        // x255 flavour: the dot's addend -128 (a0 + a1 + a2 + a3) rides above the weight byte (>= -130 560: fits;
+        // the consumer's arithmetic shift by 8 returns it exactly because the weight byte is non-negative)
+        if constexpr (U8W) pl[k].y |= (unsigned)(-(int)((a0 + a1 + a2 + a3) << 7)) << 8;
       } else {
         const float ev = valid ? e[k] : 0.f;
         const float wr1 = ly * ev, wr0 = ev - wr1;
@@ -505,13 +507,19 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
         int x[BT][4];
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
-          if constexpr (U8W) i8_sample_u(v[j], rec[j].x, -(int)((rec[j].y >> 8) << 7), magic, half, x[j]);
+          if constexpr (U8W) i8_sample_u(v[j], rec[j].x, (int)rec[j].y >> 8, magic, half, x[j]);
           else i8_sample_s(v[j], rec[j].x, magic, half, x[j]);
         }
-        unsigned w4 = rec[0].y & 0xffu;
-        if constexpr (BT > 1) w4 |= (rec[1].y & 0xffu) << 8;
-        if constexpr (BT > 2) w4 |= (rec[2].y & 0xffu) << 16;
-        if constexpr (BT > 3) w4 |= (rec[3].y & 0xffu) << 24;
+        unsigned w4;   // the four samples' softmax weight bytes (byte 0 of rec.y), sample 0 in byte 0
+        if constexpr (BT == 4) {
+          const unsigned lo = __builtin_amdgcn_perm(rec[1].y, rec[0].y, 0x0c0c0400u);
+          const unsigned hi = __builtin_amdgcn_perm(rec[3].y, rec[2].y, 0x04000c0cu);
+          w4 = lo | hi;
+        } else {
+          w4 = rec[0].y & 0xffu;
+          if constexpr (BT > 1) w4 |= (rec[1].y & 0xffu) << 8;
+          if constexpr (BT > 2) w4 |= (rec[2].y & 0xffu) << 16;
+        }
         if constexpr (U8W) {
           // unsigned softmax weights: s w = (s + 128) w - 128 w; the second term once per batch
           wsum += (int)__builtin_amdgcn_udot4(w4, 0x01010101u, 0u, false);

@@ -109,7 +109,7 @@ def test_hm_out_of_view_and_zero_pads(ctx):
         assert (d.float() - run(ctx, args, 10).float()).abs().max().item() <= 6e-3
 
 
-@pytest.mark.parametrize("variant,dtype", [(v, torch.float16) for v in (0, 10, 11, 15, 16, 17, 99)] +
+@pytest.mark.parametrize("variant,dtype", [(v, torch.float16) for v in (0, 10, 11, 15, 16, 99)] +
                          [(v, torch.float32) for v in (0, 10, 99)])     # the head-major kernels are fp16-only
 def test_camera_shared_offsets_equal_repeated(ctx, variant, dtype):
     """sampling_offsets / attention_weights passed as stride-0 expanded views (the SCA query is
