@@ -45,6 +45,20 @@ def test_query_table(lib):
         assert lib.bevops_query(name), name
     assert not lib.bevops_query(b"NoSuchPlugin")
     assert not lib.bevops_query(None)
+    # every operator entry of the header resolves through the registry to the exported symbol itself
+    # (identification / A-B switches are not operators)
+    skip = {"bevops_version", "bevops_status_string", "bevops_query"}
+    for s in _declared_symbols():
+        if s in skip or s.endswith("_set_variant"):
+            continue
+        addr = lib.bevops_query(s.encode())
+        assert addr, f"{s} missing from bevops_query's table"
+        assert addr == ctypes.cast(getattr(lib, s), ctypes.c_void_p).value, s
+    # all ten reference plugin type names (both versions) resolve
+    for plugin in ("MultiScaleDeformableAttnTRT", "RotateTRT", "GridSampler2DTRT", "GridSampler3DTRT",
+                   "BEVPoolV2TRT", "ModulatedDeformableConv2dTRT"):
+        for v in ("", "2"):
+            assert lib.bevops_query((plugin + v).encode()), plugin + v
 
 
 def test_msda_rejects_bad_params_without_gpu(lib):
