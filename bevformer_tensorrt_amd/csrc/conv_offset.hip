@@ -153,8 +153,7 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
   }
 }
 
-// ---- "rows" variant (default for large maps since round 2; bevops_conv3x3_c32_set_variant(1 / 2)
-// forces it on / off) ------------------------------------------------------------------------------
+// ---- "rows" variant (bevops_conv3x3_c32_set_variant(1); A/B only, see the dispatch below) ----------
 // The tile kernel pulls every tap of every pixel from the fabric: 9 x the image bytes, at the
 // ~11 B/clk a CU gets for data another XCD wrote.  The 9 taps of a run of consecutive pixels
 // [P0, P0 + 128) only touch the contiguous flattened range [P0 - W - 1, P0 + 128 + W + 1): this
@@ -355,10 +354,11 @@ extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __half *x = (const __half *)input_nhwc, *wp = (const __half *)packed_weight, *b = (const __half *)bias32;
   __half *o = (__half *)output_nhwc;
-  // rows-in-LDS variant: measured on hardware in round 2 (profiles/r02/int8_dcn_time.jsonl: 27.2 vs 29.6 us at the
-  // base stage-3 shape, 26.8 vs 26.3 at stage 4) -- the default where it wins (many pixel runs), variant 1 forces
-  // it, variant 2 forces the tile kernel; falls through when a row range does not fit the LDS
-  if (g_conv_variant == 1 || (g_conv_variant == 0 && (size_t)B * H * W >= 16384)) {
+  // rows-in-LDS variant (variant 1): measured on hardware in round 2 -- 27.2 vs 29.6 us at the base stage-3
+  // shape in isolation (profiles/r02/int8_dcn_time.jsonl), but inside the model, where the activation was
+  // just written by the previous kernel, the frame is SLOWER with it (base 15.88 vs 15.46 ms, small 9.49 vs
+  // 9.21 ms, profiles/r02/model_bench_conv_ab.jsonl): it stays an A/B switch, the tile kernel the default
+  if (g_conv_variant == 1) {
     const int rc = launch_conv_rows(x, wp, b, o, B, H, W, Cin, CP / 64, st);
     if (rc != BEVOPS_NOT_SUPPORTED) return rc;
   }

@@ -308,8 +308,8 @@ int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *resid
  * offset_mask_channels = 32. */
 size_t bevops_conv3x3_c32_packed_weight_size(int dtype, int Cin);
 int bevops_conv3x3_c32_pack_weight(int dtype, const void *weight, void *packed, int Cout, int Cin, void *stream);
-/* 0 = automatic (rows-in-LDS kernel for maps of >= 16384 pixels, tile kernel otherwise); 1 / 2 force the
- * rows / tile kernel (A/B, tests). Returns the previous value. */
+/* 0 (and 2) = tile kernel; 1 = the variant that stages the image rows in LDS (faster in isolation at the base
+ * stage-3 shape, slower inside the model: A/B, tests). Returns the previous value. */
 int bevops_conv3x3_c32_set_variant(int variant);
 int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const void *packed_weight,
                                     const void *bias32, void *output_nhwc, int B, int H, int W, int Cin,

@@ -45,7 +45,13 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--conv-variant", type=int, default=0, help="bevops_conv3x3_c32_set_variant (A/B)")
+    ap.add_argument("--mdconv-variant", type=int, default=0, help="bevops_mdconv_set_variant (A/B)")
     a = ap.parse_args()
+    if a.conv_variant or a.mdconv_variant:
+        from bevformer_tensorrt_amd.utils import load_library
+        load_library().bevops_conv3x3_c32_set_variant(a.conv_variant)
+        load_library().bevops_mdconv_set_variant(a.mdconv_variant)
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
         print(json.dumps(run(m, a.frames, dt, a.graph)), flush=True)
