@@ -100,6 +100,48 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_f16v_kernel(const __half *__
   }
 }
 
+// int8, HW % 4 == 0 and C % 16 == 0: 128 channels x 128 pixels per block.  A thread loads a 4 x 4 byte block
+// (4 pixels of 4 channel rows, lanes along the pixels: 128 contiguous bytes per row and half-wave), transposes
+// it in registers and writes 4 dwords (4 channels of one pixel each) into the [pixel][channel] tile; the tile
+// leaves as 16-byte vectors, 128 contiguous bytes per pixel.  (The byte-wise 32 x 32 kernel above took 12 us
+// for the 8.9 MB stage-3 image -- longer than the fp16 copy of twice the bytes.)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_s8v_kernel(const int8_t *__restrict__ in, int8_t *__restrict__ out,
+                                                               int C, int HW, unsigned flip4) {
+  constexpr int kRow = 128 + 16;   // bytes per tile row (16-byte aligned rows for the b128 reads)
+  __shared__ __attribute__((aligned(16))) unsigned char tile[128 * kRow];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int8_t *ib = in + (size_t)b * C * HW;
+  int8_t *ob = out + (size_t)b * C * HW;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = threadIdx.x + it * 256;      // 32 channel quads x 32 pixel quads
+    const int pq = v & 31, cq = v >> 5;
+    const int p = p0 + pq * 4, c = c0 + cq * 4;
+    unsigned r[4] = {0u, 0u, 0u, 0u};
+    if (p < HW && c < C) {                      // HW % 4 == 0, C % 4 == 0: the 4 x 4 block is all in or all out
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const unsigned *>(ib + (size_t)(c + k) * HW + p) ^ flip4;
+    }
+    // r[k] = 4 pixels of channel c + k  ->  o[j] = 4 channels of pixel p + j
+    const unsigned a = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), e = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+    const unsigned f = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), g = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    const unsigned o[4] = {__builtin_amdgcn_perm(f, a, 0x05040100u), __builtin_amdgcn_perm(f, a, 0x07060302u),
+                           __builtin_amdgcn_perm(g, e, 0x05040100u), __builtin_amdgcn_perm(g, e, 0x07060302u)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<unsigned *>(&tile[(pq * 4 + j) * kRow + cq * 4]) = o[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = threadIdx.x + it * 256;      // 128 pixels x 8 chunks of 16 channels
+    const int ch = v & 7, pl = v >> 3;
+    if (p0 + pl < HW && c0 + ch * 16 < C)
+      *reinterpret_cast<uint4 *>(ob + (size_t)(p0 + pl) * C + c0 + ch * 16) =
+          *reinterpret_cast<const uint4 *>(&tile[pl * kRow + ch * 16]);
+  }
+}
+
 // ---- 2. weight [Cout][Cin/g][KK] -> [Cout][KK][Cin/g] ------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void repack_weight_kernel(const T *__restrict__ w,
@@ -2003,8 +2045,12 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
                     3 * KK <= kSOmRows && Kp == Kg && (wide_blocks >= (size_t)cus || g_mdconv_variant == 9);
   const bool fused = glds || (g_mdconv_variant != 6 && cin_g % kSK == 0 && (d.Cin / d.DG) % kSK == 0 && fits32 &&
                               (g_mdconv_variant == 8 || tiles >= (size_t)2 * cus));
-  hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
-                     0, st, (const int8_t *)input, xt, d.Cin, HW, fused ? 0x80 : 0);
+  if (HW % 4 == 0 && d.Cin % 16 == 0 && aligned16(input))
+    hipLaunchKernelGGL(nchw_to_nhwc_s8v_kernel, dim3((HW + 127) / 128, (d.Cin + 127) / 128, d.B), dim3(256), 0, st,
+                       (const int8_t *)input, xt, d.Cin, HW, fused ? 0x80808080u : 0u);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<int8_t>), dim3((HW + 31) / 32, (d.Cin + 31) / 32, d.B), dim3(256),
+                       0, st, (const int8_t *)input, xt, d.Cin, HW, fused ? 0x80 : 0);
   const size_t wtot = (size_t)d.Cout * cin_g * KK;
   if (!weight_is_packed)
     hipLaunchKernelGGL((repack_weight_kernel<int8_t>), dim3((unsigned)((wtot + 255) / 256)), dim3(256), 0, st,
