@@ -286,10 +286,12 @@ def test_int8_fused_kernel_is_bit_identical_to_im2col_gemm(bev, shape):
     (3, 256, 320, 19, 23, 2, 2, 2),      # stride 2, two groups of 128 channels with their own deform group
     (1, 256, 64, 5, 7, 1, 1, 1),         # less than one pixel tile
 ])
-@pytest.mark.parametrize("variant", [0, 4])
+@pytest.mark.parametrize("variant", [0, 4, 9])
 def test_int8_lds_dma_kernel_is_bit_identical_to_im2col_gemm(bev, shape, variant):
     """dcn_glds_s8_kernel (weights by LDS-DMA, two LDS buffers, gathers a step ahead, split-K tail with int32
-    partials; variant 4: without the tail split) against the im2col + GEMM pair (variant 6)."""
+    partials; variant 4: without the tail split; variant 9: forced also where the default keeps another
+    kernel, i.e. the 64-pixel-tile instantiation, two Cout tiles, groups) against the im2col + GEMM pair
+    (variant 6)."""
     from bevformer_tensorrt_amd.utils import load_library
     lib = load_library()
     B, Cin, Cout, H, W, stride, G, DG = shape
