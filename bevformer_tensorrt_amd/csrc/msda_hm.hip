@@ -126,8 +126,34 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
   for (unsigned q = ck * (unsigned)chunk + (threadIdx.x >> 3); q < q_end; q += IPP) {
     const size_t item = ((size_t)b * d.nq + q) * d.heads + h;
     const size_t in_item = ((size_t)(d.shared ? 0u : b) * d.nq + q) * d.heads + h;
+    // all three operand streams of the item are requested before any math: round 2 found the reference
+    // points loaded behind the softmax (a second exposed round trip per item) and, for the few-point calls
+    // (TSA / decoder: 4 point steps), the taps issued and waited for one step at a time
+    unsigned offraw[PPL], refraw[PPL];
+    load_raw<PPL>(off + (in_item * LP + sub * PPL) * 2, offraw);
+    const __half *refp = ref + ((size_t)b * d.nq + q) * (unsigned)d.ppg * 2u;
+    {
+      const int jj = (int)sub * PPL;
+      int pp = jj - (jj / d.P) * d.P;
+      int gg = pp % d.ppg;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        refraw[k] = *reinterpret_cast<const unsigned *>(refp + 2 * gg);
+        ++pp; ++gg;
+        if (gg == d.ppg) gg = 0;
+        if (pp == d.P) { pp = 0; gg = 0; }
+      }
+    }
+    unsigned lgraw[(PPL + 1) / 2];
+    {
+      const __half *lp = logit + in_item * LP + sub * PPL;
+      if constexpr (PPL == 1) lgraw[0] = *reinterpret_cast<const unsigned short *>(lp);
+      else load_raw<PPL / 2>(lp, lgraw);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the three requests go out together, the math follows
     float e[PPL];
-    load_f<PPL>(logit + in_item * LP + sub * PPL, e);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) e[k] = (k & 1) ? h2f_hi(lgraw[k / 2]) : h2f_lo(lgraw[k / 2]);
     float m = e[0];
 #pragma unroll
     for (int k = 1; k < PPL; ++k) m = fmaxf(m, e[k]);
@@ -139,10 +165,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
       s += e[k];
     }
     s = quad_sum(s);
-    // this lane's 2*PPL offsets stay packed (one dword = the (x, y) pair of a point)
-    unsigned offraw[PPL];
-    load_raw<PPL>(off + (in_item * LP + sub * PPL) * 2, offraw);
-    const __half *refp = ref + ((size_t)b * d.nq + q) * (unsigned)d.ppg * 2u;
+    // (this lane's 2*PPL offsets stay packed: one dword = the (x, y) pair of a point)
 
     int j0 = (int)sub * PPL;
     int l = j0 / d.P;
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
         const int k = pass * CH + kk;
         const int4 t = lvl[l];
         const int H = t.x, W = t.y;
-        const float2 r = load_ref(refp + 2 * g);
+        const float2 r = make_float2(h2f_lo(refraw[k]), h2f_hi(refraw[k]));
         const float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
         const float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
         const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
@@ -212,8 +235,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
         fma8(r1, w1, acc);                                                                   \
       }                                                                                      \
       /* keep at most CH points (2*CH loads) in flight per lane: the scheduler otherwise */  \
-      /* hoists all 8*CH loads of the pass and spills under the 128-VGPR budget */           \
-      __builtin_amdgcn_sched_barrier(0);
+      /* hoists all 8*CH loads of the pass and spills under the 128-VGPR budget -- except */ \
+      /* for the one-point-per-lane calls, whose 8 loads fit and should fly together */      \
+      if constexpr (PPL > 1) __builtin_amdgcn_sched_barrier(0);
       BEVOPS_HM_SRC(0)
       BEVOPS_HM_SRC(1)
       BEVOPS_HM_SRC(2)
