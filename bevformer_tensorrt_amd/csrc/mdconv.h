@@ -9,6 +9,7 @@ namespace bevops {
 // A/B switches of bevops_mdconv_set_variant (defined in mdconv.hip)
 extern thread_local int g_mdconv_variant;
 extern thread_local bool g_mdconv_no_tail;
+extern thread_local bool g_mdconv_wide;
 
 namespace {
 

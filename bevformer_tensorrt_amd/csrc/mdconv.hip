@@ -28,6 +28,7 @@ namespace bevops {
 // A/B switches of bevops_mdconv_set_variant (thread-local; read by mdconv_s8.hip too)
 thread_local int g_mdconv_variant = 0;
 thread_local bool g_mdconv_no_tail = false;
+thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles whatever the tile count
 namespace {
 
 // fp16, HW % 8 == 0 and C % 8 == 0: 64 channels x 64 pixels per block, 16-byte global accesses on
@@ -845,7 +846,6 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half 
 
 
 thread_local bool g_mdconv_rotate = false;   // variant 7: fp16 LDS-DMA kernel with the wave halves in opposite phase order
-thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles  // variant 4: LDS-DMA kernel without the split-K tail
 
 template <int WN>
 int glds_resident_blocks() {
@@ -942,7 +942,9 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
               hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             return BEVOPS_FAILURE;
           const size_t wide_blocks = ((N + Glds<4>::kN - 1) / Glds<4>::kN) * ((cout_g + kFM - 1) / kFM);
-          const bool wide = g_mdconv_wide || (!g_mdconv_no_tail && wide_blocks >= (size_t)cus);
+          // ... or at least every second CU: base stage 4 (136 blocks of 128 pixels) 105 us vs 118 us with
+          // 272 blocks of 64 pixels (profiles/r02/dcn_time.jsonl) -- 16 waves on half the CUs beat 8 waves on all
+          const bool wide = g_mdconv_wide || (!g_mdconv_no_tail && wide_blocks * 2 >= (size_t)cus);
           const int rc = wide
                              ? launch_glds<4>((const __half *)xt, offset, mask, (const __half *)wt, bias, output, d, g,
                                               ws + w.col, w.total - w.col, nhwc_io, relu, !g_mdconv_no_tail, om_channels, st)

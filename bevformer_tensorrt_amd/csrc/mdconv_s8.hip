@@ -917,12 +917,12 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
   bool one_dg = cin_g <= d.Cin / d.DG;
   for (int g = 0; g < d.G && one_dg; ++g)
     one_dg = (g * cin_g) / (d.Cin / d.DG) == (g * cin_g + cin_g - 1) / (d.Cin / d.DG);
-  // ... and enough 128-pixel tiles to give every CU a block (base stage 3: 67 us vs 100 us for the
-  // register-staged kernel; stage 4 with its 136 blocks stays on the im2col + GEMM pair: 121 vs 130 us,
-  // profiles/r02); variant 9 forces it
+  // ... and enough 128-pixel tiles to give at least every second CU a block (base stage 3: 272 tiles, 67 us
+  // kernel vs 100 us for the register-staged kernel; stage 4: 136 blocks, 95 us per call vs 117 us for the
+  // im2col + GEMM pair and 121 us with 64-pixel tiles, profiles/r02/dcn_time.jsonl); variant 9 forces it
   const size_t wide_blocks = ((N + Glds<4>::kN - 1) / Glds<4>::kN) * ((cout_g + kFM - 1) / kFM);
   const bool glds = g_mdconv_variant != 6 && g_mdconv_variant != 8 && fits32 && one_dg && cin_g % 128 == 0 &&
-                    3 * KK <= kSOmRows && Kp == Kg && (wide_blocks >= (size_t)cus || g_mdconv_variant == 9);
+                    3 * KK <= kSOmRows && Kp == Kg && (wide_blocks * 2 >= (size_t)cus || g_mdconv_variant == 9 || g_mdconv_wide);
   const bool fused = glds || (g_mdconv_variant != 6 && cin_g % kSK == 0 && (d.Cin / d.DG) % kSK == 0 && fits32 &&
                               (g_mdconv_variant == 8 || tiles >= (size_t)2 * cus));
   if (HW % 4 == 0 && d.Cin % 16 == 0 && aligned16(input))
@@ -944,7 +944,7 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
       const float s_iw = s_in * s_w;
 #define BEVOPS_S8_GO(WN_, ABL_) \
   rc = launch_glds_s8<WN_, ABL_>(xt, offset, mask, wt, bias, output, d, g, Kp, pw, room, !g_mdconv_no_tail, s_off, s_mask, s_iw, s_out, st)
-      const bool w4 = wide_blocks >= (size_t)cus;
+      const bool w4 = wide_blocks * 2 >= (size_t)cus || g_mdconv_wide;
       if (!w4) BEVOPS_S8_GO(2, 0);
       else
         switch (abl) {

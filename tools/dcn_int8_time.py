@@ -36,7 +36,7 @@ def main():
         mask = torch.randint(0, 128, (B, 9, H, W), generator=g, dtype=torch.int8).cuda()
         w = torch.randint(-127, 128, (C, C, 3, 3), generator=g, dtype=torch.int8).cuda()
         b = torch.zeros(C).cuda()
-        for v in (0, 8, 6) + ((36, 21, 22, 24, 28) if C == 256 and os.environ.get('ABLATE') else ()):
+        for v in (0, 8, 6, 9, 5) + ((36, 21, 22, 24, 28) if C == 256 and os.environ.get('ABLATE') else ()):
             lib.bevops_mdconv_set_variant(v)
             try:
                 m, mn = med(lambda: bev.modulated_deformable_conv2d_int8(x, off, mask, w, b, 0.02, 0.03, 1 / 127, 0.01, 0.05, 1, 1, 1, 1, 1))
@@ -48,7 +48,7 @@ def main():
         mh = torch.rand(B, 9, H, W, generator=g).half().cuda()
         wh = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().cuda()
         bh = torch.zeros(C).half().cuda()
-        for v in (0, 7):      # 7: wave halves in opposite phase order
+        for v in (0, 7, 5):   # 7: wave halves in opposite phase order, 5: 128-pixel tiles whatever the tile count
             lib.bevops_mdconv_set_variant(v)
             try:
                 m, mn = med(lambda: bev.modulated_deformable_conv2d(xh, oh, mh, wh, bh, 1, 1, 1, 1, 1))
