@@ -31,6 +31,10 @@ def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
             raise ValueError(f"grid must be [N,2,H_out,W_out], got {tuple(grid.shape)}")
         Ho, Wo = grid.shape[2:]
         out = torch.empty((N, C, Ho, Wo), dtype=input.dtype, device=input.device)
+        if out.numel() == 0:
+            return out
+        if input.numel() == 0:      # no source pixels: every mode reads padding zeros
+            return out.zero_()
         # lend a scratch buffer: up-sampling calls stage the input channels-last (same results)
         nws = handle.bevops_grid_sampler_2d_workspace_size(dt, N, C, H, W) if dt != _lib.I8 else 0
         ws = _workspace(input.device, nws, stream) if nws and Ho * Wo >= 2 * H * W else None
@@ -47,6 +51,8 @@ def _grid_sampler(input, grid, interpolation_mode, padding_mode, align_corners,
             raise ValueError(f"grid must be [N,3,D_out,H_out,W_out], got {tuple(grid.shape)}")
         Do, Ho, Wo = grid.shape[2:]
         out = torch.empty((N, C, Do, Ho, Wo), dtype=input.dtype, device=input.device)
+        if out.numel() == 0:
+            return out
         with torch.cuda.device(input.device):
             st = handle.bevops_grid_sampler_3d_forward(
                 dt, input.data_ptr(), grid.data_ptr(), out.data_ptr(), N, C, D, H, W, Do, Ho, Wo,

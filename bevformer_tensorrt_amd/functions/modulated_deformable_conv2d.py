@@ -48,6 +48,8 @@ def _mdconv(input, offset, mask, weight, bias, stride, padding, dilation, groups
     if tuple(mask.shape) != (B, deform_groups * Kh * Kw, Ho, Wo):
         raise ValueError(f"mask shape {tuple(mask.shape)} != {(B, deform_groups * Kh * Kw, Ho, Wo)}")
     dt = _lib.torch_dtype_code(input)
+    if B == 0:      # empty batch: nothing to convolve
+        return input.new_empty((0, Cout, max(Ho, 0), max(Wo, 0)))
     dims = (B, Cin, H, W, Cout, Kh, Kw, sh, sw, ph, pw, dh, dw, groups, deform_groups)
     ws_bytes = handle.bevops_mdconv_workspace_size(dt, *dims)
     if ws_bytes == 0:

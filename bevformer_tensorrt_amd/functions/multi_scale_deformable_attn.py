@@ -92,6 +92,10 @@ def _msda(value, value_spatial_shapes, reference_points, sampling_offsets, atten
     L = value_spatial_shapes.shape[0]
     nq = sampling_offsets.shape[1]
     ppg = reference_points.shape[-1] // 2
+    if bs == 0 or nq == 0 or heads == 0 or ch == 0:
+        # empty batch / no queries: nothing to sample (the eager reference path returns the empty tensor too;
+        # the C ABI itself treats a zero dimension as a bad parameter, like a zero-sized launch)
+        return value.new_empty((bs, nq, heads, ch)) if out is None else out
     P = attention_weights.numel() // (bs * nq * heads * L)
     if sampling_offsets.numel() != bs * nq * heads * L * P * 2:
         raise ValueError("sampling_offsets / attention_weights shapes disagree")

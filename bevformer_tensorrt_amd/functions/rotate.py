@@ -37,6 +37,8 @@ def _rotate(img, angle, center, interpolation, scales=(1.0, 1.0)):
         angle, center = angle.float(), center.float()
     out = torch.empty_like(img)
     C, H, W = img.shape
+    if out.numel() == 0:
+        return out
     with torch.cuda.device(img.device):
         st = handle.bevops_rotate_forward(
             _lib.torch_dtype_code(img), img.data_ptr(), angle.data_ptr(), center.data_ptr(),
