@@ -64,6 +64,51 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_f16v_kernel(const __half *__
   }
 }
 
+// fp16, HW % 4 == 0 and C % 8 == 0: 64 channels x 128 pixels per block; a thread loads a 4 x 4 block of halves
+// (8 bytes from each of 4 channel rows, lanes along the pixels: 256 contiguous bytes per row and half-wave),
+// transposes it with 8 v_perm and writes 4 x 8 bytes (4 channels of one pixel) into the [pixel][channel] tile --
+// a quarter of the LDS write instructions of the 2-byte version above; the tile leaves as 16-byte vectors,
+// 128 contiguous bytes per pixel.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f16q_kernel(const __half *__restrict__ in, __half *__restrict__ out,
+                                                                int C, int HW) {
+  constexpr int kRow = 128 + 16;   // bytes per tile row
+  __shared__ __attribute__((aligned(16))) unsigned char tile[128 * kRow];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
+  const __half *ib = in + (size_t)b * C * HW;
+  __half *ob = out + (size_t)b * C * HW;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int v = threadIdx.x + it * 256;      // 16 channel quads x 32 pixel quads
+    const int pq = v & 31, cq = v >> 5;
+    const int p = p0 + pq * 4, c = c0 + cq * 4;
+    uint2 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = make_uint2(0u, 0u);
+    if (p < HW && c < C) {                      // HW % 4 == 0, C % 4 == 0: the 4 x 4 block is all in or all out
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const uint2 *>(ib + (size_t)(c + k) * HW + p);
+    }
+    // r[k] = pixels p .. p+3 of channel c + k  ->  o[j] = channels c .. c+3 of pixel p + j
+    uint2 o[4];
+    o[0] = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x05040100u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x05040100u));
+    o[1] = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x07060302u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x07060302u));
+    o[2] = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x05040100u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x05040100u));
+    o[3] = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x07060302u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x07060302u));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2 *>(&tile[(pq * 4 + j) * kRow + cq * 8]) = o[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = threadIdx.x + it * 256;      // 128 pixels x 8 chunks of 8 channels
+    const int ch = v & 7, pl = v >> 3;
+    if (p0 + pl < HW && c0 + ch * 8 < C)
+      *reinterpret_cast<uint4 *>(ob + (size_t)(p0 + pl) * C + c0 + ch * 8) =
+          *reinterpret_cast<const uint4 *>(&tile[pl * kRow + ch * 16]);
+  }
+}
+
 // ---- 3. deformable + modulated im2col on NHWC --------------------------------------
 // thread = (global pixel n, tap, channel vector); columns [G][N][KK][cin_g]
 template <typename T, int V>
@@ -845,6 +890,7 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half 
 }
 
 
+thread_local bool g_mdconv_old_copy = false;   // variant 12: the r01 NCHW -> NHWC copy kernel (A/B)
 thread_local bool g_mdconv_rotate = false;   // variant 7: fp16 LDS-DMA kernel with the wave halves in opposite phase order
 
 template <int WN>
@@ -916,7 +962,10 @@ int run(const void *input, const void *offset, const void *mask, const void *wei
   const bool fits32 = (size_t)d.B * d.Cin * HW * 2 < 0xFFFFFF00ull && (size_t)d.Cout * cin_g * KK * 2 < 0xFFFFFF00ull;
   if (nhwc_io)  // the caller's tensor already is the [B, H, W, Cin] image the gather wants
     xt = const_cast<T *>(static_cast<const T *>(input));
-  else if (sizeof(T) == 2 && HW % 8 == 0 && d.Cin % 8 == 0 && aligned16(input))
+  else if (sizeof(T) == 2 && HW % 4 == 0 && d.Cin % 8 == 0 && aligned16(input) && !g_mdconv_old_copy)
+    hipLaunchKernelGGL(nchw_to_nhwc_f16q_kernel, dim3((HW + 127) / 128, (d.Cin + 63) / 64, d.B), dim3(256), 0, st,
+                       (const __half *)input, (__half *)xt, d.Cin, HW);
+  else if (sizeof(T) == 2 && HW % 8 == 0 && d.Cin % 8 == 0 && aligned16(input))   // variant 12: the r01 copy kernel (A/B)
     hipLaunchKernelGGL(nchw_to_nhwc_f16v_kernel, dim3((HW + 63) / 64, (d.Cin + 63) / 64, d.B), dim3(256), 0, st,
                        (const __half *)input, (__half *)xt, d.Cin, HW);
   else
@@ -1014,7 +1063,8 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
   g_mdconv_rotate = variant == 7;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7) ? 0 : variant;
+  g_mdconv_old_copy = variant == 12;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 12) ? 0 : variant;
   return prev;
 }
 
