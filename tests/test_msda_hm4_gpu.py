@@ -155,3 +155,42 @@ def test_prepacked_equals_one_call(ctx, flavour):
     with pytest.raises(TypeError):   # packed for one flavour, sampled with the other
         bev.multi_scale_deformable_attn_prepacked(packed, ref.to(torch.float16 if rdt == torch.float32 else torch.float32).cuda(),
                                                   qo.cuda(), qw.cuda(), scales)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_pyramids_head_major_vs_layout_preserving(ctx, seed):
+    """Random (not halving, odd-sized, sometimes 1-row) pyramids, batch sizes and query counts: wherever a
+    head-major kernel accepts the call (forced variants 16 = hm3, 17 = hm4), fp16 agrees with the
+    layout-preserving generic kernel (variant 99) within the fp16 bar, and the int8 hm4 result equals the
+    layout-preserving int8 kernel (variant 10) -- the padded re-layout, the staging plan and the chunking see
+    shapes no model produces."""
+    from bevformer_tensorrt_amd.utils.lib import BevopsError
+    rng = np.random.default_rng(100 + seed)
+    L = 4 if seed % 3 else 1
+    levels = [[int(rng.integers(1 if seed == 5 else 3, 70)), int(rng.integers(3, 90))] for _ in range(L)]
+    if L == 4:
+        levels.sort(key=lambda hw: -hw[0] * hw[1])
+    shape = (int(rng.integers(1, 5)), levels, int(rng.integers(700, 5000)), 8 if L == 4 else int(rng.choice([4, 8])), 4 if L == 4 else 1)
+    args = gen(shape, dtype=torch.float16, ref_lo=-0.2, ref_hi=1.2)
+    want = run(ctx, args, 99).float()
+    took = []
+    for v in (16, 17, 0):
+        try:
+            got = run(ctx, args, v).float()
+        except BevopsError as exc:          # this plan has no instantiation in that family
+            assert exc.status == 3, exc
+            continue
+        took.append(v)
+        assert (got - want).abs().max().item() <= 1e-2 * max(1.0, want.abs().max().item()), (v, shape)
+    assert 0 in took
+    value, sh, ref, off, logit = make(shape)
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    for rdt in (torch.float32, torch.float16):
+        iargs = (qv.cuda(), sh.cuda(), ref.to(rdt).cuda(), qo.cuda(), qw.cuda())
+        b = run(ctx, iargs, 10, (s_v, s_o, s_w, 0.02))
+        try:
+            a = run(ctx, iargs, 17, (s_v, s_o, s_w, 0.02))
+        except BevopsError as exc:
+            assert exc.status == 3, exc
+            continue
+        same_as_quad(a, b, rdt, f"random{seed}")
