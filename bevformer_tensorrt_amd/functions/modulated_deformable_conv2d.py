@@ -110,14 +110,17 @@ def modulated_deformable_conv2d_int8(input, offset, mask, weight, bias, scale_in
         raise _lib.BevopsError("bevops_mdconv_workspace_size: unsupported arguments", _lib.NOT_SUPPORTED)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.int8, device=input.device)
-    packed = _packed_weight(handle, weight, _lib.I8)     # re-laid-out once per weight tensor (version)
+    # re-laid-out once per weight tensor (version); a first sighting under stream capture takes the per-call path
+    packed = _PACKED.get(weight)
+    if packed is None and not torch.cuda.is_current_stream_capturing():
+        packed = _packed_weight(handle, weight, _lib.I8)
     with torch.cuda.device(input.device):
-        st = handle.bevops_mdconv_forward_int8_packed(
-            input.data_ptr(), float(scale_in), offset.data_ptr(), float(scale_offset), mask.data_ptr(),
-            float(scale_mask), packed.data_ptr(), float(scale_weight),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(), float(scale_out),
-            ws.data_ptr(), ws_bytes, *dims, _lib.current_stream_ptr(input.device))
-    _lib.check(st, "bevops_mdconv_forward_int8_packed")
+        fn = handle.bevops_mdconv_forward_int8_packed if packed is not None else handle.bevops_mdconv_forward_int8
+        st = fn(input.data_ptr(), float(scale_in), offset.data_ptr(), float(scale_offset), mask.data_ptr(),
+                float(scale_mask), packed.data_ptr() if packed is not None else weight.data_ptr(), float(scale_weight),
+                bias.data_ptr() if bias is not None else None, out.data_ptr(), float(scale_out),
+                ws.data_ptr(), ws_bytes, *dims, _lib.current_stream_ptr(input.device))
+    _lib.check(st, "bevops_mdconv_forward_int8")
     return out
 
 
