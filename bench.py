@@ -235,9 +235,10 @@ def run_hot_path(wl, steps, warmup, dev, dist, exchange, world):
                 ex.gather(lambda i: sca_call(i).view(1, nq, embed), (nq, embed), out_dtype, dev)
             else:
                 out = sca_call() if sca_bs else empty
-                if ex is not None:
-                    part = out.view(out.shape[0], nq, embed).sum(0, keepdim=True) if out.shape[0] else \
-                        torch.zeros((1, nq, embed), dtype=out.dtype, device=dev)
+                if ex is not None:   # (int8: partial sums in int32 on every rank, whatever its camera count)
+                    acc_dt = torch.int32 if wl["int8"] else out.dtype
+                    part = out.view(out.shape[0], nq, embed).sum(0, keepdim=True, dtype=acc_dt) if out.shape[0] else \
+                        torch.zeros((1, nq, embed), dtype=acc_dt, device=dev)
                     ex.reduce(part)
             if record and sca_bs:
                 e1.record()
@@ -435,9 +436,10 @@ def main():
     elapsed, sca_events = run_hot_path(wl, args.steps, args.warmup, dev, dist, args.exchange, world)
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
-    roofline = sca_roofline(wl, sca_events) if world == 1 or args.exchange == "reduce" else None
+    roofline = sca_roofline(wl, sca_events)
     if roofline is not None and world > 1:
-        roofline["note"] = "N>1: this rank's cameras only, exchange inside the bracket"
+        roofline["note"] = ("N>1: rank 0's cameras only (bytes_per_launch counts them); the bracket spans the per-camera "
+                            "sampler calls of one encoder layer and the wait for its exchange")
 
     # extra rooflines (N=1, fp16): the model's own geometry, as the drop-in op and as the fused op
     if roofline is not None and world == 1 and args.dtype == "fp16" and not args.no_geometry_extra:
