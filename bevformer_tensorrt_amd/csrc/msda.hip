@@ -603,7 +603,9 @@ using namespace bevops;
 
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant;
-  g_variant = variant;
+  // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan
+  msda_hm4_set_no_occ(variant == 19 || variant >= 200);
+  g_variant = variant == 19 ? 17 : variant;
   return prev;
 }
 
@@ -640,7 +642,7 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
                                               num_point);
   if (a == 0 || !spatial_shapes_host) return a;
   const size_t c = msda_hm4_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
-                                            num_query, num_point);
+                                            num_query, num_point, dtype == BEVOPS_I8);
   if (dtype == BEVOPS_I8) return c;   // exact (0: shape outside the head-major domain)
   if (dtype != BEVOPS_F16) return a;
   const size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
@@ -654,7 +656,8 @@ extern "C" size_t bevops_msda_packed_size(int dtype, const int32_t *spatial_shap
   if ((dtype != BEVOPS_F16 && dtype != BEVOPS_I8) || !spatial_shapes_host || bs <= 0 || nk <= 0 || heads <= 0 ||
       num_levels <= 0 || num_query <= 0 || num_point <= 0)
     return 0;
-  return msda_hm4_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels, num_query, num_point);
+  return msda_hm4_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels, num_query, num_point,
+                                  dtype == BEVOPS_I8);
 }
 
 extern "C" int bevops_msda_pack_value(int dtype, int ref_dtype, const void *value,

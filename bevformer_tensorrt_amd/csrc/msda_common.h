@@ -224,12 +224,13 @@ int msda_hm3_forward_f16(const __half *value, const int32_t *shapes_host, const 
                          void *workspace, size_t workspace_bytes, hipStream_t st);
 // msda_hm4.hip -- software-pipelined successor of hm3 on the same padded layout idea; fp16 and
 // both int8 flavours (dtype BEVOPS_F16 / BEVOPS_I8, ref_dtype selects the int8 flavour).
-size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
+size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, bool i8);
 int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, const void *ref,
                      const void *off, const void *logit, void *out, int bs, int nk, int heads, int C, int L,
                      int nq, int P, int ppg, int shared, float s_v, float s_o, float s_w, float s_out,
                      void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st);
 bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
+void msda_hm4_set_no_occ(bool v);
 int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, int bs, int nk,
                   int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st);
 int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, size_t packed_bytes,

@@ -181,8 +181,10 @@ __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
 // 256 operand request BEHIND the first big batches (buffer loads retire in order: requested first,
 // the HBM round trip of the operands gates every tap of the iteration; requested behind batches
 // 0 .. D-1, only the later batches wait for it, after most of the iteration's own work).
+// 1024: compiled for 4 waves per SIMD (<= 128 VGPRs) so that TWO 512-thread blocks share a CU when the staged
+// planes are small (experiment: only the last level staged, variant 18).
 template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
-__global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
+__global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel(const H4Args a) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
   constexpr int PP = LP / NOWN;           // points per owner
   constexpr int BT = LP >= 4 ? 4 : LP;    // points per tap batch
@@ -692,15 +694,35 @@ __global__ __launch_bounds__(THREADS) void msda_hm4_kernel(const H4Args a) {
 constexpr int kH4Threads = 512;
 inline int h4_box_bytes(int LP) { return (kH4Threads / 8) * (LP * 16 + 16); }
 
+// INT8 calls with L*P = 32 prefer the "two blocks per CU" plan: only the planes that fit kOccStageCap bytes stay
+// LDS-resident (base SCA: the 15 x 25 level, 28 KB; the 29 x 50 level joins the big set, whose int8 taps cost one
+// cache line per sample), the kernel is compiled for 4 waves per SIMD and keeps one big batch in flight, so 16
+// waves share a CU instead of 8: 553 vs 582 us (x127 flavour), 570 vs 609 us (x255) per base SCA call, bit-identical
+// (profiles/r02/hm4_int8_occupancy_ab.jsonl).  The same plan in fp16 (two lines per big-level sample, spills
+// under the 128-register cap) takes 950 us instead of 565: fp16 keeps the one-block plan.
+constexpr int kOccStageCap = 40 * 1024;
+thread_local bool g_h4_no_occ = false;   // variant 19 / the ablation variants: the one-block plan for int8 too
+
 struct H4Plan {
   Hm3Plan p;
-  int nbig;  // tap batches served by L1/L2
+  int nbig;   // tap batches served by L1/L2
+  bool occ2;  // the two-blocks-per-CU plan
 };
 
-bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl) {
+bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl, bool i8) {
   const int LP = L * P;
-  if (!hm3_plan(shapes_host, bs, heads, L, nq, h4_box_bytes(LP), pl.p)) return false;
   const int bt = LP >= 4 ? 4 : LP;
+  pl.occ2 = false;
+  if (i8 && !g_h4_no_occ && LP == 32) {
+    // (hm3_plan budgets the staged planes as kLdsLimit - kTab - box bytes: a cap is a larger pretended box)
+    if (hm3_plan(shapes_host, bs, heads, L, nq, kLdsLimit - kTab - kOccStageCap, pl.p) && pl.p.t.ls < L &&
+        (pl.p.t.ls * P) % bt == 0 && pl.p.t.ls * P / bt == 6) {
+      pl.nbig = 6;
+      pl.occ2 = true;
+      return true;
+    }
+  }
+  if (!hm3_plan(shapes_host, bs, heads, L, nq, h4_box_bytes(LP), pl.p)) return false;
   if ((pl.p.t.ls * P) % bt) return false;  // a batch never straddles the big / staged boundary
   pl.nbig = pl.p.t.ls * P / bt;
   return true;
@@ -721,7 +743,7 @@ int h4_go(const H4Args &a, hipStream_t st) {
 // instantiated (L*P, big batches) combinations: the model's calls.  Anything else -> NOT_SUPPORTED
 // (the caller keeps its older kernels for those).
 template <bool I8, bool U8W, typename RefT, bool MASKED>
-int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
+int h4_dispatch(int LP, int nbig, bool occ2, const H4Args &a, int ablate, hipStream_t st) {
   if (ablate) {  // timing ablations, base SCA shape only (tools/hm4_probe.py)
     if constexpr (!MASKED && !U8W) {
       if (LP == 32 && nbig == 4 && a.d.ppg == 4 && a.d.P % 4 == 0) {
@@ -748,6 +770,13 @@ int h4_dispatch(int LP, int nbig, const H4Args &a, int ablate, hipStream_t st) {
     }                                                                                     \
     return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false, PROD>(a, st);                  \
   }
+  if constexpr (I8 && !MASKED) {   // the two-blocks-per-CU plan (h4_plan): <= 128 VGPRs, one big batch in flight
+    if (occ2) {
+      if (LP != 32 || nbig != 6) return BEVOPS_NOT_SUPPORTED;
+      if (rr) return h4_go<32, 6, I8, U8W, RefT, MASKED, true, PROD | 1024 | 64>(a, st);
+      return h4_go<32, 6, I8, U8W, RefT, MASKED, false, PROD | 1024 | 64>(a, st);
+    }
+  }
   BEVOPS_H4_CASE(32, 4)   // base SCA: 4 levels x 8 points, two levels staged
   BEVOPS_H4_CASE(32, 8)   //   ... nothing staged (few queries)
   BEVOPS_H4_CASE(32, 6)   //   ... one level staged
@@ -771,16 +800,18 @@ int h4_chunk(const Hm3Plan &p, int nq, int variant_chunk) {
 
 }  // namespace
 
-size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
+void msda_hm4_set_no_occ(bool v) { g_h4_no_occ = v; }
+
+size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, bool i8) {
   H4Plan pl;
-  if (C != 32 || !shapes_host || !h4_plan(shapes_host, bs, heads, L, P, nq, pl)) return 0;
+  if (C != 32 || !shapes_host || !h4_plan(shapes_host, bs, heads, L, P, nq, pl, i8)) return 0;
   return ((pl.p.g_bytes + 127) & ~size_t(127)) + 128 + pl.p.s_bytes;
 }
 
 // every level LDS-resident and an instantiated kernel: the shapes where hm4 is the fp16 default
 bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
   H4Plan pl;
-  return C == 32 && shapes_host && h4_plan(shapes_host, bs, heads, L, P, nq, pl) && pl.nbig == 0 &&
+  return C == 32 && shapes_host && h4_plan(shapes_host, bs, heads, L, P, nq, pl, false) && pl.nbig == 0 &&
          h4_instantiated(L * P, 0);
 }
 
@@ -793,7 +824,7 @@ int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *sh
                   int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st) {
   H4Plan pl;
   if (C != 32 || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) || !shapes_host ||
-      !h4_plan(shapes_host, bs, heads, L, P, nq, pl))
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl, dtype == BEVOPS_I8))
     return BEVOPS_NOT_SUPPORTED;
   if (dtype != BEVOPS_F16 && dtype != BEVOPS_I8) return BEVOPS_NOT_SUPPORTED;
   const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
@@ -820,7 +851,7 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
   const int LP = L * P;
   H4Plan pl;
   if (C != 32 || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) || !shapes_host ||
-      !h4_plan(shapes_host, bs, heads, L, P, nq, pl))
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl, dtype == BEVOPS_I8))
     return BEVOPS_NOT_SUPPORTED;
   if ((double)bs * nq * heads * LP * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
   const size_t g_room = (pl.p.g_bytes + 127) & ~size_t(127);
@@ -838,9 +869,9 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
   a.qmask = nullptr;
   a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
   const bool i8 = dtype == BEVOPS_I8;
-  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, a, ablate, st);
+  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
+  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
+  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
   return BEVOPS_NOT_SUPPORTED;
 }
 
@@ -850,7 +881,7 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
                      void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st) {
   H4Plan pl;   // (checked first so that an unsupported shape costs no launch)
   if (C != 32 || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) || !shapes_host ||
-      !h4_plan(shapes_host, bs, heads, L, P, nq, pl) || !h4_instantiated(L * P, pl.nbig))
+      !h4_plan(shapes_host, bs, heads, L, P, nq, pl, dtype == BEVOPS_I8) || !h4_instantiated(L * P, pl.nbig))
     return BEVOPS_NOT_SUPPORTED;
   const int rc = msda_hm4_pack(dtype, ref_dtype, value, shapes_host, bs, nk, heads, C, L, nq, P, workspace,
                                workspace_bytes, st);
