@@ -278,7 +278,7 @@ def pmc_traffic(int8):
         total = 0.0
         for k, v in json.load(open(f)).items():
             if int8:
-                hit = "msda_hm4_repack_i8" in k or ("msda_hm4_kernel<32" in k and ", true," in k)
+                hit = "msda_hm4_repack_i8" in k or ("msda_hm4_kernel<32" in k and ", true," in k)   # <32, 4 | 6, 512, true, ...>
             else:
                 hit = "msda_hm3_kernel<32" in k or "msda_hm3_repack_kernel" in k
             if hit and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
@@ -297,7 +297,7 @@ def sca_roofline(wl, sca_events):
     if wl["int8"]:   # reference points stay fp16 in the INT8 flavour (296.9 MB)
         byt += wl["sca_bs"] * BASE["sca"]["nq"] * 2 * BASE["sca"]["ppg"] * (2 - wl["esize"])
     achieved = byt / (avg_ms * 1e-3) / 1e9
-    kern = ("base SCA MSDA call = msda_hm4_repack_i8_kernel + msda_hm4_kernel<32,4,int8 x255 flavour>" if wl["int8"]
+    kern = ("base SCA MSDA call = msda_hm4_repack_i8_kernel + msda_hm4_kernel<32,6,int8 x255 flavour, 2 blocks/CU>" if wl["int8"]
             else "base SCA MSDA call = msda_hm3_repack_kernel + msda_hm3_kernel<32,1024>")
     r = {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None,

@@ -91,12 +91,34 @@ bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool rel
   return false;
 }
 
+// Numeric screen of a candidate algorithm: 4096 sampled outputs are recomputed in fp32 (k ascending) and compared
+// with what the algorithm wrote; *flag is set when one differs by more than 4 binary16 ulps of max(1, |value|).
+// (Round 2: an algorithm picked on speed alone once moved outputs by > 4e-3 relative -- split-K partials kept in
+// fp16 -- and which algorithm wins the timing varies from run to run.)
+__global__ __launch_bounds__(256) void linear_check_kernel(const __half *__restrict__ a, const __half *__restrict__ w,
+                                                           const __half *__restrict__ bias, const __half *__restrict__ res,
+                                                           const __half *__restrict__ out, long long M, int N, int K,
+                                                           int relu, unsigned *__restrict__ flag) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long hsh = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  const long long m = (long long)((hsh >> 20) % (unsigned long long)M);
+  const int n = (int)((hsh >> 4) % (unsigned long long)N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(__half2float(a[m * K + k]), __half2float(w[(long long)n * K + k]), acc);
+  if (bias) acc += __half2float(bias[n]);
+  if (res) acc += __half2float(res[m * N + n]);
+  if (relu) acc = fmaxf(acc, 0.f);
+  const float got = __half2float(out[m * N + n]);
+  if (!(fabsf(got - acc) <= 0.00390625f * fmaxf(1.f, fabsf(acc)))) atomicOr(flag, 1u);
+}
+
 // Selection by measurement (bevops_linear_tune), like the framework's TunableOp does for its own
 // GEMMs: every algorithm of the fp16 TN family that supports the problem (bias / ReLU epilogue,
 // beta = 1) is timed once on the caller's stream with the caller's buffers, the best few are
 // re-timed, the winner is cached for the process.  Synchronises; `out` is scratch.
 void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const void *a, const void *w,
-               const void *c, void *out, float beta, void *workspace, size_t ws_bytes, hipStream_t st) {
+               const void *c, void *out, float beta, void *workspace, size_t ws_bytes, hipStream_t st,
+               const void *bias, const void *residual, long long M, int N, int K, int relu) {
   std::vector<hipblasLtMatmulHeuristicResult_t> all;
   if (hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N, HIP_R_16F,
                                  HIP_R_16F, HIP_R_16F, HIP_R_16F, HIPBLAS_COMPUTE_32F, all) != HIPBLAS_STATUS_SUCCESS)
@@ -136,15 +158,32 @@ void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const v
     }
     return best;
   };
+  // numeric screen (needs 4 bytes of the lent workspace for its flag; the result of the last run is in `out`)
+  auto numerically_ok = [&]() {
+    if (!workspace || ws_bytes < 4) return true;
+    unsigned *flag = static_cast<unsigned *>(workspace);
+    unsigned host = 1;
+    if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return false;
+    hipLaunchKernelGGL(linear_check_kernel, dim3(16), dim3(256), 0, st, (const __half *)a, (const __half *)w,
+                       (const __half *)bias, (const __half *)residual, (const __half *)out, M, N, K, relu, flag);
+    if (hipMemcpyAsync(&host, flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return false;
+    return host == 0;
+  };
   Cand cur{p.algo, p.ws, 1e30f};
   time_one(cur, 1);  // warm the caches / clocks with the heuristic's choice
-  for (auto &cd : cands) cd.ms = time_one(cd, 1);
+  for (auto &cd : cands) {
+    cd.ms = time_one(cd, 1);
+    if (cd.ms < 1e29f && !numerically_ok()) cd.ms = 1e30f;   // fast but not the same numbers: out
+  }
+  cands.erase(std::remove_if(cands.begin(), cands.end(), [](const Cand &x) { return x.ms >= 1e29f; }), cands.end());
   std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.ms < y.ms; });
   const size_t top = std::min<size_t>(cands.size(), 8);
   for (size_t i = 0; i < top; ++i) cands[i].ms = time_one(cands[i], 5);
   cur.ms = time_one(cur, 5);
   std::sort(cands.begin(), cands.begin() + top, [](const Cand &x, const Cand &y) { return x.ms < y.ms; });
-  if (cands[0].ms < cur.ms) {
+  if (!cands.empty() && cands[0].ms < cur.ms) {
     p.algo = cands[0].algo;
     p.ws = cands[0].ws;
   }
@@ -219,7 +258,7 @@ extern "C" int bevops_linear_tune(int dtype, const void *a, const void *weight, 
   if (!desc) return BEVOPS_FAILURE;
   const float beta = residual ? 1.f : 0.f;
   tune_plan(h, plan, desc, a, weight, residual ? residual : out, out, beta, workspace, workspace ? workspace_bytes : 0,
-            static_cast<hipStream_t>(stream));
+            static_cast<hipStream_t>(stream), bias, residual, M, N, K, relu);
   hipblasLtMatmulDescDestroy(desc);
   if (plan.tuned) {
     std::lock_guard<std::mutex> lk(g_mu);
