@@ -604,7 +604,7 @@ using namespace bevops;
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant;
   // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan
-  msda_hm4_set_no_occ(variant == 19 || variant >= 200);
+  msda_hm4_set_no_occ(variant == 19 || (variant >= 200 && variant < 1000));
   g_variant = variant == 19 ? 17 : variant;
   return prev;
 }
@@ -645,8 +645,11 @@ extern "C" size_t bevops_msda_workspace_size_shapes(int dtype, const int32_t *sp
                                             num_query, num_point, dtype == BEVOPS_I8);
   if (dtype == BEVOPS_I8) return c;   // exact (0: shape outside the head-major domain)
   if (dtype != BEVOPS_F16) return a;
-  const size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
-                                            num_query, num_point);
+  size_t b = msda_hm3_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels,
+                                      num_query, num_point);
+  const size_t e = msda_hm5_workspace_bytes(spatial_shapes_host, bs, heads, channels, num_levels, num_query,
+                                            num_point);
+  if (e > b) b = e;
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
@@ -812,6 +815,16 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
               points_per_group, shared_offsets ? 1 : 0, 1.f, 1.f, 1.f, 1.f, workspace, workspace_bytes,
               g_variant >= 170 && g_variant <= 179 ? kChunks[g_variant - 170] : 0,
               g_variant >= 200 ? g_variant - 200 : 0, st);
+          if (rc != BEVOPS_NOT_SUPPORTED || g_variant != 0) return rc;
+        }
+        // hm5 (msda_hm5.hip): hm3's planes, re-scheduled, plus the exact visibility pre-pass; default
+        // for the 4-level x 8-point SCA shape.  Variants 1000 + flags select its A/B builds
+        if (spatial_shapes_host && ((g_variant >= 1000 && g_variant < 1064) || (g_variant == 0 && pays))) {
+          const int rc = msda_hm5_forward_f16(
+              (const __half *)value, spatial_shapes_host, (const __half *)reference_points,
+              (const __half *)sampling_offsets, (const __half *)attention_weights, (__half *)output,
+              bs, nk, heads, channels, num_levels, num_query, num_point, points_per_group,
+              shared_offsets ? 1 : 0, workspace, workspace_bytes, g_variant >= 1000 ? g_variant - 1000 : 0, false, st);
           if (rc != BEVOPS_NOT_SUPPORTED || g_variant != 0) return rc;
         }
         if (spatial_shapes_host && (g_variant == 16 || (g_variant == 0 && pays && LP >= 16))) {

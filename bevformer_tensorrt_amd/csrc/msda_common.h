@@ -238,6 +238,13 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
                                void *out, int bs, int nk, int heads, int C, int L, int nq, int P, int ppg,
                                int shared, float s_v, float s_o, float s_w, float s_out, int chunk_override,
                                int ablate, hipStream_t st);
+// msda_hm5.hip -- re-scheduled successor of hm3 for the 4-level x 8-point SCA shape (same planes) with an
+// exact visibility pre-pass; `flags`: see msda_hm5_forward_f16
+size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
+int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
+                         const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
+                         int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
+                         hipStream_t st);
 void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const void *tab, int bs, int nk, int heads,
                             hipStream_t st);
 size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,

@@ -1,0 +1,478 @@
+// MSDA fp16, fifth head-major generation ("hm5") for the BEVFormer-base SCA call shape
+// (4 levels x 8 points, 4 reference anchors, 32 channels per head).  Same padded head-major value
+// layout as hm3 / hm4 (msda_pad.h: 128-byte pixel-pair entries for the big levels, LDS-resident
+// 64-byte pixels for the staged tail), same arithmetic per sample as hm3 (fp32 locations / softmax /
+// area weights, combined weight rounded to binary16 once, v_dot2_f32_f16 on the big levels, packed
+// fp16 row blend + fp32 accumulation on the staged ones).  What changes is the schedule, after the
+// round-2 finding that hm3's and hm4's pipes do not overlap:
+//   * vmcnt retires loads IN ORDER.  hm3 / hm4 request the next item's logits / offsets (HBM, long
+//     latency) ahead of the current item's L2 taps, so every tap wait also waits for that request:
+//     one HBM round trip per 8 items, on every wave.  Here the operand request is the LAST vector
+//     memory instruction of an iteration and targets the item three iterations ahead (three
+//     register sets, loop unrolled by three): no tap wait ever has a younger HBM request in front
+//     of it, and a request has two full iterations to land.
+//   * interleaved phases.  Lane k of an octet owns points 4k..4k+3, i.e. ONE level (k / 2) and all
+//     four anchors.  Phase j takes point j of every lane: 8 samples = 2 per level = NB big + NS
+//     staged.  Every phase therefore has front-end work for all 64 lanes (1 record per lane, no
+//     idle owner lanes, no 16-register record store), big-level loads, LDS taps and multiply-adds;
+//     the loads of phase j fly across the LDS taps of phase j and the front end of phase j+1.
+//   * the staged taps are read with two ds_read_b64 (256 B/clk) instead of one ds_read2_b64
+//     (128 B/clk, MI355X_MICROARCH.md LDS table).
+//   * exact visibility pre-pass (msda_hm5_vis_kernel): an item (batch, query, head) all of whose
+//     L*P samples fail the reference's range gate (multiScaleDeformableAttnKernel.cu:673) contributes
+//     exactly 0 -- the pre-pass decides that from reference points + offsets alone (the gate does
+//     not involve the logits), stores the zeros and a visibility byte; the sampling kernel compacts
+//     its chunk of queries to the visible items (ballot + prefix), never reads the logits /
+//     offsets of the others and never gives them a tap slot.  Items with an anchor inside
+//     [0, 1]^2 are classified visible without reading their offsets (a classification only: the
+//     sampling kernel evaluates every sample of a listed item exactly).  On the 6-camera rig
+//     geometry 81 % of the (camera, pillar) pairs are invisible.
+#include "msda_common.h"
+#include "msda_pad.h"
+
+namespace bevops {
+namespace {
+
+template <int J>
+struct IC { static constexpr int v = J; };
+
+// LDS accesses through address_space(3) pointers built from 32-bit byte addresses: the natural
+// alignment of the pointee lets the compiler pick ds_read_b128 / ds_write_b128 / ds_read_b64
+typedef __attribute__((address_space(3))) char lds_c;
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+typedef __attribute__((address_space(3))) u32x2 lds_u2;
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+
+struct H5Set {
+  unsigned lg[2];  // 4 logits of this lane's points
+  u32x4 of;        // 4 (x, y) offsets
+  unsigned rf;     // anchor (lane & 3) of the item
+};
+
+struct H5Lane {    // per-lane level constants: lane k of an octet serves level k / 2
+  float W, H;
+  unsigned base;   // byte offset of padded (row 0, col 0): big -> in the plane set, staged -> in LDS
+  unsigned row;    // padded row bytes
+  int wp, sh;
+};
+
+__device__ __forceinline__ H5Lane h5_lane_consts(const Hm3Tab &t, unsigned lane8, unsigned bh, unsigned stage_off) {
+  const int myl = (int)(lane8 >> 1);
+  H5Lane c{1.f, 1.f, 0u, 0u, 1, 6};
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l == myl) {
+      const bool staged = l >= t.ls;
+      c.sh = staged ? 6 : 7;
+      c.W = (float)t.W[l];
+      c.H = (float)t.H[l];
+      c.wp = t.W[l] + 1;
+      c.base = (staged ? stage_off : bh * (unsigned)t.g_entries * kEntBytes) + ((unsigned)t.ent0[l] << c.sh);
+      c.row = (unsigned)(t.W[l] + 1) << c.sh;
+    }
+  }
+  return c;
+}
+
+// the reference's range gate and hm3's record arithmetic for one sample
+struct H5Loc { float x, y; bool valid; };
+__device__ __forceinline__ H5Loc h5_locate(unsigned rf, unsigned of, const H5Lane &c) {
+  H5Loc r;
+  r.x = fmaf(h2f_lo(rf), c.W, h2f_lo(of)) - 0.5f;
+  r.y = fmaf(h2f_hi(rf), c.H, h2f_hi(of)) - 0.5f;
+  r.valid = (r.y > -1.f) && (r.x > -1.f) && (r.y < c.H) && (r.x < c.W);
+  return r;
+}
+
+// ---- visibility pre-pass.  octet = item (batch, query, head); a wave takes U groups of 8
+// consecutive items (their offsets are one contiguous 1 KB run).  vis[item] = 1 when any sample
+// can contribute; otherwise the item's 32 outputs are stored as zeros here.
+template <int U>
+__global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restrict__ ref,
+                                                           const __half *__restrict__ off,
+                                                           __half *__restrict__ out,
+                                                           unsigned char *__restrict__ vis, MsdaDims d,
+                                                           Hm3Tab t, unsigned n_item) {
+  const unsigned lane8 = threadIdx.x & 7u;
+  const unsigned wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const unsigned oiw = (threadIdx.x & 63u) >> 3;
+  const H5Lane c = h5_lane_consts(t, lane8, 0u, 0u);
+  unsigned item[U], rf[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    item[u] = (wave * U + u) * 8u + oiw;
+    ok[u] = item[u] < n_item;
+    const unsigned it = ok[u] ? item[u] : n_item - 1u;
+    const unsigned bq = it / (unsigned)d.heads;  // b * nq + q
+    rf[u] = *reinterpret_cast<const unsigned *>(ref + ((size_t)bq * 4u + (lane8 & 3u)) * 2u);
+  }
+  bool need[U], anyin[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float rx = h2f_lo(rf[u]), ry = h2f_hi(rf[u]);
+    const bool inside = rx >= 0.f && rx <= 1.f && ry >= 0.f && ry <= 1.f;
+    const unsigned long long bal = __ballot(inside);
+    anyin[u] = ((bal >> (oiw * 8u)) & 0xffull) != 0ull;
+    need[u] = ok[u] && !anyin[u];
+  }
+  u32x4 of[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    of[u] = u32x4{0u, 0u, 0u, 0u};
+    if (need[u]) {
+      of[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(off + (size_t)item[u] * 64u + lane8 * 8u));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bool v = false;
+    v |= h5_locate(quad_bcast<0>(rf[u]), of[u].x, c).valid;
+    v |= h5_locate(quad_bcast<1>(rf[u]), of[u].y, c).valid;
+    v |= h5_locate(quad_bcast<2>(rf[u]), of[u].z, c).valid;
+    v |= h5_locate(quad_bcast<3>(rf[u]), of[u].w, c).valid;
+    const unsigned long long bal = __ballot(v && need[u]);
+    const bool visible = anyin[u] || (((bal >> (oiw * 8u)) & 0xffull) != 0ull);
+    if (ok[u]) {
+      if (lane8 == 0u) vis[item[u]] = visible ? 1 : 0;
+      if (!visible) *reinterpret_cast<uint2 *>(out + (size_t)item[u] * 32u + lane8 * 4u) = make_uint2(0u, 0u);
+    }
+  }
+}
+
+// ---- sampling kernel.  ABL: ablation bits for the probes (1: no big-level taps, 2: no staged
+// taps, 4: operands loaded once, 8: no store).  LISTED: items come from the visibility bytes.
+template <int NBL, int THREADS, int ABL, bool LISTED>
+__global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
+    const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
+    const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
+    __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
+    const unsigned char *__restrict__ vis) {
+  constexpr int NB = 2 * NBL;   // big-level samples per phase
+  constexpr int NS = 8 - NB;    // staged samples per phase
+  constexpr int kBox = 8 * 16 + 16;
+  constexpr unsigned OCT = THREADS / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // smem: [staged planes][mailboxes][query list][wave totals]
+  unsigned bh, ck;
+  if (d.heads == 8) {   // XCD x keeps head x; all XCDs walk the same (batch, chunk) sequence
+    const unsigned rest = blockIdx.x >> 3;
+    bh = (rest / (unsigned)nchunk) * 8u + (blockIdx.x & 7u);
+    ck = rest % (unsigned)nchunk;
+  } else {
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    bh = vb / (unsigned)nchunk;
+    ck = vb - bh * (unsigned)nchunk;
+  }
+  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  if (stage_bytes) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
+  }
+  const unsigned q0 = ck * (unsigned)chunk;
+  const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
+  unsigned n_items = q_end - q0;
+  if constexpr (LISTED) {
+    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + OCT * kBox);
+    unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + OCT * kBox + chunk * 2);
+    unsigned base_count = 0;
+    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
+      const unsigned i = t0 + threadIdx.x;
+      const bool v = i < n_items && vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
+      const unsigned long long bal = __ballot(v);
+      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
+      __syncthreads();
+      unsigned before = base_count, all = 0;
+      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
+        const unsigned cnt = wtot[w2];
+        if (w2 < wv) before += cnt;
+        all += cnt;
+      }
+      if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      base_count += all;
+      __syncthreads();
+    }
+    n_items = base_count;
+  }
+  __syncthreads();
+  const unsigned wave_first = (threadIdx.x >> 6) * 8u;
+  if (n_items <= wave_first) return;
+  const unsigned nrounds = (n_items - wave_first + OCT - 1u) / OCT;
+
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gset), 0, g_bytes, 0x00020000);
+  const unsigned n_in = (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 32u;
+  const __amdgpu_buffer_rsrc_t rs_lg =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(logit), 0, n_in * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_of =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(off), 0, n_in * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_rf = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(ref), 0, (unsigned)d.bs * (unsigned)d.nq * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      out, 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 64u, 0x00020000);
+  const unsigned lane8 = threadIdx.x & 7u;
+  const unsigned lane16 = lane8 * 16u, lane8b = lane8 * 8u;
+  const unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
+  const unsigned out_q = (unsigned)d.heads * 64u;
+  const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
+  const unsigned box = sbase + (unsigned)stage_bytes + (threadIdx.x >> 3) * kBox;
+  const unsigned qlist_a = sbase + (unsigned)stage_bytes + OCT * kBox;
+  const H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
+
+  const unsigned lg_base = ((b * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
+  const unsigned lg_q = (unsigned)d.heads * 64u;
+  const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
+  auto query_of = [&](unsigned i) -> unsigned {
+    const unsigned ii = min(i, n_items - 1u);   // octets past the end repeat the last item, unstored
+    return LISTED ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
+  };
+  auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
+    const unsigned q = query_of(i);
+    const unsigned o_lg = lg_base + q * lg_q;
+    // read-once full lines: non-temporal
+    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 2);
+    s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 2);
+    s.lg[0] = g.x; s.lg[1] = g.y;
+    s.rf = __builtin_amdgcn_raw_buffer_load_b32(rs_rf, (int)(rf_base + q * 16u), 0, 0);
+  };
+
+  // state carried from one phase / iteration to the next
+  float m = 0.f, ssum = 0.f;
+  u32x4 rec;
+  auto fe_begin = [&](const H5Set &s) __attribute__((always_inline)) {
+    const float a = fmaxf(fmaxf(h2f_lo(s.lg[0]), h2f_hi(s.lg[0])), fmaxf(h2f_lo(s.lg[1]), h2f_hi(s.lg[1])));
+    m = oct_max(a);
+    ssum = 0.f;
+  };
+  auto fe = [&](const H5Set &s, auto jc) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::v;
+    const float lgv = (J & 1) ? h2f_hi(s.lg[J >> 1]) : h2f_lo(s.lg[J >> 1]);
+    const float e = __expf(lgv - m);
+    ssum += e;
+    const unsigned ofj = J == 0 ? s.of.x : J == 1 ? s.of.y : J == 2 ? s.of.z : s.of.w;
+    const H5Loc p = h5_locate(quad_bcast<J>(s.rf), ofj, c);
+    const float xf = floorf(p.x), yf = floorf(p.y);
+    const float lx = p.x - xf, ly = p.y - yf;
+    const float ev = p.valid ? e : 0.f;
+    const float wr1 = ly * ev, wr0 = ev - wr1;
+    const float b0 = wr0 * lx, b1 = wr1 * lx;
+    rec.x = pack_h2(wr0 - b0, b0);
+    rec.y = pack_h2(wr1 - b1, b1);
+    const int rel = __mul24((int)yf + 1, c.wp) + (int)xf;
+    rec.z = c.base + ((p.valid ? (unsigned)rel : 0u) << c.sh);
+    rec.w = rec.z + c.row;
+  };
+
+  float acc[4];
+  // one item per octet: 4 phases; `cur` = this item's operands, `nxt` = the next item's (landed)
+  auto body = [&](H5Set &cur, const H5Set &nxt, unsigned i) __attribute__((always_inline)) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+    const float m_cur = m;  (void)m_cur;
+    float s_cur = 0.f;
+    auto phase = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int J = decltype(jc)::v;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      *(lds_u4 *)(size_t)(box + lane16) = rec;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // big levels: records, then all 2 * NB loads
+      u32x4 rb[NB > 0 ? NB : 1];
+      u32x4 r0[NB > 0 ? NB : 1], r1[NB > 0 ? NB : 1];
+#pragma unroll
+      for (int s = 0; s < NB; ++s) rb[s] = *(const lds_u4 *)(size_t)(box + s * 16u);
+      if constexpr (!(ABL & 1)) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          r0[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].z + lane16), 0, 0);
+          r1[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].w + lane16), 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // staged levels in two halves: records, LDS taps (two ds_read_b64 per row: the laundered second
+      // address keeps the compiler from fusing them into the half-rate ds_read2_b64), packed-fp16 row
+      // blend, fp32 accumulation.  The front end of the next phase and the big-level multiply-adds
+      // sit between the LDS reads and their use
+      constexpr int HS = (NS + 1) / 2, HB = (NB + 1) / 2;
+      u32x4 rl[HS > 0 ? HS : 1];
+      u32x2 l0[HS > 0 ? HS : 1], q0r[HS > 0 ? HS : 1], l1[HS > 0 ? HS : 1], q1r[HS > 0 ? HS : 1];
+      auto lds_issue = [&](int s0, int n) __attribute__((always_inline)) {
+        if constexpr (!(ABL & 2)) {
+#pragma unroll
+          for (int s = 0; s < HS; ++s) {
+            if (s >= n) break;
+            rl[s] = *(const lds_u4 *)(size_t)(box + (unsigned)(NB + s0 + s) * 16u);
+            const unsigned a0 = rl[s].z + lane8b, a1 = rl[s].w + lane8b;
+            unsigned a0r = a0 + (unsigned)kLdsPixBytes, a1r = a1 + (unsigned)kLdsPixBytes;
+            asm("" : "+v"(a0r));
+            asm("" : "+v"(a1r));
+            l0[s] = *(const lds_u2 *)(size_t)a0;
+            q0r[s] = *(const lds_u2 *)(size_t)a0r;
+            l1[s] = *(const lds_u2 *)(size_t)a1;
+            q1r[s] = *(const lds_u2 *)(size_t)a1r;
+          }
+        }
+      };
+      auto lds_math = [&](int n) __attribute__((always_inline)) {
+        if constexpr (!(ABL & 2)) {
+#pragma unroll
+          for (int s = 0; s < HS; ++s) {
+            if (s >= n) break;
+            const h2_t w0 = as_h2(rl[s].x), w1 = as_h2(rl[s].y);
+            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
+            h2_t a = as_h2(l0[s].x) * w00, bb = as_h2(l0[s].y) * w00;
+            a = as_h2(q0r[s].x) * w01 + a; bb = as_h2(q0r[s].y) * w01 + bb;
+            a = as_h2(l1[s].x) * w10 + a; bb = as_h2(l1[s].y) * w10 + bb;
+            a = as_h2(q1r[s].x) * w11 + a; bb = as_h2(q1r[s].y) * w11 + bb;
+            add_h2(acc[0], acc[1], a);
+            add_h2(acc[2], acc[3], bb);
+          }
+        }
+      };
+      auto big_math = [&](int s0, int n) __attribute__((always_inline)) {
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+          for (int k = 0; k < HB; ++k) {
+            if (k >= n) break;
+            const int s = s0 + k;
+            acc[0] = dot2f(r0[s].x, rb[s].x, acc[0]); acc[1] = dot2f(r0[s].y, rb[s].x, acc[1]);
+            acc[2] = dot2f(r0[s].z, rb[s].x, acc[2]); acc[3] = dot2f(r0[s].w, rb[s].x, acc[3]);
+            acc[0] = dot2f(r1[s].x, rb[s].y, acc[0]); acc[1] = dot2f(r1[s].y, rb[s].y, acc[1]);
+            acc[2] = dot2f(r1[s].z, rb[s].y, acc[2]); acc[3] = dot2f(r1[s].w, rb[s].y, acc[3]);
+          }
+        }
+      };
+      lds_issue(0, HS);
+      __builtin_amdgcn_sched_barrier(0);
+      // front end of the next phase (of the next item after the last one)
+      if constexpr (J < 3) {
+        fe(cur, IC<J + 1>{});
+      } else {
+        s_cur = ssum;
+        fe_begin(nxt);
+        fe(nxt, IC<0>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      lds_math(HS);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_issue(HS, NS - HS);
+      __builtin_amdgcn_sched_barrier(0);
+      big_math(0, HB);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_math(NS - HS);
+      __builtin_amdgcn_sched_barrier(0);
+      big_math(HB, NB - HB);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    phase(IC<0>{});
+    phase(IC<1>{});
+    phase(IC<2>{});
+    phase(IC<3>{});
+    const float s = oct_sum(s_cur);
+    const float inv = __builtin_amdgcn_rcpf(s);
+    if constexpr (!(ABL & 8)) {
+      // unconditional: an octet past the end of the list recomputes the last item and stores the
+      // same bytes again (a conditional store lets the compiler sink the last phase's loads into
+      // the branch, behind the LDS taps they are meant to overlap)
+      const unsigned q = query_of(i);
+      u32x2 v;
+      v.x = pack_h2(acc[0] * inv, acc[1] * inv);
+      v.y = pack_h2(acc[2] * inv, acc[3] * inv);
+      __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(out_base + q * out_q), 0, 2);
+    } else {
+      asm volatile("" ::"v"(acc[0] * inv), "v"(acc[1] * inv), "v"(acc[2] * inv), "v"(acc[3] * inv));
+    }
+    // the operand request is the youngest vector memory instruction of the iteration
+    if constexpr (!(ABL & 4)) request(cur, i + 3u * OCT);
+  };
+
+  H5Set A, B, C;
+  unsigned i = threadIdx.x >> 3;
+  request(A, i);
+  request(B, i + OCT);
+  request(C, i + 2u * OCT);
+  fe_begin(A);
+  fe(A, IC<0>{});
+  for (unsigned r = 0; r < nrounds; r += 3u) {
+    body(A, B, i);
+    if (r + 1u >= nrounds) break;
+    body(B, C, i + OCT);
+    if (r + 2u >= nrounds) break;
+    body(C, A, i + 2u * OCT);
+    i += 3u * OCT;
+  }
+}
+
+inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
+constexpr int kH5Chunk = 1280;
+
+template <int NBL, int THREADS, int ABL, bool LISTED>
+int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
+          const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, hipStream_t st) {
+  const int chunk = kH5Chunk;
+  const int nchunk = (d.nq + chunk - 1) / chunk;
+  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, chunk);
+  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED>>(lds)) return (int)BEVOPS_FAILURE;
+  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED>), dim3((unsigned)(d.bs * d.heads * nchunk)),
+                     dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk,
+                     nchunk, pl.stage_bytes, vis);
+  return launch_status();
+}
+
+}  // namespace
+
+static bool h5_shape_ok(int C, int L, int P, int ppg) { return C == 32 && L == 4 && P == 8 && ppg == 4; }
+
+size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
+  Hm3Plan pl;
+  if (!h5_shape_ok(C, L, P, 4) || !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl)) return 0;
+  const size_t planes = ((pl.g_bytes + 127) & ~size_t(127)) + pl.s_bytes;
+  return ((planes + 255) & ~size_t(255)) + (((size_t)bs * nq * heads + 255) & ~size_t(255));
+}
+
+// flags: 1 no visibility pre-pass, 2 768-thread blocks, 4 / 8 / 16 / 32 ablations (big taps, staged taps,
+// operand stream, store) -- the ablations imply "no pre-pass"
+int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
+                         const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
+                         int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
+                         hipStream_t st) {
+  Hm3Plan pl;
+  if (!h5_shape_ok(C, L, P, ppg) || shared || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 127u) ||
+      !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl))
+    return BEVOPS_NOT_SUPPORTED;
+  if ((double)bs * nq * heads * 32 * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
+  if (workspace_bytes < msda_hm5_workspace_bytes(shapes_host, bs, heads, C, L, nq, P)) return BEVOPS_NOT_SUPPORTED;
+  const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
+  char *gset = static_cast<char *>(workspace);
+  char *sset = gset + g_room;
+  unsigned char *vis = reinterpret_cast<unsigned char *>(gset + ((g_room + pl.s_bytes + 255) & ~size_t(255)));
+  if (!prepacked) msda_hm3_repack_launch(value, gset, sset, &pl.t, bs, nk, heads, st);
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
+  const bool listed = !(flags & 1) && !(flags & 60);
+  if (listed) {
+    constexpr int U = 4;
+    const unsigned n_item = (unsigned)bs * (unsigned)nq * (unsigned)heads;
+    const unsigned waves = (n_item + 8 * U - 1) / (8 * U);
+    hipLaunchKernelGGL(msda_hm5_vis_kernel<U>, dim3((waves + 3) / 4), dim3(256), 0, st, ref, off, out, vis, d, pl.t,
+                       n_item);
+  }
+  const int nbl = pl.t.ls;
+#define BEVOPS_H5(NBL_, THREADS_, ABL_, LISTED_) \
+  return h5_go<NBL_, THREADS_, ABL_, LISTED_>(pl, gset, sset, ref, off, logit, out, d, vis, st)
+  if (nbl == 2) {
+    if (flags & 4) BEVOPS_H5(2, 1024, 1, false);
+    if (flags & 8) BEVOPS_H5(2, 1024, 2, false);
+    if (flags & 16) BEVOPS_H5(2, 1024, 4, false);
+    if (flags & 32) BEVOPS_H5(2, 1024, 8, false);
+    if (flags & 2) {
+      if (listed) BEVOPS_H5(2, 768, 0, true);
+      BEVOPS_H5(2, 768, 0, false);
+    }
+    if (listed) BEVOPS_H5(2, 1024, 0, true);
+    BEVOPS_H5(2, 1024, 0, false);
+  }
+#undef BEVOPS_H5
+  return BEVOPS_NOT_SUPPORTED;
+}
+
+}  // namespace bevops
