@@ -92,6 +92,21 @@ def _fused_linear(ops, x, weight, bias, residual, relu):
         return None
 
 
+def _dense(ops, lin, x, residual=None, relu=False):
+    """act(lin(x) + residual) for an nn.Linear or a quantization.LinearQ.  A LinearQ is always CALLED
+    (all three of its phases live in its forward: float, calibrate -- where it must see its input --
+    and int8); a plain Linear takes the one-GEMM fused epilogue when the operator set has it."""
+    if hasattr(lin, "fake_quant_reference"):        # LinearQ (kept duck-typed: quantization imports nothing from here)
+        return lin(x, residual, relu)
+    y = _fused_linear(ops, x, lin.weight, lin.bias, residual, relu)
+    if y is not None:
+        return y
+    y = lin(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
 def _layer_norm(ops, norm, x):
     """nn.LayerNorm as one streaming pass (ops.layer_norm) when the operator set has it."""
     fn = getattr(ops, "layer_norm", None)
@@ -277,12 +292,7 @@ class FFN(nn.Module):
         self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
 
     def forward(self, x, ops=None):
-        if ops is not None:
-            h = _fused_linear(ops, x, self.fc1.weight, self.fc1.bias, None, True)
-            y = None if h is None else _fused_linear(ops, h, self.fc2.weight, self.fc2.bias, x, False)
-            if y is not None:
-                return y
-        return x + self.fc2(F.relu(self.fc1(x), inplace=True))
+        return _dense(ops, self.fc2, _dense(ops, self.fc1, x, None, True), x, False)
 
 
 class TemporalSelfAttention(nn.Module):
@@ -307,8 +317,7 @@ class TemporalSelfAttention(nn.Module):
         off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
         out = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref_2d, off, w).flatten(2)
         out = torch.mean(out, keepdim=True, dim=0)
-        y = _fused_linear(self.ops, out, self.output_proj.weight, self.output_proj.bias, identity, False)
-        return y if y is not None else self.output_proj(out) + identity
+        return _dense(self.ops, self.output_proj, out, identity, False)
 
 
 class SpatialCrossAttention(nn.Module):
@@ -329,6 +338,8 @@ class SpatialCrossAttention(nn.Module):
         off = self.sampling_offsets(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
         w = self.attention_weights(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
         ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
+        if cams is None and gather is not None and hasattr(gather, "cams"):
+            cams = gather.cams   # the exchange object knows this rank's cameras
         if cams is not None:  # camera-sharded: this rank's cameras only
             ref = ref[cams]
         fused = getattr(self.ops, "spatial_cross_attention_sample", None)
@@ -356,8 +367,7 @@ class SpatialCrossAttention(nn.Module):
             if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
                 queries = gather(queries)
             slots = (queries * bev_mask).sum(0, keepdim=True)
-        y = _fused_linear(self.ops, slots, self.output_proj.weight, self.output_proj.bias, inp_residual, False)
-        return y if y is not None else self.output_proj(slots) + inp_residual
+        return _dense(self.ops, self.output_proj, slots, inp_residual, False)
 
 
 class BEVFormerLayer(nn.Module):

@@ -1,12 +1,19 @@
 """Camera sharding of the SCA sampler across GPUs (new design --
 the reference is single-GPU).  One process per GPU; rank g owns cameras
-{c : c mod G == g}; after the per-camera MSDA each rank holds [cams_local, nq, embed]
-and ONE all-gather per encoder layer (RCCL over xGMI, backend "nccl") rebuilds
-[n_cams, nq, embed] on every rank for the replicated masked camera sum + output_proj
-(det2trt/models/modules/spatial_cross_attention.py:270-273).
+{c : c mod G == g}; after the per-camera MSDA each rank holds [cams_local, nq, embed] and the
+encoder layer's exchange (RCCL over xGMI, backend "nccl") rebuilds what the replicated masked camera
+sum + output_proj need (det2trt/models/modules/spatial_cross_attention.py:270-273).  Two exchanges,
+both behind `CameraExchange`:
 
-xGMI is point-to-point, so the exchange is a single large all_gather_into_tensor per
-layer (20.5 MB per camera at base fp16) rather than many small ones.
+  "gather"  one asynchronous all_gather_into_tensor PER LOCAL CAMERA SLOT (20.5 MB at base fp16),
+            issued as soon as that camera has been sampled, so camera i's transfer overlaps the
+            sampling of camera i + 1; waited for right before the masked sum;
+  "reduce"  each rank reduces its own cameras with the bev_mask weights and ONE all-reduce per layer
+            adds the [1, nq, embed] partial sums (6x less data).
+
+`gather_camera_features` is the plain one-collective form (used by bench.py's hot-path step and the
+primitive tests).  Staging buffers are keyed by device AND current stream: two streams (or a graph
+capture next to eager work) never share one.
 """
 import torch
 
@@ -38,7 +45,8 @@ def gather_camera_features(local, n_cams, dist, group=None):
     world = dist.get_world_size(group)
     max_local = -(-n_cams // world)
     tail = tuple(local.shape[1:])
-    key = (max_local, world, tail, local.dtype, str(local.device))
+    stream = torch.cuda.current_stream(local.device).cuda_stream if local.is_cuda else 0
+    key = (max_local, world, tail, local.dtype, str(local.device), stream)
     send, recv = _buffers(key, max_local, world, tail, local.dtype, local.device)
     if local.shape[0] == max_local and local.is_contiguous():
         src = local
@@ -84,7 +92,9 @@ class CameraExchange:
 
     def gather(self, sample, tail, dtype, device):
         """sample(i) -> [1, *tail] features of the i-th LOCAL camera.  Returns [n_cams, *tail]."""
-        key = (tuple(tail), dtype, str(device))
+        dev = torch.device(device)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (tuple(tail), dtype, str(device), stream)
         recv = self._recv.get(key)
         if recv is None:
             recv = self._recv[key] = torch.empty((self.max_local, self.world) + tuple(tail), dtype=dtype, device=device)

@@ -187,10 +187,11 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
         const int4 t = lvl[l];
         const int H = t.x, W = t.y;
         const float2 r = make_float2(h2f_lo(refraw[k]), h2f_hi(refraw[k]));
-        const float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
-        const float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
+        float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
+        float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
         const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
         any_valid |= valid;
+        if (!valid) { x = 0.f; y = 0.f; }   // non-finite locations must give 0, not NaN * 0
         const float xf = floorf(x), yf = floorf(y);
         const float lx = x - xf, ly = y - yf;
         const int x0 = (int)xf, y0 = (int)yf;
@@ -399,10 +400,11 @@ __global__ __launch_bounds__(256) void msda_hm2_kernel(
         const int4 t = lvl[l];
         const int H = t.x, W = t.y;
         const float2 r = load_ref(refp + 2 * g);
-        const float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
-        const float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
+        float x = loc_im(r.x, (float)W, h2f_lo(offraw[k]));
+        float y = loc_im(r.y, (float)H, h2f_hi(offraw[k]));
         const bool valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
         any_valid |= valid;
+        if (!valid) { x = 0.f; y = 0.f; }   // non-finite locations must give 0, not NaN * 0
         const float xf = floorf(x), yf = floorf(y);
         const float lx = x - xf, ly = y - yf;
         const int x0 = (int)xf, y0 = (int)yf;

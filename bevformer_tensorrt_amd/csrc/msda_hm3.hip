@@ -329,11 +329,14 @@ __global__ __launch_bounds__(THREADS) void msda_hm3_kernel(
       for (int k = 0; k < PP; ++k) {
         const float4 tf = *reinterpret_cast<const float4 *>(smem + lvo[k]);
         const int2 ti = *reinterpret_cast<const int2 *>(smem + lvo[k] + 16);
-        const float x = fmaf(h2f_lo(cur.rf[k]), tf.x, h2f_lo(cur.of[k])) - 0.5f;
-        const float y = fmaf(h2f_hi(cur.rf[k]), tf.y, h2f_hi(cur.of[k])) - 0.5f;
+        float x = fmaf(h2f_lo(cur.rf[k]), tf.x, h2f_lo(cur.of[k])) - 0.5f;
+        float y = fmaf(h2f_hi(cur.rf[k]), tf.y, h2f_hi(cur.of[k])) - 0.5f;
+        const bool valid = (y > -1.f) && (x > -1.f) && (y < tf.y) && (x < tf.x);
+        // outside the range gate (incl. non-finite locations: reference points of pillars behind a
+        // camera overflow binary16) -> exactly 0, never NaN * 0
+        if (!valid) { x = 0.f; y = 0.f; }
         const float xf = floorf(x), yf = floorf(y);
         const float lx = x - xf, ly = y - yf;
-        const bool valid = (y > -1.f) && (x > -1.f) && (y < tf.y) && (x < tf.x);
         any_valid |= valid;
         const float ev = valid ? e[k] : 0.f;
         const float wr1 = ly * ev, wr0 = ev - wr1;

@@ -421,9 +421,13 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
         x = fmaf(rx, tf.x, ox) - 0.5f;
         y = fmaf(ry, tf.y, oy) - 0.5f;
       }
+      const bool valid = owner && (y > -1.f) && (x > -1.f) && (y < tf.y) && (x < tf.x);
+      // a sample outside the range gate contributes exactly 0, as in the reference -- also when its
+      // location is not finite (reference points of pillars behind a camera overflow binary16):
+      // without this its fractions would be NaN and NaN * 0 would reach the output
+      if (!valid) { x = 0.f; y = 0.f; }
       const float xf = floorf(x), yf = floorf(y);
       const float lx = x - xf, ly = y - yf;
-      const bool valid = owner && (y > -1.f) && (x > -1.f) && (y < tf.y) && (x < tf.x);
       any_valid |= valid;
       if constexpr (I8) {
         const float hx = 1.f - lx, hy = 1.f - ly;

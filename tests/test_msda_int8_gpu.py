@@ -62,8 +62,13 @@ def test_int8_vs_oracle_and_fp32(bev, oracle_mod, name, ref_dtype):
                               qw.numpy(), s_w, s_out,
                               u8_weights=(ref_dtype == torch.float16)).astype(np.int32)
     d = np.abs(got - want)
-    assert d.max() <= 1, d.max()
-    assert (d > 0).mean() <= 0.01, (d > 0).mean()
+    if ref_dtype == torch.float32:
+        # <float> flavour: integer pipeline restated exactly -> bit-identical to the oracle
+        assert np.array_equal(got, want), (d.max(), (d > 0).mean())
+    else:
+        # <__half2> flavour: fp32 weight sum here, another association in the oracle
+        assert d.max() <= 1, d.max()
+        assert (d > 0).mean() <= 0.01, (d > 0).mean()
     # reference criterion 0.01 is quoted for the 32-point SCA call; 4-point calls average
     # less quantisation noise away
     lp = len(SHAPES[name][1]) * SHAPES[name][3]

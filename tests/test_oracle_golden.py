@@ -81,3 +81,23 @@ def test_rotate_oracle(oracle_mod, case):
     np.testing.assert_allclose(ob, g["bilinear"], rtol=1e-4, atol=1e-4)  # test_rotate.py fp32 1e-4
     on = oracle_mod.rotate(g["img"], g["angle"], g["center"], 1)
     assert (on != g["nearest"]).mean() <= 2e-3
+
+
+@pytest.mark.parametrize("case", ["caffe", "torch"])
+def test_image_ref_against_float64_definition(case):
+    """oracle/image_ref.py (mmcv's float32 pipeline: two roundings per pixel) against the published
+    definition of mmcv.imnormalize + impad_to_multiple evaluated in float64
+    (tests/golden/make_image_golden.py): within 2 float32 ulps of the result, padding exactly zero,
+    BGR->RGB order and the pad geometry as the definition says."""
+    import os
+    from oracle.image_ref import image_normalize_pad
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "image_norm.npz"))
+    got = image_normalize_pad(g["img"], tuple(g[case + "_mean"]), tuple(g[case + "_std"]), bool(g[case + "_to_rgb"]))
+    want = g[case + "_out64"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert (got[:, :, 37:, :] == 0).all() and (got[:, :, :, 45:] == 0).all()
+    # float32(x - float32(mean)) * float32(1/std): the subtraction's rounding (<= ulp(256)/2 = 1.5e-5) scaled by 1/std,
+    # plus the product's own rounding
+    inv = 1.0 / g[case + "_std"].reshape(1, 3, 1, 1)
+    tol = 1.6e-5 * inv + 2 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) + np.abs(want) * 1.2e-7
+    assert (np.abs(got.astype(np.float64) - want) <= tol).all()

@@ -131,3 +131,33 @@ def test_int8_plugin_ops_plumbing():
     q.begin_frame()
     q.multi_scale_deformable_attn(v, shapes, ref, o, w)
     assert fake.calls[-1][1] == round(scales["msda#0.value"], 9)
+
+
+def test_quantize_dense_layers_sees_inputs_through_the_model_blocks():
+    """The model's blocks must CALL a LinearQ (not read its float weights into the fused-GEMM entry):
+    otherwise calibration collects nothing and freeze() has no scale.  The operator set here
+    has a `linear_bias_act` entry that must never be reached for a swapped layer."""
+    import torch
+    from bevformer_tensorrt_amd import bevformer as M
+    from bevformer_tensorrt_amd.quantization import MinMaxCalibrator, quantize_dense_layers, LinearQ
+
+    class Ops:
+        def linear_bias_act(self, *a):
+            raise AssertionError("fused float GEMM used for a quantised layer")
+
+    torch.manual_seed(0)
+    ffn = M.FFN(64, 128)
+    cal = MinMaxCalibrator()
+    swapped = quantize_dense_layers(ffn, cal)
+    assert len(swapped) == 2 and all(isinstance(m, LinearQ) for m in (ffn.fc1, ffn.fc2))
+    x = torch.randn(1, 10, 64)
+    want = x + torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, ffn.fc1.weight, ffn.fc1.bias)),
+                                          ffn.fc2.weight, ffn.fc2.bias)
+    for m in swapped:
+        m.calibrate()
+    got = ffn(x, Ops())
+    assert torch.allclose(got, want, atol=1e-6)
+    for m in swapped:           # every swapped layer has seen its input -> freeze() finds its scale
+        m.freeze()
+        assert m.mode == "int8" and m.scale_in > 0 and m.weight_q.dtype == torch.int8
+    assert abs(ffn.fc1.scale_in - float(x.abs().max()) / 127.0) < 1e-9

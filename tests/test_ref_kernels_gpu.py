@@ -67,8 +67,8 @@ def test_msda_int8(bev, case):
     sc = [float(g[k]) for k in ("s_value", "s_off", "s_logit", "s_out")]
     args = lambda ref: (cu(g["value_q"]), cu(g["shapes"]), ref, cu(g["off_q"]), cu(g["logit_q"]), *sc)
     o = bev.multi_scale_deformable_attn_int8(*args(cu(g["ref"]))).cpu().numpy()
-    d = lsb(o, g["out_s8_f32ref"])
-    assert d.max() <= 1 and (d > 0).mean() <= 0.01, (d.max(), (d > 0).mean())
+    # <float> flavour: the reference's integer pipeline restated operation for operation -> bit-exact
+    assert np.array_equal(o, g["out_s8_f32ref"]), (lsb(o, g["out_s8_f32ref"]).max(), (o != g["out_s8_f32ref"]).mean())
     o = bev.multi_scale_deformable_attn_int8(*args(cu(g["ref"], torch.float16))).cpu().numpy()
     d = lsb(o, g["out_s8_f16ref"])
     assert (d == 0).mean() >= 0.80 and (d <= 3).mean() >= 0.999, ((d == 0).mean(), (d <= 3).mean())

@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def R():
     from oracle import refkernels
-    if not refkernels.available():
-        pytest.skip("oracle/_ref/libbevref.so not built")
+    # under `-m gpu` the reference-built checker must be there (it travels with the snapshot, built by
+    # __graft_entry__.build()): a missing library is a FAILURE, not a silent coverage drop
+    assert refkernels.available(), "oracle/_ref/libbevref.so not built -- run `make -C oracle` where /root/reference exists"
     refkernels.lib()
     return refkernels
 
@@ -87,8 +88,8 @@ def test_msda_int8_vs_live_reference_kernels(bev, R, name):
     s_out = float(np.abs(R.msda(v, sh, r, o, w, R.F32)).max() / 127)
     want = R.msda_s8(vq, sv, sh, r, oq, so, wq, sw, s_out, ref_half=False)
     got = bev.multi_scale_deformable_attn_int8(cu(vq), cu(sh), cu(r), cu(oq), cu(wq), sv, so, sw, s_out).cpu().numpy()
-    d = lsb(got, want)
-    assert d.max() <= 1 and (d > 0).mean() <= 0.01, (d.max(), (d > 0).mean())
+    # <float> flavour: bit-exact against the reference's own kernel
+    assert np.array_equal(got, want), (lsb(got, want).max(), (got != want).mean())
     want = R.msda_s8(vq, sv, sh, r.astype(np.float16), oq, so, wq, sw, s_out, ref_half=True)
     got = bev.multi_scale_deformable_attn_int8(cu(vq), cu(sh), cu(r, torch.float16), cu(oq), cu(wq), sv, so, sw,
                                                s_out).cpu().numpy()

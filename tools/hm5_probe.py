@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times the hm5 builds (bevops_msda_set_variant(1000 + flags)) against hm3 on the base SCA call,
 op-test reference points and the 6-camera rig geometry, interleaved; one JSON line per (refs, variant).
-flags: 1 no pre-pass, 2 768 threads, 4 no big taps, 8 no staged taps, 16 operands once, 32 no store."""
+flags: 1 no pre-pass, 2 768 threads (512 with 64), 4 no big taps, 8 no staged taps, 16 operands once, 32 no store,
+64 two phases of loads in flight (768 threads), 128 chunks of 2560 queries."""
 import json
 import os
 import sys
@@ -16,7 +17,7 @@ from msda_sweep import SHAPES, gen, time_call  # noqa: E402
 
 
 def main():
-    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "16,1000,1001,1002,1003,1004,1008,1016,1032").split(",")]
+    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "16,1000,1001,1003,1064,1065,1067,1129,1193,1005,1009,1017,1033,1049,1053,1057,1061,1081,1089,1121").split(",")]
     dists = (sys.argv[2] if len(sys.argv) > 2 else "uniform,rig").split(",")
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     lib = load_library()
