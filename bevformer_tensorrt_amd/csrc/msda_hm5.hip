@@ -161,7 +161,12 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 
 // ---- sampling kernel.  ABL: ablation bits for the probes (1: no big-level taps, 2: no staged
 // taps, 4: operands loaded once, 8: no store).  LISTED: items come from the visibility bytes.
-template <int NBL, int THREADS, int ABL, bool LISTED>
+// MBOX: the 8 records of a phase reach the octet's lanes through an LDS mailbox (one ds_write_b128 per
+// lane, one broadcast ds_read_b128 per record: 36 LDS cycles per phase and wave, ~70 us of LDS-pipe
+// time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
+// every lane the record of slot (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot
+// and dword does the rest (26 more VALU instructions per phase, no LDS traffic).
+template <int NBL, int THREADS, int ABL, bool LISTED, bool MBOX>
 __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
@@ -184,11 +189,6 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     ck = vb - bh * (unsigned)nchunk;
   }
   const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
-  if (stage_bytes) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
-  }
   const unsigned q0 = ck * (unsigned)chunk;
   const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
   unsigned n_items = q_end - q0;
@@ -214,6 +214,12 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
       __syncthreads();
     }
     n_items = base_count;
+  }
+  if (n_items == 0) return;   // nothing of this chunk is visible from this camera: no plane copy either
+  if (stage_bytes) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
   }
   __syncthreads();
   const unsigned wave_first = (threadIdx.x >> 6) * 8u;
@@ -288,20 +294,57 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   };
 
   float acc[4];
+  // record of slot S for every lane of the octet.  MBOX: read from the mailbox; else DPP broadcast
+  u32x4 rlo, rhi;   // DPP: records of slot (lane & 3) and of slot 4 + (lane & 3)
+  auto spread = [&]() __attribute__((always_inline)) {
+    if constexpr (MBOX) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      *(lds_u4 *)(size_t)(box + lane16) = rec;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+      // lanes 4..7 of every octet take lane - 4's record (row_shr:4 into banks 1, 3), the others keep
+      // their own; and the other way round (row_shl:4 into banks 0, 2)
+      rlo.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x114, 0xf, 0xa, false);
+      rlo.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x114, 0xf, 0xa, false);
+      rlo.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x114, 0xf, 0xa, false);
+      rhi.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x104, 0xf, 0x5, false);
+      rhi.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x104, 0xf, 0x5, false);
+      rhi.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x104, 0xf, 0x5, false);
+    }
+  };
+  auto record = [&](auto sc) __attribute__((always_inline)) -> u32x4 {
+    constexpr int S = decltype(sc)::v;
+    if constexpr (MBOX) {
+      return *(const lds_u4 *)(size_t)(box + S * 16u);
+    } else {
+      const u32x4 &src = S < 4 ? rlo : rhi;
+      u32x4 r;
+      r.x = quad_bcast<S & 3>(src.x);
+      r.y = quad_bcast<S & 3>(src.y);
+      r.z = quad_bcast<S & 3>(src.z);
+      // second row: the slot's level is lane-independent (slot S serves level S / 2)
+      r.w = r.z + (((unsigned)t.W[S >> 1] + 1u) << ((S >> 1) >= t.ls ? 6 : 7));
+      return r;
+    }
+  };
   // one item per octet: 4 phases; `cur` = this item's operands, `nxt` = the next item's (landed)
   auto body = [&](H5Set &cur, const H5Set &nxt, unsigned i, H5Set &far) __attribute__((always_inline)) {
     acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
     float s_cur = 0.f;
     auto phase = [&](auto jc) __attribute__((always_inline)) {
       constexpr int J = decltype(jc)::v;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      *(lds_u4 *)(size_t)(box + lane16) = rec;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      spread();
       // big levels: records, then all 2 * NB loads
       u32x4 rb[NB > 0 ? NB : 1];
       u32x4 r0[NB > 0 ? NB : 1], r1[NB > 0 ? NB : 1];
-#pragma unroll
-      for (int s = 0; s < NB; ++s) rb[s] = *(const lds_u4 *)(size_t)(box + s * 16u);
+      if constexpr (NB > 0) rb[0] = record(IC<0>{});
+      if constexpr (NB > 1) rb[1] = record(IC<1>{});
+      if constexpr (NB > 2) rb[2] = record(IC<2>{});
+      if constexpr (NB > 3) rb[3] = record(IC<3>{});
+      if constexpr (NB > 4) rb[4] = record(IC<4>{});
+      if constexpr (NB > 5) rb[5] = record(IC<5>{});
+      if constexpr (NB > 6) rb[6] = record(IC<6>{});
+      if constexpr (NB > 7) rb[7] = record(IC<7>{});
       if constexpr (!(ABL & 1)) {
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
@@ -317,12 +360,10 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
       constexpr int HS = (NS + 1) / 2, HB = (NB + 1) / 2;
       u32x4 rl[HS > 0 ? HS : 1];
       u32x2 l0[HS > 0 ? HS : 1], q0r[HS > 0 ? HS : 1], l1[HS > 0 ? HS : 1], q1r[HS > 0 ? HS : 1];
-      auto lds_issue = [&](int s0, int n) __attribute__((always_inline)) {
-        if constexpr (!(ABL & 2)) {
-#pragma unroll
-          for (int s = 0; s < HS; ++s) {
-            if (s >= n) break;
-            rl[s] = *(const lds_u4 *)(size_t)(box + (unsigned)(NB + s0 + s) * 16u);
+      auto lds_one = [&](auto sc, auto ic) __attribute__((always_inline)) {
+        constexpr int s = decltype(ic)::v;
+        if constexpr (decltype(sc)::v < 8 && s < HS) {
+            rl[s] = record(sc);
             const unsigned a0 = rl[s].z + lane8b, a1 = rl[s].w + lane8b;
             unsigned a0r = a0 + (unsigned)kLdsPixBytes, a1r = a1 + (unsigned)kLdsPixBytes;
             asm("" : "+v"(a0r));
@@ -331,7 +372,16 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
             q0r[s] = *(const lds_u2 *)(size_t)a0r;
             l1[s] = *(const lds_u2 *)(size_t)a1;
             q1r[s] = *(const lds_u2 *)(size_t)a1r;
-          }
+        }
+      };
+      // half `H` (0 / 1) of the staged slots
+      auto lds_issue = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int H0 = decltype(hc)::v * HS;
+        if constexpr (!(ABL & 2)) {
+          if constexpr (H0 + 0 < NS) lds_one(IC<NB + H0 + 0>{}, IC<0>{});
+          if constexpr (H0 + 1 < NS && HS > 1) lds_one(IC<NB + H0 + 1>{}, IC<1>{});
+          if constexpr (H0 + 2 < NS && HS > 2) lds_one(IC<NB + H0 + 2>{}, IC<2>{});
+          if constexpr (H0 + 3 < NS && HS > 3) lds_one(IC<NB + H0 + 3>{}, IC<3>{});
         }
       };
       auto lds_math = [&](int n) __attribute__((always_inline)) {
@@ -363,7 +413,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
           }
         }
       };
-      lds_issue(0, HS);
+      lds_issue(IC<0>{});
       __builtin_amdgcn_sched_barrier(0);
       // front end of the next phase (of the next item after the last one)
       if constexpr (J < 3) {
@@ -376,7 +426,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
       __builtin_amdgcn_sched_barrier(0);
       lds_math(HS);
       __builtin_amdgcn_sched_barrier(0);
-      lds_issue(HS, NS - HS);
+      lds_issue(IC<1>{});
       __builtin_amdgcn_sched_barrier(0);
       big_math(0, HB);
       __builtin_amdgcn_sched_barrier(0);
@@ -427,307 +477,17 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   }
 }
 
-// ---- sampling kernel, two phases of big-level loads in flight ("D2").  Same phases as above, but the
-// loads of phase j are consumed only after those of phase j + 1 have been issued (the last phase of an
-// item after the first phase of the next one), so the L2 path always holds 2 * NB line pairs per octet and
-// the distance from the operand request to the first load wait that has to cover it is two phases, not
-// one.  Costs a second tap register set and a second accumulator set:
-// 768-thread blocks (168 registers, 12 waves).
-template <int NBL, int THREADS, int ABL, bool LISTED>
-__global__ __launch_bounds__(THREADS) void msda_hm5d_kernel(
-    const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
-    const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
-    __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
-    const unsigned char *__restrict__ vis) {
-  constexpr int NB = 2 * NBL, NS = 8 - NB;
-  static_assert(NB > 0 && NS > 0, "D2 needs both level classes");
-  constexpr int kBox = 8 * 16 + 16;
-  constexpr unsigned OCT = THREADS / 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // smem: [staged planes][mailboxes][query list][wave totals]
-  unsigned bh, ck;
-  if (d.heads == 8) {
-    const unsigned rest = blockIdx.x >> 3;
-    bh = (rest / (unsigned)nchunk) * 8u + (blockIdx.x & 7u);
-    ck = rest % (unsigned)nchunk;
-  } else {
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    bh = vb / (unsigned)nchunk;
-    ck = vb - bh * (unsigned)nchunk;
-  }
-  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
-  if (stage_bytes) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
-  }
-  const unsigned q0 = ck * (unsigned)chunk;
-  const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
-  unsigned n_items = q_end - q0;
-  if constexpr (LISTED) {
-    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + OCT * kBox);
-    unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + OCT * kBox + chunk * 2);
-    unsigned base_count = 0;
-    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
-      const unsigned i = t0 + threadIdx.x;
-      const bool v = i < n_items && vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
-      const unsigned long long bal = __ballot(v);
-      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
-      __syncthreads();
-      unsigned before = base_count, all = 0;
-      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
-        const unsigned cnt = wtot[w2];
-        if (w2 < wv) before += cnt;
-        all += cnt;
-      }
-      if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
-      base_count += all;
-      __syncthreads();
-    }
-    n_items = base_count;
-  }
-  __syncthreads();
-  const unsigned wave_first = (threadIdx.x >> 6) * 8u;
-  if (n_items <= wave_first) return;
-  const unsigned nrounds = (n_items - wave_first + OCT - 1u) / OCT;
-
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gset), 0, g_bytes, 0x00020000);
-  const unsigned n_in = (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 32u;
-  const __amdgpu_buffer_rsrc_t rs_lg =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(logit), 0, n_in * 2u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_of =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(off), 0, n_in * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_rf = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__half *>(ref), 0, (unsigned)d.bs * (unsigned)d.nq * 16u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      out, 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 64u, 0x00020000);
-  const unsigned lane8 = threadIdx.x & 7u;
-  const unsigned lane16 = lane8 * 16u, lane8b = lane8 * 8u;
-  const unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
-  const unsigned out_q = (unsigned)d.heads * 64u;
-  const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
-  const unsigned box0 = sbase + (unsigned)stage_bytes + (threadIdx.x >> 3) * kBox;
-  const unsigned box1 = box0;   // every record is read inside its own phase: one mailbox is enough
-  const unsigned qlist_a = sbase + (unsigned)stage_bytes + OCT * kBox;
-  const H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
-  const unsigned lg_base = ((b * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
-  const unsigned lg_q = (unsigned)d.heads * 64u;
-  const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
-  auto query_of = [&](unsigned i) -> unsigned {
-    const unsigned ii = min(i, n_items - 1u);
-    return LISTED ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
-  };
-  auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
-    const unsigned q = query_of(i);
-    const unsigned o_lg = lg_base + q * lg_q;
-    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 2);
-    s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 2);
-    s.lg[0] = g.x; s.lg[1] = g.y;
-    s.rf = __builtin_amdgcn_raw_buffer_load_b32(rs_rf, (int)(rf_base + q * 16u), 0, 0);
-  };
-  float m = 0.f, ssum = 0.f;
-  u32x4 rec;
-  auto fe_begin = [&](const H5Set &s) __attribute__((always_inline)) {
-    const float a = fmaxf(fmaxf(h2f_lo(s.lg[0]), h2f_hi(s.lg[0])), fmaxf(h2f_lo(s.lg[1]), h2f_hi(s.lg[1])));
-    m = oct_max(a);
-    ssum = 0.f;
-  };
-  auto fe = [&](const H5Set &s, auto jc) __attribute__((always_inline)) {
-    constexpr int J = decltype(jc)::v;
-    const float lgv = (J & 1) ? h2f_hi(s.lg[J >> 1]) : h2f_lo(s.lg[J >> 1]);
-    const float e = __expf(lgv - m);
-    ssum += e;
-    const unsigned ofj = J == 0 ? s.of.x : J == 1 ? s.of.y : J == 2 ? s.of.z : s.of.w;
-    H5Loc p = h5_locate(quad_bcast<J>(s.rf), ofj, c);
-    if (!p.valid) { p.x = 0.f; p.y = 0.f; }
-    const float xf = floorf(p.x), yf = floorf(p.y);
-    const float lx = p.x - xf, ly = p.y - yf;
-    const float ev = p.valid ? e : 0.f;
-    const float wr1 = ly * ev, wr0 = ev - wr1;
-    const float b0 = wr0 * lx, b1 = wr1 * lx;
-    rec.x = pack_h2(wr0 - b0, b0);
-    rec.y = pack_h2(wr1 - b1, b1);
-    const int rel = __mul24((int)yf + 1, c.wp) + (int)xf;
-    rec.z = c.base + ((p.valid ? (unsigned)rel : 0u) << c.sh);
-    rec.w = rec.z + c.row;
-  };
-
-  // big-level taps in flight: set 0 (even phases) and set 1 (odd phases)
-  u32x4 ta0[2][NB], ta1[2][NB];
-  u32x2 tw[2][NB];
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};      // the item being sampled
-  float accp[4] = {0.f, 0.f, 0.f, 0.f};     // the previous item, waiting for its last phase's loads
-  float s_prev = 1.f;
-  unsigned o_prev = 0u;
-  bool have_prev = false;
-
-  auto big_math = [&](float (&a)[4], auto pc) __attribute__((always_inline)) {
-    constexpr int PS = decltype(pc)::v;
-    if constexpr (!(ABL & 1)) {
-#pragma unroll
-      for (int s = 0; s < NB; ++s) {
-        a[0] = dot2f(ta0[PS][s].x, tw[PS][s].x, a[0]); a[1] = dot2f(ta0[PS][s].y, tw[PS][s].x, a[1]);
-        a[2] = dot2f(ta0[PS][s].z, tw[PS][s].x, a[2]); a[3] = dot2f(ta0[PS][s].w, tw[PS][s].x, a[3]);
-        a[0] = dot2f(ta1[PS][s].x, tw[PS][s].y, a[0]); a[1] = dot2f(ta1[PS][s].y, tw[PS][s].y, a[1]);
-        a[2] = dot2f(ta1[PS][s].z, tw[PS][s].y, a[2]); a[3] = dot2f(ta1[PS][s].w, tw[PS][s].y, a[3]);
-      }
-    }
-  };
-  auto finish_prev = [&]() __attribute__((always_inline)) {
-    const float inv = __builtin_amdgcn_rcpf(oct_sum(s_prev));
-    if constexpr (!(ABL & 8)) {
-      u32x2 v;
-      v.x = pack_h2(accp[0] * inv, accp[1] * inv);
-      v.y = pack_h2(accp[2] * inv, accp[3] * inv);
-      __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)o_prev, 0, 2);
-    } else {
-      asm volatile("" ::"v"(accp[0] * inv), "v"(accp[1] * inv), "v"(accp[2] * inv), "v"(accp[3] * inv));
-    }
-  };
-
-  auto body = [&](H5Set &cur, const H5Set &nxt, unsigned i, H5Set &far) __attribute__((always_inline)) {
-    float s_cur = 0.f;
-    auto phase = [&](auto jc) __attribute__((always_inline)) {
-      constexpr int J = decltype(jc)::v;
-      constexpr int PS = J & 1;
-      const unsigned box = PS ? box1 : box0;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      *(lds_u4 *)(size_t)(box + lane16) = rec;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (int s = 0; s < NB; ++s) {
-        const u32x4 rb = *(const lds_u4 *)(size_t)(box + s * 16u);
-        tw[PS][s] = u32x2{rb.x, rb.y};
-        if constexpr (!(ABL & 1)) {
-          ta0[PS][s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb.z + lane16), 0, 0);
-          ta1[PS][s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb.w + lane16), 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      constexpr int HS = (NS + 1) / 2;
-      u32x4 rl[HS];
-      u32x2 l0[HS], q0r[HS], l1[HS], q1r[HS];
-      auto lds_issue = [&](int s0, int n) __attribute__((always_inline)) {
-        if constexpr (!(ABL & 2)) {
-#pragma unroll
-          for (int s = 0; s < HS; ++s) {
-            if (s >= n) break;
-            rl[s] = *(const lds_u4 *)(size_t)(box + (unsigned)(NB + s0 + s) * 16u);
-            const unsigned a0 = rl[s].z + lane8b, a1 = rl[s].w + lane8b;
-            unsigned a0r = a0 + (unsigned)kLdsPixBytes, a1r = a1 + (unsigned)kLdsPixBytes;
-            asm("" : "+v"(a0r));
-            asm("" : "+v"(a1r));
-            l0[s] = *(const lds_u2 *)(size_t)a0;
-            q0r[s] = *(const lds_u2 *)(size_t)a0r;
-            l1[s] = *(const lds_u2 *)(size_t)a1;
-            q1r[s] = *(const lds_u2 *)(size_t)a1r;
-          }
-        }
-      };
-      auto lds_math = [&](int n) __attribute__((always_inline)) {
-        if constexpr (!(ABL & 2)) {
-#pragma unroll
-          for (int s = 0; s < HS; ++s) {
-            if (s >= n) break;
-            const h2_t w0 = as_h2(rl[s].x), w1 = as_h2(rl[s].y);
-            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
-            h2_t a = as_h2(l0[s].x) * w00, bb = as_h2(l0[s].y) * w00;
-            a = as_h2(q0r[s].x) * w01 + a; bb = as_h2(q0r[s].y) * w01 + bb;
-            a = as_h2(l1[s].x) * w10 + a; bb = as_h2(l1[s].y) * w10 + bb;
-            a = as_h2(q1r[s].x) * w11 + a; bb = as_h2(q1r[s].y) * w11 + bb;
-            add_h2(acc[0], acc[1], a);
-            add_h2(acc[2], acc[3], bb);
-          }
-        }
-      };
-      lds_issue(0, HS);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (J < 3) {
-        fe(cur, IC<J + 1>{});
-      } else {
-        s_cur = ssum;
-        fe_begin(nxt);
-        fe(nxt, IC<0>{});
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      lds_math(HS);
-      __builtin_amdgcn_sched_barrier(0);
-      lds_issue(HS, NS - HS);
-      __builtin_amdgcn_sched_barrier(0);
-      // the loads of the PREVIOUS phase (the other register set): this item's, or -- in phase 0 --
-      // the last phase of the previous item, which is then normalised and stored
-      if constexpr (J == 0) {
-        if (have_prev) {
-          big_math(accp, IC<1>{});
-          finish_prev();
-        }
-      } else {
-        big_math(acc, IC<1 - PS>{});
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      lds_math(NS - HS);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    phase(IC<0>{});
-    phase(IC<1>{});
-    phase(IC<2>{});
-    phase(IC<3>{});
-    // hand the item over: its last phase's loads are consumed inside the next item's phase 0
-    accp[0] = acc[0]; accp[1] = acc[1]; accp[2] = acc[2]; accp[3] = acc[3];
-    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-    s_prev = s_cur;
-    o_prev = out_base + query_of(i) * out_q;
-    have_prev = true;
-    cur = nxt;
-    if constexpr (!(ABL & 4)) {
-      const_cast<H5Set &>(nxt) = far;
-      request(far, i + 3u * OCT);
-    }
-  };
-
-  H5Set S0, S1, S2;   // as in msda_hm5_kernel
-  unsigned i = threadIdx.x >> 3;
-  request(S0, i);
-  request(S1, i + OCT);
-  request(S2, i + 2u * OCT);
-  fe_begin(S0);
-  fe(S0, IC<0>{});
-  for (unsigned r = 0; r < nrounds; ++r) {
-    body(S0, S1, i, S2);
-    i += OCT;
-  }
-  big_math(accp, IC<1>{});
-  finish_prev();
-}
-
-inline int h5_lds_extra(int threads, int chunk, int boxes = 1) {
-  return boxes * (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128;
-}
+inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
 constexpr int kH5Chunk = 1280;
 
-template <int NBL, int THREADS, int ABL, bool LISTED>
-int h5d_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
-           const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
-  const int nchunk = (d.nq + chunk - 1) / chunk;
-  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, chunk);
-  if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<msda_hm5d_kernel<NBL, THREADS, ABL, LISTED>>(lds)) return (int)BEVOPS_FAILURE;
-  hipLaunchKernelGGL((msda_hm5d_kernel<NBL, THREADS, ABL, LISTED>), dim3((unsigned)(d.bs * d.heads * nchunk)),
-                     dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk,
-                     nchunk, pl.stage_bytes, vis);
-  return launch_status();
-}
-
-template <int NBL, int THREADS, int ABL, bool LISTED>
+template <int NBL, int THREADS, int ABL, bool LISTED, bool MBOX = true>
 int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
           const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
   const int nchunk = (d.nq + chunk - 1) / chunk;
   const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, chunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED>>(lds)) return (int)BEVOPS_FAILURE;
-  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED>), dim3((unsigned)(d.bs * d.heads * nchunk)),
+  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX>>(lds)) return (int)BEVOPS_FAILURE;
+  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX>), dim3((unsigned)(d.bs * d.heads * nchunk)),
                      dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk,
                      nchunk, pl.stage_bytes, vis);
   return launch_status();
@@ -744,9 +504,9 @@ size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
   return ((planes + 255) & ~size_t(255)) + (((size_t)bs * nq * heads + 255) & ~size_t(255));
 }
 
-// flags: 1 no visibility pre-pass; 2 768-thread blocks; bits 2..5 ablations (4 big taps, 8 staged taps, 16
-// operand stream, 32 store; they imply "no pre-pass"); 64 the two-phases-in-flight kernel (768 threads);
-// 128 chunks of 2560 queries
+// flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
+// bits 2..5 ablations (4 big taps, 8 staged taps, 16 operand stream, 32 store; they imply "no pre-pass");
+// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
@@ -775,35 +535,29 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   const int chunk = (flags & 128) ? 2 * kH5Chunk : kH5Chunk;
 #define BEVOPS_H5(KERN_, THREADS_, ABL_, LISTED_) \
   return KERN_<2, THREADS_, ABL_, LISTED_>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
-  if (flags & 64) {
+  if (!(flags & 256)) {   // default: records through DPP
+#define BEVOPS_H5X(THREADS_, ABL_, LISTED_) \
+  return h5_go<2, THREADS_, ABL_, LISTED_, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
+    if (flags & 2) {
+      if (abl) return BEVOPS_NOT_SUPPORTED;
+      if (listed) BEVOPS_H5X(768, 0, true);
+      BEVOPS_H5X(768, 0, false);
+    }
     switch (abl) {
-      case 0: if (flags & 2) { if (listed) BEVOPS_H5(h5d_go, 512, 0, true); BEVOPS_H5(h5d_go, 512, 0, false); }
-              if (listed) BEVOPS_H5(h5d_go, 768, 0, true); BEVOPS_H5(h5d_go, 768, 0, false);
-      case 1: BEVOPS_H5(h5d_go, 768, 1, false);
-      case 4: BEVOPS_H5(h5d_go, 768, 4, false);
-      case 6: BEVOPS_H5(h5d_go, 768, 6, false);
-      case 14: BEVOPS_H5(h5d_go, 768, 14, false);
+      case 0: if (listed) BEVOPS_H5X(1024, 0, true); BEVOPS_H5X(1024, 0, false);
+      case 1: BEVOPS_H5X(1024, 1, false);
+      case 2: BEVOPS_H5X(1024, 2, false);
+      case 4: BEVOPS_H5X(1024, 4, false);
+      case 8: BEVOPS_H5X(1024, 8, false);
+      case 12: BEVOPS_H5X(1024, 12, false);
+      case 14: BEVOPS_H5X(1024, 14, false);
       default: return BEVOPS_NOT_SUPPORTED;
     }
+#undef BEVOPS_H5X
   }
-  if (flags & 2) {
-    if (abl) return BEVOPS_NOT_SUPPORTED;
-    if (listed) BEVOPS_H5(h5_go, 768, 0, true);
-    BEVOPS_H5(h5_go, 768, 0, false);
-  }
-  switch (abl) {
-    case 0: if (listed) BEVOPS_H5(h5_go, 1024, 0, true); BEVOPS_H5(h5_go, 1024, 0, false);
-    case 1: BEVOPS_H5(h5_go, 1024, 1, false);
-    case 2: BEVOPS_H5(h5_go, 1024, 2, false);
-    case 4: BEVOPS_H5(h5_go, 1024, 4, false);
-    case 8: BEVOPS_H5(h5_go, 1024, 8, false);
-    case 6: BEVOPS_H5(h5_go, 1024, 6, false);
-    case 12: BEVOPS_H5(h5_go, 1024, 12, false);
-    case 13: BEVOPS_H5(h5_go, 1024, 13, false);
-    case 14: BEVOPS_H5(h5_go, 1024, 14, false);
-    case 15: BEVOPS_H5(h5_go, 1024, 15, false);
-    default: return BEVOPS_NOT_SUPPORTED;
-  }
+  if (abl) return BEVOPS_NOT_SUPPORTED;
+  if (listed) BEVOPS_H5(h5_go, 1024, 0, true);
+  BEVOPS_H5(h5_go, 1024, 0, false);
 #undef BEVOPS_H5
 }
 

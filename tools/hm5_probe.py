@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Times the hm5 builds (bevops_msda_set_variant(1000 + flags)) against hm3 on the base SCA call,
 op-test reference points and the 6-camera rig geometry, interleaved; one JSON line per (refs, variant).
-flags: 1 no pre-pass, 2 768 threads (512 with 64), 4 no big taps, 8 no staged taps, 16 operands once, 32 no store,
-64 two phases of loads in flight (768 threads), 128 chunks of 2560 queries."""
+flags: 1 no pre-pass, 2 768 threads, 4 no big taps, 8 no staged taps, 16 operands once, 32 no store,
+128 chunks of 2560 queries, 256 records through the LDS mailbox instead of DPP."""
 import json
 import os
 import sys
@@ -17,12 +17,17 @@ from msda_sweep import SHAPES, gen, time_call  # noqa: E402
 
 
 def main():
-    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "16,1000,1001,1003,1064,1065,1067,1129,1193,1005,1009,1017,1033,1049,1053,1057,1061,1081,1089,1121").split(",")]
+    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "16,1000,1001,1256,1257,1128,1005,1009,1017,1033,1049,1057").split(",")]
     dists = (sys.argv[2] if len(sys.argv) > 2 else "uniform,rig").split(",")
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     lib = load_library()
+    shapes = dict(SHAPES)
+    # same sample counts, smaller level 0 (plane 2.3 MB instead of 3.7): how much of the call is L2 capacity?
+    shapes["sca_small_l0"] = (6, [[82, 141], [58, 100], [29, 50], [15, 25]], 40000, 8, 4)
+    shapes["sca_tiny_l0"] = (6, [[58, 100], [58, 100], [29, 50], [15, 25]], 40000, 8, 4)
+    shape = os.environ.get("SHAPE", "base_sca")
     for dist in dists:
-        args, byt = gen(SHAPES["base_sca"], torch.float16, dist)
+        args, byt = gen(shapes[shape], torch.float16, dist)
         lib.bevops_msda_set_variant(16)
         want = bev.multi_scale_deformable_attn(*args).float()
         lib.bevops_msda_set_variant(0)
@@ -39,7 +44,7 @@ def main():
                     lib.bevops_msda_set_variant(0)
         for v in variants:
             med = sorted(res[v])[len(res[v]) // 2]
-            print(json.dumps({"call": "base_sca", "refs": dist, "variant": v, "us": res[v], "us_med": med,
+            print(json.dumps({"call": shape, "refs": dist, "variant": v, "us": res[v], "us_med": med,
                               "frac_of_8TBs": round(byt / med / 8e6, 4), "max_abs_vs_hm3": err[v]}), flush=True)
 
 
