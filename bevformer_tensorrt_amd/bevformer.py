@@ -42,12 +42,14 @@ from .utils import lib as _lib
 
 CONFIGS = {
     # name: backbone depth, DCN stages, FPN inputs/outs, padded image (h, w), BEV size, encoder layers
+    # style: which convolution of a bottleneck carries the stride -- "pytorch": the 3x3, "caffe": the first
+    # 1x1 (configs/bevformer/bevformer_tiny.py:62, bevformer_small.py:58, bevformer_base.py:50)
     "tiny": dict(depth=50, dcn=(False, False, False, False), fpn_in=[2048], out_indices=(3,), levels=1,
-                 image=(480, 800), bev=(50, 50), enc_layers=3),
+                 image=(480, 800), bev=(50, 50), enc_layers=3, style="pytorch"),
     "small": dict(depth=101, dcn=(False, False, True, True), fpn_in=[2048], out_indices=(3,), levels=1,
-                  image=(736, 1280), bev=(150, 150), enc_layers=3),
+                  image=(736, 1280), bev=(150, 150), enc_layers=3, style="caffe"),
     "base": dict(depth=101, dcn=(False, False, True, True), fpn_in=[512, 1024, 2048], out_indices=(1, 2, 3),
-                 levels=4, image=(928, 1600), bev=(200, 200), enc_layers=6),
+                 levels=4, image=(928, 1600), bev=(200, 200), enc_layers=6, style="caffe"),
 }
 PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
 EMBED, HEADS, NUM_QUERY, NUM_CAMS = 256, 8, 900, 6
@@ -196,12 +198,14 @@ class DCNv2Pack(nn.Module):
 
 
 class Bottleneck(nn.Module):
-    """ResNet bottleneck, caffe style (stride on the first 1x1), BN folded."""
+    """ResNet bottleneck (det2trt/models/backbones/resnet.py:106-260), BN folded.  style "caffe": the
+    stride sits on the first 1x1, "pytorch": on the 3x3 (resnet.py:163-170)."""
 
-    def __init__(self, cin, planes, stride, dcn, ops, downsample):
+    def __init__(self, cin, planes, stride, dcn, ops, downsample, style="caffe"):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, planes, 1, stride)
-        self.conv2 = DCNv2Pack(planes, planes, ops) if dcn else nn.Conv2d(planes, planes, 3, 1, 1)
+        s1, s2 = (stride, 1) if style == "caffe" else (1, stride)
+        self.conv1 = nn.Conv2d(cin, planes, 1, s1)
+        self.conv2 = DCNv2Pack(planes, planes, ops, s2) if dcn else nn.Conv2d(planes, planes, 3, s2, 1)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1)
         self.downsample = nn.Conv2d(cin, planes * 4, 1, stride) if downsample else None
 
@@ -222,7 +226,7 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, depth, dcn, out_indices, ops):
+    def __init__(self, depth, dcn, out_indices, ops, style="caffe"):
         super().__init__()
         blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
         self.out_indices = out_indices
@@ -231,7 +235,7 @@ class ResNet(nn.Module):
         for i, n in enumerate(blocks):
             planes, layers = 64 * 2 ** i, []
             for j in range(n):
-                layers.append(Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, dcn[i], ops, j == 0))
+                layers.append(Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, dcn[i], ops, j == 0, style))
                 cin = planes * 4
             stages.append(nn.Sequential(*layers))
         self.stages = nn.ModuleList(stages)
@@ -441,7 +445,7 @@ class BEVFormer(nn.Module):
         self._nhwc_ready = False
         self.bev_h, self.bev_w = cfg["bev"]
         nq = self.bev_h * self.bev_w
-        self.backbone = ResNet(cfg["depth"], cfg["dcn"], cfg["out_indices"], ops)
+        self.backbone = ResNet(cfg["depth"], cfg["dcn"], cfg["out_indices"], ops, cfg["style"])
         self.neck = FPN(cfg["fpn_in"], EMBED, cfg["levels"])
         # head (bevformer_head.py): embeddings, learned positional encoding, branches
         self.bev_embedding = nn.Embedding(nq, EMBED)

@@ -477,341 +477,6 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   }
 }
 
-// ---- sampling kernel with specialised waves ("hm5s").  The homogeneous kernel above still runs its pipes
-// largely one after the other: per round of 128 items the L2 path needs ~8.2 k cycles, but a wave's own chain
-// (LDS taps behind the other waves' LDS taps, then its VALU work behind three other waves of its SIMD) is
-// longer than that, so the loads are issued too late to keep the L2 path busy (profiles/r03: big-level taps
-// alone 270 us, staged taps alone 230 us, together 370 us).  Here the 16 waves of a block split the WORK
-// instead of interleaving it: waves 0..7 take the big-level samples of an item (L2 path only: front end of
-// their 16 samples, 32 loads, 128 multiply-adds), waves 8..15 the staged samples of the SAME item (LDS taps
-// only) and the finish: wave w hands its partial accumulators and exponent sum to wave w + 8 through a
-// two-slot LDS ring (release / acquire on two per-pair counters), wave w + 8 adds its own, normalises and
-// stores.  Lane k of an octet owns samples 2k, 2k + 1 of its role's 16, i.e. level k / 4 of the role's two
-// and anchors (0, 1) or (2, 3); records reach the octet by DPP as above.  Both roles read the item's 32
-// logits (the softmax maximum must be the same on both sides) and their own half of the offsets.
-struct H5sSet {
-  u32x2 lgm;   // the 4 logits 4k..4k+3 (for the maximum over all 32)
-  unsigned lg; // my 2 logits
-  u32x2 of;    // my 2 (x, y) offsets
-  u32x2 rf;    // my 2 anchors
-};
-
-template <int THREADS, bool LISTED>
-__global__ __launch_bounds__(THREADS) void msda_hm5s_kernel(
-    const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
-    const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
-    __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
-    const unsigned char *__restrict__ vis) {
-  constexpr unsigned NP = THREADS / 128;   // wave pairs
-  constexpr unsigned OCT = NP * 8;         // items per round
-  constexpr unsigned RING = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // smem: [staged planes][query list][wave totals][ring: acc 16 B x 64 lanes x RING x NP][ring: sums][counters]
-  unsigned bh, ck;
-  if (d.heads == 8) {
-    const unsigned rest = blockIdx.x >> 3;
-    bh = (rest / (unsigned)nchunk) * 8u + (blockIdx.x & 7u);
-    ck = rest % (unsigned)nchunk;
-  } else {
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    bh = vb / (unsigned)nchunk;
-    ck = vb - bh * (unsigned)nchunk;
-  }
-  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
-  const unsigned q0 = ck * (unsigned)chunk;
-  const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
-  unsigned n_items = q_end - q0;
-  const unsigned list_off = (unsigned)stage_bytes;
-  const unsigned wtot_off = list_off + (unsigned)chunk * 2u;
-  const unsigned acc_off = wtot_off + 128u;
-  const unsigned sum_off = acc_off + NP * RING * 1024u;
-  const unsigned cnt_off = sum_off + NP * RING * 256u;
-  if (threadIdx.x < 2 * NP) *reinterpret_cast<unsigned *>(smem + cnt_off + threadIdx.x * 4u) = 0u;
-  if constexpr (LISTED) {
-    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + list_off);
-    unsigned *wtot = reinterpret_cast<unsigned *>(smem + wtot_off);
-    unsigned base_count = 0;
-    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
-      const unsigned i = t0 + threadIdx.x;
-      const bool v = i < n_items && vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
-      const unsigned long long bal = __ballot(v);
-      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
-      __syncthreads();
-      unsigned before = base_count, all = 0;
-      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
-        const unsigned cnt = wtot[w2];
-        if (w2 < wv) before += cnt;
-        all += cnt;
-      }
-      if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
-      base_count += all;
-      __syncthreads();
-    }
-    n_items = base_count;
-  }
-  if (n_items == 0) return;
-  if (stage_bytes) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
-  }
-  __syncthreads();
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const unsigned pw = wave % NP;
-  const unsigned wave_first = pw * 8u;
-  if (n_items <= wave_first) return;   // both waves of the pair leave together
-  const unsigned nrounds = (n_items - wave_first + OCT - 1u) / OCT;
-
-  const unsigned n_in = (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 32u;
-  const __amdgpu_buffer_rsrc_t rs_lg =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(logit), 0, n_in * 2u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_of =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(off), 0, n_in * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_rf = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__half *>(ref), 0, (unsigned)d.bs * (unsigned)d.nq * 16u, 0x00020000);
-  const unsigned lane8 = threadIdx.x & 7u;
-  const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
-  const unsigned qlist_a = sbase + list_off;
-  const unsigned acc_a = sbase + acc_off + pw * (RING * 1024u) + lane * 16u;
-  const unsigned sum_a = sbase + sum_off + pw * (RING * 256u) + lane * 4u;
-  unsigned *prod = reinterpret_cast<unsigned *>(smem + cnt_off + pw * 8u);
-  unsigned *cons = prod + 1;
-  auto query_of = [&](unsigned i) -> unsigned {
-    const unsigned ii = min(i, n_items - 1u);
-    return LISTED ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
-  };
-  // bounded spin on one of the pair's counters (a stuck partner must not hang the GPU: give up after ~0.2 s)
-  auto wait_for = [&](unsigned *ctr, unsigned need) __attribute__((always_inline)) {
-    for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-      const unsigned v = __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if ((int)(__builtin_amdgcn_readfirstlane((int)v) - (int)need) >= 0) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-  };
-
-  auto run = [&](auto rolec) __attribute__((always_inline)) {
-    constexpr int ROLE = decltype(rolec)::v;   // 0: big levels (0, 1), 1: staged levels (2, 3)
-    constexpr unsigned SB = ROLE ? 16u : 0u;
-    // per-lane level constants: lane k serves level 2 * ROLE + k / 4
-    H5Lane c{1.f, 1.f, 0u, 0u, 1, 6};
-    {
-      const int myl = 2 * ROLE + (int)(lane8 >> 2);
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        if (l == myl) {
-          c.sh = ROLE ? 6 : 7;
-          c.W = (float)t.W[l];
-          c.H = (float)t.H[l];
-          c.wp = t.W[l] + 1;
-          c.base = (ROLE ? sbase : bh * (unsigned)t.g_entries * kEntBytes) + ((unsigned)t.ent0[l] << c.sh);
-        }
-      }
-    }
-    const unsigned lgm_base = ((b * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
-    const unsigned lg_base = ((b * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + SB + lane8 * 2u) * 2u;
-    const unsigned lg_q = (unsigned)d.heads * 64u;
-    const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 1u) * 8u;
-    auto request = [&](H5sSet &s, unsigned i) __attribute__((always_inline)) {
-      const unsigned q = query_of(i);
-      s.lgm = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)(lgm_base + q * lg_q), 0, 0);
-      s.lg = __builtin_amdgcn_raw_buffer_load_b32(rs_lg, (int)(lg_base + q * lg_q), 0, 0);
-      s.of = __builtin_amdgcn_raw_buffer_load_b64(rs_of, (int)(2u * (lg_base + q * lg_q)), 0, 2);
-      s.rf = __builtin_amdgcn_raw_buffer_load_b64(rs_rf, (int)(rf_base + q * 16u), 0, 0);
-    };
-    // front end of my two samples of one item: records (weights, first-row address) + my exponent sum
-    u32x4 rec0, rec1;
-    float ssum = 0.f;
-    auto fe2 = [&](const H5sSet &s) __attribute__((always_inline)) {
-      const float a = fmaxf(fmaxf(h2f_lo(s.lgm.x), h2f_hi(s.lgm.x)), fmaxf(h2f_lo(s.lgm.y), h2f_hi(s.lgm.y)));
-      const float m = oct_max(a);
-      auto one = [&](float lgv, unsigned rfj, unsigned ofj, u32x4 &rec) __attribute__((always_inline)) -> float {
-        const float e = __expf(lgv - m);
-        H5Loc p = h5_locate(rfj, ofj, c);
-        if (!p.valid) { p.x = 0.f; p.y = 0.f; }
-        const float xf = floorf(p.x), yf = floorf(p.y);
-        const float lx = p.x - xf, ly = p.y - yf;
-        const float ev = p.valid ? e : 0.f;
-        const float wr1 = ly * ev, wr0 = ev - wr1;
-        const float b0 = wr0 * lx, b1 = wr1 * lx;
-        rec.x = pack_h2(wr0 - b0, b0);
-        rec.y = pack_h2(wr1 - b1, b1);
-        const int rel = __mul24((int)yf + 1, c.wp) + (int)xf;
-        rec.z = c.base + ((p.valid ? (unsigned)rel : 0u) << c.sh);
-        return e;
-      };
-      const float e0 = one(h2f_lo(s.lg), s.rf.x, s.of.x, rec0);
-      const float e1 = one(h2f_hi(s.lg), s.rf.y, s.of.y, rec1);
-      ssum = e0 + e1;
-    };
-    // DPP distribution: after `spread`, lo[j] / hi[j] hold sample j of lane (k & 3) / of lane 4 + (k & 3)
-    u32x4 lo[2], hi[2];
-    auto spread = [&]() __attribute__((always_inline)) {
-#define BEVOPS_SHR(v) (unsigned)__builtin_amdgcn_update_dpp((int)(v), (int)(v), 0x114, 0xf, 0xa, false)
-#define BEVOPS_SHL(v) (unsigned)__builtin_amdgcn_update_dpp((int)(v), (int)(v), 0x104, 0xf, 0x5, false)
-      lo[0].x = BEVOPS_SHR(rec0.x); lo[0].y = BEVOPS_SHR(rec0.y); lo[0].z = BEVOPS_SHR(rec0.z);
-      lo[1].x = BEVOPS_SHR(rec1.x); lo[1].y = BEVOPS_SHR(rec1.y); lo[1].z = BEVOPS_SHR(rec1.z);
-      hi[0].x = BEVOPS_SHL(rec0.x); hi[0].y = BEVOPS_SHL(rec0.y); hi[0].z = BEVOPS_SHL(rec0.z);
-      hi[1].x = BEVOPS_SHL(rec1.x); hi[1].y = BEVOPS_SHL(rec1.y); hi[1].z = BEVOPS_SHL(rec1.z);
-#undef BEVOPS_SHR
-#undef BEVOPS_SHL
-    };
-    // record of sample (owner lane K, j) for every lane of the octet; .w = second row
-    auto record = [&](auto kc, auto jc) __attribute__((always_inline)) -> u32x4 {
-      constexpr int K = decltype(kc)::v, J = decltype(jc)::v;
-      const u32x4 &src = K < 4 ? lo[J] : hi[J];
-      u32x4 r;
-      r.x = quad_bcast<K & 3>(src.x);
-      r.y = quad_bcast<K & 3>(src.y);
-      r.z = quad_bcast<K & 3>(src.z);
-      r.w = r.z + (((unsigned)t.W[2 * ROLE + (K >> 2)] + 1u) << (ROLE ? 6 : 7));
-      return r;
-    };
-    float acc[4];
-    // keeps the multiply-adds where they are written: without it the compiler sinks the whole accumulation
-    // chain below the hand-over spin loop (all 32 loads' registers live at once -> spills)
-    auto pin = [&]() __attribute__((always_inline)) {
-      asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-    };
-    // S1 = the next item's operands (landed), S2 = the one after (in flight); this item's were consumed
-    // by the front end at the end of the previous trip
-    H5sSet S1, S2;
-    unsigned i = pw * 8u + (lane >> 3);
-    {
-      H5sSet first;
-      request(first, i);
-      request(S1, i + OCT);
-      request(S2, i + 2u * OCT);
-      fe2(first);
-    }
-    for (unsigned r = 0; r < nrounds; ++r) {
-      acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-      spread();
-      const float s_mine = ssum;
-      if constexpr (ROLE == 0) {
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gset), 0, g_bytes, 0x00020000);
-        const unsigned lane16 = lane8 * 16u;
-        // eight groups of 2 samples (owner lane g): 4 loads each, three groups in flight
-        constexpr int NBUF = 3;
-        u32x4 x0[NBUF][2], x1[NBUF][2];
-        u32x2 w[NBUF][2];
-        auto issue = [&](auto gc) __attribute__((always_inline)) {
-          constexpr int G = decltype(gc)::v, B = G % 3;
-          const u32x4 q0 = record(IC<G>{}, IC<0>{}), q1 = record(IC<G>{}, IC<1>{});
-          w[B][0] = u32x2{q0.x, q0.y}; w[B][1] = u32x2{q1.x, q1.y};
-          x0[B][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(q0.z + lane16), 0, 0);
-          x1[B][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(q0.w + lane16), 0, 0);
-          x0[B][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(q1.z + lane16), 0, 0);
-          x1[B][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(q1.w + lane16), 0, 0);
-        };
-        auto math = [&](auto gc) __attribute__((always_inline)) {
-          constexpr int B = decltype(gc)::v % 3;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            acc[0] = dot2f(x0[B][s].x, w[B][s].x, acc[0]); acc[1] = dot2f(x0[B][s].y, w[B][s].x, acc[1]);
-            acc[2] = dot2f(x0[B][s].z, w[B][s].x, acc[2]); acc[3] = dot2f(x0[B][s].w, w[B][s].x, acc[3]);
-            acc[0] = dot2f(x1[B][s].x, w[B][s].y, acc[0]); acc[1] = dot2f(x1[B][s].y, w[B][s].y, acc[1]);
-            acc[2] = dot2f(x1[B][s].z, w[B][s].y, acc[2]); acc[3] = dot2f(x1[B][s].w, w[B][s].y, acc[3]);
-          }
-        };
-        issue(IC<0>{}); issue(IC<1>{}); issue(IC<2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        math(IC<0>{}); pin(); issue(IC<3>{}); __builtin_amdgcn_sched_barrier(0);
-        math(IC<1>{}); pin(); issue(IC<4>{}); __builtin_amdgcn_sched_barrier(0);
-        math(IC<2>{}); pin(); issue(IC<5>{}); __builtin_amdgcn_sched_barrier(0);
-        math(IC<3>{}); pin(); issue(IC<6>{}); __builtin_amdgcn_sched_barrier(0);
-        math(IC<4>{}); pin(); issue(IC<7>{}); __builtin_amdgcn_sched_barrier(0);
-        // front end of the next item while the last loads fly
-        fe2(S1);
-        __builtin_amdgcn_sched_barrier(0);
-        math(IC<5>{}); math(IC<6>{}); math(IC<7>{});
-        pin();
-        // hand over: slot r % RING must have been consumed (item r - RING)
-        if (r >= RING) wait_for(cons, r - RING + 1u);
-        const unsigned slot = r % RING;
-        *(lds_u4 *)(size_t)(acc_a + slot * 1024u) = u32x4{__float_as_uint(acc[0]), __float_as_uint(acc[1]),
-                                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-        *(__attribute__((address_space(3))) float *)(size_t)(sum_a + slot * 256u) = s_mine;
-        __hip_atomic_store(prod, r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        const unsigned lane8b = lane8 * 8u;
-        // eight groups of 2 samples; LDS taps with two ds_read_b64 per row (see msda_hm5_kernel); the
-        // reads of group g + 1 are issued before the arithmetic of group g
-        u32x4 rl[2][2];
-        u32x2 l0[2][2], q0r[2][2], l1[2][2], q1r[2][2];
-        auto issue = [&](auto gc) __attribute__((always_inline)) {
-          constexpr int G = decltype(gc)::v, B = G & 1;
-          rl[B][0] = record(IC<G>{}, IC<0>{});
-          rl[B][1] = record(IC<G>{}, IC<1>{});
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const unsigned a0 = rl[B][s].z + lane8b, a1 = rl[B][s].w + lane8b;
-            unsigned a0r = a0 + (unsigned)kLdsPixBytes, a1r = a1 + (unsigned)kLdsPixBytes;
-            asm("" : "+v"(a0r));
-            asm("" : "+v"(a1r));
-            l0[B][s] = *(const lds_u2 *)(size_t)a0;
-            q0r[B][s] = *(const lds_u2 *)(size_t)a0r;
-            l1[B][s] = *(const lds_u2 *)(size_t)a1;
-            q1r[B][s] = *(const lds_u2 *)(size_t)a1r;
-          }
-        };
-        auto math = [&](auto gc) __attribute__((always_inline)) {
-          constexpr int B = decltype(gc)::v & 1;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const h2_t w0 = as_h2(rl[B][s].x), w1 = as_h2(rl[B][s].y);
-            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
-            h2_t a = as_h2(l0[B][s].x) * w00, bb = as_h2(l0[B][s].y) * w00;
-            a = as_h2(q0r[B][s].x) * w01 + a; bb = as_h2(q0r[B][s].y) * w01 + bb;
-            a = as_h2(l1[B][s].x) * w10 + a; bb = as_h2(l1[B][s].y) * w10 + bb;
-            a = as_h2(q1r[B][s].x) * w11 + a; bb = as_h2(q1r[B][s].y) * w11 + bb;
-            add_h2(acc[0], acc[1], a);
-            add_h2(acc[2], acc[3], bb);
-          }
-        };
-        issue(IC<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        issue(IC<1>{}); __builtin_amdgcn_sched_barrier(0); math(IC<0>{}); pin();
-        issue(IC<2>{}); __builtin_amdgcn_sched_barrier(0); math(IC<1>{}); pin();
-        issue(IC<3>{}); __builtin_amdgcn_sched_barrier(0); math(IC<2>{}); pin();
-        issue(IC<4>{}); __builtin_amdgcn_sched_barrier(0); math(IC<3>{}); pin();
-        issue(IC<5>{}); __builtin_amdgcn_sched_barrier(0); math(IC<4>{}); pin();
-        issue(IC<6>{}); __builtin_amdgcn_sched_barrier(0); math(IC<5>{}); pin();
-        issue(IC<7>{}); __builtin_amdgcn_sched_barrier(0); math(IC<6>{}); pin();
-        fe2(S1);
-        __builtin_amdgcn_sched_barrier(0);
-        math(IC<7>{});
-        pin();
-        // the partner's half of item r, then normalise and store
-        wait_for(prod, r + 1u);
-        const unsigned slot = r % RING;
-        const u32x4 pa = *(const lds_u4 *)(size_t)(acc_a + slot * 1024u);
-        const float ps = *(const __attribute__((address_space(3))) float *)(size_t)(sum_a + slot * 256u);
-        __hip_atomic_store(cons, r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const float inv = __builtin_amdgcn_rcpf(oct_sum(s_mine + ps));
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-            out, 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 64u, 0x00020000);
-        u32x2 v;
-        v.x = pack_h2((acc[0] + __uint_as_float(pa.x)) * inv, (acc[1] + __uint_as_float(pa.y)) * inv);
-        v.y = pack_h2((acc[2] + __uint_as_float(pa.z)) * inv, (acc[3] + __uint_as_float(pa.w)) * inv);
-        const unsigned q = query_of(i);
-        __builtin_amdgcn_raw_buffer_store_b64(
-            v, rs_out, (int)((b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b + q * (unsigned)d.heads * 64u), 0, 2);
-      }
-      S1 = S2;
-      request(S2, i + 3u * OCT);
-      i += OCT;
-    }
-  };
-  if (wave >= NP) run(IC<1>{}); else run(IC<0>{});
-}
-
-inline int h5s_lds_extra(int threads, int chunk) {
-  const int np = threads / 128;
-  return chunk * 2 + 128 + np * 2 * 1024 + np * 2 * 256 + 64;
-}
-
 inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
 constexpr int kH5Chunk = 1280;
 
@@ -828,19 +493,6 @@ int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *r
   return launch_status();
 }
 
-template <int THREADS, bool LISTED>
-int h5s_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
-           const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
-  const int nchunk = (d.nq + chunk - 1) / chunk;
-  const size_t lds = (size_t)pl.stage_bytes + h5s_lds_extra(THREADS, chunk);
-  if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<msda_hm5s_kernel<THREADS, LISTED>>(lds)) return (int)BEVOPS_FAILURE;
-  hipLaunchKernelGGL((msda_hm5s_kernel<THREADS, LISTED>), dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(THREADS),
-                     lds, st, gset, (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk,
-                     pl.stage_bytes, vis);
-  return launch_status();
-}
-
 }  // namespace
 
 static bool h5_shape_ok(int C, int L, int P, int ppg) { return C == 32 && L == 4 && P == 8 && ppg == 4; }
@@ -854,7 +506,7 @@ size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
 
 // flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
 // bits 2..5 ablations (4 big taps, 8 staged taps, 16 operand stream, 32 store; they imply "no pre-pass");
-// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP; 512 specialised waves
+// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
@@ -883,11 +535,6 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   const int chunk = (flags & 128) ? 2 * kH5Chunk : kH5Chunk;
 #define BEVOPS_H5(KERN_, THREADS_, ABL_, LISTED_) \
   return KERN_<2, THREADS_, ABL_, LISTED_>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
-  if (flags & 512) {   // specialised waves
-    if (abl) return BEVOPS_NOT_SUPPORTED;
-    if (listed) return h5s_go<1024, true>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-    return h5s_go<1024, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-  }
   if (!(flags & 256)) {   // default: records through DPP
 #define BEVOPS_H5X(THREADS_, ABL_, LISTED_) \
   return h5_go<2, THREADS_, ABL_, LISTED_, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
