@@ -123,6 +123,9 @@ def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
     if s > 1:
         x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
+    if hasattr(conv, "lin"):     # quantization.Conv2dQ: the LinearQ over the [N*H*W, C] rows (all three phases)
+        y = conv.lin(_rows(x), None if residual is None else _rows(residual), relu)
+        return _from_rows(y, n, h, w)
     wt = conv.weight.view(conv.out_channels, c).t()
     if residual is not None:
         # one GEMM with shift + identity + ReLU in its epilogue; else GEMM, then one fused pass (addmm

@@ -356,3 +356,25 @@ def quantize_dense_layers(model, calibrator, select=lambda name, mod: True):
                 setattr(mod, child_name, q)
                 swapped.append(q)
     return swapped
+
+
+def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True):
+    """Swap the 1x1 convolutions of the backbone / neck (bottleneck conv1, conv3, downsample, FPN laterals;
+    `Conv2dQ` of the reference, det2trt/models/utils/register.py:79, configs/bevformer/plugin/
+    bevformer_base_trt_p2_q.py) for Conv2dQ sharing their parameters: in the channels-last data path they
+    are the LinearQ GEMM over the [N*H*W, C] rows with shift / identity / ReLU in its epilogue.  3x3 / 7x7
+    convolutions stay on the library in the model's dtype.  Returns the swapped modules (`.calibrate()`,
+    calibration frames, `.freeze()`)."""
+    swapped = []
+    for name, mod in list(model.named_modules()):
+        if not name.startswith(("backbone", "neck")):
+            continue
+        for child_name, child in list(mod.named_children()):
+            full = f"{name}.{child_name}"
+            if type(child) is torch.nn.Conv2d and child.kernel_size == (1, 1) and child.groups == 1 \
+                    and child.in_channels % 16 == 0 and child.out_channels % 4 == 0 and select(full, child):
+                q = Conv2dQ(child, calibrator, "conv:" + full)
+                q = q.to(child.weight.device, child.weight.dtype)
+                setattr(mod, child_name, q)
+                swapped.append(q)
+    return swapped
