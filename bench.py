@@ -352,10 +352,12 @@ def geometry_rooflines(bev, wl, dev):
 class ModelFrames:
     """The whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random weights, synthetic
     6-camera frames) behind the reference's stateful frame loop (tools/bevformer/evaluate_trt.py:76-154).
-    kind "fp16": fp16 operators; "int8": the PTQ build -- every plugin call site on the INT8 operators
-    (quantization.Int8PluginOps), the encoder / decoder dense layers as LinearQ and the backbone / neck 1x1
-    convolutions as Conv2dQ (det2trt/models/utils/register.py:78-84, configs/bevformer/plugin/
-    bevformer_base_trt_p2_q.py), scales from the native entropy calibrator over `calib` synthetic frames.
+    kind "fp16": fp16 operators; "int8": the PTQ build -- the TSA / decoder MSDA and rotate call sites on the
+    INT8 operators (quantization.Int8PluginOps), the encoder / decoder dense layers as LinearQ and the
+    backbone / neck 1x1 convolutions as Conv2dQ (int8 x int8 MFMA GEMMs; det2trt/models/utils/register.py:
+    78-84, configs/bevformer/plugin/bevformer_base_trt_p2_q.py), scales from the native entropy calibrator
+    over `calib` synthetic frames; the channels-last DCNv2 block and the fused SCA sampler stay fp16 (a mixed
+    engine, as TensorRT builds them).
     N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and the
     frame runs eagerly with the RCCL exchange inside."""
 
@@ -376,8 +378,8 @@ class ModelFrames:
         self.note = None
         if kind == "int8":
             from bevformer_tensorrt_amd.quantization import Int8PluginOps, quantize_backbone_convs, quantize_dense_layers
-            qops = Int8PluginOps("entropy")
-            model = B.BEVFormer("base", ops=qops, seed=0).to(dev, dtype)
+            qops = Int8PluginOps("entropy", channels_last=True, fused_sca=True)
+            model = B.BEVFormer("base", ops=qops, seed=0, backbone_layout="nhwc").to(dev, dtype)
             qops.attach(model)
             q = quantize_dense_layers(model, qops.cal, lambda n, m: n.startswith(("encoder.", "decoder.")))
             q += quantize_backbone_convs(model, qops.cal)

@@ -284,8 +284,14 @@ class FPN(nn.Module):
 
     def forward_nhwc(self, feats, ops):
         lat = [_conv1x1_nhwc(ops, f, l, False) for l, f in zip(self.lateral, feats)]
+        up_add = getattr(ops, "upsample_add_nhwc_", None)
         for i in range(len(lat) - 1, 0, -1):
-            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+            a, b = lat[i - 1], lat[i]
+            if up_add is not None and _FUSED_LINEAR["enabled"] and a.dtype == torch.float16 and a.is_cuda \
+                    and a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last):
+                up_add(a, b)     # one in-place pass: a += nearest-up-sampled b
+            else:
+                lat[i - 1] = a + F.interpolate(b, size=a.shape[2:], mode="nearest")
         outs = [_conv_nhwc(ops, x.contiguous(memory_format=torch.channels_last), c, False) for c, x in zip(self.fpn, lat)]
         for e in self.extra:
             outs.append(_conv_nhwc(ops, F.relu(outs[-1]), e, False))
@@ -523,14 +529,27 @@ class BEVFormer(nn.Module):
         bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
         feats, level_hw = [], []
         cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]
-        for lvl, feat in enumerate(mlvl):
-            level_hw.append(feat.shape[-2:])
-            if feat.is_contiguous(memory_format=torch.channels_last):            # already [cams, h, w, 256]
-                f = feat.permute(0, 2, 3, 1).reshape(feat.shape[0], -1, feat.shape[1])
-            else:
-                f = feat.flatten(2).permute(0, 2, 1)                              # [cams, hw, 256]
-            feats.append(f + cam_embed.to(dtype)[:, None, :] + self.level_embeds[lvl].to(dtype)[None, None, :])
-        feat_flatten = torch.cat(feats, dim=1)                                   # [cams, sum hw, 256]
+        embed_fn = getattr(self.ops, "feat_embed_nhwc", None)
+        fused_embed = embed_fn is not None and _FUSED_LINEAR["enabled"] and dtype == torch.float16 and image.is_cuda \
+            and all(f.is_contiguous(memory_format=torch.channels_last) for f in mlvl) and mlvl[0].shape[0] > 0
+        if fused_embed:   # one pass per level straight into the concatenated tensor (no adds, no cat)
+            level_hw = [f.shape[-2:] for f in mlvl]
+            feat_flatten = torch.empty((mlvl[0].shape[0], sum(h * w for h, w in level_hw), EMBED), dtype=dtype, device=dev)
+            row = 0
+            for lvl, feat in enumerate(mlvl):
+                hw = feat.shape[2] * feat.shape[3]
+                embed_fn(feat.permute(0, 2, 3, 1).reshape(feat.shape[0], hw, feat.shape[1]), cam_embed,
+                         self.level_embeds[lvl], feat_flatten[:, row:row + hw, :])
+                row += hw
+        else:
+            for lvl, feat in enumerate(mlvl):
+                level_hw.append(feat.shape[-2:])
+                if feat.is_contiguous(memory_format=torch.channels_last):            # already [cams, h, w, 256]
+                    f = feat.permute(0, 2, 3, 1).reshape(feat.shape[0], -1, feat.shape[1])
+                else:
+                    f = feat.flatten(2).permute(0, 2, 1)                              # [cams, hw, 256]
+                feats.append(f + cam_embed.to(dtype)[:, None, :] + self.level_embeds[lvl].to(dtype)[None, None, :])
+            feat_flatten = torch.cat(feats, dim=1)                                   # [cams, sum hw, 256]
         # shape tensors live on the HOST: the operators cache a device copy per distinct value
         # and never have to synchronise to learn the pyramid geometry
         spatial_shapes, _ = G.level_layout(level_hw, "cpu")
@@ -559,7 +578,7 @@ class BEVFormer(nn.Module):
         query_pos, query = torch.split(self.query_embedding.weight.to(dtype).unsqueeze(1), EMBED, dim=2)
         reference_points = self.reference_points(query_pos).sigmoid().view(1, NUM_QUERY, 3)
         init_reference = reference_points
-        inter, inter_refs = [], []
+        inter, inter_refs, regs = [], [], []
         out = query
         for lid, layer in enumerate(self.decoder):
             out = layer(out, bev_embed, query_pos, reference_points[..., :2].unsqueeze(2).contiguous(), bev_shapes)
@@ -567,22 +586,38 @@ class BEVFormer(nn.Module):
             reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
             inter.append(out)
             inter_refs.append(reference_points)
+            regs.append(tmp)
 
-        # ---- head (bevformer_head.py:247-282)
-        classes, coords = [], []
-        for lvl in range(6):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_refs[lvl - 1])
-            hs = inter[lvl].view(1, NUM_QUERY, EMBED)
-            cls = self.cls_branches[lvl](hs)
-            crd = self.reg_branches[lvl](hs).clone()
-            crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
-            crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
-            crd[..., 0:1] = crd[..., 0:1] * (PC_RANGE[3] - PC_RANGE[0]) + PC_RANGE[0]
-            crd[..., 1:2] = crd[..., 1:2] * (PC_RANGE[4] - PC_RANGE[1]) + PC_RANGE[1]
-            crd[..., 4:5] = crd[..., 4:5] * (PC_RANGE[5] - PC_RANGE[2]) + PC_RANGE[2]
-            classes.append(cls)
-            coords.append(crd)
-        return bev_embed, torch.stack(classes), torch.stack(coords)
+        # ---- head (bevformer_head.py:247-282).  The regression branch of level l on inter[l] is the tensor
+        # the decoder loop already evaluated (same module, same input); the six levels' post-processing and
+        # classification branches run as ONE batch over [6, 900, .] (element-wise ops: identical values;
+        # branches: batched GEMMs with the stacked weights) instead of 6 x ~25 small launches
+        crd = torch.stack(regs)                                                        # [6, 1, 900, 10]
+        reference = inverse_sigmoid(torch.stack([init_reference] + inter_refs[:-1]))   # [6, 1, 900, 3]
+        crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
+        crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
+        crd[..., 0:1] = crd[..., 0:1] * (PC_RANGE[3] - PC_RANGE[0]) + PC_RANGE[0]
+        crd[..., 1:2] = crd[..., 1:2] * (PC_RANGE[4] - PC_RANGE[1]) + PC_RANGE[1]
+        crd[..., 4:5] = crd[..., 4:5] * (PC_RANGE[5] - PC_RANGE[2]) + PC_RANGE[2]
+        hs = torch.stack(inter).view(6, NUM_QUERY, EMBED)
+        return bev_embed, self._cls_batched(hs).view(6, 1, NUM_QUERY, -1), crd
+
+    def _cls_batched(self, hs):
+        """cls_branches[l](hs[l]) for the six decoder levels as batched GEMMs: Linear -> LayerNorm -> ReLU ->
+        Linear -> LayerNorm -> ReLU -> Linear with the per-level parameters stacked along the batch."""
+        key = tuple(p._version for p in self.cls_branches.parameters()) + (hs.dtype, hs.device)
+        if getattr(self, "_cls_stack", None) is None or self._cls_stack[0] != key:
+            st = lambda k, attr: torch.stack([getattr(b[k], attr).detach() for b in self.cls_branches]).to(hs.dtype)
+            self._cls_stack = (key, [(st(k, "weight").transpose(1, 2).contiguous(), st(k, "bias").unsqueeze(1)) for k in (0, 3, 6)],
+                               [(st(k, "weight").unsqueeze(1), st(k, "bias").unsqueeze(1), self.cls_branches[0][k].eps) for k in (1, 4)])
+        _, lin, norm = self._cls_stack
+        x = hs
+        for i in range(3):
+            x = torch.baddbmm(lin[i][1], x, lin[i][0])
+            if i < 2:
+                g, b, eps = norm[i]
+                x = F.relu(F.layer_norm(x, (x.shape[-1],), None, None, eps) * g + b, inplace=True)
+        return x
 
 
 def use_tuned_gemms(path=None):
@@ -610,8 +645,11 @@ class FrameRunner:
     """Stateful frame loop of tools/bevformer/evaluate_trt.py:76-154 with `prev_bev` kept on the
     device: can_bus position/angle deltas against the previous frame, `use_prev_bev = 0` on a
     scene change.  With `graph=True` the whole device-side frame (about 1 300 kernels at base)
-    is captured once into a HIP graph and replayed per frame from static input buffers --
-    shapes are static, exactly the property TensorRT exploits in the reference."""
+    is captured into a HIP graph and replayed per frame from static input buffers -- shapes are
+    static, exactly the property TensorRT exploits in the reference.  `use_prev_bev` is known on the
+    host (a scene change), so it is a host value of the forward and there is one graph per value: the
+    first frame of a scene replays the "no history" graph, every other frame the "history" graph, and
+    neither carries the per-layer select between prev_bev and the repeated query."""
 
     def __init__(self, model, device, dtype, graph=False, cams=None, gather=None):
         self.model, self.device, self.dtype = model, device, dtype
@@ -620,17 +658,20 @@ class FrameRunner:
         nq = model.bev_h * model.bev_w
         self.prev_bev = torch.zeros(nq, 1, EMBED, device=device, dtype=dtype)
         self.prev = {"scene": None, "pos": None, "angle": None}
-        self.use_graph, self._graph = graph, None
+        self.use_graph, self._graphs, self._use = graph, {}, 0.0
         H, W = model.cfg["image"]
         self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
                         can_bus=torch.zeros(18, device=device), lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
                         use=torch.zeros((), device=device, dtype=dtype),
                         shift=torch.zeros(1, 2, device=device))
-        self._out = None
+
+    @property
+    def _graph(self):   # the graph of the current use_prev_bev value (None: not captured yet)
+        return self._graphs.get(self._use, (None, None))[0]
 
     def _forward(self):
         i = self._in
-        return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,
+        return self.model(i["image"], self.prev_bev, self._use, i["can_bus"], i["lidar2img"], self.cams, self.gather,
                           shift=i["shift"])
 
     def _capture(self):
@@ -640,11 +681,11 @@ class FrameRunner:
             for _ in range(2):
                 self._forward()
         torch.cuda.current_stream().wait_stream(s)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
             bev, cls, crd = self._forward()
             self.prev_bev.copy_(bev)     # state update is part of the graph
-        self._out = (cls, crd)
+        self._graphs[self._use] = (graph, (cls, crd))
 
     def step_raw(self, raw_images, can_bus, lidar2img, scene_token):
         """Frame from RAW camera images [6, H0, W0, 3] (uint8 or fp32, BGR, on the device): the
@@ -677,15 +718,17 @@ class FrameRunner:
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / m.bev_h, (PC_RANGE[3] - PC_RANGE[0]) / m.bev_w)
         i["shift"].copy_(G.bev_shift(can_bus.cpu(), m.bev_h, m.bev_w, grid_length), non_blocking=True)
         i["use"].fill_(use_prev)
+        self._use = use_prev
         if self.use_graph:
             if self._graph is None:
                 saved = self.prev_bev.clone()
                 self._capture()
                 self.prev_bev.copy_(saved)   # capture/warm-up ran the model on scratch state
-            self._graph.replay()
+            graph, outs = self._graphs[self._use]
+            graph.replay()
             # the capture's output buffers are overwritten by the next replay: hand out copies
             # (2 x 54 000 values), as the eager path hands out fresh tensors
-            return tuple(t.clone() for t in self._out)
+            return tuple(t.clone() for t in outs)
         bev_embed, cls, crd = self._forward()
         self.prev_bev = bev_embed                                               # stays on device (:144)
         return cls, crd

@@ -55,6 +55,8 @@ const Entry kTable[] = {
     {"bevops_mdconv_forward_nhwc", (void *)&bevops_mdconv_forward_nhwc},
     {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
+    {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
+    {"bevops_feat_embed_nhwc", (void *)&bevops_feat_embed_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},
     {"bevops_quantize_rows", (void *)&bevops_quantize_rows},

@@ -106,10 +106,92 @@ __global__ __launch_bounds__(256) void layer_norm_f16_kernel(const __half *__res
   *reinterpret_cast<uint4 *>(out + row * C + lane * 8) = o;
 }
 
+// FPN top-down step on channels-last activations: a[n, h, w, :] += b[n, sh(h), sw(w), :] with the source
+// index of aten's nearest up-sampling (floor(dst * in / out) in float, clamped) -- the reference's
+// `laterals[i - 1] += F.interpolate(laterals[i], size=prev_shape, mode="nearest")` (necks/fpn.py:170-176) as
+// ONE pass instead of an up-sampled copy, a layout copy and an add.  thread = 8 channels of one pixel.
+__global__ __launch_bounds__(256) void upsample_add_f16_kernel(__half *__restrict__ a, const __half *__restrict__ b,
+                                                               int N, int H, int W, int Hb, int Wb, int C,
+                                                               float sh, float sw) {
+  const size_t vpp = (size_t)C / 8;
+  const size_t nvec = (size_t)N * H * W * vpp;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const size_t pix = i / vpp;
+  const int cv = (int)(i - pix * vpp);
+  const int w = (int)(pix % (size_t)W);
+  const size_t r = pix / (size_t)W;
+  const int h = (int)(r % (size_t)H);
+  const size_t n = r / (size_t)H;
+  const int hb = min((int)floorf((float)h * sh), Hb - 1), wb = min((int)floorf((float)w * sw), Wb - 1);
+  const uint4 x = reinterpret_cast<const uint4 *>(a)[i];
+  const uint4 y = *reinterpret_cast<const uint4 *>(b + (((n * Hb + hb) * (size_t)Wb + wb) * C + (size_t)cv * 8));
+  uint4 o;
+  o.x = pack_h2(h2f_lo(x.x) + h2f_lo(y.x), h2f_hi(x.x) + h2f_hi(y.x));
+  o.y = pack_h2(h2f_lo(x.y) + h2f_lo(y.y), h2f_hi(x.y) + h2f_hi(y.y));
+  o.z = pack_h2(h2f_lo(x.z) + h2f_lo(y.z), h2f_hi(x.z) + h2f_hi(y.z));
+  o.w = pack_h2(h2f_lo(x.w) + h2f_lo(y.w), h2f_hi(x.w) + h2f_hi(y.w));
+  reinterpret_cast<uint4 *>(a)[i] = o;
+}
+
+// Encoder input assembly (modules/transformer.py:138-152): dst[n, row0 + r, :] = (src[n, r, :] + cam_embed[n, :])
+// + level_embed[:], each sum rounded to binary16 like the two framework adds it replaces, written straight
+// into the level's rows of the concatenated [cams, sum hw, C] feature tensor (no torch.cat copy).
+__global__ __launch_bounds__(256) void feat_embed_f16_kernel(const __half *__restrict__ src,
+                                                             const __half *__restrict__ cam,
+                                                             const __half *__restrict__ lvl,
+                                                             __half *__restrict__ dst, int N, size_t rows, int C,
+                                                             size_t dst_stride) {
+  const size_t vpr = (size_t)C / 8;
+  const size_t per = rows * vpr;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per * (size_t)N) return;
+  const size_t n = i / per, k = i - n * per;
+  const int cv = (int)(k % vpr);
+  const uint4 x = reinterpret_cast<const uint4 *>(src)[i];
+  const uint4 c = *reinterpret_cast<const uint4 *>(cam + n * C + (size_t)cv * 8);
+  const uint4 l = *reinterpret_cast<const uint4 *>(lvl + (size_t)cv * 8);
+  auto two = [](unsigned a, unsigned b, unsigned d) {
+    const unsigned t = pack_h2(h2f_lo(a) + h2f_lo(b), h2f_hi(a) + h2f_hi(b));
+    return pack_h2(h2f_lo(t) + h2f_lo(d), h2f_hi(t) + h2f_hi(d));
+  };
+  uint4 o;
+  o.x = two(x.x, c.x, l.x); o.y = two(x.y, c.y, l.y); o.z = two(x.z, c.z, l.z); o.w = two(x.w, c.w, l.w);
+  *reinterpret_cast<uint4 *>(dst + n * dst_stride + k * 8) = o;
+}
+
 }  // namespace
 }  // namespace bevops
 
 using namespace bevops;
+
+extern "C" int bevops_upsample_add_nhwc(int dtype, void *a, const void *b, int n, int h, int w, int hb, int wb,
+                                        int channels, void *stream) {
+  if (!a || !b || n <= 0 || h <= 0 || w <= 0 || hb <= 0 || wb <= 0 || channels <= 0) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16 || channels % 8 != 0) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(a) || !aligned16(b)) return BEVOPS_BAD_PARAM;
+  const size_t nvec = (size_t)n * h * w * (channels / 8);
+  if ((nvec + 255) / 256 > 0x7fffffffull) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL(upsample_add_f16_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (__half *)a, (const __half *)b, n, h, w, hb, wb, channels,
+                     (float)hb / (float)h, (float)wb / (float)w);
+  return launch_status();
+}
+
+extern "C" int bevops_feat_embed_nhwc(int dtype, const void *src, const void *cam_embed, const void *level_embed,
+                                      void *dst, int n, size_t rows, int channels, size_t dst_batch_stride,
+                                      void *stream) {
+  if (!src || !cam_embed || !level_embed || !dst || n <= 0 || channels <= 0) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16 || channels % 8 != 0 || dst_batch_stride % 8 != 0) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(src) || !aligned16(cam_embed) || !aligned16(level_embed) || !aligned16(dst)) return BEVOPS_BAD_PARAM;
+  if (rows == 0) return BEVOPS_SUCCESS;
+  const size_t nvec = (size_t)n * rows * (channels / 8);
+  if ((nvec + 255) / 256 > 0x7fffffffull) return BEVOPS_NOT_SUPPORTED;
+  hipLaunchKernelGGL(feat_embed_f16_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const __half *)src, (const __half *)cam_embed,
+                     (const __half *)level_embed, (__half *)dst, n, rows, channels, dst_batch_stride);
+  return launch_status();
+}
 
 extern "C" int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                                  size_t rows, int channels, float eps, void *stream) {

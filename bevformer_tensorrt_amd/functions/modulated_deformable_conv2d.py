@@ -195,6 +195,38 @@ def bias_act_nhwc_(x, bias=None, residual=None, relu=False):
     return x
 
 
+def upsample_add_nhwc_(a, b):
+    """In place: a += nearest-up-sampled b (to a's spatial size), both channels-last fp16 [N, C, H, W] -- the
+    FPN top-down step in one pass (bevops_upsample_add_nhwc), bit-equal to `a + F.interpolate(b, size=...)`."""
+    assert a.is_cuda and a.dtype == torch.float16 and b.dtype == torch.float16 and a.dim() == 4 and b.dim() == 4
+    assert a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last)
+    assert a.shape[0] == b.shape[0] and a.shape[1] == b.shape[1]
+    handle = _lib.load_library()
+    with torch.cuda.device(a.device):
+        st = handle.bevops_upsample_add_nhwc(_lib.F16, a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[2], a.shape[3],
+                                             b.shape[2], b.shape[3], a.shape[1], _lib.current_stream_ptr(a.device))
+    _lib.check(st, "bevops_upsample_add_nhwc")
+    return a
+
+
+def feat_embed_nhwc(src, cam_embed, level_embed, dst):
+    """dst[n, r, :] = (src[n, r, :] + cam_embed[n, :]) + level_embed (fp16, two roundings as the two adds of
+    transformer.py:146-150).  src [N, rows, C] dense; dst = a [N, rows, C] slice (row range) of the concatenated
+    [N, sum rows, C] feature tensor: written in place of the torch.cat copy."""
+    assert src.is_cuda and src.dtype == torch.float16 and src.is_contiguous() and src.dim() == 3
+    n, rows, c = src.shape
+    assert dst.shape == src.shape and dst.dtype == src.dtype and dst.stride(2) == 1 and dst.stride(1) == c
+    cam = cam_embed.to(src.dtype).contiguous()
+    lvl = level_embed.to(src.dtype).contiguous()
+    assert cam.shape == (n, c) and lvl.shape == (c,)
+    handle = _lib.load_library()
+    with torch.cuda.device(src.device):
+        st = handle.bevops_feat_embed_nhwc(_lib.F16, src.data_ptr(), cam.data_ptr(), lvl.data_ptr(), dst.data_ptr(),
+                                           n, rows, c, dst.stride(0), _lib.current_stream_ptr(src.device))
+    _lib.check(st, "bevops_feat_embed_nhwc")
+    return dst
+
+
 _PACKED_C32 = _TensorCache()
 
 

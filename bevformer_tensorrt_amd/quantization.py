@@ -156,7 +156,15 @@ class Int8PluginOps:
     exposed, so a model built on this namespace takes the reference op sequence.
     """
 
-    def __init__(self, calibrator="entropy", fp_ops=None):
+    # fp entries a `channels_last=True` namespace passes through: the channels-last backbone (its DCNv2
+    # block, offset convolution and epilogues stay in the model's dtype there -- the INT8 DCNv2 operator
+    # exists for the plugin layout only), the fused dense / norm entries for layers that were not swapped
+    # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
+    # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
+    _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
+             "linear_bias_act", "image_normalize_pad")
+
+    def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
         from . import functions as _f
         self.fp = fp_ops if fp_ops is not None else _f
         self.cal = get_calibrator(calibrator)() if isinstance(calibrator, str) else calibrator
@@ -164,6 +172,12 @@ class Int8PluginOps:
         self._scales = {}
         self._n = {}
         self._wq = _TensorCache()      # float weight tensor -> (int8 weight, scale)
+        self._pass = self._PASS + (("spatial_cross_attention_sample",) if fused_sca else ()) if channels_last else ()
+
+    def __getattr__(self, name):       # only reached for names this class does not define
+        if name in self.__dict__.get("_pass", ()) and hasattr(self.fp, name):
+            return getattr(self.fp, name)
+        raise AttributeError(name)
 
     # ---- bookkeeping
     def begin_frame(self):

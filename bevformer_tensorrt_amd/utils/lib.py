@@ -57,6 +57,9 @@ SIGNATURES = {
     "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                    [c_void_p]),
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "bevops_upsample_add_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "bevops_feat_embed_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_size_t,
+                                       c_void_p]),
     "bevops_conv3x3_c32_set_variant": (c_int, [c_int]),
     "bevops_conv3x3_c32_packed_weight_size": (c_size_t, [c_int, c_int]),
     "bevops_conv3x3_c32_pack_weight": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -298,6 +298,20 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+
+/* FPN top-down step of the re-hosted neck on channels-last fp16 activations (not a reference plugin):
+ * a[n, y, x, :] += b[n, sy(y), sx(x), :], source indices as aten's nearest up-sampling -- the reference's
+ * `laterals[i-1] += F.interpolate(laterals[i], size=..., mode="nearest")`
+ * (third_party/bev_mmdet3d/models/necks/fpn.py:170-176) in one pass, bit-equal to it.  In place on `a`. */
+int bevops_upsample_add_nhwc(int dtype, void *a, const void *b, int n, int h, int w, int hb, int wb,
+                             int channels, void *stream);
+
+/* Encoder input assembly (det2trt/models/modules/transformer.py:138-152): dst[n, r, :] = (src[n, r, :] +
+ * cam_embed[n, :]) + level_embed[:], both sums rounded to fp16 like the two tensor adds they replace; `dst` is
+ * the level's first row inside the concatenated [cams, sum hw, C] feature tensor, `dst_batch_stride` its
+ * element stride between cameras (so no torch.cat copy is needed).  src: [n, rows, C] dense. */
+int bevops_feat_embed_nhwc(int dtype, const void *src, const void *cam_embed, const void *level_embed, void *dst,
+                           int n, size_t rows, int channels, size_t dst_batch_stride, void *stream);
 /* The DCNv2 pack's offset convolution (cnn/dcn.py:62-70: 3x3, stride 1, pad 1, Cout <= 32) on
  * channels-last fp16 activations with its bias in the epilogue:
  *   output_nhwc[B, H, W, 32] = conv3x3(input_nhwc[B, H, W, Cin], weight[Cout, Cin, 3, 3]) + bias32

@@ -1,0 +1,35 @@
+"""GPU parity of the small fused epilogue passes of the re-hosted neck / encoder input (not reference plugins):
+bit-equal to the framework op sequences they replace."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [((6, 256, 116, 200), (58, 100)), ((2, 64, 7, 9), (4, 5)), ((1, 8, 5, 3), (2, 1))])
+def test_upsample_add_matches_interpolate_plus_add(shape):
+    import bevformer_tensorrt_amd as bev
+    (n, c, h, w), (hb, wb) = shape
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(n, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(n, c, hb, wb, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    want = a + torch.nn.functional.interpolate(b, size=(h, w), mode="nearest")
+    got = bev.upsample_add_nhwc_(a.clone(memory_format=torch.channels_last), b)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+def test_feat_embed_matches_adds_and_cat():
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(1)
+    levels = [(6, 7), (3, 4), (2, 2)]
+    feats = [torch.randn(6, h * w, 256, generator=g).half().cuda() for h, w in levels]
+    cam = (torch.randn(6, 256, generator=g) * 0.1).half().cuda()
+    lvl = (torch.randn(3, 256, generator=g) * 0.1).half().cuda()
+    want = torch.cat([f + cam[:, None, :] + lvl[i][None, None, :] for i, f in enumerate(feats)], dim=1)
+    out = torch.full_like(want, float("nan"))
+    row = 0
+    for i, f in enumerate(feats):
+        bev.feat_embed_nhwc(f, cam, lvl[i], out[:, row:row + f.shape[1], :])
+        row += f.shape[1]
+    assert torch.equal(out, want)

@@ -29,5 +29,18 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     can[0], can[-1] = 2.0, 3.0
     runner.step(img, can, l2i, "scene")
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=rows,
-                                                          max_name_column_width=40, max_shapes_column_width=70))
+ka = prof.key_averages(group_by_input_shape=True)
+limit = rows
+lines = []
+for e in ka:
+    dev_us = getattr(e, "self_device_time_total", None)
+    if dev_us is None:
+        dev_us = e.self_cuda_time_total
+    if dev_us <= 0 or not e.key.startswith(("aten::", "bevops", "miopen")):
+        continue
+    lines.append((dev_us, e.count, e.key, str(e.input_shapes)[:150]))
+lines.sort(reverse=True)
+tot = sum(r[0] for r in lines)
+print(f"device time in framework / library operators: {tot / 1e3:.2f} ms over {sum(r[1] for r in lines)} calls")
+for dev_us, n, key, shapes in lines[:limit]:
+    print(f"{dev_us / 1e3:8.3f} ms  x{n:<4d} {key:<34s} {shapes}")
