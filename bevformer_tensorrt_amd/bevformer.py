@@ -76,6 +76,7 @@ def _from_rows(y, n, h, w):
 
 
 _FUSED_LINEAR = {"enabled": os.environ.get("BEVOPS_FUSED_LINEAR", "1") != "0"}   # A/B switch
+_R3 = {"enabled": os.environ.get("BEVOPS_R3_FUSIONS", "1") != "0"}   # A/B switch of the round-3 launch-count work
 
 
 def _fused_linear(ops, x, weight, bias, residual, relu):
@@ -287,7 +288,7 @@ class FPN(nn.Module):
         up_add = getattr(ops, "upsample_add_nhwc_", None)
         for i in range(len(lat) - 1, 0, -1):
             a, b = lat[i - 1], lat[i]
-            if up_add is not None and _FUSED_LINEAR["enabled"] and a.dtype == torch.float16 and a.is_cuda \
+            if up_add is not None and _FUSED_LINEAR["enabled"] and _R3["enabled"] and a.dtype == torch.float16 and a.is_cuda \
                     and a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last):
                 up_add(a, b)     # one in-place pass: a += nearest-up-sampled b
             else:
@@ -339,6 +340,7 @@ class SpatialCrossAttention(nn.Module):
     def __init__(self, ops, levels, points=8):
         super().__init__()
         self.ops = ops
+        self._proj_ok = True
         self.sampling_offsets = nn.Linear(EMBED, HEADS * levels * points * 2)
         self.attention_weights = nn.Linear(EMBED, HEADS * levels * points)
         self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
@@ -346,6 +348,21 @@ class SpatialCrossAttention(nn.Module):
     def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None):
         inp_residual = query
         ncam, nk, nq = value.shape[0], value.shape[1], query.shape[1]   # ncam may be 0 (rank without cameras)
+        projected = getattr(self.ops, "spatial_cross_attention_projected", None)
+        if projected is not None and gather is None and cams is None and _R3["enabled"] and self._proj_ok \
+                and value.dtype == torch.float16 and value.is_cuda and not hasattr(self.value_proj, "fake_quant_reference"):
+            # value_proj's GEMM writes the sampler's planes itself; the fused sampling reads them
+            off = self.sampling_offsets(query).view(1, nq, HEADS, -1)
+            w = self.attention_weights(query).view(1, nq, HEADS, -1)
+            ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
+            try:
+                slots = projected(value.reshape(ncam, nk, EMBED), self.value_proj.weight, self.value_proj.bias,
+                                  spatial_shapes, ref, off, w, bev_mask, HEADS)
+                return _dense(self.ops, self.output_proj, slots, inp_residual, False)
+            except _lib.BevopsError as exc:
+                if exc.status != _lib.NOT_SUPPORTED:
+                    raise
+                self._proj_ok = False   # another pyramid (tiny / small: one level): the separate projection below
         value = self.value_proj(value.reshape(ncam, nk, EMBED)).view(ncam, nk, HEADS, EMBED // HEADS)
         # the per-camera copies of `query` are identical: project once, expand (stride 0)
         off = self.sampling_offsets(query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
@@ -530,7 +547,7 @@ class BEVFormer(nn.Module):
         feats, level_hw = [], []
         cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]
         embed_fn = getattr(self.ops, "feat_embed_nhwc", None)
-        fused_embed = embed_fn is not None and _FUSED_LINEAR["enabled"] and dtype == torch.float16 and image.is_cuda \
+        fused_embed = embed_fn is not None and _FUSED_LINEAR["enabled"] and _R3["enabled"] and dtype == torch.float16 and image.is_cuda \
             and all(f.is_contiguous(memory_format=torch.channels_last) for f in mlvl) and mlvl[0].shape[0] > 0
         if fused_embed:   # one pass per level straight into the concatenated tensor (no adds, no cat)
             level_hw = [f.shape[-2:] for f in mlvl]
@@ -592,6 +609,20 @@ class BEVFormer(nn.Module):
         # the decoder loop already evaluated (same module, same input); the six levels' post-processing and
         # classification branches run as ONE batch over [6, 900, .] (element-wise ops: identical values;
         # branches: batched GEMMs with the stacked weights) instead of 6 x ~25 small launches
+        if not _R3["enabled"]:   # A/B: the per-level loop of the reference head
+            classes, coords = [], []
+            for lvl in range(6):
+                reference = inverse_sigmoid(init_reference if lvl == 0 else inter_refs[lvl - 1])
+                hs = inter[lvl].view(1, NUM_QUERY, EMBED)
+                crd = self.reg_branches[lvl](hs).clone()
+                crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
+                crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
+                crd[..., 0:1] = crd[..., 0:1] * (PC_RANGE[3] - PC_RANGE[0]) + PC_RANGE[0]
+                crd[..., 1:2] = crd[..., 1:2] * (PC_RANGE[4] - PC_RANGE[1]) + PC_RANGE[1]
+                crd[..., 4:5] = crd[..., 4:5] * (PC_RANGE[5] - PC_RANGE[2]) + PC_RANGE[2]
+                classes.append(self.cls_branches[lvl](hs))
+                coords.append(crd)
+            return bev_embed, torch.stack(classes), torch.stack(coords)
         crd = torch.stack(regs)                                                        # [6, 1, 900, 10]
         reference = inverse_sigmoid(torch.stack([init_reference] + inter_refs[:-1]))   # [6, 1, 900, 3]
         crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
@@ -671,6 +702,9 @@ class FrameRunner:
 
     def _forward(self):
         i = self._in
+        if not _R3["enabled"]:   # A/B: the device-side flag (one graph, per-layer select)
+            return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,
+                              shift=i["shift"])
         return self.model(i["image"], self.prev_bev, self._use, i["can_bus"], i["lidar2img"], self.cams, self.gather,
                           shift=i["shift"])
 

@@ -56,6 +56,11 @@ const Entry kTable[] = {
     {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
     {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
+    {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
+    {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},
+    {"bevops_value_proj_packed", (void *)&bevops_value_proj_packed},
+    {"bevops_sca_prepacked_workspace_size", (void *)&bevops_sca_prepacked_workspace_size},
+    {"bevops_sca_forward_prepacked", (void *)&bevops_sca_forward_prepacked},
     {"bevops_feat_embed_nhwc", (void *)&bevops_feat_embed_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},

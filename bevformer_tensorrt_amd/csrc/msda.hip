@@ -743,6 +743,39 @@ extern "C" int bevops_sca_forward(int dtype, const void *value, const int32_t *s
                                   static_cast<hipStream_t>(stream));
 }
 
+extern "C" size_t bevops_sca_prepacked_workspace_size(int num_cams, int heads, int channels, int num_query) {
+  if (num_cams <= 0 || heads <= 0 || channels <= 0 || num_query <= 0) return 0;
+  return (size_t)num_cams * num_query * heads * channels * sizeof(__half);
+}
+
+extern "C" int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_bytes,
+                                            const int32_t *spatial_shapes_host, const void *reference_points_cam,
+                                            const void *sampling_offsets, const void *attention_weights,
+                                            const void *bev_mask, void *output, int num_cams, int nk, int heads,
+                                            int channels, int num_levels, int num_query, int num_point,
+                                            int points_per_group, void *workspace, size_t workspace_bytes,
+                                            void *stream) {
+  if (!packed || !spatial_shapes_host || !reference_points_cam || !sampling_offsets || !attention_weights || !bev_mask ||
+      !output || !workspace)
+    return BEVOPS_BAD_PARAM;
+  if (num_cams <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0 ||
+      points_per_group <= 0)
+    return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (workspace_bytes < bevops_sca_prepacked_workspace_size(num_cams, heads, channels, num_query) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u))
+    return BEVOPS_BAD_PARAM;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  __half *sampled = static_cast<__half *>(workspace);
+  const int rc = msda_hm5_sca_sample_f16(packed, packed_bytes, spatial_shapes_host, (const __half *)reference_points_cam,
+                                         (const __half *)sampling_offsets, (const __half *)attention_weights,
+                                         (const __half *)bev_mask, sampled, num_cams, nk, heads, channels, num_levels,
+                                         num_query, num_point, points_per_group, st);
+  if (rc != BEVOPS_SUCCESS) return rc;
+  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, st);
+  return launch_status();
+}
+
 extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_shapes,
                                    const int32_t *spatial_shapes_host,
                                    const void *reference_points, int ref_dtype,

@@ -245,6 +245,13 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
                          hipStream_t st);
+int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host, const __half *ref,
+                            const __half *off, const __half *logit, const __half *qmask, __half *sampled, int bs,
+                            int nk, int heads, int C, int L, int nq, int P, int ppg, hipStream_t st);
+void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
+                            hipStream_t st);
+bool msda_hm5_layout(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, void *tab,
+                     size_t *g_room, size_t *s_bytes);
 void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const void *tab, int bs, int nk, int heads,
                             hipStream_t st);
 size_t msda_hm3_sca_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,

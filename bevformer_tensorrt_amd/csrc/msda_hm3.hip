@@ -461,6 +461,13 @@ void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const voi
                      static_cast<const __half *>(value), gset, sset, t, bs, nk, heads);
 }
 
+void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
+                            hipStream_t st) {
+  const size_t threads = (size_t)nq * (width / 8);
+  hipLaunchKernelGGL(sca_camera_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sampled,
+                     qmask, out, bs, nq, width);
+}
+
 size_t msda_hm3_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
                                 int P) {
   Hm3Plan pl;

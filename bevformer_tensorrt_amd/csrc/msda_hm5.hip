@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 }
 
 // ---- sampling kernel.  ABL: ablation bits for the probes (1: no big-level taps, 2: no staged
-// taps, 4: operands loaded once, 8: no store).  LISTED: items come from the visibility bytes.
+// taps, 4: operands loaded once, 8: no store).  LISTED: 0 every query of the chunk, 1 the items whose
+// visibility byte is set (pre-pass), 2 the (batch, query) pairs with a non-zero `qmask` weight (fused SCA:
+// `vis` then points at the [bs, nq] fp16 bev_mask and the offsets / logits are shared by all batches).
 // MBOX: the 8 records of a phase reach the octet's lanes through an LDS mailbox (one ds_write_b128 per
 // lane, one broadcast ds_read_b128 per record: 36 LDS cycles per phase and wave, ~70 us of LDS-pipe
 // time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
 // every lane the record of slot (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot
 // and dword does the rest (26 more VALU instructions per phase, no LDS traffic).
-template <int NBL, int THREADS, int ABL, bool LISTED, bool MBOX>
+template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX>
 __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
@@ -198,7 +200,11 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     unsigned base_count = 0;
     for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
       const unsigned i = t0 + threadIdx.x;
-      const bool v = i < n_items && vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
+      bool v = i < n_items;
+      if (v) {
+        if constexpr (LISTED == 2) v = (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q0 + i] & 0x7fffu) != 0;   // not +-0
+        else v = vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
+      }
       const unsigned long long bal = __ballot(v);
       const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
       if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
 
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gset), 0, g_bytes, 0x00020000);
-  const unsigned n_in = (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 32u;
+  const unsigned n_in = (unsigned)(d.shared ? 1 : d.bs) * (unsigned)d.nq * (unsigned)d.heads * 32u;
   const __amdgpu_buffer_rsrc_t rs_lg =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(logit), 0, n_in * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_of =
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   const unsigned qlist_a = sbase + (unsigned)stage_bytes + OCT * kBox;
   const H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
 
-  const unsigned lg_base = ((b * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
+  const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
   const unsigned lg_q = (unsigned)d.heads * 64u;
   const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
   auto query_of = [&](unsigned i) -> unsigned {
@@ -256,9 +262,15 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
     const unsigned q = query_of(i);
     const unsigned o_lg = lg_base + q * lg_q;
-    // read-once full lines: non-temporal
-    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 2);
-    s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 2);
+    // read-once full lines: non-temporal (shared offsets / logits are re-read by every camera: default policy)
+    u32x2 g;
+    if constexpr (LISTED == 2) {
+      g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 0);
+      s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 0);
+    } else {
+      g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 2);
+      s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 2);
+    }
     s.lg[0] = g.x; s.lg[1] = g.y;
     s.rf = __builtin_amdgcn_raw_buffer_load_b32(rs_rf, (int)(rf_base + q * 16u), 0, 0);
   };
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
 inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
 constexpr int kH5Chunk = 1280;
 
-template <int NBL, int THREADS, int ABL, bool LISTED, bool MBOX = true>
+template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX = true>
 int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
           const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
   const int nchunk = (d.nq + chunk - 1) / chunk;
@@ -497,11 +509,45 @@ int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *r
 
 static bool h5_shape_ok(int C, int L, int P, int ppg) { return C == 32 && L == 4 && P == 8 && ppg == 4; }
 
+// The padded-plane layout hm5 reads, for producers that write it directly (tsgemm.hip: the value projection's
+// epilogue).  `tab` receives the Hm3Tab (untyped: the struct lives in each translation unit's unnamed
+// namespace), `g_room` the bytes reserved for the big set (the staged set follows).
+bool msda_hm5_layout(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, void *tab,
+                     size_t *g_room, size_t *s_bytes) {
+  Hm3Plan pl;
+  if (!h5_shape_ok(C, L, P, 4) || !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl) ||
+      pl.t.ls != 2)
+    return false;
+  *static_cast<Hm3Tab *>(tab) = pl.t;
+  *g_room = (pl.g_bytes + 127) & ~size_t(127);
+  *s_bytes = pl.s_bytes;
+  return true;
+}
+
 size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P) {
   Hm3Plan pl;
   if (!h5_shape_ok(C, L, P, 4) || !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl)) return 0;
   const size_t planes = ((pl.g_bytes + 127) & ~size_t(127)) + pl.s_bytes;
   return ((planes + 255) & ~size_t(255)) + (((size_t)bs * nq * heads + 255) & ~size_t(255));
+}
+
+// Fused SCA sampling on the planes `packed` already holds (written by the value projection's GEMM
+// epilogue, bevops_value_proj_packed, or by msda_hm3_repack_launch): camera-shared offsets / logits, the
+// (camera, query) pairs with bev_mask weight 0 skipped, `sampled` [cams, nq, heads, 32] written for the others.
+int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host, const __half *ref,
+                            const __half *off, const __half *logit, const __half *qmask, __half *sampled, int bs,
+                            int nk, int heads, int C, int L, int nq, int P, int ppg, hipStream_t st) {
+  Hm3Plan pl;
+  if (!h5_shape_ok(C, L, P, ppg) || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) ||
+      !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl) || pl.t.ls != 2)
+    return BEVOPS_NOT_SUPPORTED;
+  if ((double)nq * heads * 32 * 4.0 >= 4294967040.0 || (double)bs * nq * heads * 64.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;
+  const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
+  if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
+  const char *gset = static_cast<const char *>(packed);
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
+  return h5_go<2, 1024, 0, 2, false>(pl, gset, gset + g_room, ref, off, logit, sampled, d,
+                                     reinterpret_cast<const unsigned char *>(qmask), kH5Chunk, st);
 }
 
 // flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
@@ -534,10 +580,10 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   }
   const int chunk = (flags & 128) ? 2 * kH5Chunk : kH5Chunk;
 #define BEVOPS_H5(KERN_, THREADS_, ABL_, LISTED_) \
-  return KERN_<2, THREADS_, ABL_, LISTED_>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
+  return KERN_<2, THREADS_, ABL_, LISTED_ ? 1 : 0>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
   if (!(flags & 256)) {   // default: records through DPP
 #define BEVOPS_H5X(THREADS_, ABL_, LISTED_) \
-  return h5_go<2, THREADS_, ABL_, LISTED_, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
+  return h5_go<2, THREADS_, ABL_, LISTED_ ? 1 : 0, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
     if (flags & 2) {
       if (abl) return BEVOPS_NOT_SUPPORTED;
       if (listed) BEVOPS_H5X(768, 0, true);

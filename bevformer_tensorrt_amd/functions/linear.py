@@ -137,3 +137,34 @@ def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False
             M, N, K, int(bool(relu)), _lib.current_stream_ptr(a_q.device))
     _lib.check(st, "bevops_linear_int8")
     return out.view(*a_q.shape[:-1], N)
+
+
+def tsgemm(x, weight, bias=None, residual=None, relu=False, out=None):
+    """act(x @ weight.T + bias + residual) on the hand-written tall-skinny MFMA GEMM (bevops_tsgemm_f16):
+    x [..., K] fp16 contiguous rows, weight [N, K], residual / out [..., N].  Raises BevopsError with status
+    NOT_SUPPORTED outside its domain (K % 64, N % 256)."""
+    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
+    K, N = x.shape[-1], weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {K}]")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    weight = weight.contiguous()
+    M = x2.shape[0]
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(M, N)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_tsgemm_f16(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K,
+                                      int(bool(relu)), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_tsgemm_f16")
+    return out.view(*x.shape[:-1], N)

@@ -61,3 +61,53 @@ def spatial_cross_attention_sample(value, value_spatial_shapes, reference_points
                                        heads, ch, L, nq, P, ppg, ws.data_ptr(), ws.numel(), stream)
     _lib.check(st, "bevops_sca_forward")
     return out
+
+
+def spatial_cross_attention_projected(features, weight, bias, value_spatial_shapes, reference_points_cam,
+                                      sampling_offsets, attention_weights, bev_mask, num_heads=8):
+    """value_proj + fused SCA sampling in two launches without the [cams, keys, heads, 32] tensor in between
+    (spatial_cross_attention.py:754 followed by :254-270): the value projection runs on the tall-skinny MFMA
+    GEMM whose epilogue stores straight into the sampler's padded head-major planes
+    (bevops_value_proj_packed), then the fused sampling reads them (bevops_sca_forward_prepacked).
+
+        features: (num_cams, num_keys, embed) fp16 -- the encoder input (FPN levels + camera / level embeddings)
+        weight, bias: value_proj parameters [embed, embed], [embed]
+        the other arguments as spatial_cross_attention_sample
+    Returns (1, num_query, embed).  Raises BevopsError (NOT_SUPPORTED) outside the 4-level x 8-point domain."""
+    assert features.is_cuda and features.dtype == torch.float16
+    handle = _lib.load_library()
+    ncam, nk, embed = features.shape
+    heads, ch = num_heads, embed // num_heads
+    nq = sampling_offsets.shape[1]
+    L = value_spatial_shapes.shape[0]
+    ppg = reference_points_cam.shape[-1] // 2
+    P = attention_weights.numel() // (nq * heads * L)
+    if sampling_offsets.shape[0] != 1 or attention_weights.shape[0] != 1:
+        raise ValueError("sampling_offsets / attention_weights must be the camera-shared [1, nq, heads, .] tensors")
+    mask = bev_mask.reshape(ncam, nq)
+    feats, ref, off, w, mask = (t.to(torch.float16).contiguous()
+                                for t in (features, reference_points_cam, sampling_offsets, attention_weights, mask))
+    weight = weight.to(torch.float16).contiguous()
+    bias = None if bias is None else bias.to(torch.float16).contiguous()
+    shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, features.device)
+    if shapes_host is None:
+        shapes_host = _host_shapes(shapes_dev)
+    out = torch.empty((1, nq, embed), dtype=features.dtype, device=features.device)
+    with torch.cuda.device(features.device):
+        stream = _lib.current_stream_ptr(features.device)
+        pk_bytes = handle.bevops_value_proj_packed_size(shapes_host.data_ptr(), ncam, nk, heads, ch, L, nq, P)
+        if pk_bytes == 0:
+            raise _lib.BevopsError("bevops_value_proj_packed_size: shape outside the packed-projection domain",
+                                   _lib.NOT_SUPPORTED)
+        ws_bytes = handle.bevops_sca_prepacked_workspace_size(ncam, heads, ch, nq)
+        pk_room = (pk_bytes + 255) & ~255
+        ws = _workspace(pk_room + ws_bytes, features.device, stream)
+        st = handle.bevops_value_proj_packed(feats.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             shapes_host.data_ptr(), ws.data_ptr(), pk_bytes, ncam, nk, heads, ch, L, nq,
+                                             P, stream)
+        _lib.check(st, "bevops_value_proj_packed")
+        st = handle.bevops_sca_forward_prepacked(_lib.F16, ws.data_ptr(), pk_bytes, shapes_host.data_ptr(), ref.data_ptr(),
+                                                 off.data_ptr(), w.data_ptr(), mask.data_ptr(), out.data_ptr(), ncam, nk,
+                                                 heads, ch, L, nq, P, ppg, ws.data_ptr() + pk_room, ws_bytes, stream)
+    _lib.check(st, "bevops_sca_forward_prepacked")
+    return out

@@ -57,6 +57,12 @@ SIGNATURES = {
     "bevops_mdconv_forward_nhwc": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                    [c_void_p]),
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "bevops_value_proj_packed_size": (c_size_t, [c_void_p] + [c_int] * 7),
+    "bevops_value_proj_packed": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 7 + [c_void_p]),
+    "bevops_sca_prepacked_workspace_size": (c_size_t, [c_int] * 4),
+    "bevops_sca_forward_prepacked": (c_int, [c_int, c_void_p, c_size_t] + [c_void_p] * 6 + [c_int] * 8 +
+                                     [c_void_p, c_size_t, c_void_p]),
+    "bevops_tsgemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_upsample_add_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "bevops_feat_embed_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_size_t,
                                        c_void_p]),

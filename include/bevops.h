@@ -395,6 +395,36 @@ size_t bevops_linear_workspace_size(void);
 int bevops_linear_bias_act(int dtype, const void *a, const void *weight, const void *bias,
                            const void *residual, void *out, long long M, int N, int K, int relu,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* The encoder's value projection written straight into the sampler's planes, and the fused SCA sampling on
+ * them (round 3; not reference plugins).  bevops_value_proj_packed: value = x @ weight.T + bias
+ * (spatial_cross_attention.py:754, x [num_cams * nk, embed], weight [embed, embed]) computed by the tall-skinny
+ * MFMA GEMM whose epilogue stores every output row into the padded head-major planes (csrc/msda_pad.h) instead
+ * of a [cams, nk, heads, 32] tensor -- the separate re-layout pass of the sampler disappears.  `packed` (>=
+ * bevops_value_proj_packed_size bytes, 128-byte aligned) then feeds bevops_sca_forward_prepacked: the fused
+ * SCA sampling of bevops_sca_forward (camera-shared offsets / logits, pairs with bev_mask == 0 skipped, masked
+ * camera sum) on those planes; workspace >= bevops_sca_prepacked_workspace_size bytes.  Domain: 4 levels x 8
+ * points, 32 channels per head, embed % 256 == 0; BEVOPS_NOT_SUPPORTED otherwise. */
+size_t bevops_value_proj_packed_size(const int32_t *spatial_shapes_host, int num_cams, int nk, int heads, int channels,
+                                     int num_levels, int num_query, int num_point);
+int bevops_value_proj_packed(const void *x, const void *weight, const void *bias, const int32_t *spatial_shapes_host,
+                             void *packed, size_t packed_bytes, int num_cams, int nk, int heads, int channels,
+                             int num_levels, int num_query, int num_point, void *stream);
+size_t bevops_sca_prepacked_workspace_size(int num_cams, int heads, int channels, int num_query);
+int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_bytes, const int32_t *spatial_shapes_host,
+                                 const void *reference_points_cam, const void *sampling_offsets,
+                                 const void *attention_weights, const void *bev_mask, void *output, int num_cams,
+                                 int nk, int heads, int channels, int num_levels, int num_query, int num_point,
+                                 int points_per_group, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Hand-written tall-skinny fp16 GEMM on the matrix cores (csrc/tsgemm.hip) for the dense layers that wrap the
+ * samplers (the reference runs them as cuBLAS / TensorRT layers: spatial_cross_attention.py:694-768,
+ * backbones/resnet.py:326-686): out[m, n] = act(sum_k x[m, k] w[n, k] + bias[n] (+ residual[m, n])), x [M, K],
+ * w [N, K], residual / out [M, N] row-major fp16, fp32 accumulation, one rounding.  Persistent blocks stream
+ * their rows once; both operands reach LDS by DMA.  BEVOPS_NOT_SUPPORTED outside K % 64 == 0, N % 256 == 0
+ * (the caller keeps its library GEMM). */
+int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
+                      long long m, int n, int k, int relu, void *stream);
+
 /* OPTIONAL, BLOCKING: pick the hipBLASLt algorithm for one bevops_linear_bias_act problem (same
  * arguments) by timing every supporting algorithm on `stream` with the caller's buffers, and cache
  * it for the process.  `out` is scratch and must not alias `residual`.  Synchronises the host;

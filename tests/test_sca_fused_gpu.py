@@ -104,3 +104,33 @@ def test_new_entry_points_reject_bad_arguments():
     assert h.bevops_bias_act_nhwc(L.F16, x.data_ptr() + 2, None, None, 4, 24, 1, st) == BAD  # misaligned
     assert h.bevops_bias_act_nhwc(L.F32, x.data_ptr(), None, None, 4, 24, 1, st) == UNSUP
     torch.cuda.synchronize()
+
+
+def test_projected_path_matches_projection_plus_fused_sampling():
+    """bevops_value_proj_packed + bevops_sca_forward_prepacked (the value projection's GEMM epilogue writes the
+    sampler's planes) against F.linear + spatial_cross_attention_sample on the same inputs: the planes hold the
+    fp16 rounding of the same fp32 sums up to the GEMM's summation order, the sampling arithmetic is shared."""
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd import geometry as G
+    g = torch.Generator().manual_seed(0)
+    levels = [[116, 200], [58, 100], [29, 50], [15, 25]]
+    nk = sum(h * w for h, w in levels)
+    nq, heads, embed = 40000, 8, 256
+    feats = (torch.randn(6, nk, embed, generator=g) * 0.5).half().cuda()
+    wgt = (torch.randn(embed, embed, generator=g) / 16).half().cuda()
+    bias = (torch.randn(embed, generator=g) * 0.1).half().cuda()
+    ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
+    cam, mask = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img((928, 1600)), (928, 1600))
+    ref = cam.reshape(6, nq, 1, 8).half().cuda()
+    bm = mask.reshape(6, nq, -1).any(-1).half().cuda()
+    off = torch.randn(1, nq, heads, 64, generator=g).half().cuda()
+    w = torch.randn(1, nq, heads, 32, generator=g).half().cuda()
+    sh = torch.tensor(levels, dtype=torch.int32)
+    value = torch.nn.functional.linear(feats, wgt, bias).view(6, nk, heads, 32)
+    want = bev.spatial_cross_attention_sample(value, sh, ref, off, w, bm).float()
+    got = bev.spatial_cross_attention_projected(feats, wgt, bias, sh, ref, off, w, bm, heads).float()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    assert err.max().item() <= 2e-2 and err.mean().item() <= 5e-4, (err.max().item(), err.mean().item())
+    # determinism
+    assert torch.equal(bev.spatial_cross_attention_projected(feats, wgt, bias, sh, ref, off, w, bm, heads).float(), got)
