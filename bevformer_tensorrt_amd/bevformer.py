@@ -87,6 +87,15 @@ def _fused_linear(ops, x, weight, bias, residual, relu):
     fn = getattr(ops, "linear_bias_act", None)
     if fn is None or not _FUSED_LINEAR["enabled"] or x.dtype != torch.float16 or not x.is_cuda:
         return None
+    ts = getattr(ops, "tsgemm", None)
+    if ts is not None and _R3["enabled"] and weight.shape[0] == 256 and weight.shape[1] % 64 == 0:
+        # 256-column layers (output_proj, value_proj, FFN fc2): the hand-written tall-skinny MFMA GEMM is
+        # 10-30 % faster than the tuned library algorithm there (profiles/r03/tsgemm_time.jsonl)
+        try:
+            return ts(x, weight, bias, residual, relu)
+        except _lib.BevopsError as exc:
+            if exc.status != _lib.NOT_SUPPORTED:
+                raise
     try:
         return fn(x, weight, bias, residual, relu)
     except _lib.BevopsError as exc:   # only NOT_SUPPORTED (no algorithm for this shape) falls back
@@ -324,7 +333,7 @@ class TemporalSelfAttention(nn.Module):
         query = query + bev_pos
         nq = query.shape[1]
         query = torch.cat([value[:1], query], -1)
-        value = self.value_proj(value).view(2, nq, HEADS, EMBED // HEADS)
+        value = _dense(self.ops, self.value_proj, value).view(2, nq, HEADS, EMBED // HEADS)
         off = self.sampling_offsets(query).view(1, nq, HEADS, 2, 1, self.points, 2)
         w = self.attention_weights(query).view(1, nq, HEADS, 2, 1, self.points)
         w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
