@@ -33,7 +33,11 @@ for name, out in (("bench.json", "bench_n1.json"), ("sweep.jsonl", "msda_sweep.j
                   ("model_bench.jsonl", "model_bench.jsonl"), ("dcn_time.jsonl", "dcn_time.jsonl"),
                   ("pytest.log", "pytest_gpu_tail.log"), ("smoke.log", "smoke.log"),
                   ("ops_timing.jsonl", "ops_timing.jsonl"), ("bevdet_slice.jsonl", "bevdet_slice.jsonl"),
-                  ("hm4_probe.jsonl", "hm4_probe.jsonl"), ("rocminfo.txt", "rocminfo.txt")):
+                  ("hm4_probe.jsonl", "hm4_probe.jsonl"), ("rocminfo.txt", "rocminfo.txt"),
+                  ("hm5_probe.jsonl", "hm5_probe.jsonl"), ("tsgemm_time.jsonl", "tsgemm_time.jsonl"),
+                  ("sca_projected_time.jsonl", "sca_projected_time.jsonl"),
+                  ("model_bench_r3_ab.jsonl", "model_bench_r3_ab.jsonl"),
+                  ("model_frame_kernel_trace.txt", "model_frame_kernel_trace.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         lines = [l for l in open(p) if "amdgpu.ids" not in l]
