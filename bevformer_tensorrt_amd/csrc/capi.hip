@@ -59,6 +59,7 @@ const Entry kTable[] = {
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},
     {"bevops_value_proj_packed", (void *)&bevops_value_proj_packed},
+    {"bevops_value_pack_planes", (void *)&bevops_value_pack_planes},
     {"bevops_sca_prepacked_workspace_size", (void *)&bevops_sca_prepacked_workspace_size},
     {"bevops_sca_forward_prepacked", (void *)&bevops_sca_forward_prepacked},
     {"bevops_feat_embed_nhwc", (void *)&bevops_feat_embed_nhwc},

@@ -402,3 +402,21 @@ extern "C" int bevops_value_proj_packed(const void *x, const void *weight, const
                      (const __half *)bias, (const __half *)nullptr, (__half *)nullptr, (int)m, n, k, 0, units, pk);
   return launch_status();
 }
+
+// The same planes from an already projected value tensor [num_cams, nk, heads, 32] (the re-layout pass of the
+// drop-in call as an entry of its own): what bevops_value_proj_packed must reproduce byte for byte when
+// `value` is its own GEMM's output.
+extern "C" int bevops_value_pack_planes(const void *value, const int32_t *spatial_shapes_host, void *packed,
+                                        size_t packed_bytes, int num_cams, int nk, int heads, int channels,
+                                        int num_levels, int num_query, int num_point, void *stream) {
+  if (!value || !spatial_shapes_host || !packed) return BEVOPS_BAD_PARAM;
+  TsPacked pk{};
+  size_t g_room = 0, s_bytes = 0;
+  if (!msda_hm5_layout(spatial_shapes_host, num_cams, heads, channels, num_levels, num_query, num_point, &pk.t, &g_room,
+                       &s_bytes))
+    return BEVOPS_NOT_SUPPORTED;
+  if (packed_bytes < g_room + s_bytes || (reinterpret_cast<uintptr_t>(packed) & 127u)) return BEVOPS_BAD_PARAM;
+  msda_hm3_repack_launch(value, static_cast<char *>(packed), static_cast<char *>(packed) + g_room, &pk.t, num_cams, nk,
+                         heads, static_cast<hipStream_t>(stream));
+  return launch_status();
+}

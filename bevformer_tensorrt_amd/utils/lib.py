@@ -59,6 +59,7 @@ SIGNATURES = {
     "bevops_bias_act_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "bevops_value_proj_packed_size": (c_size_t, [c_void_p] + [c_int] * 7),
     "bevops_value_proj_packed": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 7 + [c_void_p]),
+    "bevops_value_pack_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
     "bevops_sca_prepacked_workspace_size": (c_size_t, [c_int] * 4),
     "bevops_sca_forward_prepacked": (c_int, [c_int, c_void_p, c_size_t] + [c_void_p] * 6 + [c_int] * 8 +
                                      [c_void_p, c_size_t, c_void_p]),

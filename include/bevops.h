@@ -409,6 +409,9 @@ size_t bevops_value_proj_packed_size(const int32_t *spatial_shapes_host, int num
 int bevops_value_proj_packed(const void *x, const void *weight, const void *bias, const int32_t *spatial_shapes_host,
                              void *packed, size_t packed_bytes, int num_cams, int nk, int heads, int channels,
                              int num_levels, int num_query, int num_point, void *stream);
+int bevops_value_pack_planes(const void *value, const int32_t *spatial_shapes_host, void *packed, size_t packed_bytes,
+                             int num_cams, int nk, int heads, int channels, int num_levels, int num_query,
+                             int num_point, void *stream);   /* the re-layout alone, from a projected value tensor */
 size_t bevops_sca_prepacked_workspace_size(int num_cams, int heads, int channels, int num_query);
 int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_bytes, const int32_t *spatial_shapes_host,
                                  const void *reference_points_cam, const void *sampling_offsets,

@@ -134,3 +134,36 @@ def test_projected_path_matches_projection_plus_fused_sampling():
     assert err.max().item() <= 2e-2 and err.mean().item() <= 5e-4, (err.max().item(), err.mean().item())
     # determinism
     assert torch.equal(bev.spatial_cross_attention_projected(feats, wgt, bias, sh, ref, off, w, bm, heads).float(), got)
+
+
+def test_packed_projection_planes_are_bit_identical_to_repacking_its_own_gemm():
+    """The planes the value projection's GEMM epilogue writes (bevops_value_proj_packed) against the re-layout
+    pass (bevops_value_pack_planes) applied to the SAME GEMM's row-major output (bevops_tsgemm_f16: identical
+    accumulation order and rounding): every byte of the big and the staged set equal -- pads, pair partners
+    across tile boundaries, level boundaries and cameras included."""
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.utils import lib as L
+    handle = L.load_library()
+    g = torch.Generator().manual_seed(3)
+    levels = [[116, 200], [58, 100], [29, 50], [15, 25]]
+    nk = sum(h * w for h, w in levels)
+    ncam, heads, embed, nq, P = 6, 8, 256, 40000, 8
+    feats = (torch.randn(ncam, nk, embed, generator=g) * 0.5).half().cuda()
+    wgt = (torch.randn(embed, embed, generator=g) / 16).half().cuda()
+    bias = (torch.randn(embed, generator=g) * 0.1).half().cuda()
+    sh = torch.tensor(levels, dtype=torch.int32)
+    st = L.current_stream_ptr(feats.device)
+    nbytes = handle.bevops_value_proj_packed_size(sh.data_ptr(), ncam, nk, heads, 32, 4, nq, P)
+    assert nbytes > 0
+    a = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")     # poisoned: every byte must be written
+    b = torch.full((nbytes,), 0xCD, dtype=torch.uint8, device="cuda")
+    L.check(handle.bevops_value_proj_packed(feats.data_ptr(), wgt.data_ptr(), bias.data_ptr(), sh.data_ptr(), a.data_ptr(),
+                                            nbytes, ncam, nk, heads, 32, 4, nq, P, st), "bevops_value_proj_packed")
+    value = bev.tsgemm(feats.view(-1, embed), wgt, bias).view(ncam, nk, heads, 32).contiguous()
+    L.check(handle.bevops_value_pack_planes(value.data_ptr(), sh.data_ptr(), b.data_ptr(), nbytes, ncam, nk, heads, 32, 4,
+                                            nq, P, st), "bevops_value_pack_planes")
+    torch.cuda.synchronize()
+    # the planes = everything before the visibility bytes (the last bs * nq * heads bytes, rounded up to 256)
+    planes = nbytes - ((ncam * nq * heads + 255) // 256) * 256
+    diff = (a[:planes] != b[:planes])
+    assert int(diff.sum()) == 0, (int(diff.sum()), int(diff.nonzero()[0]))
