@@ -195,8 +195,8 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
   unsigned n_items = q_end - q0;
   if constexpr (LISTED) {
-    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + OCT * kBox);
-    unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + OCT * kBox + chunk * 2);
+    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + (THREADS / 8) * kBox);
+    unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
     unsigned base_count = 0;
     for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
       const unsigned i = t0 + threadIdx.x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   const unsigned out_q = (unsigned)d.heads * 64u;
   const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
   const unsigned box = sbase + (unsigned)stage_bytes + (threadIdx.x >> 3) * kBox;
-  const unsigned qlist_a = sbase + (unsigned)stage_bytes + OCT * kBox;
+  const unsigned qlist_a = sbase + (unsigned)stage_bytes + (THREADS / 8) * kBox;
   const H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
 
   const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
@@ -345,6 +345,9 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     float s_cur = 0.f;
     auto phase = [&](auto jc) __attribute__((always_inline)) {
       constexpr int J = decltype(jc)::v;
+      // the segment that ends with the big-level loads runs at raised priority: a wave that is about to feed
+      // the L2 path goes before waves that are in their multiply-add segments (518 vs 524 us; ABL & 16: off)
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(3);
       spread();
       // big levels: records, then all 2 * NB loads
       u32x4 rb[NB > 0 ? NB : 1];
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
           r1[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].w + lane16), 0, 0);
         }
       }
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       // staged levels in two halves: records, LDS taps (two ds_read_b64 per row: the laundered second
       // address keeps the compiler from fusing them into the half-rate ds_read2_b64), packed-fp16 row
@@ -552,7 +556,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 
 // flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
 // bits 2..5 ablations (4 big taps, 8 staged taps, 16 operand stream, 32 store; they imply "no pre-pass");
-// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP
+// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP; 1024 no raised priority for the
+// load-issuing segment
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
@@ -588,6 +593,10 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
       if (abl) return BEVOPS_NOT_SUPPORTED;
       if (listed) BEVOPS_H5X(768, 0, true);
       BEVOPS_H5X(768, 0, false);
+    }
+    if ((flags & 1024) && abl == 0) {   // A/B: WITHOUT the raised priority of the load-issuing segment
+      if (listed) BEVOPS_H5X(1024, 16, true);
+      BEVOPS_H5X(1024, 16, false);
     }
     switch (abl) {
       case 0: if (listed) BEVOPS_H5X(1024, 0, true); BEVOPS_H5X(1024, 0, false);
