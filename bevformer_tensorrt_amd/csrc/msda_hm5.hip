@@ -168,69 +168,86 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 // time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
 // every lane the record of slot (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot
 // and dword does the rest (26 more VALU instructions per phase, no LDS traffic).
-template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX>
+template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX, bool PERSIST>
 __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
     __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
-    const unsigned char *__restrict__ vis) {
+    const unsigned char *__restrict__ vis, unsigned *__restrict__ queue) {
   constexpr int NB = 2 * NBL;   // big-level samples per phase
   constexpr int NS = 8 - NB;    // staged samples per phase
   constexpr int kBox = 8 * 16 + 16;
   constexpr unsigned OCT = THREADS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // smem: [staged planes][mailboxes][query list][wave totals]
-  unsigned bh, ck;
+  // PERSIST: 32 blocks per (batch, head) plane; block j takes the 256-query sub-chunks j, j + 32, j + 64, ...
+  // of its plane, appending their visible queries to its list until it holds >= 1024 items (or its sub-chunks
+  // are used up), and samples them.  A strided sample of the plane sees the plane's average visibility, so the
+  // 32 blocks carry equal work whatever the visibility pattern (one block per contiguous 1 280-query chunk:
+  // 0 .. 830 visible items per block on the rig geometry), their rounds of 128 octets are full, and the
+  // assignment is the same for all heads -- the 8 XCDs still walk the queries together, which the operand
+  // stream needs (a per-plane atomic queue let the heads drift apart: 601 vs 539 us, the 8 heads' pieces of an
+  // offsets row were no longer fetched together).  Measured equal on uniform points (542 vs 542 us) and slower
+  // on the rig geometry (278 vs 271 us: every block copies the plane, none is empty) -- so the DEFAULT stays
+  // !PERSIST: one block per chunk of `chunk` queries; PERSIST is an A/B build (flag 512).
+  constexpr unsigned kSub = 256, kBatch = 1024, kBpp = 32;
+  unsigned bh, ck = 0;
+  const unsigned per_plane = PERSIST ? kBpp : (unsigned)nchunk;
   if (d.heads == 8) {   // XCD x keeps head x; all XCDs walk the same (batch, chunk) sequence
     const unsigned rest = blockIdx.x >> 3;
-    bh = (rest / (unsigned)nchunk) * 8u + (blockIdx.x & 7u);
-    ck = rest % (unsigned)nchunk;
+    bh = (rest / per_plane) * 8u + (blockIdx.x & 7u);
+    ck = rest % per_plane;
   } else {
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    bh = vb / (unsigned)nchunk;
-    ck = vb - bh * (unsigned)nchunk;
+    bh = vb / per_plane;
+    ck = vb - bh * per_plane;
   }
   const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
-  const unsigned q0 = ck * (unsigned)chunk;
-  const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
-  unsigned n_items = q_end - q0;
-  if constexpr (LISTED) {
-    unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + (THREADS / 8) * kBox);
-    unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
-    unsigned base_count = 0;
-    for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
-      const unsigned i = t0 + threadIdx.x;
-      bool v = i < n_items;
-      if (v) {
-        if constexpr (LISTED == 2) v = (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q0 + i] & 0x7fffu) != 0;   // not +-0
-        else v = vis[((size_t)b * d.nq + q0 + i) * d.heads + h] != 0;
-      }
-      const unsigned long long bal = __ballot(v);
-      const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-      if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
-      __syncthreads();
-      unsigned before = base_count, all = 0;
-      for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
-        const unsigned cnt = wtot[w2];
-        if (w2 < wv) before += cnt;
-        all += cnt;
-      }
-      if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
-      base_count += all;
-      __syncthreads();
+  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + (THREADS / 8) * kBox);
+  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
+  auto visible = [&](unsigned q) -> bool {
+    if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
+    else if constexpr (LISTED == 1) return vis[((size_t)b * d.nq + q) * d.heads + h] != 0;
+    else return true;
+  };
+  auto stage_plane = [&]() {
+    if (stage_bytes) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
+      uint4 *dst = reinterpret_cast<uint4 *>(smem);
+      for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
     }
-    n_items = base_count;
+  };
+  unsigned q0 = 0, n_items = 0;
+  if constexpr (!PERSIST) {
+    q0 = ck * (unsigned)chunk;
+    const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
+    n_items = q_end - q0;
+    if constexpr (LISTED) {
+      unsigned base_count = 0;
+      for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
+        const unsigned i = t0 + threadIdx.x;
+        const bool v = i < n_items && visible(q0 + i);
+        const unsigned long long bal = __ballot(v);
+        const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = base_count, all = 0;
+        for (unsigned w2 = 0; w2 < THREADS / 64; ++w2) {
+          const unsigned cnt = wtot[w2];
+          if (w2 < wv) before += cnt;
+          all += cnt;
+        }
+        if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        base_count += all;
+        __syncthreads();
+      }
+      n_items = base_count;
+    }
+    if (n_items == 0) return;   // nothing of this chunk is visible from this camera: no plane copy either
+    stage_plane();
+    __syncthreads();
   }
-  if (n_items == 0) return;   // nothing of this chunk is visible from this camera: no plane copy either
-  if (stage_bytes) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
-  }
-  __syncthreads();
   const unsigned wave_first = (threadIdx.x >> 6) * 8u;
-  if (n_items <= wave_first) return;
-  const unsigned nrounds = (n_items - wave_first + OCT - 1u) / OCT;
 
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gset), 0, g_bytes, 0x00020000);
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
   auto query_of = [&](unsigned i) -> unsigned {
     const unsigned ii = min(i, n_items - 1u);   // octets past the end repeat the last item, unstored
-    return LISTED ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
+    return (LISTED || PERSIST) ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
   };
   auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
     const unsigned q = query_of(i);
@@ -480,32 +497,75 @@ __global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
   // S0 = this item's operands, S1 = the next item's (landed), S2 = the one after (in flight).  One body
   // per loop trip; the sets move down by register copies: S2 was requested BEFORE this trip's taps,
   // which have all been waited for, so copying it never stalls
-  H5Set S0, S1, S2;
-  unsigned i = threadIdx.x >> 3;
-  request(S0, i);
-  request(S1, i + OCT);
-  request(S2, i + 2u * OCT);
-  fe_begin(S0);
-  fe(S0, IC<0>{});
-  for (unsigned r = 0; r < nrounds; ++r) {
-    body(S0, S1, i, S2);
-    i += OCT;
+  auto run_items = [&]() __attribute__((always_inline)) {
+    if (n_items <= wave_first) return;   // this wave's octets are all past the end of the list
+    const unsigned nrounds = (n_items - wave_first + OCT - 1u) / OCT;
+    H5Set S0, S1, S2;
+    unsigned i = threadIdx.x >> 3;
+    request(S0, i);
+    request(S1, i + OCT);
+    request(S2, i + 2u * OCT);
+    fe_begin(S0);
+    fe(S0, IC<0>{});
+    for (unsigned r = 0; r < nrounds; ++r) {
+      body(S0, S1, i, S2);
+      i += OCT;
+    }
+  };
+  if constexpr (!PERSIST) {
+    run_items();
+  } else {
+    const unsigned nsub = ((unsigned)d.nq + kSub - 1u) / kSub;
+    bool done = false, staged = false;
+    unsigned next_sub = ck;   // this block's index within its plane
+    while (!done) {
+      unsigned count = 0;
+      while (count < kBatch) {
+        __syncthreads();   // the list and the wave totals are free again
+        const unsigned sub = next_sub;
+        if (sub >= nsub) { done = true; break; }
+        next_sub += kBpp;
+        const unsigned q = sub * kSub + threadIdx.x;
+        const bool v = threadIdx.x < kSub && q < (unsigned)d.nq && visible(q);
+        const unsigned long long bal = __ballot(v);
+        const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        if (lane == 0 && wv < kSub / 64) wtot[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = count, all = 0;
+#pragma unroll
+        for (unsigned w2 = 0; w2 < kSub / 64; ++w2) {
+          const unsigned cnt = wtot[w2];
+          if (w2 < wv) before += cnt;
+          all += cnt;
+        }
+        if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)q;
+        count += all;
+      }
+      if (count == 0) break;
+      if (!staged) { stage_plane(); staged = true; }
+      __syncthreads();
+      n_items = count;
+      run_items();
+    }
   }
 }
 
 inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
 constexpr int kH5Chunk = 1280;
 
-template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX = true>
+template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX = true, bool PERSIST = false>
 int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
-          const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
+          const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st,
+          unsigned *queue = nullptr) {
   const int nchunk = (d.nq + chunk - 1) / chunk;
   const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, chunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX>>(lds)) return (int)BEVOPS_FAILURE;
-  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX>), dim3((unsigned)(d.bs * d.heads * nchunk)),
-                     dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk,
-                     nchunk, pl.stage_bytes, vis);
+  if (PERSIST && (d.nq > 65535 || chunk < 1280)) return BEVOPS_NOT_SUPPORTED;   // list entries are absolute u16 queries
+  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX, PERSIST>>(lds)) return (int)BEVOPS_FAILURE;
+  const unsigned planes = (unsigned)(d.bs * d.heads);
+  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX, PERSIST>),
+                     dim3(PERSIST ? planes * 32u : planes * (unsigned)nchunk), dim3(THREADS), lds, st, gset,
+                     (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk, pl.stage_bytes, vis, queue);
   return launch_status();
 }
 
@@ -532,7 +592,7 @@ size_t msda_hm5_workspace_bytes(const int32_t *shapes_host, int bs, int heads, i
   Hm3Plan pl;
   if (!h5_shape_ok(C, L, P, 4) || !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl)) return 0;
   const size_t planes = ((pl.g_bytes + 127) & ~size_t(127)) + pl.s_bytes;
-  return ((planes + 255) & ~size_t(255)) + (((size_t)bs * nq * heads + 255) & ~size_t(255));
+  return ((planes + 255) & ~size_t(255)) + (((size_t)bs * nq * heads + 255) & ~size_t(255));   // [planes][visibility bytes]
 }
 
 // Fused SCA sampling on the planes `packed` already holds (written by the value projection's GEMM
@@ -550,14 +610,15 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
   if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
-  return h5_go<2, 1024, 0, 2, false>(pl, gset, gset + g_room, ref, off, logit, sampled, d,
-                                     reinterpret_cast<const unsigned char *>(qmask), kH5Chunk, st);
+  unsigned *queue = nullptr;
+  return h5_go<2, 1024, 0, 2, false, false>(pl, gset, gset + g_room, ref, off, logit, sampled, d,
+                                            reinterpret_cast<const unsigned char *>(qmask), kH5Chunk, st, queue);
 }
 
 // flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
 // bits 2..5 ablations (4 big taps, 8 staged taps, 16 operand stream, 32 store; they imply "no pre-pass");
-// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP; 1024 no raised priority for the
-// load-issuing segment
+// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP; 512 32 persistent blocks per plane on strided
+// 256-query sub-chunks instead of one block per 1 280-query chunk (rig geometry 278 vs 271 us); 1024 no raised priority for the load-issuing segment
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
@@ -573,6 +634,7 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   char *gset = static_cast<char *>(workspace);
   char *sset = gset + g_room;
   unsigned char *vis = reinterpret_cast<unsigned char *>(gset + ((g_room + pl.s_bytes + 255) & ~size_t(255)));
+  unsigned *queue = nullptr;
   if (!prepacked) msda_hm3_repack_launch(value, gset, sset, &pl.t, bs, nk, heads, st);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
   const int abl = (flags >> 2) & 15;
@@ -597,6 +659,10 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
     if ((flags & 1024) && abl == 0) {   // A/B: WITHOUT the raised priority of the load-issuing segment
       if (listed) BEVOPS_H5X(1024, 16, true);
       BEVOPS_H5X(1024, 16, false);
+    }
+    if (abl == 0 && (flags & 512) && !(flags & 128)) {   // A/B: 32 persistent blocks per plane on strided sub-chunks
+      if (listed) return h5_go<2, 1024, 0, 1, false, true>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st, queue);
+      return h5_go<2, 1024, 0, 0, false, true>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st, queue);
     }
     switch (abl) {
       case 0: if (listed) BEVOPS_H5X(1024, 0, true); BEVOPS_H5X(1024, 0, false);

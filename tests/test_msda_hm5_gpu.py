@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 LEVELS = [[116, 200], [58, 100], [29, 50], [15, 25]]
 VARIANTS = {"hm5": 1000, "hm5_no_prepass": 1001, "hm5_768": 1002, "hm5_768_no_prepass": 1003,
-            "hm5_chunk2560": 1128, "hm5_mailbox": 1256, "hm5_mailbox_no_prepass": 1257}
+            "hm5_chunk2560": 1128, "hm5_mailbox": 1256, "hm5_mailbox_no_prepass": 1257,
+            "hm5_persistent_strided": 1512, "hm5_persistent_strided_no_prepass": 1513}
 
 
 @pytest.fixture(scope="module")
