@@ -361,7 +361,7 @@ class ModelFrames:
     N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and the
     frame runs eagerly with the RCCL exchange inside."""
 
-    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4):
+    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True):
         from bevformer_tensorrt_amd import bevformer as B, geometry as G
         self.B, self.dev, self.kind = B, dev, kind
         dtype = torch.float16
@@ -394,7 +394,7 @@ class ModelFrames:
             self.note = {"int8_plugin_sites": len(scales), "int8_dense_layers": len(q), "calibration_frames": calib}
         else:
             model = B.BEVFormer("base", seed=0).to(dev, dtype)
-        self.graph = world == 1
+        self.graph = world == 1 and graph
         self.runner = B.FrameRunner(model, dev, dtype, cams=cams, gather=gather, graph=self.graph)
         self.i = 0
 

@@ -1,0 +1,336 @@
+// Dense layers of the re-hosted network as ONE tiled matrix-core GEMM skeleton in three operand flavours
+// (not reference plugins -- TensorRT owns these layers there):
+//     out[m, n] = act( (sum_k a[m, k] w[n, k]) * scale[n] + bias[n] (+ residual[m, n]) )
+//   S8    a int8 [M, K], w int8 [N, K]: v_mfma_i32_32x32x32_i8, int32 sums (exact)      bevops_linear_int8
+//   F16Q  a fp16, quantised with 1 / s_a ON ITS WAY into LDS, then as S8                  bevops_linear_int8_fused
+//   F16   a fp16, w fp16: v_mfma_f32_32x32x16_f16, fp32 sums                             bevops_tile_gemm_f16
+// a, w row-major (nn.Linear / 1x1-convolution weight layout).  These layers are memory-bound at batch 1 (M is
+// 8 700 .. 556 800 pixel or query rows, K and N are 64 .. 2 048): what matters is that the activation rows
+// stream from HBM once at full rate while enough independent work is resident to cover the latency.
+//
+// MI355X mapping.  128 x 128 output tiles, 256 threads = 4 waves of 64 x 64 (2 x 2 MFMA blocks of 32 x 32),
+// 64 BYTES of k per step and row in every flavour (64 int8 / 32 fp16 values: the LDS images, the 16-byte
+// fragment reads and the staging loads are the same code).  Operands are register-staged ONE step ahead
+// (buffer loads: rows past M / N read as zero, no branches) and written into the OTHER of two LDS images while
+// the current one is multiplied: one barrier per step.  40 KB LDS and <= 168 VGPRs keep THREE blocks on a
+// CU -- their prologues, k-loops and epilogues interleave, which is what covers the HBM latency (a persistent
+// one-block-per-CU kernel with DMA operands, tsgemm.hip, is faster only for 256-column layers with K >= 256).
+// Tiles are numbered so that the column tiles of one row tile run on the same XCD back to back (block b runs on
+// XCD b % 8): the activation rows come from HBM once and from that XCD's L2 afterwards.
+// F16Q: q = clamp(rne(x * (1 / s)), -127, 127); the product and the add of 1.5 * 2^23 are ONE fused
+// multiply-add (v_fma_mix_f32 on the fp16 halves: single rounding), the clamp one v_med3_i32 on the float's bits,
+// the integer its low mantissa byte: 2.75 VALU operations per element.  x * fl(1 / s) against the fl(x / s) of
+// bevops_quantize_rows: the two can disagree (by one step) only where x / s is within 1e-5 of a rounding tie
+// (4.7e-5 of the elements of a Gaussian tensor; tests/test_linear_q_gpu.py emulates this quantiser bit for bit).
+// Epilogue: the identity rows are requested before the k-loop ends (they do not depend on it); the raw sums go
+// through LDS per wave (32 rows x 64 columns at a time) so that a thread owns 8 consecutive columns of a row:
+// scale, bias, identity, ReLU in fp32 on 16-byte accesses, ONE rounding to fp16 (or the requantisation to int8
+// for a following int8 layer).
+#include <type_traits>
+
+#include "common.h"
+
+namespace bevops {
+namespace {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+enum { kS8 = 0, kF16Q = 1, kF16 = 2 };
+
+constexpr int kTM = 128, kTN = 128, kTKB = 64, kTLd = kTKB + 16;  // 64 bytes of k per row and step; +16: conflict-free b128 reads
+constexpr float kQMagic = 12582912.f;          // 1.5 * 2^23: bits 0x4B400000, low byte 0
+constexpr int kQMagicBits = 0x4B400000;
+constexpr int kEpiStride = 64 * 4 + 16;        // staging row: 64 x 4 bytes + pad
+constexpr unsigned kOob = 0xFFFFFF00u;         // beyond any buffer: reads as zero
+
+__device__ __forceinline__ unsigned quant4(unsigned h01, unsigned h23, float r) {
+  int b0 = __float_as_int(__builtin_fmaf(h2f_lo(h01), r, kQMagic));
+  int b1 = __float_as_int(__builtin_fmaf(h2f_hi(h01), r, kQMagic));
+  int b2 = __float_as_int(__builtin_fmaf(h2f_lo(h23), r, kQMagic));
+  int b3 = __float_as_int(__builtin_fmaf(h2f_hi(h23), r, kQMagic));
+  b0 = min(max(b0, kQMagicBits - 127), kQMagicBits + 127);
+  b1 = min(max(b1, kQMagicBits - 127), kQMagicBits + 127);
+  b2 = min(max(b2, kQMagicBits - 127), kQMagicBits + 127);
+  b3 = min(max(b3, kQMagicBits - 127), kQMagicBits + 127);
+  // low bytes of b0..b3 -> one word
+  return __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u) |
+         __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x04000c0cu);
+}
+
+__device__ __forceinline__ uint4 quant16(const uint4 &lo, const uint4 &hi, float r) {
+  return make_uint4(quant4(lo.x, lo.y, r), quant4(lo.z, lo.w, r), quant4(hi.x, hi.y, r), quant4(hi.z, hi.w, r));
+}
+
+struct TileArgs {
+  const void *a, *w, *bias, *res;   // bias: fp32 (S8 / F16Q) or fp16 (F16); res fp16
+  const float *wscale;              // per output channel (S8 / F16Q) or null
+  void *out;
+  float inv_sa, s_aw, inv_s_out;
+  int M, N, K, relu, tiles_n, tiles_total;
+};
+
+template <int MODE, bool OUT8>
+__global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + kTN) * kTLd];   // 40 KB: [image][A rows | W rows][80]
+  constexpr int kAB = MODE == kS8 ? 1 : 2;     // bytes per activation element in memory
+  constexpr int kWB = MODE == kF16 ? 2 : 1;    // bytes per weight element
+  constexpr int kAV = MODE == kF16Q ? 2 : 1;   // 16-byte loads per activation row and step
+  constexpr int kStepK = MODE == kF16 ? kTKB / 2 : kTKB;   // k-values per step
+  const int M = p.M, N = p.N, K = p.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: the 8 XCDs take contiguous runs of the (row tile, column tile) sequence
+  const int per_xcd = (p.tiles_total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= p.tiles_total) return;
+  const int m0 = (logical / p.tiles_n) * kTM, n0 = (logical % p.tiles_n) * kTN;
+  const int r0 = tid >> 2, r1 = r0 + 64;       // 128 rows x 4 chunks of 16 bytes of k
+  const int kce = (tid & 3) * (kStepK / 4);    // this thread's first k-value inside a step
+  typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+  const int nk = (K + kStepK - 1) / kStepK;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(p.a), 0, (unsigned)((size_t)M * K * kAB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(p.w), 0, (unsigned)((size_t)N * K * kWB), 0x00020000);
+  const unsigned a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * K + kce) * kAB) : kOob;
+  const unsigned a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
+  const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
+  const unsigned w_off1 = n0 + r1 < N ? (unsigned)(((size_t)(n0 + r1) * K + kce) * kWB) : kOob;
+  uint4 ra0[kAV], ra1[kAV], rb0, rb1;
+  auto bload = [](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+  };
+  auto gload = [&](int kt) {
+    const int ks = kt * kStepK;
+    const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
+#pragma unroll
+    for (int h = 0; h < kAV; ++h) {
+      ra0[h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
+      ra1[h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+    }
+    rb0 = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
+    rb1 = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
+  };
+  const int lchunk = (tid & 3) * 16;           // byte position of the thread's chunk in an LDS row
+  auto lstore = [&](int buf) {
+    char *As = smem + buf * (kTM + kTN) * kTLd, *Ws = As + kTM * kTLd;
+    if constexpr (MODE == kF16Q) {
+      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[0], ra0[1], p.inv_sa);
+      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[0], ra1[1], p.inv_sa);
+    } else {
+      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = ra0[0];
+      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[0];
+    }
+    *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0;
+    *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1;
+  };
+  // ---- epilogue roles, fixed before the loop so that the identity rows can be requested early
+  const int c8 = lane & 7;                       // this lane's 8-column chunk of the wave's 64 columns
+  const int ncol = n0 + wn * 64 + c8 * 8;
+  const bool col_ok = ncol < N;
+  const bool vec = (N & 7) == 0;                 // rows 16-byte aligned and the chunk all in or all out; else per element
+  const __half *res = static_cast<const __half *>(p.res);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__half *>(res), 0, res ? (unsigned)((size_t)M * N * 2) : 0u, 0x00020000);
+  uint4 rres[2][4];
+  auto res_request = [&](int j) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = m0 + wm * 64 + j * 32 + it * 8 + (lane >> 3);
+      rres[j][it] = bload(rs_r, (m < M && col_ok) ? (unsigned)(((size_t)m * N + ncol) * 2) : kOob, 0);
+    }
+  };
+  const bool res_vec = res != nullptr && vec;
+
+  gload(0);
+  lstore(0);
+  if (nk > 1) gload(1);
+  if (res_vec) res_request(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    // image (kt + 1) & 1 was last read in step kt - 1, which every wave left through the barrier below
+    if (kt + 1 < nk) lstore((kt + 1) & 1);
+    if (kt + 2 < nk) gload(kt + 2);
+    const char *As = smem + (kt & 1) * (kTM + kTN) * kTLd, *Ws = As + kTM * kTLd;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 32 + (lane >> 5) * 16;
+      // MFMA operand A = the weight rows (output columns n), B = the activation rows (m): a lane's 4
+      // consecutive accumulator rows are then 4 consecutive n of one output row m
+      i32x4_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const i32x4_t *>(Ws + (wn * 64 + i * 32 + (lane & 31)) * kTLd + kk);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const i32x4_t *>(As + (wm * 64 + j * 32 + (lane & 31)) * kTLd + kk);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (MODE == kF16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i]),
+                                                               __builtin_bit_cast(f16x8_t, b[j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*64 + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*64 + j*32 + (lane & 31)
+  // (the barrier that ended the last step also freed both LDS images)
+  if (res_vec) res_request(1);
+  char *stage = smem + wave * 32 * kEpiStride;
+  float sc[8], bs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bool ok = ncol + c < N;
+    if constexpr (MODE == kF16) {
+      sc[c] = 1.f;
+      bs[c] = (p.bias && ok) ? __half2float(static_cast<const __half *>(p.bias)[ncol + c]) : 0.f;
+    } else {
+      sc[c] = (p.wscale && ok) ? p.s_aw * p.wscale[ncol + c] : p.s_aw;
+      bs[c] = (p.bias && ok) ? static_cast<const float *>(p.bias)[ncol + c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<i32x4_t *>(stage + (lane & 31) * kEpiStride + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
+            i32x4_t{__builtin_bit_cast(int, acc[i][j][4 * g]), __builtin_bit_cast(int, acc[i][j][4 * g + 1]),
+                    __builtin_bit_cast(int, acc[i][j][4 * g + 2]), __builtin_bit_cast(int, acc[i][j][4 * g + 3])};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = m0 + wm * 64 + j * 32 + row;
+      const i32x4_t lo = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32);
+      const i32x4_t hi = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32 + 16);
+      if (m >= M || !col_ok) continue;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (MODE == kF16) {
+          v[c] = __builtin_bit_cast(float, lo[c]) + bs[c];
+          v[4 + c] = __builtin_bit_cast(float, hi[c]) + bs[4 + c];
+        } else {
+          v[c] = (float)lo[c] * sc[c] + bs[c];
+          v[4 + c] = (float)hi[c] * sc[4 + c] + bs[4 + c];
+        }
+      }
+      if (res) {
+        if (vec) {
+          const uint4 q = rres[j][it];
+          v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
+          v[4] += h2f_lo(q.z); v[5] += h2f_hi(q.z); v[6] += h2f_lo(q.w); v[7] += h2f_hi(q.w);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (ncol + c < N) v[c] += __half2float(res[(size_t)m * N + ncol + c]);
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      if constexpr (OUT8) {
+        int8_t *o8 = static_cast<int8_t *>(p.out) + (size_t)m * N + ncol;
+        unsigned pk[2] = {0, 0};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          pk[c >> 2] |= ((unsigned)(int)fminf(fmaxf(rintf(v[c] * p.inv_s_out), -127.f), 127.f) & 0xffu) << (8 * (c & 3));
+        if (vec) {
+          *reinterpret_cast<uint2 *>(o8) = make_uint2(pk[0], pk[1]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (ncol + c < N) o8[c] = (int8_t)((pk[c >> 2] >> (8 * (c & 3))) & 0xffu);
+        }
+      } else {
+        __half *oh = static_cast<__half *>(p.out) + (size_t)m * N + ncol;
+        if (vec) {
+          uint4 o;
+          o.x = pack_h2(v[0], v[1]); o.y = pack_h2(v[2], v[3]); o.z = pack_h2(v[4], v[5]); o.w = pack_h2(v[6], v[7]);
+          *reinterpret_cast<uint4 *>(oh) = o;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (ncol + c < N) oh[c] = __float2half_rn(v[c]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int MODE>
+int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w_scales, float scale_w,
+                     const void *bias, const void *residual, int out_dtype, void *out, float scale_out, long long M,
+                     int N, int K, int relu, void *stream) {
+  if (!a || !w || !out || M < 0 || N <= 0 || K <= 0) return BEVOPS_BAD_PARAM;
+  if (MODE != kF16 && (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f)))) return BEVOPS_BAD_PARAM;
+  constexpr int kChunk = MODE == kF16 ? 8 : 16;   // k-values a staging thread handles per step
+  if (K % kChunk != 0 || !aligned16(a) || !aligned16(w) || !aligned16(residual) ||
+      (reinterpret_cast<uintptr_t>(out) & (out_dtype == BEVOPS_I8 ? 7u : 15u)) || M > 0x7fffffffLL)
+    return BEVOPS_NOT_SUPPORTED;
+  if (out_dtype == BEVOPS_I8 && (MODE == kF16 || !(scale_out > 0.f))) return BEVOPS_BAD_PARAM;
+  if (out_dtype != BEVOPS_I8 && out_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  // operands (and the identity) are addressed through 32-bit buffer offsets
+  if ((unsigned long long)M * K * (MODE == kS8 ? 1 : 2) >= kOob || (unsigned long long)N * K * (MODE == kF16 ? 2 : 1) >= kOob ||
+      (residual && (unsigned long long)M * N * 2 >= kOob))
+    return BEVOPS_NOT_SUPPORTED;
+  if (M == 0) return BEVOPS_SUCCESS;
+  TileArgs p;
+  p.a = a; p.w = w; p.bias = bias; p.res = residual; p.wscale = w_scales; p.out = out;
+  p.inv_sa = MODE == kF16 ? 1.f : 1.0f / scale_a;
+  p.s_aw = MODE == kF16 ? 1.f : (w_scales ? scale_a : scale_a * scale_w);
+  p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
+  p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
+  p.tiles_n = (N + kTN - 1) / kTN;
+  const long long tiles = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
+  if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
+  p.tiles_total = (int)tiles;
+  const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (out_dtype == BEVOPS_F16) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false>), grid, dim3(256), 0, st, p);
+  else if constexpr (MODE != kF16) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true>), grid, dim3(256), 0, st, p);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace bevops
+
+using namespace bevops;
+
+extern "C" int bevops_linear_int8(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
+                                  float scale_w, const float *bias, const void *residual, int out_dtype,
+                                  void *out, float scale_out, long long M, int N, int K, int relu, void *stream) {
+  return launch_tile_gemm<kS8>(a_q, scale_a, w_q, w_scales, scale_w, bias, residual, out_dtype, out, scale_out, M, N, K,
+                               relu, stream);
+}
+
+extern "C" int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, const float *w_scales,
+                                        float scale_w, const float *bias, const void *residual, int out_dtype,
+                                        void *out, float scale_out, long long M, int N, int K, int relu, void *stream) {
+  return launch_tile_gemm<kF16Q>(x_f16, scale_a, w_q, w_scales, scale_w, bias, residual, out_dtype, out, scale_out, M, N,
+                                 K, relu, stream);
+}
+
+extern "C" int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
+                                    void *out, long long M, int N, int K, int relu, void *stream) {
+  return launch_tile_gemm<kF16>(x, 1.f, weight, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f, M, N, K, relu, stream);
+}

@@ -115,10 +115,12 @@ def quantize_rows(x, scale, out=None):
 
 def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False, out_dtype=torch.float16,
                 scale_out=1.0):
-    """INT8 GEMM with de-quantising epilogue (bevops_linear_int8): a_q [..., K] int8, w_q [N, K] int8,
-    scale_w a float (per tensor) or an fp32 [N] tensor (per output channel), bias fp32 [N], residual fp16
-    [..., N] -> fp16 (or int8 requantised with scale_out)."""
-    assert a_q.is_cuda and a_q.dtype == torch.int8 and w_q.dtype == torch.int8
+    """INT8 GEMM with de-quantising epilogue: a_q [..., K] int8 (bevops_linear_int8) -- or the fp16 activation
+    itself, quantised with scale_a inside the GEMM's operand load (bevops_linear_int8_fused: no quantise pass)
+    --, w_q [N, K] int8, scale_w a float (per tensor) or an fp32 [N] tensor (per output channel), bias fp32
+    [N], residual fp16 [..., N] -> fp16 (or int8 requantised with scale_out)."""
+    assert a_q.is_cuda and a_q.dtype in (torch.int8, torch.float16) and w_q.dtype == torch.int8
+    fused = a_q.dtype == torch.float16
     K, N = a_q.shape[-1], w_q.shape[0]
     a2 = a_q.reshape(-1, K).contiguous()
     w_q = w_q.contiguous()
@@ -130,12 +132,12 @@ def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False
     out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
     handle = _lib.load_library()
     with torch.cuda.device(a_q.device):
-        st = handle.bevops_linear_int8(
+        st = (handle.bevops_linear_int8_fused if fused else handle.bevops_linear_int8)(
             a2.data_ptr(), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,
             1.0 if per_channel else float(scale_w), b.data_ptr() if b is not None else None,
             r.data_ptr() if r is not None else None, _lib.torch_dtype_code(out), out.data_ptr(), float(scale_out),
             M, N, K, int(bool(relu)), _lib.current_stream_ptr(a_q.device))
-    _lib.check(st, "bevops_linear_int8")
+    _lib.check(st, "bevops_linear_int8_fused" if fused else "bevops_linear_int8")
     return out.view(*a_q.shape[:-1], N)
 
 
@@ -168,3 +170,109 @@ def tsgemm(x, weight, bias=None, residual=None, relu=False, out=None):
                                       int(bool(relu)), _lib.current_stream_ptr(x.device))
     _lib.check(st, "bevops_tsgemm_f16")
     return out.view(*x.shape[:-1], N)
+
+
+def tile_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
+    """act(x @ weight.T + bias + residual) on the tiled MFMA GEMM (bevops_tile_gemm_f16, csrc/tile_gemm.hip:
+    128 x 128 tiles, three blocks per CU): x [..., K] fp16 contiguous rows, weight [N, K], bias [N] fp16,
+    residual / out [..., N].  K % 8 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
+    K, N = x.shape[-1], weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {K}]")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    weight = weight.contiguous()
+    M = x2.shape[0]
+    r2 = None
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.numel() != M * N:
+            raise ValueError("residual must be fp16 with M*N elements")
+        r2 = residual.reshape(M, N)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_tile_gemm_f16(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K,
+                                         int(bool(relu)), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_tile_gemm_f16")
+    return out.view(*x.shape[:-1], N)
+
+
+# ---- measured choice between the dense-layer implementations -------------------------------------------------
+def _torch_dense(x, weight, bias, residual, relu):
+    if residual is not None or bias is None:
+        raise _lib.BevopsError("torch addmm path: bias required, no identity term", _lib.NOT_SUPPORTED)
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch._addmm_activation(bias, x2, weight.t()) if relu else torch.addmm(bias, x2, weight.t())
+    return y.view(*x.shape[:-1], weight.shape[0])
+
+
+_DENSE = {"tsgemm": tsgemm, "tile": tile_gemm, "blaslt": linear_bias_act, "torch": _torch_dense}
+_DENSE_CHOICE = {}     # problem -> name of the fastest implementation measured in this process
+DENSE_LOG = []         # (problem, {name: us}) of every measurement, for tools / profiles
+
+
+def _dense_default(N, K, has_res):
+    """Choice without a measurement (inside stream capture before the problem was seen, or BEVOPS_DENSE_TUNE=0)."""
+    if N == 256 and K % 64 == 0 and K >= 256:
+        return "tsgemm"
+    return "blaslt"
+
+
+def dense_auto(x, weight, bias=None, residual=None, relu=False):
+    """act(x @ weight.T + bias + residual), fp16, on whichever of the implementations is fastest for the
+    problem on THIS device: the tall-skinny persistent GEMM (tsgemm), the tiled GEMM (tile_gemm), the hipBLASLt
+    entry with the fused epilogue (linear_bias_act) or the framework's addmm.  Measured once per
+    (M, N, K, epilogue) outside stream capture -- BLOCKING, like bevops_linear_tune: a few launches of each
+    candidate into scratch outputs between device synchronisations -- then cached for the process.  All
+    candidates accumulate in fp32 and round once; they differ in summation order only."""
+    import os
+    K, N = x.shape[-1], weight.shape[0]
+    M = x.numel() // K
+    key = (str(x.device), M, N, K, bool(relu), bias is not None, residual is not None)
+    name = _DENSE_CHOICE.get(key)
+    if name is None:
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("BEVOPS_DENSE_TUNE", "1") == "0" or M < 64:
+            name = _dense_default(N, K, residual is not None)
+        else:
+            name = _DENSE_CHOICE[key] = _dense_measure(key, x, weight, bias, residual, relu)
+    try:
+        return _DENSE[name](x, weight, bias, residual, relu)
+    except _lib.BevopsError as exc:
+        if exc.status != _lib.NOT_SUPPORTED or name == "blaslt":
+            raise
+        return linear_bias_act(x, weight, bias, residual, relu)
+
+
+def _dense_measure(key, x, weight, bias, residual, relu, rounds=3, iters=4):
+    times = {}
+    with torch.cuda.device(x.device):
+        for name, fn in _DENSE.items():
+            try:
+                for _ in range(2):
+                    fn(x, weight, bias, residual, relu)
+                times[name] = float("inf")
+            except Exception:          # outside the candidate's domain / no library algorithm
+                continue
+        for _ in range(rounds):
+            for name in list(times):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(iters):
+                    _DENSE[name](x, weight, bias, residual, relu)
+                b.record()
+                b.synchronize()
+                times[name] = min(times[name], a.elapsed_time(b) * 1e3 / iters)
+    DENSE_LOG.append((key, {k: round(v, 1) for k, v in times.items()}))
+    if not times:
+        return "blaslt"
+    return min(times, key=times.get)

@@ -102,8 +102,8 @@ def refine_reference_points(tmp, reference_points):
     uses ITS OWN inverse_sigmoid (decoder.py:24-40: one clamp to [eps, 1-eps]); the head uses
     mmdet's (bevformer_head.py:6,254: clamp to [0, 1], then each factor to >= eps) -- they differ
     below eps, so both are restated."""
-    return torch.cat([tmp[..., :2] + inverse_sigmoid_decoder(reference_points[..., :2]),
-                      tmp[..., 4:5] + inverse_sigmoid_decoder(reference_points[..., 2:3])], dim=-1).sigmoid()
+    # (x, y) and z refined in one pass over [.., 3] (element-wise: the same values as the reference's two slices)
+    return (torch.cat([tmp[..., :2], tmp[..., 4:5]], dim=-1) + inverse_sigmoid_decoder(reference_points)).sigmoid()
 
 
 def inverse_sigmoid_decoder(x, eps=1e-5):

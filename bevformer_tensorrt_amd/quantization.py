@@ -22,6 +22,8 @@ called per boundary tensor per calibration frame; `scales()` returns {name: scal
 """
 import math
 
+import os
+
 import torch
 
 from .functions.multi_scale_deformable_attn import _TensorCache
@@ -162,7 +164,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "image_normalize_pad")
+             "linear_bias_act", "dense_auto", "image_normalize_pad")
 
     def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
         from . import functions as _f
@@ -201,6 +203,10 @@ class Int8PluginOps:
 
     def _q(self, name, t):
         s = self._scales[name]
+        if t.is_cuda and t.dtype == torch.float16 and t.numel() % 8 == 0 and hasattr(self.fp, "quantize_rows"):
+            # one pass (bevops_quantize_rows: clamp(rne(x / s)) with the division in fp32, the calibrators' host
+            # formula) instead of the five framework launches and the fp32 copy of `_Base.quantize`
+            return self.fp.quantize_rows(t.contiguous(), s), s
         return self.cal.quantize(t, s), s
 
     # ---- call sites
@@ -257,6 +263,9 @@ class Int8PluginOps:
     modulated_deformable_conv2d2 = modulated_deformable_conv2d
 
 
+FUSED_QUANT = {"enabled": os.environ.get("BEVOPS_FUSED_QUANT", "1") != "0"}   # A/B: LinearQ hands the fp16 activation to bevops_linear_int8_fused
+
+
 class LinearQ(torch.nn.Linear):
     """`LinearQ` of the reference (det2trt/models/utils/register.py:83: pytorch_quantization's
     QuantLinear, selected through LINEAR_LAYERS at modules/spatial_cross_attention.py:58,329): a
@@ -281,6 +290,7 @@ class LinearQ(torch.nn.Linear):
         self.scale_in = None
         self.register_buffer("weight_q", None, persistent=False)
         self.scale_w = None
+        self.bias_f32 = None      # the epilogue's fp32 shift, made once at freeze()
 
     @classmethod
     def from_linear(cls, lin, calibrator, site):
@@ -300,6 +310,7 @@ class LinearQ(torch.nn.Linear):
         wc.collect("w", self.weight.detach())
         self.scale_w = float(wc.scale("w"))
         self.weight_q = _Base.quantize(self.weight.detach(), self.scale_w).contiguous()
+        self.bias_f32 = None if self.bias is None else self.bias.detach().float().contiguous()
         self.mode = "int8"
         return self
 
@@ -318,10 +329,13 @@ class LinearQ(torch.nn.Linear):
             return torch.relu(y) if relu else y
         from . import functions as _f
         xh = x if x.dtype == torch.float16 else x.to(torch.float16)
-        q = _f.quantize_rows(xh, self.scale_in)
         res = None if residual is None else residual.to(torch.float16)
-        y = _f.linear_int8(q, self.scale_in, self.weight_q, self.scale_w, self.bias, res, relu)
-        return y.to(x.dtype)
+        if self.bias_f32 is None and self.bias is not None:
+            self.bias_f32 = self.bias.detach().float().contiguous()
+        # the fp16 activation goes straight into the GEMM (quantised in its operand load: no quantise pass)
+        a = xh if FUSED_QUANT["enabled"] and xh.shape[-1] % 16 == 0 else _f.quantize_rows(xh, self.scale_in)
+        y = _f.linear_int8(a, self.scale_in, self.weight_q, self.scale_w, self.bias_f32, res, relu)
+        return y if y.dtype == x.dtype else y.to(x.dtype)
 
 
 class Conv2dQ(torch.nn.Conv2d):

@@ -83,6 +83,9 @@ SIGNATURES = {
     "bevops_quantize_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "bevops_linear_int8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                    c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    "bevops_linear_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
+                                         c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                               c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),

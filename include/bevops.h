@@ -349,11 +349,25 @@ int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *b
  *   bevops_linear_int8:   out[M, N] = act((a_q[M, K] . w_q[N, K]^T) * scale_a * w_scale[n] + bias[n]
  *                         + residual[M, N]); w_scales (device, fp32 [N]) per output channel, or NULL
  *                         for the per-tensor scale_w; bias fp32 (device) optional; residual fp16
- *                         optional; out fp16, or int8 requantised with scale_out.  K % 16 == 0, N % 4 == 0. */
+ *                         optional; out fp16, or int8 requantised with scale_out.  K % 16 == 0.
+ *   bevops_linear_int8_fused: the same layer taking the fp16 activation x[M, K] itself: it is quantised
+ *                         inside the GEMM's operand load, q = clamp(rne(x * (1 / scale_a)), -127, 127) with
+ *                         the product and the rounding in one fused multiply-add -- no quantise pass, no int8
+ *                         copy of the activation.  (x * fl(1 / s) against fl(x / s): the two quantisers can
+ *                         differ by one step only where x / s is within 1e-5 of a rounding tie.) */
 int bevops_quantize_rows(int dtype, const void *x, void *q, size_t count, float scale, void *stream);
 int bevops_linear_int8(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
                        float scale_w, const float *bias, const void *residual, int out_dtype,
                        void *out, float scale_out, long long M, int N, int K, int relu, void *stream);
+int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, const float *w_scales,
+                             float scale_w, const float *bias, const void *residual, int out_dtype,
+                             void *out, float scale_out, long long M, int N, int K, int relu, void *stream);
+/* The same tiled GEMM skeleton (csrc/tile_gemm.hip) with fp16 operands: out[M, N] = act(x[M, K] . w[N, K]^T +
+ * bias[n] + residual[M, N]), fp32 accumulation, one rounding; bias / residual fp16, optional.  K % 8 == 0.
+ * One of the implementations the host layer's measured dispatch (functions/linear.py: dense_auto) picks from,
+ * next to bevops_tsgemm_f16 and bevops_linear_bias_act. */
+int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
+                         void *out, long long M, int N, int K, int relu, void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

@@ -41,6 +41,16 @@ def test_linear_int8_vs_integer_reference(M, K, N, per_channel):
     want = torch.relu(acc.double() * scale + b.double() + r[rows].cpu().double())
     err = (out[rows].cpu().double() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
+    # the fp16 activation quantised inside the GEMM's operand load (bevops_linear_int8_fused):
+    # q = clamp(rne(x * fl(1 / s_x))) with product and rounding in one fma -- emulated here in float64 (the
+    # product of an fp16 and an fp32 value is exact there); the GEMM on those integers must be bit-identical
+    r32 = np.float32(1.0) / np.float32(s_x)
+    q_f = np.clip(np.rint(x.cpu().numpy().astype(np.float64) * np.float64(r32)), -127, 127).astype(np.int8)
+    flips = float((q_f != q.cpu().numpy()).mean())
+    assert flips <= 1e-3, flips                      # the two quantisers differ on near-ties of x / s_x only
+    out_f = bev.linear_int8(x, s_x, wq.cuda(), sw_arg, b.cuda(), r, relu=True)
+    out_q = bev.linear_int8(torch.from_numpy(q_f).cuda(), s_x, wq.cuda(), sw_arg, b.cuda(), r, relu=True)
+    assert torch.equal(out_f, out_q)
     # int8 output for a following int8 layer
     o8 = bev.linear_int8(q, s_x, wq.cuda(), sw_arg, b.cuda(), None, relu=False, out_dtype=torch.int8, scale_out=0.05)
     want8 = torch.clamp(torch.round((acc.double() * scale + b.double()).float() / 0.05), -127, 127)
@@ -67,3 +77,27 @@ def test_linearq_module_three_phases():
         assert (y.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
         rel = (y.float() - lin(x).float()).abs().mean().item() / lin(x).float().abs().mean().item()
         assert rel <= tol, rel      # 8-bit per-tensor quantisation noise of a 256-deep dot product
+
+
+def test_linear_int8_fused_quantiser_is_the_row_quantiser_off_ties():
+    """x on a grid that has no near-ties (integers times the scale, +- 0.25 step): the fused operand load and
+    bevops_quantize_rows must produce the same integers, hence bit-identical outputs; and saturation."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 3000, 192, 136
+    s_x = 0.03125                                            # a power of two: k * s_x is exact in fp16
+    k = torch.randint(-200, 201, (M, K), generator=g).float()           # beyond +-127: clamps
+    x = ((k + 0.25 * torch.randint(-1, 2, (M, K), generator=g)) * s_x).half().cuda()
+    wq = torch.randint(-127, 128, (N, K), generator=g).to(torch.int8).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    q = bev.quantize_rows(x, s_x)
+    assert int(q.max()) == 127 and int(q.min()) == -127
+    a = bev.linear_int8(q, s_x, wq, 0.01, b, None, relu=False)
+    f = bev.linear_int8(x, s_x, wq, 0.01, b, None, relu=False)
+    assert torch.equal(a, f)
+    a8 = bev.linear_int8(q, s_x, wq, 0.01, b, None, relu=True, out_dtype=torch.int8, scale_out=0.5)
+    f8 = bev.linear_int8(x, s_x, wq, 0.01, b, None, relu=True, out_dtype=torch.int8, scale_out=0.5)
+    assert torch.equal(a8, f8)
+    want = torch.relu((q.cpu().long() @ wq.cpu().long().t()).double() * (s_x * 0.01) + b.cpu().double())
+    d = (a8.cpu().double() - torch.clamp(torch.round(want / 0.5), -127, 127)).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3

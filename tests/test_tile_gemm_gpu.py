@@ -1,0 +1,76 @@
+"""bevops_tile_gemm_f16 (csrc/tile_gemm.hip, the fp16 flavour of the tiled GEMM skeleton) against
+torch.nn.functional.linear evaluated in fp32 on the same fp16 operands: one rounding to fp16 is the only
+difference (bar: 1 fp16 ulp of the result + fp32 summation-order noise), over the dense-layer shapes of the
+re-hosted model and the edge cases of the tiling (row / column / k tails, N not a multiple of 8, tiny M);
+and the measured dispatch (functions/linear.py: dense_auto) over its candidates."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(34800, 256, 1024), (34800, 1024, 256), (139200, 128, 512), (40000, 512, 256), (900, 256, 256),
+          (333, 100, 64), (1, 8, 8), (129, 136, 72), (8700, 2048, 512)]
+
+
+def _ref(x, w, b, r, relu):
+    y = torch.nn.functional.linear(x.float(), w.float(), None if b is None else b.float())
+    if r is not None:
+        y = y + r.float()
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_res", "bias_res_relu"])
+def test_tile_gemm_matches_fp32_linear(M, N, K, epi):
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    b = torch.randn(N, generator=g).half().cuda() if epi != "plain" else None
+    r = torch.randn(M, N, generator=g).half().cuda() if "res" in epi else None
+    relu = "relu" in epi
+    out = bev.tile_gemm(x, w, b, r, relu)
+    rows = slice(0, min(M, 4096))
+    want = _ref(x[rows], w, b, None if r is None else r[rows], relu)
+    err = (out[rows].float() - want).abs()
+    tol = 1e-3 * want.abs().clamp_min(1.0) + 2e-3       # fp16 rounding of the result + summation order
+    assert bool((err <= tol).all()), float(err.max())
+    if M > 4096:                                          # the last row tile (row tail) too
+        tail = slice(M - 300, M)
+        want = _ref(x[tail], w, b, None if r is None else r[tail], relu)
+        assert bool(((out[tail].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+
+
+def test_tile_gemm_rejects_unsupported_k():
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.utils.lib import BevopsError, NOT_SUPPORTED
+    x = torch.randn(64, 12).half().cuda()
+    w = torch.randn(16, 12).half().cuda()
+    with pytest.raises(BevopsError) as e:
+        bev.tile_gemm(x, w)
+    assert e.value.status == NOT_SUPPORTED
+
+
+def test_dense_auto_measures_once_and_matches():
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.functions import linear as L
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 40000, 256, 512
+    x = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    b = torch.randn(N, generator=g).half().cuda()
+    r = torch.randn(M, N, generator=g).half().cuda()
+    n_log = len(L.DENSE_LOG)
+    y1 = bev.dense_auto(x, w, b, r, False)
+    y2 = bev.dense_auto(x, w, b, r, False)
+    assert len(L.DENSE_LOG) == n_log + 1                 # one measurement for the problem
+    key, times = L.DENSE_LOG[-1]
+    assert {"tsgemm", "tile", "blaslt"} <= set(times) and "torch" not in times   # addmm has no identity term
+    assert L._DENSE_CHOICE[key] == min(times, key=times.get)
+    assert torch.equal(y1, y2)
+    want = _ref(x[:2048], w, b, r[:2048], False)
+    assert bool(((y1[:2048].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+    y3 = bev.dense_auto(x, w, b, None, True)             # no identity: the framework path is a candidate too
+    assert "torch" in L.DENSE_LOG[-1][1]
+    want = _ref(x[:2048], w, b, None, True)
+    assert bool(((y3[:2048].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())

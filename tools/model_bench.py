@@ -16,10 +16,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
 
 
-def run(name, frames, dtype, graph=False):
+def run(name, frames, dtype, graph=False, int8=False):
     dev = torch.device("cuda")
-    model = B.BEVFormer(name).to(dev, dtype)
-    runner = B.FrameRunner(model, dev, dtype, graph=graph)
+    if int8:    # the PTQ build of bench.py (base only): int8 plugin sites + LinearQ / Conv2dQ dense layers
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        runner = bench.ModelFrames(dev, "int8", 1, 0, None, None, graph=graph).runner
+    else:
+        model = B.BEVFormer(name).to(dev, dtype)
+        runner = B.FrameRunner(model, dev, dtype, graph=graph)
     H, W = B.CONFIGS[name]["image"]
     l2i = G.synthetic_lidar2img((H, W)).to(dev)
     g = torch.Generator().manual_seed(0)
@@ -35,7 +40,7 @@ def run(name, frames, dtype, graph=False):
         ts.append((time.perf_counter() - t0) * 1e3)
     core = ts[1:-1]
     ms = sum(core) / len(core)
-    return dict(model=name, dtype=str(dtype)[6:], graph=graph, frames=frames, ms_per_frame=round(ms, 3),
+    return dict(model=name, dtype="int8 build" if int8 else str(dtype)[6:], graph=graph, frames=frames, ms_per_frame=round(ms, 3),
                 fps=round(1000.0 / ms, 2), first_frame_ms=round(ts[0], 1))
 
 
@@ -45,6 +50,7 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--int8", action="store_true", help="the INT8 (PTQ) build of the base model, as bench.py makes it")
     ap.add_argument("--conv-variant", type=int, default=0, help="bevops_conv3x3_c32_set_variant (A/B)")
     ap.add_argument("--mdconv-variant", type=int, default=0, help="bevops_mdconv_set_variant (A/B)")
     a = ap.parse_args()
@@ -54,4 +60,4 @@ if __name__ == "__main__":
         load_library().bevops_mdconv_set_variant(a.mdconv_variant)
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
-        print(json.dumps(run(m, a.frames, dt, a.graph)), flush=True)
+        print(json.dumps(run(m, a.frames, dt, a.graph, a.int8)), flush=True)

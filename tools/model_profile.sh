@@ -1,9 +1,9 @@
 #!/bin/bash
 # Kernel-level breakdown of one steady-state frame of the re-hosted model (eager, so every kernel
-# has its own name).  usage: tools/model_profile.sh <tag> [model]
-TAG=$1; MODEL=${2:-base}
+# has its own name).  usage: tools/model_profile.sh <tag> [model] [--int8]
+TAG=$1; MODEL=${2:-base}; EXTRA=$3
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o m -- python $GRAFT_REPO_ROOT/tools/model_bench.py $MODEL --frames 6 > $OUT/run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o m -- python $GRAFT_REPO_ROOT/tools/model_bench.py $MODEL --frames 6 $EXTRA > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 f = glob.glob("$OUT/prof/**/*kernel_trace.csv", recursive=True)[0]
@@ -20,6 +20,6 @@ for r in fr:
     agg[n][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(v[1] for v in agg.values())
 print(f"frame span {span:.2f} ms, kernels {len(fr)}, busy {tot/1e3:.2f} ms")
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f"{t/1e3:8.3f} ms {100*t/tot:5.1f}%  x{c:<4d} {n}")
 PY
