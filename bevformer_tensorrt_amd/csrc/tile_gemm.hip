@@ -60,6 +60,9 @@ __device__ __forceinline__ unsigned quant4(unsigned h01, unsigned h23, float r) 
          __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x04000c0cu);
 }
 
+__device__ __forceinline__ int sum_bits(float v) { return __float_as_int(v); }
+__device__ __forceinline__ int sum_bits(int v) { return v; }
+
 __device__ __forceinline__ uint4 quant16(const uint4 &lo, const uint4 &hi, float r) {
   return make_uint4(quant4(lo.x, lo.y, r), quant4(lo.z, lo.w, r), quant4(hi.x, hi.y, r), quant4(hi.z, hi.w, r));
 }
@@ -70,6 +73,7 @@ struct TileArgs {
   void *out;
   float inv_sa, s_aw, inv_s_out;
   int M, N, K, relu, tiles_n, tiles_total;
+  int conv_cin, conv_h, conv_w;     // conv_cin > 0: implicit 3x3 / stride 1 / pad 1 convolution over [B, H, W, Cin] rows
 };
 
 template <int MODE, bool OUT8>
@@ -98,11 +102,36 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
   const int nk = (K + kStepK - 1) / kStepK;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void *>(p.a), 0, (unsigned)((size_t)M * K * kAB), 0x00020000);
+      const_cast<void *>(p.a), 0, (unsigned)((size_t)M * (p.conv_cin > 0 ? p.conv_cin : K) * kAB), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void *>(p.w), 0, (unsigned)((size_t)N * K * kWB), 0x00020000);
-  const unsigned a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * K + kce) * kAB) : kOob;
-  const unsigned a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
+  // conv mode (implicit GEMM): output row m is pixel (b, y, x); its k-values are [tap 9][Cin] with tap (dy, dx)
+  // read from pixel (y + dy - 1, x + dx - 1) of the same image, zero outside it.  A step never straddles a tap
+  // (Cin % 32 == 0, host check): per step the tap moves the row's base address by a block-uniform delta and
+  // a per-row validity bit decides between that address and the beyond-the-buffer one.
+  const int cin = p.conv_cin;
+  const bool conv = cin > 0;
+  const int arow = conv ? cin : K;             // k-values per activation row in memory
+  unsigned a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * arow + kce) * kAB) : kOob;
+  unsigned a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * arow + kce) * kAB) : kOob;
+  unsigned tapmask0 = 0, tapmask1 = 0;
+  if (conv) {
+    auto mask_of = [&](int m) {
+      if (m >= M) return 0u;
+      const int pix = m % (p.conv_h * p.conv_w);
+      const int y = pix / p.conv_w, x = pix - y * p.conv_w;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        mk |= (yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w) ? (1u << t) : 0u;
+      }
+      return mk;
+    };
+    tapmask0 = mask_of(m0 + r0);
+    tapmask1 = mask_of(m0 + r1);
+  }
+  int g_tap = 0, g_c = 0;                      // conv mode: the (tap, channel) position of the NEXT gload
   const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
   const unsigned w_off1 = n0 + r1 < N ? (unsigned)(((size_t)(n0 + r1) * K + kce) * kWB) : kOob;
   uint4 ra0[kAV], ra1[kAV], rb0, rb1;
@@ -112,10 +141,23 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   auto gload = [&](int kt) {
     const int ks = kt * kStepK;
     const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
+    if (conv) {                      // (block-uniform branch)
+      const int delta = ((g_tap / 3 - 1) * p.conv_w + (g_tap % 3 - 1)) * cin * kAB;
+      const unsigned v0 = (tapmask0 >> g_tap) & 1u ? a_off0 + (unsigned)delta : kOob;
+      const unsigned v1 = (tapmask1 >> g_tap) & 1u ? a_off1 + (unsigned)delta : kOob;
 #pragma unroll
-    for (int h = 0; h < kAV; ++h) {
-      ra0[h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
-      ra1[h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+      for (int h = 0; h < kAV; ++h) {
+        ra0[h] = bload(rs_a, v0 + 16u * h, g_c * kAB);
+        ra1[h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
+      }
+      g_c += kStepK;
+      if (g_c >= cin) { g_c = 0; ++g_tap; }
+    } else {
+#pragma unroll
+      for (int h = 0; h < kAV; ++h) {
+        ra0[h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
+        ra1[h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+      }
     }
     rb0 = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
     rb1 = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
@@ -209,8 +251,8 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<i32x4_t *>(stage + (lane & 31) * kEpiStride + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
-            i32x4_t{__builtin_bit_cast(int, acc[i][j][4 * g]), __builtin_bit_cast(int, acc[i][j][4 * g + 1]),
-                    __builtin_bit_cast(int, acc[i][j][4 * g + 2]), __builtin_bit_cast(int, acc[i][j][4 * g + 3])};
+            i32x4_t{sum_bits(acc[i][j][4 * g]), sum_bits(acc[i][j][4 * g + 1]), sum_bits(acc[i][j][4 * g + 2]),
+                    sum_bits(acc[i][j][4 * g + 3])};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -224,8 +266,9 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if constexpr (MODE == kF16) {
-          v[c] = __builtin_bit_cast(float, lo[c]) + bs[c];
-          v[4 + c] = __builtin_bit_cast(float, hi[c]) + bs[4 + c];
+          const int l = lo[c], h = hi[c];          // (element reads first: a bit cast of a vector ELEMENT expression reads element 0)
+          v[c] = __int_as_float(l) + bs[c];
+          v[4 + c] = __int_as_float(h) + bs[4 + c];
         } else {
           v[c] = (float)lo[c] * sc[c] + bs[c];
           v[4 + c] = (float)hi[c] * sc[4 + c] + bs[4 + c];
@@ -280,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 template <int MODE>
 int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w_scales, float scale_w,
                      const void *bias, const void *residual, int out_dtype, void *out, float scale_out, long long M,
-                     int N, int K, int relu, void *stream) {
+                     int N, int K, int relu, void *stream, int conv_cin = 0, int conv_h = 0, int conv_w = 0) {
   if (!a || !w || !out || M < 0 || N <= 0 || K <= 0) return BEVOPS_BAD_PARAM;
   if (MODE != kF16 && (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f)))) return BEVOPS_BAD_PARAM;
   constexpr int kChunk = MODE == kF16 ? 8 : 16;   // k-values a staging thread handles per step
@@ -300,6 +343,7 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   p.s_aw = MODE == kF16 ? 1.f : (w_scales ? scale_a : scale_a * scale_w);
   p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
   p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
+  p.conv_cin = conv_cin; p.conv_h = conv_h; p.conv_w = conv_w;
   p.tiles_n = (N + kTN - 1) / kTN;
   const long long tiles = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
@@ -333,4 +377,12 @@ extern "C" int bevops_linear_int8_fused(const void *x_f16, float scale_a, const 
 extern "C" int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                                     void *out, long long M, int N, int K, int relu, void *stream) {
   return launch_tile_gemm<kF16>(x, 1.f, weight, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f, M, N, K, relu, stream);
+}
+
+extern "C" int bevops_conv3x3_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
+                                       void *out, int B, int H, int W, int Cin, int Cout, int relu, void *stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BEVOPS_BAD_PARAM;
+  if (Cin % 32 != 0) return BEVOPS_NOT_SUPPORTED;      // a 32-value k-step must not straddle two taps
+  return launch_tile_gemm<kF16>(x, 1.f, weight_taps, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f,
+                                (long long)B * H * W, Cout, 9 * Cin, relu, stream, Cin, H, W);
 }

@@ -1,0 +1,89 @@
+"""Plain 3x3 convolutions of the channels-last backbone / neck (ResNet stages without DCN:
+det2trt/models/backbones/resnet.py:106-260; FPN output convolutions: third_party/bev_mmdet3d/models/necks/
+fpn.py:140-155) on the tiled MFMA GEMM skeleton as an implicit GEMM (bevops_conv3x3_tile_f16, csrc/tile_gemm.hip):
+no column buffer, shift + identity + ReLU in the epilogue.  Not a reference plugin (TensorRT owns these layers
+there).  `conv3x3_auto` measures it once per problem against the library convolution + epilogue pass and keeps
+the faster one (BLOCKING on its first call per shape, outside stream capture)."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from ..utils import lib as _lib
+from .modulated_deformable_conv2d import bias_act_nhwc_
+
+_PACKED = {}          # id(weight) -> (version key, weight ref, taps-major copy)
+_CHOICE = {}          # problem -> "tile" | "library"
+CONV_LOG = []         # (problem, {name: us})
+
+
+def pack_taps(weight):
+    """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] contiguous (k = tap-major, channels innermost), cached per weight."""
+    key = (weight._version, weight.data_ptr(), weight.dtype, str(weight.device))
+    hit = _PACKED.get(id(weight))
+    if hit is None or hit[0] != key or hit[1] is not weight:
+        hit = (key, weight, weight.detach().permute(0, 2, 3, 1).contiguous())
+        _PACKED[id(weight)] = hit
+    return hit[2]
+
+
+def conv3x3_nhwc(x, weight, bias=None, relu=False, residual=None):
+    """x [B, Cin, H, W] channels-last fp16, weight [Cout, Cin, 3, 3] -> act(conv2d(x, weight, stride 1, pad 1) +
+    bias + residual) [B, Cout, H, W] channels-last.  Cin % 32 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and weight.shape[2:] == (3, 3)
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError("weight does not match the input channels")
+    wt = pack_taps(weight)
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype
+        assert residual.is_contiguous(memory_format=torch.channels_last)
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_conv3x3_tile_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                            B, H, W, Cin, Cout, int(bool(relu)), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_conv3x3_tile_f16")
+    return out
+
+
+def _library(x, weight, bias, relu, residual):
+    y = F.conv2d(x, weight, None, 1, 1)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    return bias_act_nhwc_(y, bias, residual, relu)
+
+
+def conv3x3_auto(x, weight, bias=None, relu=False, residual=None):
+    """conv3x3_nhwc or the library convolution + one epilogue pass, whichever measured faster for the problem."""
+    B, Cin, H, W = x.shape
+    key = (str(x.device), B, H, W, Cin, weight.shape[0], bool(relu), residual is not None)
+    name = _CHOICE.get(key)
+    if name is None:
+        if Cin % 32 != 0:
+            name = _CHOICE[key] = "library"
+        elif torch.cuda.is_current_stream_capturing() or os.environ.get("BEVOPS_DENSE_TUNE", "1") == "0":
+            name = "library"
+        else:
+            times = {}
+            for cand, fn in (("tile", conv3x3_nhwc), ("library", _library)):
+                for _ in range(2):
+                    fn(x, weight, bias, relu, residual)
+                best = float("inf")
+                for _ in range(3):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(3):
+                        fn(x, weight, bias, relu, residual)
+                    b.record()
+                    b.synchronize()
+                    best = min(best, a.elapsed_time(b) * 1e3 / 3)
+                times[cand] = round(best, 1)
+            CONV_LOG.append((key, times))
+            name = _CHOICE[key] = min(times, key=times.get)
+    return (conv3x3_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual)

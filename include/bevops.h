@@ -368,6 +368,13 @@ int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, 
  * next to bevops_tsgemm_f16 and bevops_linear_bias_act. */
 int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                          void *out, long long M, int N, int K, int relu, void *stream);
+/* 3x3 / stride 1 / pad 1 convolution on channels-last fp16 activations as an implicit GEMM on the same tiled
+ * skeleton (no column buffer): x [B, H, W, Cin], weight_taps [Cout][3][3][Cin] (= weight.permute(0, 2, 3, 1)),
+ * out [B, H, W, Cout] = act(conv(x) + bias[n] + residual); bias / residual fp16, optional.  Cin % 32 == 0.
+ * The plain 3x3 convolutions of the re-hosted backbone / neck (ResNet stages without DCN: resnet.py:106-260; FPN
+ * output convolutions: necks/fpn.py:140-155) with their shift and ReLU in the epilogue. */
+int bevops_conv3x3_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
+                            void *out, int B, int H, int W, int Cin, int Cout, int relu, void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

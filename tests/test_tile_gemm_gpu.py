@@ -74,3 +74,50 @@ def test_dense_auto_measures_once_and_matches():
     assert "torch" in L.DENSE_LOG[-1][1]
     want = _ref(x[:2048], w, b, None, True)
     assert bool(((y3[:2048].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout", [(2, 64, 37, 53, 64), (1, 128, 16, 20, 128), (6, 64, 232, 400, 64),
+                                         (3, 32, 5, 3, 20), (1, 256, 29, 50, 256), (1, 96, 1, 1, 8)])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_res_relu"])
+def test_conv3x3_tile_matches_fp32_conv(B, C, H, W, Cout, epi):
+    """bevops_conv3x3_tile_f16 (implicit GEMM: taps as k, zero padding by the buffer range check) vs
+    F.conv2d in fp32 on the same fp16 operands; image borders, single-pixel images, Cout not a multiple of 8."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(B * C + H * W + Cout)
+    x = torch.randn(B, C, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).half().cuda()
+    b = torch.randn(Cout, generator=g).half().cuda() if epi != "plain" else None
+    r = torch.randn(B, Cout, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last) \
+        if "res" in epi else None
+    relu = "relu" in epi
+    nb = min(B, 2)
+    out = bev.conv3x3_nhwc(x, w, b, relu, r)
+    assert out.shape == (B, Cout, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    want = torch.nn.functional.conv2d(x[:nb].float(), w.float(), None if b is None else b.float(), 1, 1)
+    if r is not None:
+        want = want + r[:nb].float()
+    if relu:
+        want = torch.relu(want)
+    err = (out[:nb].float() - want).abs()
+    assert bool((err <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all()), float(err.max())
+    if B > nb:     # the last image (row tail of the pixel tiling)
+        want = torch.nn.functional.conv2d(x[-1:].float(), w.float(), None if b is None else b.float(), 1, 1)
+        if r is not None:
+            want = want + r[-1:].float()
+        if relu:
+            want = torch.relu(want)
+        assert bool(((out[-1:].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+
+
+def test_conv3x3_auto_picks_a_measured_winner():
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.functions import conv as Cv
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 128, 116, 200, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).half().cuda()
+    b = torch.randn(128, generator=g).half().cuda()
+    y = bev.conv3x3_auto(x, w, b, True)
+    key, times = Cv.CONV_LOG[-1]
+    assert set(times) == {"tile", "library"} and Cv._CHOICE[key] == min(times, key=times.get)
+    want = torch.relu(torch.nn.functional.conv2d(x[:1].float(), w.float(), b.float(), 1, 1))
+    assert bool(((y[:1].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
