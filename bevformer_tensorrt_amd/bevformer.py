@@ -154,6 +154,11 @@ def _layer_norm(ops, norm, x):
 def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
     s = conv.stride[0]
     if s > 1:
+        strided = getattr(ops, "conv_nhwc", None)
+        if strided is not None and _R3["enabled"] and _FUSED_LINEAR["enabled"] and x.dtype == torch.float16 and x.is_cuda \
+                and not hasattr(conv, "lin") and conv.in_channels % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+            # the stride goes into the GEMM's row addressing: no sub-sampled copy of the activation
+            return strided(x, conv.weight, conv.bias, relu, residual, s)
         x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
     if hasattr(conv, "lin"):     # quantization.Conv2dQ: the LinearQ over the [N*H*W, C] rows (all three phases)
@@ -178,11 +183,12 @@ def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
 def _conv_nhwc(ops, x, conv, relu, residual=None):
     auto = getattr(ops, "conv3x3_auto", None)
     if auto is not None and _R3["enabled"] and _FUSED_LINEAR["enabled"] and x.dtype == torch.float16 and x.is_cuda \
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 \
-            and conv.dilation == (1, 1) and conv.in_channels % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+            and conv.kernel_size == (3, 3) and conv.stride[0] == conv.stride[1] and conv.padding == (1, 1) \
+            and conv.groups == 1 and conv.dilation == (1, 1) and conv.in_channels % 32 == 0 \
+            and x.is_contiguous(memory_format=torch.channels_last):
         # implicit GEMM on the tiled MFMA skeleton with the shift / ReLU in its epilogue, or the library
         # convolution + one epilogue pass: measured once per problem
-        return auto(x, conv.weight, conv.bias, relu, residual)
+        return auto(x, conv.weight, conv.bias, relu, residual, conv.stride[0])
     y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)

@@ -66,10 +66,11 @@ const Entry kTable[] = {
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},
     {"bevops_quantize_rows", (void *)&bevops_quantize_rows},
+    {"bevops_dequantize_rows", (void *)&bevops_dequantize_rows},
     {"bevops_linear_int8", (void *)&bevops_linear_int8},
     {"bevops_linear_int8_fused", (void *)&bevops_linear_int8_fused},
     {"bevops_tile_gemm_f16", (void *)&bevops_tile_gemm_f16},
-    {"bevops_conv3x3_tile_f16", (void *)&bevops_conv3x3_tile_f16},
+    {"bevops_conv_tile_f16", (void *)&bevops_conv_tile_f16},
     {"bevops_image_normalize_pad", (void *)&bevops_image_normalize_pad},
     {"bevops_msda_packed_size", (void *)&bevops_msda_packed_size},
     {"bevops_msda_pack_value", (void *)&bevops_msda_pack_value},

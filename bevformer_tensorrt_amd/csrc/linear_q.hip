@@ -28,6 +28,24 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const __half *__rest
   reinterpret_cast<uint2 *>(q)[i] = *reinterpret_cast<const uint2 *>(r);
 }
 
+// int8 -> fp16 with one per-tensor scale: out = fp16(q * scale) (product in fp32, one rounding) -- what
+// `q.to(fp16) * scale` computes, in one pass instead of a conversion and a scaling pass
+__global__ __launch_bounds__(256) void dequantize_rows_kernel(const int8_t *__restrict__ q, __half *__restrict__ out,
+                                                              size_t nvec, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const uint2 v = reinterpret_cast<const uint2 *>(q)[i];
+  float f[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[k] = (float)(int8_t)((v.x >> (8 * k)) & 0xffu) * scale;
+    f[4 + k] = (float)(int8_t)((v.y >> (8 * k)) & 0xffu) * scale;
+  }
+  uint4 o;
+  o.x = pack_h2(f[0], f[1]); o.y = pack_h2(f[2], f[3]); o.z = pack_h2(f[4], f[5]); o.w = pack_h2(f[6], f[7]);
+  reinterpret_cast<uint4 *>(out)[i] = o;
+}
+
 }  // namespace
 }  // namespace bevops
 
@@ -44,3 +62,14 @@ extern "C" int bevops_quantize_rows(int dtype, const void *x, void *q, size_t co
   return launch_status();
 }
 
+
+extern "C" int bevops_dequantize_rows(int dtype, const void *q, void *out, size_t count, float scale, void *stream) {
+  if (!q || !out) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16 || count % 8 != 0 || !aligned16(out) || (reinterpret_cast<uintptr_t>(q) & 7u))
+    return BEVOPS_NOT_SUPPORTED;
+  if (count == 0) return BEVOPS_SUCCESS;
+  const size_t nvec = count / 8;
+  hipLaunchKernelGGL(dequantize_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const int8_t *)q, (__half *)out, nvec, scale);
+  return launch_status();
+}

@@ -8,7 +8,8 @@
 // 8 700 .. 556 800 pixel or query rows, K and N are 64 .. 2 048): what matters is that the activation rows
 // stream from HBM once at full rate while enough independent work is resident to cover the latency.
 //
-// MI355X mapping.  128 x 128 output tiles, 256 threads = 4 waves of 64 x 64 (2 x 2 MFMA blocks of 32 x 32),
+// MI355X mapping.  128 x 128 output tiles (128 x 64 for layers with N <= 64), 256 threads = 4 waves of 64 x 64
+// (2 x 2 MFMA blocks of 32 x 32; 64 x 32 in the narrow flavour),
 // 64 BYTES of k per step and row in every flavour (64 int8 / 32 fp16 values: the LDS images, the 16-byte
 // fragment reads and the staging loads are the same code).  Operands are register-staged ONE step ahead
 // (buffer loads: rows past M / N read as zero, no branches) and written into the OTHER of two LDS images while
@@ -26,6 +27,10 @@
 // through LDS per wave (32 rows x 64 columns at a time) so that a thread owns 8 consecutive columns of a row:
 // scale, bias, identity, ReLU in fp32 on 16-byte accesses, ONE rounding to fp16 (or the requantisation to int8
 // for a following int8 layer).
+// Convolution mode (bevops_conv_tile_f16): the same kernel as an implicit GEMM over channels-last activations --
+// output row m is pixel (b, yo, xo), its k-values are [tap][Cin]; a tap moves the row's base address by a
+// block-uniform delta and a per-row validity bit (zero padding) selects the beyond-the-buffer address; a stride
+// only changes the row -> pixel map.  No column buffer, no sub-sampled copy.
 #include <type_traits>
 
 #include "common.h"
@@ -40,7 +45,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 enum { kS8 = 0, kF16Q = 1, kF16 = 2 };
 
-constexpr int kTM = 128, kTN = 128, kTKB = 64, kTLd = kTKB + 16;  // 64 bytes of k per row and step; +16: conflict-free b128 reads
+constexpr int kTM = 128, kTKB = 64, kTLd = kTKB + 16;  // 64 bytes of k per row and step; +16: conflict-free b128 reads
 constexpr float kQMagic = 12582912.f;          // 1.5 * 2^23: bits 0x4B400000, low byte 0
 constexpr int kQMagicBits = 0x4B400000;
 constexpr int kEpiStride = 64 * 4 + 16;        // staging row: 64 x 4 bytes + pad
@@ -73,12 +78,18 @@ struct TileArgs {
   void *out;
   float inv_sa, s_aw, inv_s_out;
   int M, N, K, relu, tiles_n, tiles_total;
-  int conv_cin, conv_h, conv_w;     // conv_cin > 0: implicit 3x3 / stride 1 / pad 1 convolution over [B, H, W, Cin] rows
+  unsigned a_bytes;                 // size of the activation buffer (range check of its loads)
+  // conv_cin > 0: implicit convolution over channels-last [B, Hin, Win, Cin] activations: kernel ks x ks
+  // (1 or 3), pad ks / 2, stride `conv_s`, output rows [B, Hout, Wout]
+  int conv_cin, conv_hin, conv_win, conv_hout, conv_wout, conv_s, conv_ks;
 };
 
-template <int MODE, bool OUT8>
+// NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
+// matrix work on columns that do not exist)
+template <int MODE, bool OUT8, int NI>
 __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + kTN) * kTLd];   // 40 KB: [image][A rows | W rows][80]
+  constexpr int kTN = 64 * NI;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + 128) * kTLd];   // 40 KB: [image][A rows | W rows][80]
   constexpr int kAB = MODE == kS8 ? 1 : 2;     // bytes per activation element in memory
   constexpr int kWB = MODE == kF16 ? 2 : 1;    // bytes per weight element
   constexpr int kAV = MODE == kF16Q ? 2 : 1;   // 16-byte loads per activation row and step
@@ -93,16 +104,16 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   const int m0 = (logical / p.tiles_n) * kTM, n0 = (logical % p.tiles_n) * kTN;
   const int r0 = tid >> 2, r1 = r0 + 64;       // 128 rows x 4 chunks of 16 bytes of k
   const int kce = (tid & 3) * (kStepK / 4);    // this thread's first k-value inside a step
-  typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[2][2];
+  typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
   const int nk = (K + kStepK - 1) / kStepK;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void *>(p.a), 0, (unsigned)((size_t)M * (p.conv_cin > 0 ? p.conv_cin : K) * kAB), 0x00020000);
+      const_cast<void *>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void *>(p.w), 0, (unsigned)((size_t)N * K * kWB), 0x00020000);
   // conv mode (implicit GEMM): output row m is pixel (b, y, x); its k-values are [tap 9][Cin] with tap (dy, dx)
@@ -111,29 +122,31 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   // a per-row validity bit decides between that address and the beyond-the-buffer one.
   const int cin = p.conv_cin;
   const bool conv = cin > 0;
-  const int arow = conv ? cin : K;             // k-values per activation row in memory
-  unsigned a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * arow + kce) * kAB) : kOob;
-  unsigned a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * arow + kce) * kAB) : kOob;
-  unsigned tapmask0 = 0, tapmask1 = 0;
+  const int taps = p.conv_ks * p.conv_ks, pad = p.conv_ks >> 1;
+  unsigned a_off0, a_off1, tapmask0 = 0, tapmask1 = 0;
   if (conv) {
-    auto mask_of = [&](int m) {
-      if (m >= M) return 0u;
-      const int pix = m % (p.conv_h * p.conv_w);
-      const int y = pix / p.conv_w, x = pix - y * p.conv_w;
-      unsigned mk = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        mk |= (yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w) ? (1u << t) : 0u;
+    auto place = [&](int m, unsigned &off, unsigned &mk) {
+      off = kOob; mk = 0;
+      if (m >= M) return;
+      const int per = p.conv_hout * p.conv_wout;
+      const int b = m / per, pix = m - b * per;
+      const int yo = pix / p.conv_wout, xo = pix - yo * p.conv_wout;
+      const int y = yo * p.conv_s, x = xo * p.conv_s;           // centre tap in the input image
+      off = (unsigned)((((size_t)b * p.conv_hin + y) * p.conv_win + x) * cin + kce) * kAB;
+      for (int t = 0; t < taps; ++t) {
+        const int yy = y + t / p.conv_ks - pad, xx = x + t % p.conv_ks - pad;
+        mk |= (yy >= 0 && yy < p.conv_hin && xx >= 0 && xx < p.conv_win) ? (1u << t) : 0u;
       }
-      return mk;
     };
-    tapmask0 = mask_of(m0 + r0);
-    tapmask1 = mask_of(m0 + r1);
+    place(m0 + r0, a_off0, tapmask0);
+    place(m0 + r1, a_off1, tapmask1);
+  } else {
+    a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * K + kce) * kAB) : kOob;
+    a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
   }
   int g_tap = 0, g_c = 0;                      // conv mode: the (tap, channel) position of the NEXT gload
   const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
-  const unsigned w_off1 = n0 + r1 < N ? (unsigned)(((size_t)(n0 + r1) * K + kce) * kWB) : kOob;
+  const unsigned w_off1 = (NI == 2 && n0 + r1 < N) ? (unsigned)(((size_t)(n0 + r1) * K + kce) * kWB) : kOob;
   uint4 ra0[kAV], ra1[kAV], rb0, rb1;
   auto bload = [](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, int soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
     const int ks = kt * kStepK;
     const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
     if (conv) {                      // (block-uniform branch)
-      const int delta = ((g_tap / 3 - 1) * p.conv_w + (g_tap % 3 - 1)) * cin * kAB;
+      const int delta = ((g_tap / p.conv_ks - pad) * p.conv_win + (g_tap % p.conv_ks - pad)) * cin * kAB;
       const unsigned v0 = (tapmask0 >> g_tap) & 1u ? a_off0 + (unsigned)delta : kOob;
       const unsigned v1 = (tapmask1 >> g_tap) & 1u ? a_off1 + (unsigned)delta : kOob;
 #pragma unroll
@@ -160,11 +173,11 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
       }
     }
     rb0 = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
-    rb1 = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
+    if constexpr (NI == 2) rb1 = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
   };
   const int lchunk = (tid & 3) * 16;           // byte position of the thread's chunk in an LDS row
   auto lstore = [&](int buf) {
-    char *As = smem + buf * (kTM + kTN) * kTLd, *Ws = As + kTM * kTLd;
+    char *As = smem + buf * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
     if constexpr (MODE == kF16Q) {
       *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[0], ra0[1], p.inv_sa);
       *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[0], ra1[1], p.inv_sa);
@@ -173,21 +186,23 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
       *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[0];
     }
     *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0;
-    *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1;
+    if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1;
   };
   // ---- epilogue roles, fixed before the loop so that the identity rows can be requested early
-  const int c8 = lane & 7;                       // this lane's 8-column chunk of the wave's 64 columns
-  const int ncol = n0 + wn * 64 + c8 * 8;
+  constexpr int kCH = 4 * NI;                    // 8-column chunks per row of the wave's 32 NI columns
+  constexpr int kIT = kCH / 2;                   // read-back passes over the wave's 32 staged rows (64 / kCH rows each)
+  const int c8 = lane & (kCH - 1);               // this lane's 8-column chunk
+  const int ncol = n0 + wn * 32 * NI + c8 * 8;
   const bool col_ok = ncol < N;
   const bool vec = (N & 7) == 0;                 // rows 16-byte aligned and the chunk all in or all out; else per element
   const __half *res = static_cast<const __half *>(p.res);
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__half *>(res), 0, res ? (unsigned)((size_t)M * N * 2) : 0u, 0x00020000);
-  uint4 rres[2][4];
+  uint4 rres[2][kIT];
   auto res_request = [&](int j) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int m = m0 + wm * 64 + j * 32 + it * 8 + (lane >> 3);
+    for (int it = 0; it < kIT; ++it) {
+      const int m = m0 + wm * 64 + j * 32 + it * (64 / kCH) + lane / kCH;
       rres[j][it] = bload(rs_r, (m < M && col_ok) ? (unsigned)(((size_t)m * N + ncol) * 2) : kOob, 0);
     }
   };
@@ -202,21 +217,21 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
     // image (kt + 1) & 1 was last read in step kt - 1, which every wave left through the barrier below
     if (kt + 1 < nk) lstore((kt + 1) & 1);
     if (kt + 2 < nk) gload(kt + 2);
-    const char *As = smem + (kt & 1) * (kTM + kTN) * kTLd, *Ws = As + kTM * kTLd;
+    const char *As = smem + (kt & 1) * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 32 + (lane >> 5) * 16;
       // MFMA operand A = the weight rows (output columns n), B = the activation rows (m): a lane's 4
       // consecutive accumulator rows are then 4 consecutive n of one output row m
-      i32x4_t a[2], b[2];
+      i32x4_t a[NI], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const i32x4_t *>(Ws + (wn * 64 + i * 32 + (lane & 31)) * kTLd + kk);
+      for (int i = 0; i < NI; ++i)
+        a[i] = *reinterpret_cast<const i32x4_t *>(Ws + (wn * 32 * NI + i * 32 + (lane & 31)) * kTLd + kk);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         b[j] = *reinterpret_cast<const i32x4_t *>(As + (wm * 64 + j * 32 + (lane & 31)) * kTLd + kk);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (MODE == kF16)
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
     }
     __syncthreads();
   }
-  // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*64 + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*64 + j*32 + (lane & 31)
+  // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*32*NI + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*64 + j*32 + (lane & 31)
   // (the barrier that ended the last step also freed both LDS images)
   if (res_vec) res_request(1);
   char *stage = smem + wave * 32 * kEpiStride;
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<i32x4_t *>(stage + (lane & 31) * kEpiStride + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
@@ -256,8 +271,8 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + (lane >> 3);
+    for (int it = 0; it < kIT; ++it) {
+      const int row = it * (64 / kCH) + lane / kCH;
       const int m = m0 + wm * 64 + j * 32 + row;
       const i32x4_t lo = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32);
       const i32x4_t hi = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32 + 16);
@@ -320,10 +335,12 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   }
 }
 
+struct ConvGeom { int cin = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, ks = 1; size_t in_elems = 0; };
+
 template <int MODE>
 int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w_scales, float scale_w,
                      const void *bias, const void *residual, int out_dtype, void *out, float scale_out, long long M,
-                     int N, int K, int relu, void *stream, int conv_cin = 0, int conv_h = 0, int conv_w = 0) {
+                     int N, int K, int relu, void *stream, const ConvGeom &cg = ConvGeom()) {
   if (!a || !w || !out || M < 0 || N <= 0 || K <= 0) return BEVOPS_BAD_PARAM;
   if (MODE != kF16 && (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f)))) return BEVOPS_BAD_PARAM;
   constexpr int kChunk = MODE == kF16 ? 8 : 16;   // k-values a staging thread handles per step
@@ -333,7 +350,9 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   if (out_dtype == BEVOPS_I8 && (MODE == kF16 || !(scale_out > 0.f))) return BEVOPS_BAD_PARAM;
   if (out_dtype != BEVOPS_I8 && out_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
   // operands (and the identity) are addressed through 32-bit buffer offsets
-  if ((unsigned long long)M * K * (MODE == kS8 ? 1 : 2) >= kOob || (unsigned long long)N * K * (MODE == kF16 ? 2 : 1) >= kOob ||
+  const unsigned long long a_bytes = (cg.cin > 0 ? (unsigned long long)cg.in_elems : (unsigned long long)M * K) *
+                                     (MODE == kS8 ? 1 : 2);
+  if (a_bytes >= kOob || (unsigned long long)N * K * (MODE == kF16 ? 2 : 1) >= kOob ||
       (residual && (unsigned long long)M * N * 2 >= kOob))
     return BEVOPS_NOT_SUPPORTED;
   if (M == 0) return BEVOPS_SUCCESS;
@@ -343,15 +362,24 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   p.s_aw = MODE == kF16 ? 1.f : (w_scales ? scale_a : scale_a * scale_w);
   p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
   p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
-  p.conv_cin = conv_cin; p.conv_h = conv_h; p.conv_w = conv_w;
-  p.tiles_n = (N + kTN - 1) / kTN;
+  p.a_bytes = (unsigned)a_bytes;
+  p.conv_cin = cg.cin; p.conv_hin = cg.hin; p.conv_win = cg.win; p.conv_hout = cg.hout; p.conv_wout = cg.wout;
+  p.conv_s = cg.stride; p.conv_ks = cg.ks;
+  const bool narrow = N <= 64;                    // 64-column tiles: no matrix work on columns that do not exist
+  const int tn = narrow ? 64 : 128;
+  p.tiles_n = (N + tn - 1) / tn;
   const long long tiles = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
   p.tiles_total = (int)tiles;
   const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (out_dtype == BEVOPS_F16) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false>), grid, dim3(256), 0, st, p);
-  else if constexpr (MODE != kF16) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true>), grid, dim3(256), 0, st, p);
+  if (out_dtype == BEVOPS_F16) {
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2>), grid, dim3(256), 0, st, p);
+  } else if constexpr (MODE != kF16) {
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 2>), grid, dim3(256), 0, st, p);
+  }
   return launch_status();
 }
 
@@ -379,10 +407,17 @@ extern "C" int bevops_tile_gemm_f16(const void *x, const void *weight, const voi
   return launch_tile_gemm<kF16>(x, 1.f, weight, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f, M, N, K, relu, stream);
 }
 
-extern "C" int bevops_conv3x3_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
-                                       void *out, int B, int H, int W, int Cin, int Cout, int relu, void *stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BEVOPS_BAD_PARAM;
-  if (Cin % 32 != 0) return BEVOPS_NOT_SUPPORTED;      // a 32-value k-step must not straddle two taps
+extern "C" int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
+                                    void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                                    void *stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || stride <= 0) return BEVOPS_BAD_PARAM;
+  if ((ksize != 1 && ksize != 3) || Cin % 32 != 0) return BEVOPS_NOT_SUPPORTED;   // a 32-value k-step must not straddle two taps
+  ConvGeom cg;
+  cg.cin = Cin; cg.hin = H; cg.win = W; cg.stride = stride; cg.ks = ksize;
+  const int pad = ksize / 2;
+  cg.hout = (H + 2 * pad - ksize) / stride + 1;
+  cg.wout = (W + 2 * pad - ksize) / stride + 1;
+  cg.in_elems = (size_t)B * H * W * Cin;
   return launch_tile_gemm<kF16>(x, 1.f, weight_taps, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f,
-                                (long long)B * H * W, Cout, 9 * Cin, relu, stream, Cin, H, W);
+                                (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
 }

@@ -1,7 +1,8 @@
 """Plain 3x3 convolutions of the channels-last backbone / neck (ResNet stages without DCN:
 det2trt/models/backbones/resnet.py:106-260; FPN output convolutions: third_party/bev_mmdet3d/models/necks/
-fpn.py:140-155) on the tiled MFMA GEMM skeleton as an implicit GEMM (bevops_conv3x3_tile_f16, csrc/tile_gemm.hip):
-no column buffer, shift + identity + ReLU in the epilogue.  Not a reference plugin (TensorRT owns these layers
+fpn.py:140-155) and the stride-2 1x1 convolutions at the head of a ResNet stage on the tiled MFMA GEMM skeleton as
+an implicit GEMM (bevops_conv_tile_f16, csrc/tile_gemm.hip): no column buffer, no strided copy, shift + identity +
+ReLU in the epilogue.  Not a reference plugin (TensorRT owns these layers
 there).  `conv3x3_auto` measures it once per problem against the library convolution + epilogue pass and keeps
 the faster one (BLOCKING on its first call per shape, outside stream capture)."""
 import os
@@ -18,7 +19,7 @@ CONV_LOG = []         # (problem, {name: us})
 
 
 def pack_taps(weight):
-    """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] contiguous (k = tap-major, channels innermost), cached per weight."""
+    """[Cout, Cin, k, k] -> [Cout, k, k, Cin] contiguous (k = tap-major, channels innermost), cached per weight."""
     key = (weight._version, weight.data_ptr(), weight.dtype, str(weight.device))
     hit = _PACKED.get(id(weight))
     if hit is None or hit[0] != key or hit[1] is not weight:
@@ -27,17 +28,18 @@ def pack_taps(weight):
     return hit[2]
 
 
-def conv3x3_nhwc(x, weight, bias=None, relu=False, residual=None):
-    """x [B, Cin, H, W] channels-last fp16, weight [Cout, Cin, 3, 3] -> act(conv2d(x, weight, stride 1, pad 1) +
-    bias + residual) [B, Cout, H, W] channels-last.  Cin % 32 == 0."""
-    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and weight.shape[2:] == (3, 3)
+def conv_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
+    """x [B, Cin, H, W] channels-last fp16, weight [Cout, Cin, k, k] with k in {1, 3} -> act(conv2d(x, weight,
+    stride, pad k // 2) + bias + residual) [B, Cout, Hout, Wout] channels-last.  Cin % 32 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and weight.shape[2] == weight.shape[3]
     assert x.is_contiguous(memory_format=torch.channels_last)
     B, Cin, H, W = x.shape
-    Cout = weight.shape[0]
+    Cout, k = weight.shape[0], weight.shape[2]
     if weight.shape[1] != Cin:
         raise ValueError("weight does not match the input channels")
     wt = pack_taps(weight)
-    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == x.dtype
         assert residual.is_contiguous(memory_format=torch.channels_last)
@@ -45,24 +47,30 @@ def conv3x3_nhwc(x, weight, bias=None, relu=False, residual=None):
         bias = bias.to(torch.float16).contiguous()
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
-        st = handle.bevops_conv3x3_tile_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                            residual.data_ptr() if residual is not None else None, out.data_ptr(),
-                                            B, H, W, Cin, Cout, int(bool(relu)), _lib.current_stream_ptr(x.device))
-    _lib.check(st, "bevops_conv3x3_tile_f16")
+        st = handle.bevops_conv_tile_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                         B, H, W, Cin, Cout, k, int(stride), int(bool(relu)),
+                                         _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_conv_tile_f16")
     return out
 
 
-def _library(x, weight, bias, relu, residual):
-    y = F.conv2d(x, weight, None, 1, 1)
+def conv3x3_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
+    assert weight.shape[2:] == (3, 3)
+    return conv_nhwc(x, weight, bias, relu, residual, stride)
+
+
+def _library(x, weight, bias, relu, residual, stride=1):
+    y = F.conv2d(x, weight, None, stride, weight.shape[2] // 2)
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)
     return bias_act_nhwc_(y, bias, residual, relu)
 
 
-def conv3x3_auto(x, weight, bias=None, relu=False, residual=None):
-    """conv3x3_nhwc or the library convolution + one epilogue pass, whichever measured faster for the problem."""
+def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
+    """conv_nhwc or the library convolution + one epilogue pass, whichever measured faster for the problem."""
     B, Cin, H, W = x.shape
-    key = (str(x.device), B, H, W, Cin, weight.shape[0], bool(relu), residual is not None)
+    key = (str(x.device), B, H, W, Cin, weight.shape[0], weight.shape[2], stride, bool(relu), residual is not None)
     name = _CHOICE.get(key)
     if name is None:
         if Cin % 32 != 0:
@@ -71,19 +79,19 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None):
             name = "library"
         else:
             times = {}
-            for cand, fn in (("tile", conv3x3_nhwc), ("library", _library)):
+            for cand, fn in (("tile", conv_nhwc), ("library", _library)):
                 for _ in range(2):
-                    fn(x, weight, bias, relu, residual)
+                    fn(x, weight, bias, relu, residual, stride)
                 best = float("inf")
                 for _ in range(3):
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     for _ in range(3):
-                        fn(x, weight, bias, relu, residual)
+                        fn(x, weight, bias, relu, residual, stride)
                     b.record()
                     b.synchronize()
                     best = min(best, a.elapsed_time(b) * 1e3 / 3)
                 times[cand] = round(best, 1)
             CONV_LOG.append((key, times))
             name = _CHOICE[key] = min(times, key=times.get)
-    return (conv3x3_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual)
+    return (conv_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual, stride)

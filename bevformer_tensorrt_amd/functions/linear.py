@@ -113,6 +113,21 @@ def quantize_rows(x, scale, out=None):
     return out
 
 
+def dequantize_rows(q, scale):
+    """int8 tensor -> fp16, q * scale with the product in fp32 and one rounding (bevops_dequantize_rows)."""
+    assert q.is_cuda and q.dtype == torch.int8
+    q = q.contiguous()
+    if q.numel() % 8:
+        raise ValueError("element count must be a multiple of 8")
+    out = torch.empty(q.shape, dtype=torch.float16, device=q.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(q.device):
+        st = handle.bevops_dequantize_rows(_lib.F16, q.data_ptr(), out.data_ptr(), q.numel(), float(scale),
+                                           _lib.current_stream_ptr(q.device))
+    _lib.check(st, "bevops_dequantize_rows")
+    return out
+
+
 def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False, out_dtype=torch.float16,
                 scale_out=1.0):
     """INT8 GEMM with de-quantising epilogue: a_q [..., K] int8 (bevops_linear_int8) -- or the fp16 activation

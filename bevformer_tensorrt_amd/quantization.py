@@ -164,7 +164,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "conv3x3_auto", "image_normalize_pad")
+             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "image_normalize_pad")
 
     def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
         from . import functions as _f
@@ -209,6 +209,12 @@ class Int8PluginOps:
             return self.fp.quantize_rows(t.contiguous(), s), s
         return self.cal.quantize(t, s), s
 
+    def _dq(self, q, s, dtype):
+        """int8 result of a plugin -> the model's dtype: q * s, one pass when the operator set has the entry."""
+        if q.is_cuda and dtype == torch.float16 and q.numel() % 8 == 0 and hasattr(self.fp, "dequantize_rows"):
+            return self.fp.dequantize_rows(q, s)
+        return q.to(dtype) * s
+
     # ---- call sites
     def multi_scale_deformable_attn(self, value, shapes, ref, off, w):
         site = self._site("msda")
@@ -223,7 +229,7 @@ class Int8PluginOps:
         # reference points stay fp16: the <__half2> flavour (multiScaleDeformableAttnPlugin.cpp:118-125)
         out = self.fp.multi_scale_deformable_attn_int8(qv, shapes, ref.to(torch.float16).contiguous(),
                                                        qo.contiguous(), qw.contiguous(), sv, so, sw, s_out)
-        return (out.to(value.dtype) * s_out)
+        return self._dq(out, s_out, value.dtype)
 
     multi_scale_deformable_attn2 = multi_scale_deformable_attn
 
@@ -235,7 +241,7 @@ class Int8PluginOps:
             return out
         q, s = self._q(f"{site}.img", img)
         out = self.fp.rotate_int8(q.contiguous(), angle, center, s, s, interpolation)
-        return out.to(img.dtype) * s
+        return self._dq(out, s, img.dtype)
 
     rotate2 = rotate
 
@@ -258,7 +264,7 @@ class Int8PluginOps:
         out = self.fp.modulated_deformable_conv2d_int8(qx, qo, qm, qw, None if bias is None else bias.float(),
                                                        sx, so, sm, sw, s_out, stride, padding, dilation, groups,
                                                        deform_groups)
-        return out.to(x.dtype) * s_out
+        return self._dq(out, s_out, x.dtype)
 
     modulated_deformable_conv2d2 = modulated_deformable_conv2d
 

@@ -81,12 +81,13 @@ SIGNATURES = {
     "bevops_image_normalize_pad": (c_int, [c_int, c_void_p, c_int, c_void_p] + [c_int] * 5 +
                                    [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_int, c_int, c_void_p]),
     "bevops_quantize_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
+    "bevops_dequantize_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "bevops_linear_int8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                    c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_linear_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                          c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
-    "bevops_conv3x3_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                               c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),

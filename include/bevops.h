@@ -354,8 +354,10 @@ int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *b
  *                         inside the GEMM's operand load, q = clamp(rne(x * (1 / scale_a)), -127, 127) with
  *                         the product and the rounding in one fused multiply-add -- no quantise pass, no int8
  *                         copy of the activation.  (x * fl(1 / s) against fl(x / s): the two quantisers can
- *                         differ by one step only where x / s is within 1e-5 of a rounding tie.) */
+ *                         differ by one step only where x / s is within 1e-5 of a rounding tie.)
+ *   bevops_dequantize_rows: out (fp16) = q (int8) * scale, product in fp32, one rounding; count % 8 == 0. */
 int bevops_quantize_rows(int dtype, const void *x, void *q, size_t count, float scale, void *stream);
+int bevops_dequantize_rows(int dtype, const void *q, void *out, size_t count, float scale, void *stream);
 int bevops_linear_int8(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
                        float scale_w, const float *bias, const void *residual, int out_dtype,
                        void *out, float scale_out, long long M, int N, int K, int relu, void *stream);
@@ -368,13 +370,16 @@ int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, 
  * next to bevops_tsgemm_f16 and bevops_linear_bias_act. */
 int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                          void *out, long long M, int N, int K, int relu, void *stream);
-/* 3x3 / stride 1 / pad 1 convolution on channels-last fp16 activations as an implicit GEMM on the same tiled
- * skeleton (no column buffer): x [B, H, W, Cin], weight_taps [Cout][3][3][Cin] (= weight.permute(0, 2, 3, 1)),
- * out [B, H, W, Cout] = act(conv(x) + bias[n] + residual); bias / residual fp16, optional.  Cin % 32 == 0.
- * The plain 3x3 convolutions of the re-hosted backbone / neck (ResNet stages without DCN: resnet.py:106-260; FPN
- * output convolutions: necks/fpn.py:140-155) with their shift and ReLU in the epilogue. */
-int bevops_conv3x3_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
-                            void *out, int B, int H, int W, int Cin, int Cout, int relu, void *stream);
+/* Convolution on channels-last fp16 activations as an implicit GEMM on the same tiled skeleton (no column
+ * buffer, no strided copy): kernel ksize x ksize in {1, 3}, pad ksize / 2, any stride.  x [B, H, W, Cin],
+ * weight_taps [Cout][ksize][ksize][Cin] (= weight.permute(0, 2, 3, 1)), out [B, Hout, Wout, Cout] =
+ * act(conv(x) + bias[n] + residual); bias / residual fp16, optional.  Cin % 32 == 0.  The plain 3x3
+ * convolutions of the re-hosted backbone / neck (ResNet stages without DCN: resnet.py:106-260; FPN output
+ * and extra convolutions: necks/fpn.py:140-155) and the stride-2 1x1 convolutions at the head of a stage,
+ * with their shift and ReLU in the epilogue. */
+int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
+                         void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                         void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

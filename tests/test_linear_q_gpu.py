@@ -101,3 +101,13 @@ def test_linear_int8_fused_quantiser_is_the_row_quantiser_off_ties():
     want = torch.relu((q.cpu().long() @ wq.cpu().long().t()).double() * (s_x * 0.01) + b.cpu().double())
     d = (a8.cpu().double() - torch.clamp(torch.round(want / 0.5), -127, 127)).abs()
     assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3
+
+
+def test_dequantize_rows_is_the_two_pass_formula():
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(6)
+    q = torch.randint(-127, 128, (3, 4001, 8), generator=g).to(torch.int8)
+    for s in (0.0371, 1.0, 3.1e-4):
+        got = bev.dequantize_rows(q.cuda(), s)
+        want = (q.float() * s).half()          # product in fp32, one rounding
+        assert got.shape == q.shape and torch.equal(got.cpu(), want)

@@ -121,3 +121,45 @@ def test_conv3x3_auto_picks_a_measured_winner():
     assert set(times) == {"tile", "library"} and Cv._CHOICE[key] == min(times, key=times.get)
     want = torch.relu(torch.nn.functional.conv2d(x[:1].float(), w.float(), b.float(), 1, 1))
     assert bool(((y[:1].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout,k,stride", [(2, 64, 37, 53, 128, 1, 2), (6, 256, 116, 200, 128, 1, 2),
+                                                   (1, 256, 29, 50, 256, 3, 2), (2, 32, 7, 9, 24, 3, 2),
+                                                   (2, 64, 8, 8, 64, 1, 1), (1, 32, 5, 4, 16, 3, 3)])
+def test_conv_tile_strided_and_pointwise(B, C, H, W, Cout, k, stride):
+    """bevops_conv_tile_f16 with a stride (the row addressing sub-samples: no strided copy) and as a 1x1
+    convolution, vs F.conv2d in fp32; bias + identity + ReLU epilogue."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(B + C + H + W + Cout + k + stride)
+    x = torch.randn(B, C, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C, k, k, generator=g) / (k * k * C) ** 0.5).half().cuda()
+    b = torch.randn(Cout, generator=g).half().cuda()
+    want = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride, k // 2)
+    r = torch.randn(want.shape, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    want = torch.relu(want + r.float())
+    out = bev.conv_nhwc(x, w, b, True, r, stride)
+    assert out.shape == want.shape and out.is_contiguous(memory_format=torch.channels_last)
+    err = (out.float() - want).abs()
+    assert bool((err <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all()), float(err.max())
+
+
+def test_narrow_tile_layers():
+    """N <= 64 takes the 64-column tile flavour (fp16 and both int8 flavours)."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(9)
+    for M, N, K in ((556800, 64, 64), (4099, 40, 96), (300, 64, 256)):
+        x = torch.randn(M, K, generator=g).half().cuda()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+        b = torch.randn(N, generator=g).half().cuda()
+        r = torch.randn(M, N, generator=g).half().cuda()
+        out = bev.tile_gemm(x, w, b, r, True)
+        rows = slice(max(0, M - 3000), M)
+        want = _ref(x[rows], w, b, r[rows], True)
+        assert bool(((out[rows].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
+        s_x, s_w = float(x.abs().max()) / 127, float(w.abs().max()) / 127
+        wq = torch.clamp(torch.round(w.float() / s_w), -127, 127).to(torch.int8)
+        q = bev.quantize_rows(x[rows].contiguous(), s_x)
+        o8 = bev.linear_int8(q, s_x, wq, s_w, b.float(), r[rows].contiguous(), relu=True)
+        acc = q.cpu().long() @ wq.cpu().long().t()
+        want8 = torch.relu(acc.double() * (s_x * s_w) + b.cpu().double() + r[rows].cpu().double())
+        assert (o8.cpu().double() - want8).abs().max().item() <= 2e-3 * max(1.0, want8.abs().max().item())
