@@ -301,7 +301,15 @@ class ResNet(nn.Module):
 
     def forward_nhwc(self, x, ops):
         x = x.contiguous(memory_format=torch.channels_last)
-        x = F.max_pool2d(_conv_nhwc(ops, x, self.stem, True), 3, 2, 1)
+        pool = getattr(ops, "bias_relu_maxpool_nhwc", None)
+        if pool is not None and _R3["enabled"] and _FUSED_LINEAR["enabled"] and x.dtype == torch.float16 and x.is_cuda:
+            # stem: library convolution, then shift + ReLU + 3x3 / 2 max-pool as ONE pass over its output
+            y = F.conv2d(x, self.stem.weight, None, self.stem.stride, self.stem.padding)
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            x = pool(y, self.stem.bias)
+        else:
+            x = F.max_pool2d(_conv_nhwc(ops, x, self.stem, True), 3, 2, 1)
         outs = []
         for i, st in enumerate(self.stages):
             for blk in st:

@@ -55,6 +55,7 @@ const Entry kTable[] = {
     {"bevops_mdconv_forward_nhwc", (void *)&bevops_mdconv_forward_nhwc},
     {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
+    {"bevops_bias_relu_maxpool_nhwc", (void *)&bevops_bias_relu_maxpool_nhwc},
     {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},

@@ -43,6 +43,53 @@ __global__ __launch_bounds__(256) void bias_act_f16_kernel(__half *__restrict__ 
   }
 }
 
+// stem epilogue of the channels-last backbone: max_pool2d(relu(x + bias), 3, stride 2, pad 1) in ONE pass over the
+// convolution's raw output (resnet.py: conv1 -> norm1 (folded) -> relu -> maxpool).  A thread owns 8 channels of
+// one output pixel: up to nine 16-byte loads, max in fp32 of the shifted values, ReLU, one rounding -- rounding is
+// monotonic, so this IS max over the fp16 values relu(x + bias) the two-pass form pools.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_f16_kernel(const __half *__restrict__ x,
+                                                                    const __half *__restrict__ bias,
+                                                                    __half *__restrict__ out, int B, int H, int W,
+                                                                    int C, int Ho, int Wo) {
+  const int cv = C / 8;
+  const size_t total = (size_t)B * Ho * Wo * cv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % cv);
+  size_t pix = i / cv;
+  const int xo = (int)(pix % Wo);
+  pix /= Wo;
+  const int yo = (int)(pix % Ho), b = (int)(pix / Ho);
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int y = 2 * yo - 1 + dy;
+    if (y < 0 || y >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = 2 * xo - 1 + dx;
+      if (xx < 0 || xx >= W) continue;
+      const uint4 v = *reinterpret_cast<const uint4 *>(x + (((size_t)b * H + y) * W + xx) * C + c8 * 8);
+      m[0] = fmaxf(m[0], h2f_lo(v.x)); m[1] = fmaxf(m[1], h2f_hi(v.x)); m[2] = fmaxf(m[2], h2f_lo(v.y));
+      m[3] = fmaxf(m[3], h2f_hi(v.y)); m[4] = fmaxf(m[4], h2f_lo(v.z)); m[5] = fmaxf(m[5], h2f_hi(v.z));
+      m[6] = fmaxf(m[6], h2f_lo(v.w)); m[7] = fmaxf(m[7], h2f_hi(v.w));
+    }
+  }
+  float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    const uint4 bv = *reinterpret_cast<const uint4 *>(bias + c8 * 8);
+    bb[0] = h2f_lo(bv.x); bb[1] = h2f_hi(bv.x); bb[2] = h2f_lo(bv.y); bb[3] = h2f_hi(bv.y);
+    bb[4] = h2f_lo(bv.z); bb[5] = h2f_hi(bv.z); bb[6] = h2f_lo(bv.w); bb[7] = h2f_hi(bv.w);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k] + bb[k], 0.f);   // max(x) + b = max(x + b): the shift is per channel
+  uint4 o;
+  o.x = pack_h2(m[0], m[1]); o.y = pack_h2(m[2], m[3]); o.z = pack_h2(m[4], m[5]); o.w = pack_h2(m[6], m[7]);
+  *reinterpret_cast<uint4 *>(out + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8) = o;
+}
+
 // layer_norm over the last dimension of x[rows, C], C = 8 * L with L in {8, 16, 32, 64} lanes per
 // row: a lane keeps its 8 channels in registers (one 16-byte load), mean and variance are two
 // shuffle reductions over the row's lanes in fp32 (two-pass: sum, then sum of squared deviations),
@@ -238,5 +285,18 @@ extern "C" int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const 
   blocks = (blocks + unit - 1) / unit * unit;
   hipLaunchKernelGGL(bias_act_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      (__half *)x, (const __half *)bias, (const __half *)residual, nvec, channels, relu);
+  return launch_status();
+}
+
+extern "C" int bevops_bias_relu_maxpool_nhwc(int dtype, const void *x, const void *bias, void *out, int n, int h, int w,
+                                             int channels, void *stream) {
+  if (!x || !out || n <= 0 || h <= 0 || w <= 0 || channels <= 0) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16 || channels % 8 != 0 || !aligned16(x) || !aligned16(out) || !aligned16(bias))
+    return BEVOPS_NOT_SUPPORTED;
+  const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;     // floor((h + 2 - 3) / 2) + 1
+  const size_t total = (size_t)n * ho * wo * (channels / 8);
+  hipLaunchKernelGGL(bias_relu_maxpool_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const __half *)x, (const __half *)bias, (__half *)out, n, h, w,
+                     channels, ho, wo);
   return launch_status();
 }

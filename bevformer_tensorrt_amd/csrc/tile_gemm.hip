@@ -86,7 +86,7 @@ struct TileArgs {
 
 // NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
 // matrix work on columns that do not exist)
-template <int MODE, bool OUT8, int NI>
+template <int MODE, bool OUT8, int NI, bool CONV>
 __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   constexpr int kTN = 64 * NI;
   __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + 128) * kTLd];   // 40 KB: [image][A rows | W rows][80]
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   // (Cin % 32 == 0, host check): per step the tap moves the row's base address by a block-uniform delta and
   // a per-row validity bit decides between that address and the beyond-the-buffer one.
   const int cin = p.conv_cin;
-  const bool conv = cin > 0;
+  constexpr bool conv = CONV;
   const int taps = p.conv_ks * p.conv_ks, pad = p.conv_ks >> 1;
   unsigned a_off0, a_off1, tapmask0 = 0, tapmask1 = 0;
   if (conv) {
@@ -147,46 +147,52 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   int g_tap = 0, g_c = 0;                      // conv mode: the (tap, channel) position of the NEXT gload
   const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
   const unsigned w_off1 = (NI == 2 && n0 + r1 < N) ? (unsigned)(((size_t)(n0 + r1) * K + kce) * kWB) : kOob;
-  uint4 ra0[kAV], ra1[kAV], rb0, rb1;
+  // register staging: kDepth sets (set = step parity).  Two sets keep the loads of TWO steps in flight per
+  // block (the step's latency is what bounds the long-K layers); the fused-quantise flavour stages twice the
+  // activation bytes per step and stays at one set (168 VGPRs = three blocks per CU)
+  constexpr int kDepth = MODE == kF16Q ? 1 : 2;
+  uint4 ra0[kDepth][kAV], ra1[kDepth][kAV], rb0[kDepth], rb1[kDepth];
   auto bload = [](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, int soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
   };
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, auto setc) {
+    constexpr int S = decltype(setc)::value;
     const int ks = kt * kStepK;
     const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
-    if (conv) {                      // (block-uniform branch)
+    if constexpr (CONV) {
       const int delta = ((g_tap / p.conv_ks - pad) * p.conv_win + (g_tap % p.conv_ks - pad)) * cin * kAB;
       const unsigned v0 = (tapmask0 >> g_tap) & 1u ? a_off0 + (unsigned)delta : kOob;
       const unsigned v1 = (tapmask1 >> g_tap) & 1u ? a_off1 + (unsigned)delta : kOob;
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
-        ra0[h] = bload(rs_a, v0 + 16u * h, g_c * kAB);
-        ra1[h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
+        ra0[S][h] = bload(rs_a, v0 + 16u * h, g_c * kAB);
+        ra1[S][h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
       }
       g_c += kStepK;
       if (g_c >= cin) { g_c = 0; ++g_tap; }
     } else {
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
-        ra0[h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
-        ra1[h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+        ra0[S][h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
+        ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
       }
     }
-    rb0 = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
-    if constexpr (NI == 2) rb1 = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
+    rb0[S] = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
+    if constexpr (NI == 2) rb1[S] = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
   };
   const int lchunk = (tid & 3) * 16;           // byte position of the thread's chunk in an LDS row
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, auto setc) {
+    constexpr int S = decltype(setc)::value;
     char *As = smem + buf * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
     if constexpr (MODE == kF16Q) {
-      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[0], ra0[1], p.inv_sa);
-      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[0], ra1[1], p.inv_sa);
+      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[S][0], ra0[S][1], p.inv_sa);
+      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
     } else {
-      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = ra0[0];
-      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[0];
+      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = ra0[S][0];
+      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[S][0];
     }
-    *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0;
-    if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1;
+    *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0[S];
+    if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1[S];
   };
   // ---- epilogue roles, fixed before the loop so that the identity rows can be requested early
   constexpr int kCH = 4 * NI;                    // 8-column chunks per row of the wave's 32 NI columns
@@ -208,15 +214,11 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   };
   const bool res_vec = res != nullptr && vec;
 
-  gload(0);
-  lstore(0);
-  if (nk > 1) gload(1);
-  if (res_vec) res_request(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    // image (kt + 1) & 1 was last read in step kt - 1, which every wave left through the barrier below
-    if (kt + 1 < nk) lstore((kt + 1) & 1);
-    if (kt + 2 < nk) gload(kt + 2);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, kDepth - 1>;      // kDepth == 1: the one set
+  // step s is staged in set s % kDepth; with two sets the loads of step s + 2 are issued as soon as set s % 2
+  // has been written to LDS, i.e. two steps of multiply ahead of their use
+  auto compute = [&](int kt) {
     const char *As = smem + (kt & 1) * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -241,7 +243,30 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+  };
+  // (loads past the last step are issued too -- beyond-the-buffer addresses, they read as zero -- and so are
+  // the LDS writes of a step that does not exist, into the image nobody reads: without branches around them the
+  // compiler's wait counts are exact, vmcnt(4..7) in front of the LDS writes instead of a drain to 0)
+  gload(0, Set0{});
+  lstore(0, Set0{});
+  gload(1, Set1{});
+  if constexpr (kDepth == 2) gload(2, Set0{});
+  if (res_vec) res_request(0);
+  __syncthreads();
+  // one step: image (kt + 1) & 1 was last read in step kt - 1, which every wave left through the barrier
+  auto step = [&](int kt, auto next_set) {
+    lstore((kt + 1) & 1, next_set);           // step kt + 1 sits in set (kt + 1) % kDepth
+    gload(kt + 1 + kDepth, next_set);         // ... which is free again: reload it
+    compute(kt);
     __syncthreads();
+  };
+  if constexpr (kDepth == 2) {
+    for (int kt = 0; kt < nk; kt += 2) {      // (an odd step count runs one step on zeros: adds nothing)
+      step(kt, Set1{});
+      step(kt + 1, Set0{});
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) step(kt, Set0{});
   }
   // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*32*NI + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*64 + j*32 + (lane & 31)
   // (the barrier that ended the last step also freed both LDS images)
@@ -374,11 +399,20 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (out_dtype == BEVOPS_F16) {
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2>), grid, dim3(256), 0, st, p);
+    if constexpr (MODE == kF16) {
+      if (cg.cin > 0) {
+        if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2, true>), grid, dim3(256), 0, st, p);
+        return launch_status();
+      }
+    }
+    if (cg.cin > 0) return BEVOPS_NOT_SUPPORTED;
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2, false>), grid, dim3(256), 0, st, p);
   } else if constexpr (MODE != kF16) {
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 2>), grid, dim3(256), 0, st, p);
+    if (cg.cin > 0) return BEVOPS_NOT_SUPPORTED;
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 1, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 2, false>), grid, dim3(256), 0, st, p);
   }
   return launch_status();
 }

@@ -195,6 +195,24 @@ def bias_act_nhwc_(x, bias=None, residual=None, relu=False):
     return x
 
 
+def bias_relu_maxpool_nhwc(x, bias=None):
+    """max_pool2d(relu(x + bias), 3, 2, 1) on a channels-last fp16 activation in one pass
+    (bevops_bias_relu_maxpool_nhwc): the stem epilogue of the re-hosted ResNet."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device,
+                      memory_format=torch.channels_last)
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_bias_relu_maxpool_nhwc(_lib.F16, x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                  out.data_ptr(), n, h, w, c, _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_bias_relu_maxpool_nhwc")
+    return out
+
+
 def upsample_add_nhwc_(a, b):
     """In place: a += nearest-up-sampled b (to a's spatial size), both channels-last fp16 [N, C, H, W] -- the
     FPN top-down step in one pass (bevops_upsample_add_nhwc), bit-equal to `a + F.interpolate(b, size=...)`."""

@@ -164,7 +164,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "image_normalize_pad")
+             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "bias_relu_maxpool_nhwc", "image_normalize_pad")
 
     def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
         from . import functions as _f

@@ -298,6 +298,11 @@ int bevops_mdconv_forward_nhwc(int dtype, const void *input_nhwc, const void *of
  * folded-BN convolution epilogue of the re-hosted backbone as one pass (fp16, channels % 8 == 0). */
 int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *residual, size_t rows,
                          int channels, int relu, void *stream);
+/* Stem epilogue of the channels-last backbone in one pass: out [N, Ho, Wo, C] = max_pool2d(relu(x + bias), 3,
+ * stride 2, pad 1) over the convolution's raw output x [N, H, W, C] (fp16, C % 8 == 0; Ho = (H - 1) / 2 + 1).
+ * Bit-equal to bevops_bias_act_nhwc followed by the framework's max_pool2d (rounding is monotonic). */
+int bevops_bias_relu_maxpool_nhwc(int dtype, const void *x, const void *bias, void *out, int n, int h, int w,
+                                  int channels, void *stream);
 
 /* FPN top-down step of the re-hosted neck on channels-last fp16 activations (not a reference plugin):
  * a[n, y, x, :] += b[n, sy(y), sx(x), :], source indices as aten's nearest up-sampling -- the reference's

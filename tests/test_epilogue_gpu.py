@@ -33,3 +33,17 @@ def test_feat_embed_matches_adds_and_cat():
         bev.feat_embed_nhwc(f, cam, lvl[i], out[:, row:row + f.shape[1], :])
         row += f.shape[1]
     assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(6, 64, 464, 800), (2, 64, 7, 9), (1, 8, 1, 1), (3, 16, 2, 5)])
+def test_bias_relu_maxpool_equals_two_pass_form(n, c, h, w):
+    """bevops_bias_relu_maxpool_nhwc == max_pool2d(bias_act(x), 3, 2, 1), bit for bit (odd sizes, borders)."""
+    import torch.nn.functional as F
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(n + c + h + w)
+    x = torch.randn(n, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(c, generator=g).half().cuda()
+    got = bev.bias_relu_maxpool_nhwc(x, b)
+    want = F.max_pool2d(bev.bias_act_nhwc_(x.clone(memory_format=torch.channels_last), b, None, True), 3, 2, 1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
