@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the judged evidence of one tools/gpu_round.sh / gpu_round2.sh visit into profiles/<round>/.
+"""Copy the judged evidence of one tools/gpu_round3.sh visit into profiles/<round>/.
 usage: tools/collect_profiles.py gpurun_out/<tag> profiles/<round>"""
 import collections, csv, glob, json, os, re, shutil, sys
 
@@ -37,7 +37,10 @@ for name, out in (("bench.json", "bench_n1.json"), ("sweep.jsonl", "msda_sweep.j
                   ("hm5_probe.jsonl", "hm5_probe.jsonl"), ("tsgemm_time.jsonl", "tsgemm_time.jsonl"),
                   ("sca_projected_time.jsonl", "sca_projected_time.jsonl"),
                   ("model_bench_r3_ab.jsonl", "model_bench_r3_ab.jsonl"),
-                  ("model_frame_kernel_trace.txt", "model_frame_kernel_trace.txt")):
+                  ("model_frame_kernel_trace.txt", "model_frame_kernel_trace.txt"),
+                  ("model_frame_int8_kernel_trace.txt", "model_frame_int8_kernel_trace.txt"),
+                  ("dense_time.jsonl", "dense_time.jsonl"), ("linear_q_time.jsonl", "linear_q_time.jsonl"),
+                  ("conv_time.jsonl", "conv_time.jsonl")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         lines = [l for l in open(p) if "amdgpu.ids" not in l]
