@@ -159,6 +159,14 @@ def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
                 and not hasattr(conv, "lin") and conv.in_channels % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last):
             # the stride goes into the GEMM's row addressing: no sub-sampled copy of the activation
             return strided(x, conv.weight, conv.bias, relu, residual, s)
+        lin = getattr(conv, "lin", None)
+        int8_conv = getattr(ops, "conv_int8_nhwc", None)
+        if lin is not None and getattr(lin, "mode", None) == "int8" and int8_conv is not None and _R3["enabled"] \
+                and x.dtype == torch.float16 and x.is_cuda and conv.in_channels % 64 == 0 \
+                and x.is_contiguous(memory_format=torch.channels_last):
+            # Conv2dQ with a stride: the int8 GEMM sub-samples in its row addressing (no strided copy)
+            return int8_conv(x, lin.scale_in, lin.weight_q.view(conv.out_channels, 1, 1, conv.in_channels), lin.scale_w,
+                             lin.bias_f32, relu, residual, s)
         x = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
     if hasattr(conv, "lin"):     # quantization.Conv2dQ: the LinearQ over the [N*H*W, C] rows (all three phases)
@@ -181,6 +189,11 @@ def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
 
 
 def _conv_nhwc(ops, x, conv, relu, residual=None):
+    qmode = getattr(conv, "qmode", None)     # quantization.ConvTapsQ (kept duck-typed, as LinearQ above)
+    if qmode == "calibrate":
+        conv.collect(x)
+    elif qmode == "int8" and x.is_contiguous(memory_format=torch.channels_last):
+        return conv.int8_nhwc(x, residual, relu)
     auto = getattr(ops, "conv3x3_auto", None)
     if auto is not None and _R3["enabled"] and _FUSED_LINEAR["enabled"] and x.dtype == torch.float16 and x.is_cuda \
             and conv.kernel_size == (3, 3) and conv.stride[0] == conv.stride[1] and conv.padding == (1, 1) \

@@ -72,6 +72,7 @@ const Entry kTable[] = {
     {"bevops_linear_int8_fused", (void *)&bevops_linear_int8_fused},
     {"bevops_tile_gemm_f16", (void *)&bevops_tile_gemm_f16},
     {"bevops_conv_tile_f16", (void *)&bevops_conv_tile_f16},
+    {"bevops_conv_tile_int8_fused", (void *)&bevops_conv_tile_int8_fused},
     {"bevops_image_normalize_pad", (void *)&bevops_image_normalize_pad},
     {"bevops_msda_packed_size", (void *)&bevops_msda_packed_size},
     {"bevops_msda_pack_value", (void *)&bevops_msda_pack_value},

@@ -399,7 +399,7 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (out_dtype == BEVOPS_F16) {
-    if constexpr (MODE == kF16) {
+    if constexpr (MODE == kF16 || MODE == kF16Q) {
       if (cg.cin > 0) {
         if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2, true>), grid, dim3(256), 0, st, p);
@@ -441,17 +441,34 @@ extern "C" int bevops_tile_gemm_f16(const void *x, const void *weight, const voi
   return launch_tile_gemm<kF16>(x, 1.f, weight, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f, M, N, K, relu, stream);
 }
 
-extern "C" int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
-                                    void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
-                                    void *stream) {
+static int conv_geometry(ConvGeom &cg, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int step_k) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || stride <= 0) return BEVOPS_BAD_PARAM;
-  if ((ksize != 1 && ksize != 3) || Cin % 32 != 0) return BEVOPS_NOT_SUPPORTED;   // a 32-value k-step must not straddle two taps
-  ConvGeom cg;
+  if ((ksize != 1 && ksize != 3) || Cin % step_k != 0) return BEVOPS_NOT_SUPPORTED;   // a k-step must not straddle two taps
   cg.cin = Cin; cg.hin = H; cg.win = W; cg.stride = stride; cg.ks = ksize;
   const int pad = ksize / 2;
   cg.hout = (H + 2 * pad - ksize) / stride + 1;
   cg.wout = (W + 2 * pad - ksize) / stride + 1;
   cg.in_elems = (size_t)B * H * W * Cin;
+  return BEVOPS_SUCCESS;
+}
+
+extern "C" int bevops_conv_tile_int8_fused(const void *x_f16, float scale_a, const void *w_q_taps, const float *w_scales,
+                                           float scale_w, const float *bias, const void *residual, void *out, int B,
+                                           int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                                           void *stream) {
+  ConvGeom cg;
+  const int rc = conv_geometry(cg, B, H, W, Cin, Cout, ksize, stride, 64);
+  if (rc != BEVOPS_SUCCESS) return rc;
+  return launch_tile_gemm<kF16Q>(x_f16, scale_a, w_q_taps, w_scales, scale_w, bias, residual, BEVOPS_F16, out, 1.f,
+                                 (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
+}
+
+extern "C" int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
+                                    void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                                    void *stream) {
+  ConvGeom cg;
+  const int rc = conv_geometry(cg, B, H, W, Cin, Cout, ksize, stride, 32);
+  if (rc != BEVOPS_SUCCESS) return rc;
   return launch_tile_gemm<kF16>(x, 1.f, weight_taps, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f,
                                 (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
 }

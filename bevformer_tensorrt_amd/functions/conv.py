@@ -55,6 +55,34 @@ def conv_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
     return out
 
 
+def conv_int8_nhwc(x, scale_a, w_q_taps, scale_w, bias=None, relu=False, residual=None, stride=1):
+    """The INT8 flavour (bevops_conv_tile_int8_fused): x [B, Cin, H, W] channels-last fp16, quantised with scale_a
+    inside the kernel; w_q_taps [Cout, k, k, Cin] int8 (taps-major), scale_w a float or an fp32 [Cout] tensor; bias
+    fp32; residual fp16 channels-last -> fp16 [B, Cout, Hout, Wout] channels-last.  Cin % 64 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and w_q_taps.dtype == torch.int8
+    assert x.is_contiguous(memory_format=torch.channels_last) and w_q_taps.is_contiguous()
+    B, Cin, H, W = x.shape
+    Cout, k = w_q_taps.shape[0], w_q_taps.shape[1]
+    assert w_q_taps.shape == (Cout, k, k, Cin)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype
+        assert residual.is_contiguous(memory_format=torch.channels_last)
+    per_channel = torch.is_tensor(scale_w)
+    ws = scale_w.float().contiguous() if per_channel else None
+    b = bias.float().contiguous() if bias is not None else None
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_conv_tile_int8_fused(
+            x.data_ptr(), float(scale_a), w_q_taps.data_ptr(), ws.data_ptr() if per_channel else None,
+            1.0 if per_channel else float(scale_w), b.data_ptr() if b is not None else None,
+            residual.data_ptr() if residual is not None else None, out.data_ptr(), B, H, W, Cin, Cout, k, int(stride),
+            int(bool(relu)), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_conv_tile_int8_fused")
+    return out
+
+
 def conv3x3_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
     assert weight.shape[2:] == (3, 3)
     return conv_nhwc(x, weight, bias, relu, residual, stride)

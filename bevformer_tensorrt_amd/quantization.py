@@ -164,7 +164,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "bias_relu_maxpool_nhwc", "image_normalize_pad")
+             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "image_normalize_pad")
 
     def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
         from . import functions as _f
@@ -376,6 +376,61 @@ class Conv2dQ(torch.nn.Conv2d):
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
 
+class ConvTapsQ(torch.nn.Conv2d):
+    """`Conv2dQ` (register.py:79) for the plain 3x3 convolutions of the channels-last backbone / neck (and, when
+    built with a stride, for strided 1x1 convolutions): the same three phases as LinearQ, the int8 phase running
+    `bevops_conv_tile_int8_fused` -- fp16 activation quantised inside the kernel's operand load, int8 weights in
+    the taps-major layout, de-quantising epilogue with shift / identity / ReLU.  The channels-last data path
+    (`bevformer._conv_nhwc`) reads `qmode` / `int8_nhwc`; in the float and calibrate phases it runs this module's
+    weights through its ordinary fp16 path (and `collect` sees the input)."""
+
+    def __init__(self, conv, calibrator, site):
+        k = conv.kernel_size[0]
+        assert conv.kernel_size == (k, k) and k in (1, 3) and conv.groups == 1 and conv.padding == (k // 2, k // 2) \
+            and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1)
+        super().__init__(conv.in_channels, conv.out_channels, k, conv.stride, k // 2, bias=conv.bias is not None)
+        self.weight, self.bias = conv.weight, conv.bias
+        self.cal, self.site, self.qmode = calibrator, site, "float"
+        self.scale_in = self.scale_w = None
+        self.register_buffer("weight_q", None, persistent=False)
+        self.bias_f32 = None
+
+    def calibrate(self):
+        self.qmode = "calibrate"
+        return self
+
+    def collect(self, x):
+        self.cal.collect(self.site, x)
+
+    def freeze(self, weight_calibrator=None):
+        self.scale_in = float(self.cal.scale(self.site))
+        wc = (weight_calibrator or MinMaxCalibrator)()
+        wc.collect("w", self.weight.detach())
+        self.scale_w = float(wc.scale("w"))
+        self.weight_q = _Base.quantize(self.weight.detach().permute(0, 2, 3, 1), self.scale_w).contiguous()   # taps-major
+        self.bias_f32 = None if self.bias is None else self.bias.detach().float().contiguous()
+        self.qmode = "int8"
+        return self
+
+    def int8_nhwc(self, x, residual=None, relu=False):
+        from . import functions as _f
+        return _f.conv_int8_nhwc(x, self.scale_in, self.weight_q, self.scale_w, self.bias_f32, relu, residual,
+                                 self.stride[0])
+
+    def fake_quant_reference(self, x):
+        xq = torch.clamp(torch.round(x.float() / self.scale_in), -127, 127) * self.scale_in
+        wq = self.weight_q.permute(0, 3, 1, 2).float() * self.scale_w
+        return torch.nn.functional.conv2d(xq, wq, None if self.bias is None else self.bias.float(), self.stride,
+                                          self.padding)
+
+    def forward(self, x):
+        if self.qmode == "int8" and x.is_cuda and x.dtype == torch.float16:
+            return self.int8_nhwc(x.contiguous(memory_format=torch.channels_last))
+        if self.qmode == "calibrate":
+            self.collect(x)
+        return super().forward(x)
+
+
 def quantize_dense_layers(model, calibrator, select=lambda name, mod: True):
     """Swap every nn.Linear of `model` accepted by `select(name, module)` (K % 16 == 0, N % 4 == 0)
     for a LinearQ sharing its parameters and calibrator.  Returns the list of swapped modules; call
@@ -392,12 +447,14 @@ def quantize_dense_layers(model, calibrator, select=lambda name, mod: True):
     return swapped
 
 
-def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True):
+def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True, conv3x3=True):
     """Swap the 1x1 convolutions of the backbone / neck (bottleneck conv1, conv3, downsample, FPN laterals;
     `Conv2dQ` of the reference, det2trt/models/utils/register.py:79, configs/bevformer/plugin/
     bevformer_base_trt_p2_q.py) for Conv2dQ sharing their parameters: in the channels-last data path they
-    are the LinearQ GEMM over the [N*H*W, C] rows with shift / identity / ReLU in its epilogue.  3x3 / 7x7
-    convolutions stay on the library in the model's dtype.  Returns the swapped modules (`.calibrate()`,
+    are the LinearQ GEMM over the [N*H*W, C] rows with shift / identity / ReLU in its epilogue; `conv3x3`: the
+    plain 3x3 convolutions with Cin % 64 == 0 (bottleneck conv2 of the stages without DCN, FPN output convolutions)
+    become ConvTapsQ (int8 implicit GEMM).  The 7x7 stem and the DCNv2 pack's offset convolution stay in the model's
+    dtype.  Returns the swapped modules (`.calibrate()`,
     calibration frames, `.freeze()`)."""
     swapped = []
     for name, mod in list(model.named_modules()):
@@ -405,9 +462,16 @@ def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True):
             continue
         for child_name, child in list(mod.named_children()):
             full = f"{name}.{child_name}"
-            if type(child) is torch.nn.Conv2d and child.kernel_size == (1, 1) and child.groups == 1 \
-                    and child.in_channels % 16 == 0 and child.out_channels % 4 == 0 and select(full, child):
+            if type(child) is not torch.nn.Conv2d or child.groups != 1 or not select(full, child):
+                continue
+            q = None
+            if child.kernel_size == (1, 1) and child.in_channels % 16 == 0 and child.out_channels % 4 == 0:
                 q = Conv2dQ(child, calibrator, "conv:" + full)
+            elif conv3x3 and child.kernel_size == (3, 3) and child.padding == (1, 1) and child.dilation == (1, 1) \
+                    and child.in_channels % 64 == 0 and child_name != "conv_offset":
+                # (the DCNv2 pack's offset convolution feeds sampling positions and stays in fp16)
+                q = ConvTapsQ(child, calibrator, "conv:" + full)
+            if q is not None:
                 q = q.to(child.weight.device, child.weight.dtype)
                 setattr(mod, child_name, q)
                 swapped.append(q)

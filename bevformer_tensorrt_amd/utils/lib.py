@@ -89,6 +89,8 @@ SIGNATURES = {
     "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "bevops_bias_relu_maxpool_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bevops_conv_tile_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]
+                                    + [c_int] * 8 + [c_void_p]),
     "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                               c_void_p, c_size_t, c_void_p]),
     "bevops_mdconv_packed_weight_size": (c_size_t, [c_int] * 5),

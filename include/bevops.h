@@ -385,6 +385,12 @@ int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, co
 int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
                          void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                          void *stream);
+/* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
+ * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
+ * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */
+int bevops_conv_tile_int8_fused(const void *x_f16, float scale_a, const void *w_q_taps, const float *w_scales,
+                                float scale_w, const float *bias, const void *residual, void *out, int B, int H,
+                                int W, int Cin, int Cout, int ksize, int stride, int relu, void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

@@ -111,3 +111,44 @@ def test_dequantize_rows_is_the_two_pass_formula():
         got = bev.dequantize_rows(q.cuda(), s)
         want = (q.float() * s).half()          # product in fp32, one rounding
         assert got.shape == q.shape and torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout,k,stride", [(2, 64, 37, 53, 64, 3, 1), (6, 128, 116, 200, 128, 3, 1),
+                                                   (1, 256, 29, 50, 256, 3, 2), (2, 256, 20, 30, 128, 1, 2),
+                                                   (1, 64, 3, 2, 24, 3, 1)])
+def test_conv_int8_matches_integer_reference(B, C, H, W, Cout, k, stride):
+    """bevops_conv_tile_int8_fused (ConvTapsQ / strided Conv2dQ): the integers of the in-kernel quantiser (emulated
+    in float64) convolved exactly (int64) then de-quantised, bias + identity + ReLU; zero padding, stride, tails."""
+    import bevformer_tensorrt_amd as bev
+    g = torch.Generator().manual_seed(B + C + H + W + Cout + k + stride)
+    x = torch.randn(B, C, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, C, k, k, generator=g) / (k * k * C) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    s_x, s_w = float(x.abs().max()) / 127, float(w.abs().max()) / 127
+    wq = torch.clamp(torch.round(w / s_w), -127, 127).to(torch.int8)
+    r32 = np.float32(1.0) / np.float32(s_x)
+    q = np.clip(np.rint(x.cpu().numpy().astype(np.float64) * np.float64(r32)), -127, 127)
+    acc = torch.nn.functional.conv2d(torch.from_numpy(q).double(), wq.double(), None, stride, k // 2)   # exact integers
+    r = torch.randn(acc.shape, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    want = torch.relu(acc * (s_x * s_w) + b.double().view(1, -1, 1, 1) + r.cpu().double())
+    out = bev.conv_int8_nhwc(x, s_x, wq.permute(0, 2, 3, 1).contiguous().cuda(), s_w, b.cuda(), True, r, stride)
+    assert out.shape == want.shape and out.is_contiguous(memory_format=torch.channels_last)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
+
+
+def test_convtapsq_module_three_phases():
+    from bevformer_tensorrt_amd.quantization import ConvTapsQ, MinMaxCalibrator
+    g = torch.Generator().manual_seed(8)
+    conv = torch.nn.Conv2d(128, 64, 3, 1, 1).cuda().half()
+    m = ConvTapsQ(conv, MinMaxCalibrator(), "site").cuda().half()
+    x = torch.randn(2, 128, 24, 40, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(m(x), conv(x))
+    m.calibrate()
+    m(x)
+    m.freeze()
+    y = m(x)
+    ref = m.fake_quant_reference(x)
+    assert (y.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    rel = (y.float() - conv(x).float()).abs().mean().item() / conv(x).float().abs().mean().item()
+    assert rel <= 3e-2, rel
