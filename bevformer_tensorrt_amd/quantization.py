@@ -447,14 +447,16 @@ def quantize_dense_layers(model, calibrator, select=lambda name, mod: True):
     return swapped
 
 
-def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True, conv3x3=True):
+def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True, conv3x3=False):
     """Swap the 1x1 convolutions of the backbone / neck (bottleneck conv1, conv3, downsample, FPN laterals;
     `Conv2dQ` of the reference, det2trt/models/utils/register.py:79, configs/bevformer/plugin/
     bevformer_base_trt_p2_q.py) for Conv2dQ sharing their parameters: in the channels-last data path they
-    are the LinearQ GEMM over the [N*H*W, C] rows with shift / identity / ReLU in its epilogue; `conv3x3`: the
-    plain 3x3 convolutions with Cin % 64 == 0 (bottleneck conv2 of the stages without DCN, FPN output convolutions)
-    become ConvTapsQ (int8 implicit GEMM).  The 7x7 stem and the DCNv2 pack's offset convolution stay in the model's
-    dtype.  Returns the swapped modules (`.calibrate()`,
+    are the LinearQ GEMM over the [N*H*W, C] rows with shift / identity / ReLU in its epilogue (a stride goes into
+    the int8 GEMM's row addressing).  `conv3x3=True` additionally turns the plain 3x3 convolutions with Cin % 64 == 0
+    (bottleneck conv2 of the stages without DCN, FPN output convolutions) into ConvTapsQ (int8 implicit GEMM) -- off
+    by default: the implicit GEMM re-reads and RE-QUANTISES an input pixel once per tap, and on one box the INT8
+    frame was 6 % slower with them than with the fp16 convolution kernel (18.5 vs 17.5 ms).  The 7x7 stem and the
+    DCNv2 pack's offset convolution stay in the model's dtype.  Returns the swapped modules (`.calibrate()`,
     calibration frames, `.freeze()`)."""
     swapped = []
     for name, mod in list(model.named_modules()):

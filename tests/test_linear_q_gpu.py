@@ -143,7 +143,8 @@ def test_convtapsq_module_three_phases():
     conv = torch.nn.Conv2d(128, 64, 3, 1, 1).cuda().half()
     m = ConvTapsQ(conv, MinMaxCalibrator(), "site").cuda().half()
     x = torch.randn(2, 128, 24, 40, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
-    assert torch.equal(m(x), conv(x))
+    # float phase = the library convolution on the shared weights (two calls of it may pick different algorithms)
+    assert (m(x).float() - conv(x).float()).abs().max().item() <= 4e-3
     m.calibrate()
     m(x)
     m.freeze()
