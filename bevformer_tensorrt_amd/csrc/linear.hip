@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void linear_check_kernel(const __half *__restr
 void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const void *a, const void *w,
                const void *c, void *out, float beta, void *workspace, size_t ws_bytes, hipStream_t st,
                const void *bias, const void *residual, long long M, int N, int K, int relu) {
+  // no memory for the numeric screen's flag: no selection by speed alone -- the heuristic's algorithm stays
+  if (!workspace || ws_bytes < 4) return;
   std::vector<hipblasLtMatmulHeuristicResult_t> all;
   if (hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N, HIP_R_16F,
                                  HIP_R_16F, HIP_R_16F, HIP_R_16F, HIPBLAS_COMPUTE_32F, all) != HIPBLAS_STATUS_SUCCESS)
@@ -160,7 +162,6 @@ void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const v
   };
   // numeric screen (needs 4 bytes of the lent workspace for its flag; the result of the last run is in `out`)
   auto numerically_ok = [&]() {
-    if (!workspace || ws_bytes < 4) return true;
     unsigned *flag = static_cast<unsigned *>(workspace);
     unsigned host = 1;
     if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return false;
@@ -172,7 +173,8 @@ void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const v
     return host == 0;
   };
   Cand cur{p.algo, p.ws, 1e30f};
-  time_one(cur, 1);  // warm the caches / clocks with the heuristic's choice
+  const bool cur_ran = time_one(cur, 1) < 1e29f;  // warm the caches / clocks with the heuristic's choice
+  const bool cur_ok = cur_ran && numerically_ok();   // ... which is screened like every other candidate
   for (auto &cd : cands) {
     cd.ms = time_one(cd, 1);
     if (cd.ms < 1e29f && !numerically_ok()) cd.ms = 1e30f;   // fast but not the same numbers: out
@@ -183,7 +185,7 @@ void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const v
   for (size_t i = 0; i < top; ++i) cands[i].ms = time_one(cands[i], 5);
   cur.ms = time_one(cur, 5);
   std::sort(cands.begin(), cands.begin() + top, [](const Cand &x, const Cand &y) { return x.ms < y.ms; });
-  if (!cands.empty() && cands[0].ms < cur.ms) {
+  if (!cands.empty() && (cands[0].ms < cur.ms || !cur_ok)) {   // the fastest candidate that passed the screen
     p.algo = cands[0].algo;
     p.ws = cands[0].ws;
   }

@@ -281,9 +281,17 @@ class LinearQ(torch.nn.Linear):
 
       "float"     plain Linear (what a freshly built or un-calibrated module does);
       "calibrate" plain Linear while the calibrator collects the input under `self.site`;
-      "int8"      after `freeze()`: the input is quantised (bevops_quantize_rows), the product runs
-                  as an int8 x int8 -> int32 GEMM on the matrix cores with the de-quantising epilogue
-                  (bevops_linear_int8), output in the input's dtype.
+      "int8"      after `freeze()`: the fp16 input goes straight into an int8 x int8 -> int32 GEMM on the matrix
+                  cores that quantises it in its operand load, q = clamp(rne(x * fl(1 / s)), +-127)
+                  (bevops_linear_int8_fused; FUSED_QUANT off: bevops_quantize_rows, q = clamp(rne(x / s)), then
+                  bevops_linear_int8), de-quantising epilogue, output in the input's dtype.
+
+    Deviations from the reference's set-up (det2trt/quantization/calibrator_qdq.py:8-26), both at the level of
+    rounding ties / the calibrator's choice, neither of the data flow: pytorch_quantization rounds x * (127 / amax),
+    here the scale is s = amax / 127 and the quantiser multiplies by fl(1 / s) (fused) or divides by s (pass) -- the
+    three forms agree except on near-ties; and `freeze()` calibrates the WEIGHT with max calibration unless a
+    calibrator class is passed (the reference's init_quant_desc gives weights the same calib_method as inputs, "max"
+    or "histogram": pass `weight_calibrator=type(self.cal)` for the histogram set-up).
 
     `fake_quant_reference(x)` is the QuantLinear formula itself -- F.linear(dq(q(x)), dq(q(w))) + b --
     which the int8 path must reproduce up to the fp32 summation order."""
