@@ -161,3 +161,51 @@ def test_quantize_dense_layers_sees_inputs_through_the_model_blocks():
         m.freeze()
         assert m.mode == "int8" and m.scale_in > 0 and m.weight_q.dtype == torch.int8
     assert abs(ffn.fc1.scale_in - float(x.abs().max()) / 127.0) < 1e-9
+
+
+def test_convtapsq_phases_on_the_host():
+    """ConvTapsQ (Conv2dQ for plain 3x3 / strided convolutions): float phase = the convolution itself, calibrate
+    collects the input under its site, freeze quantises the weight into the taps-major int8 layout the kernel reads
+    (k = [tap][Cin]) and the fake-quant reference stays within 8-bit noise of the float layer."""
+    import torch
+    from bevformer_tensorrt_amd.quantization import ConvTapsQ, MinMaxCalibrator
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 24, 3, 2, 1)
+    cal = MinMaxCalibrator()
+    q = ConvTapsQ(conv, cal, "conv:site")
+    x = torch.randn(2, 64, 9, 7)
+    assert torch.equal(q(x), conv(x)) and q.qmode == "float"
+    q.calibrate()
+    q(x)
+    assert abs(cal.scale("conv:site") - float(x.abs().max()) / 127) < 1e-7
+    q.freeze()
+    assert q.qmode == "int8" and q.weight_q.dtype == torch.int8 and tuple(q.weight_q.shape) == (24, 3, 3, 64)
+    w_back = q.weight_q.permute(0, 3, 1, 2).float() * q.scale_w
+    assert (w_back - conv.weight).abs().max().item() <= 0.5 * q.scale_w + 1e-7
+    ref, want = q.fake_quant_reference(x), conv(x)
+    assert ref.shape == want.shape
+    assert (ref - want).abs().mean().item() <= 0.03 * want.abs().mean().item()
+
+
+def test_quantize_backbone_convs_selection():
+    """1x1 convolutions -> Conv2dQ always; plain 3x3 with Cin % 64 == 0 -> ConvTapsQ only on request; the 7x7 stem and
+    the DCNv2 pack's offset convolution never."""
+    import torch
+    from bevformer_tensorrt_amd import bevformer as B
+    from bevformer_tensorrt_amd.quantization import Conv2dQ, ConvTapsQ, MinMaxCalibrator, quantize_backbone_convs
+
+    def kinds(conv3x3):
+        model = B.BEVFormer("small", seed=0)
+        swapped = quantize_backbone_convs(model, MinMaxCalibrator(), conv3x3=conv3x3)
+        names = {n for n, m in model.named_modules() if isinstance(m, (Conv2dQ, ConvTapsQ))}
+        return model, swapped, names
+
+    model, swapped, names = kinds(False)
+    assert swapped and all(isinstance(m, Conv2dQ) for m in swapped)
+    n_1x1 = len(swapped)
+    model, swapped, names = kinds(True)
+    taps = [m for m in swapped if isinstance(m, ConvTapsQ)]
+    assert len(swapped) - len(taps) == n_1x1 and taps
+    assert all(m.kernel_size == (3, 3) and m.in_channels % 64 == 0 for m in taps)
+    assert not any(n.endswith("conv_offset") or n.endswith("stem") for n in names)
+    assert type(model.backbone.stem) is torch.nn.Conv2d
