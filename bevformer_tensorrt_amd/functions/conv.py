@@ -45,6 +45,8 @@ def conv_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
         assert residual.is_contiguous(memory_format=torch.channels_last)
     if bias is not None:
         bias = bias.to(torch.float16).contiguous()
+    if B == 0:
+        return out
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_conv_tile_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -72,6 +74,8 @@ def conv_int8_nhwc(x, scale_a, w_q_taps, scale_w, bias=None, relu=False, residua
     per_channel = torch.is_tensor(scale_w)
     ws = scale_w.float().contiguous() if per_channel else None
     b = bias.float().contiguous() if bias is not None else None
+    if B == 0:
+        return out
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_conv_tile_int8_fused(
@@ -98,6 +102,8 @@ def _library(x, weight, bias, relu, residual, stride=1):
 def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
     """conv_nhwc or the library convolution + one epilogue pass, whichever measured faster for the problem."""
     B, Cin, H, W = x.shape
+    if B == 0 and Cin % 32 == 0:
+        return conv_nhwc(x, weight, bias, relu, residual, stride)      # (empty result, nothing to measure)
     key = (str(x.device), B, H, W, Cin, weight.shape[0], weight.shape[2], stride, bool(relu), residual is not None)
     name = _CHOICE.get(key)
     if name is None:

@@ -58,6 +58,8 @@ def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     else:
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
+    if M == 0:
+        return out.view(*x.shape[:-1], N)
     handle = _lib.load_library()
     nbytes = handle.bevops_linear_workspace_size()
     stream = _lib.current_stream_ptr(x.device)
@@ -88,6 +90,8 @@ def layer_norm(x, weight=None, bias=None, eps=1e-5, out=None):
         assert out.is_contiguous() and out.numel() == x2.numel() and out.dtype == x.dtype
     w = weight.to(torch.float16).contiguous() if weight is not None else None
     b = bias.to(torch.float16).contiguous() if bias is not None else None
+    if x2.shape[0] == 0:
+        return out.view(x.shape)
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_layer_norm(_lib.F16, x2.data_ptr(), w.data_ptr() if w is not None else None,
@@ -105,6 +109,8 @@ def quantize_rows(x, scale, out=None):
         raise ValueError("element count must be a multiple of 8")
     if out is None:
         out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    if x.numel() == 0:
+        return out
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_quantize_rows(_lib.F16, x.data_ptr(), out.data_ptr(), x.numel(), float(scale),
@@ -120,6 +126,8 @@ def dequantize_rows(q, scale):
     if q.numel() % 8:
         raise ValueError("element count must be a multiple of 8")
     out = torch.empty(q.shape, dtype=torch.float16, device=q.device)
+    if q.numel() == 0:
+        return out
     handle = _lib.load_library()
     with torch.cuda.device(q.device):
         st = handle.bevops_dequantize_rows(_lib.F16, q.data_ptr(), out.data_ptr(), q.numel(), float(scale),
@@ -145,6 +153,8 @@ def linear_int8(a_q, scale_a, w_q, scale_w, bias=None, residual=None, relu=False
     b = bias.float().contiguous() if bias is not None else None
     r = residual.reshape(M, N).contiguous() if residual is not None else None
     out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
+    if M == 0:
+        return out.view(*a_q.shape[:-1], N)
     handle = _lib.load_library()
     with torch.cuda.device(a_q.device):
         st = (handle.bevops_linear_int8_fused if fused else handle.bevops_linear_int8)(
@@ -178,6 +188,8 @@ def tsgemm(x, weight, bias=None, residual=None, relu=False, out=None):
         bias = bias.to(torch.float16).contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return out.view(*x.shape[:-1], N)
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_tsgemm_f16(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -213,6 +225,8 @@ def tile_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     else:
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
+    if M == 0:
+        return out.view(*x.shape[:-1], N)
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_tile_gemm_f16(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -253,6 +267,8 @@ def dense_auto(x, weight, bias=None, residual=None, relu=False):
     import os
     K, N = x.shape[-1], weight.shape[0]
     M = x.numel() // K
+    if M == 0:          # a rank of the camera-sharded path that owns no camera
+        return x.new_empty((*x.shape[:-1], N))
     key = (str(x.device), M, N, K, bool(relu), bias is not None, residual is not None)
     name = _DENSE_CHOICE.get(key)
     if name is None:

@@ -162,6 +162,8 @@ def modulated_deformable_conv2d_nhwc(input, offset, mask, weight, bias=None, str
                       memory_format=torch.channels_last)
     if bias is not None:
         bias = bias.to(input.dtype).contiguous()
+    if B == 0:          # a rank of the camera-sharded path that owns no camera
+        return out
     with torch.cuda.device(input.device):
         st = handle.bevops_mdconv_forward_nhwc(
             _lib.F16, input.data_ptr(), offset.data_ptr(), mask.data_ptr() if mask is not None else None,
@@ -183,6 +185,8 @@ def bias_act_nhwc_(x, bias=None, residual=None, relu=False):
         assert x.is_contiguous()
         C = x.shape[-1]
     rows = x.numel() // C
+    if rows == 0:
+        return x
     if residual is not None:
         assert residual.shape == x.shape and residual.dtype == x.dtype
         assert residual.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4 else residual.is_contiguous()
@@ -205,6 +209,8 @@ def bias_relu_maxpool_nhwc(x, bias=None):
                       memory_format=torch.channels_last)
     if bias is not None:
         bias = bias.to(torch.float16).contiguous()
+    if n == 0:
+        return out
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
         st = handle.bevops_bias_relu_maxpool_nhwc(_lib.F16, x.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -219,6 +225,8 @@ def upsample_add_nhwc_(a, b):
     assert a.is_cuda and a.dtype == torch.float16 and b.dtype == torch.float16 and a.dim() == 4 and b.dim() == 4
     assert a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last)
     assert a.shape[0] == b.shape[0] and a.shape[1] == b.shape[1]
+    if a.numel() == 0:
+        return a
     handle = _lib.load_library()
     with torch.cuda.device(a.device):
         st = handle.bevops_upsample_add_nhwc(_lib.F16, a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[2], a.shape[3],
@@ -282,6 +290,8 @@ def conv_offset_nhwc(input, weight, bias=None):
         b32[:Cout].copy_(bias.detach())
         hit[2] = (id(bias), bias._version)
     out = torch.empty((B, 32, H, W), dtype=input.dtype, device=input.device, memory_format=torch.channels_last)
+    if B == 0:
+        return out
     with torch.cuda.device(input.device):
         st = handle.bevops_conv3x3_c32_forward_nhwc(_lib.F16, input.data_ptr(), packed.data_ptr(),
                                                     b32.data_ptr() if bias is not None else None,

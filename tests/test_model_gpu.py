@@ -295,3 +295,23 @@ def test_decoder_layer_fused_attention_equals_modules():
     assert a.shape == b.shape == (900, 1, 256)
     assert (a.float() - b.float()).abs().max().item() <= 3e-2
     assert (a.float() - b.float()).abs().mean().item() <= 3e-3
+
+
+def test_backbone_with_no_local_camera():
+    """A rank of the camera-sharded path can own NO camera (6 cameras on 8 GPUs): backbone + neck on an empty image
+    batch must run through every operator wrapper (empty in, empty out) and give the pyramid's shapes."""
+    import bevformer_tensorrt_amd.functions as hip_ops
+    from bevformer_tensorrt_amd import bevformer as B
+    dev = torch.device("cuda")
+    for name in ("tiny", "small"):
+        model = B.BEVFormer(name, ops=hip_ops, seed=0).to(dev, torch.float16)
+        H, W = B.CONFIGS[name]["image"]
+        img = torch.randn(1, 6, 3, H, W).to(dev, torch.float16)
+        full = model.extract_feat(img, None)
+        none = model.extract_feat(img, [])
+        assert len(none) == len(full)
+        for a, b in zip(none, full):
+            assert a.shape[0] == 0 and tuple(a.shape[1:]) == tuple(b.shape[1:])
+        one = model.extract_feat(img, [2])
+        for a, b in zip(one, full):
+            assert (a[0].float() - b[2].float()).abs().max().item() <= 3e-2 * max(1.0, b[2].float().abs().max().item())

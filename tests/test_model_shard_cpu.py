@@ -68,7 +68,7 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("mode", ["gather", "reduce"])
 def test_sharded_model_equals_single_process(world, mode):
     ctx = mp.get_context("spawn")
