@@ -72,7 +72,7 @@ def _rows(x):
 
 
 def _from_rows(y, n, h, w):
-    return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+    return y.view(n, h, w, y.shape[-1]).permute(0, 3, 1, 2)   # (explicit: n may be 0 on a rank without cameras)
 
 
 _FUSED_LINEAR = {"enabled": os.environ.get("BEVOPS_FUSED_LINEAR", "1") != "0"}   # A/B switch
@@ -741,7 +741,7 @@ class BEVFormer(nn.Module):
             for lvl, feat in enumerate(mlvl):
                 level_hw.append(feat.shape[-2:])
                 if feat.is_contiguous(memory_format=torch.channels_last):            # already [cams, h, w, 256]
-                    f = feat.permute(0, 2, 3, 1).reshape(feat.shape[0], -1, feat.shape[1])
+                    f = feat.permute(0, 2, 3, 1).reshape(feat.shape[0], feat.shape[2] * feat.shape[3], feat.shape[1])
                 else:
                     f = feat.flatten(2).permute(0, 2, 1)                              # [cams, hw, 256]
                 feats.append(f + cam_embed.to(dtype)[:, None, :] + self.level_embeds[lvl].to(dtype)[None, None, :])
