@@ -315,3 +315,29 @@ def test_backbone_with_no_local_camera():
         one = model.extract_feat(img, [2])
         for a, b in zip(one, full):
             assert (a[0].float() - b[2].float()).abs().max().item() <= 3e-2 * max(1.0, b[2].float().abs().max().item())
+
+
+class _NoCameraExchange:
+    """Stand-in for camera_shard.CameraExchange on a rank that owns no camera, exchange "reduce" with nobody else."""
+    mode, cams = "reduce", []
+
+    def reduce(self, x):
+        return x
+
+
+def test_whole_frame_on_a_rank_without_cameras():
+    """The full forward of the re-host for a rank that owns no camera (world 8, 6 cameras): empty backbone batch,
+    empty value tensor in every SCA layer, zero partial sums into the exchange; finite outputs of the usual shapes."""
+    import bevformer_tensorrt_amd.functions as hip_ops
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    dev, dtype = torch.device("cuda"), torch.float16
+    model = B.BEVFormer("small", ops=hip_ops, seed=0).to(dev, dtype)
+    H, W = B.CONFIGS["small"]["image"]
+    img = torch.randn(1, 6, 3, H, W).to(dev, dtype)
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    nq = model.bev_h * model.bev_w
+    prev = torch.zeros(nq, 1, B.EMBED, device=dev, dtype=dtype)
+    can = torch.zeros(18, device=dev)
+    bev, cls, crd = model(img, prev, torch.tensor(0.0, device=dev), can, l2i, [], _NoCameraExchange())
+    assert bev.shape == (nq, 1, B.EMBED) and cls.shape[0] == 6 and crd.shape[-1] == 10
+    assert torch.isfinite(bev.float()).all() and torch.isfinite(cls.float()).all() and torch.isfinite(crd.float()).all()
