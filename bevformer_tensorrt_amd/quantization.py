@@ -45,6 +45,11 @@ class _Base:
     def scales(self):
         return {k: self.scale(k) for k in self._stats}
 
+    def has(self, name):
+        """False for a site that never saw data (a layer fed empty tensors only: a rank of the camera-sharded
+        path without cameras runs its per-camera layers on empty batches)."""
+        return name in self._stats
+
     @staticmethod
     def quantize(tensor, scale):
         """real -> int8 with round-to-nearest-even and saturation to [-127, 127]."""
@@ -53,6 +58,8 @@ class _Base:
 
 class MinMaxCalibrator(_Base):
     def collect(self, name, tensor):
+        if tensor.numel() == 0:
+            return
         m = float(tensor.detach().abs().max())
         self._stats[name] = max(self._stats.get(name, 0.0), m)
 
@@ -65,6 +72,8 @@ class _Histogram(_Base):
     pairwise, so earlier batches stay exactly accounted for)."""
 
     def collect(self, name, tensor):
+        if tensor.numel() == 0:
+            return
         x = tensor.detach().abs().float().flatten()
         amax = float(x.max())
         st = self._stats.get(name)
@@ -319,7 +328,8 @@ class LinearQ(torch.nn.Linear):
     def freeze(self, weight_calibrator=None):
         """Fix the input scale from the collected statistics, quantise the weight (per tensor;
         max calibration unless a calibrator class is given, as QuantDescriptor's weight default)."""
-        self.scale_in = float(self.cal.scale(self.site))
+        # (a site without statistics only ever sees empty batches: any positive scale will do)
+        self.scale_in = float(self.cal.scale(self.site)) if self.cal.has(self.site) else 1.0
         wc = (weight_calibrator or MinMaxCalibrator)()
         wc.collect("w", self.weight.detach())
         self.scale_w = float(wc.scale("w"))
@@ -411,7 +421,7 @@ class ConvTapsQ(torch.nn.Conv2d):
         self.cal.collect(self.site, x)
 
     def freeze(self, weight_calibrator=None):
-        self.scale_in = float(self.cal.scale(self.site))
+        self.scale_in = float(self.cal.scale(self.site)) if self.cal.has(self.site) else 1.0
         wc = (weight_calibrator or MinMaxCalibrator)()
         wc.collect("w", self.weight.detach())
         self.scale_w = float(wc.scale("w"))

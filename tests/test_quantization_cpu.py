@@ -209,3 +209,19 @@ def test_quantize_backbone_convs_selection():
     assert all(m.kernel_size == (3, 3) and m.in_channels % 64 == 0 for m in taps)
     assert not any(n.endswith("conv_offset") or n.endswith("stem") for n in names)
     assert type(model.backbone.stem) is torch.nn.Conv2d
+
+
+def test_sites_that_only_saw_empty_batches():
+    """A rank of the camera-sharded path without cameras feeds its per-camera layers empty batches: the calibrators
+    ignore them, and a layer without statistics freezes with a placeholder scale instead of failing."""
+    import torch
+    from bevformer_tensorrt_amd.quantization import EntropyCalibrator, LinearQ, MinMaxCalibrator
+    for cal in (MinMaxCalibrator(), EntropyCalibrator()):
+        cal.collect("site", torch.zeros(0, 256))
+        assert not cal.has("site") and cal.scales() == {}
+        m = LinearQ.from_linear(torch.nn.Linear(32, 16), cal, "site").calibrate()
+        assert m(torch.zeros(0, 32)).shape == (0, 16)
+        m.freeze()
+        assert m.mode == "int8" and m.scale_in == 1.0 and m.weight_q.dtype == torch.int8
+        cal.collect("site", torch.ones(4, 32))
+        assert cal.has("site")
