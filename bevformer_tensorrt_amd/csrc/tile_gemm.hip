@@ -11,9 +11,10 @@
 // MI355X mapping.  128 x 128 output tiles (128 x 64 for layers with N <= 64), 256 threads = 4 waves of 64 x 64
 // (2 x 2 MFMA blocks of 32 x 32; 64 x 32 in the narrow flavour),
 // 64 BYTES of k per step and row in every flavour (64 int8 / 32 fp16 values: the LDS images, the 16-byte
-// fragment reads and the staging loads are the same code).  Operands are register-staged ONE step ahead
-// (buffer loads: rows past M / N read as zero, no branches) and written into the OTHER of two LDS images while
-// the current one is multiplied: one barrier per step.  40 KB LDS and <= 168 VGPRs keep THREE blocks on a
+// fragment reads and the staging loads are the same code).  Operands are register-staged through buffer loads
+// (rows past M / N read as zero, no branches) in TWO register sets -- the loads of two steps are in flight per block
+// (one set in the F16Q flavour, whose activation loads are twice as wide) -- and written into the OTHER of two LDS
+// images while the current one is multiplied: one barrier per step.  40 KB LDS and <= 158 VGPRs keep THREE blocks on a
 // CU -- their prologues, k-loops and epilogues interleave, which is what covers the HBM latency (a persistent
 // one-block-per-CU kernel with DMA operands, tsgemm.hip, is faster only for 256-column layers with K >= 256).
 // Tiles are numbered so that the column tiles of one row tile run on the same XCD back to back (block b runs on
@@ -27,7 +28,8 @@
 // through LDS per wave (32 rows x 64 columns at a time) so that a thread owns 8 consecutive columns of a row:
 // scale, bias, identity, ReLU in fp32 on 16-byte accesses, ONE rounding to fp16 (or the requantisation to int8
 // for a following int8 layer).
-// Convolution mode (bevops_conv_tile_f16): the same kernel as an implicit GEMM over channels-last activations --
+// Convolution mode (bevops_conv_tile_f16, bevops_conv_tile_int8_fused): the same kernel as an implicit GEMM over
+// channels-last activations --
 // output row m is pixel (b, yo, xo), its k-values are [tap][Cin]; a tap moves the row's base address by a
 // block-uniform delta and a per-row validity bit (zero padding) selects the beyond-the-buffer address; a stride
 // only changes the row -> pixel map.  No column buffer, no sub-sampled copy.
