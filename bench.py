@@ -352,12 +352,12 @@ def geometry_rooflines(bev, wl, dev):
 class ModelFrames:
     """The whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random weights, synthetic
     6-camera frames) behind the reference's stateful frame loop (tools/bevformer/evaluate_trt.py:76-154).
-    kind "fp16": fp16 operators; "int8": the PTQ build -- the TSA / decoder MSDA and rotate call sites on the
-    INT8 operators (quantization.Int8PluginOps), the encoder / decoder dense layers as LinearQ and the
-    backbone / neck 1x1 convolutions as Conv2dQ (int8 x int8 MFMA GEMMs; det2trt/models/utils/register.py:
-    78-84, configs/bevformer/plugin/bevformer_base_trt_p2_q.py), scales from the native entropy calibrator
-    over `calib` synthetic frames; the channels-last DCNv2 block and the fused SCA sampler stay fp16 (a mixed
-    engine, as TensorRT builds them).
+    kind "fp16": fp16 operators; "int8": the PTQ build (quantization.build_int8_engine) -- the backbone as an int8
+    ACTIVATION CHAIN (every 1x1 / 3x3 / DCNv2 layer of every bottleneck reads and writes int8, identity rows
+    included; det2trt/models/utils/register.py:78-84, configs/bevformer/plugin/bevformer_base_trt_p2_q.py), the
+    encoder's dense layers as LinearQ, TSA's MSDA on the INT8 plugin; scales from the native entropy calibrator
+    over `calib` synthetic frames; layers whose fp16 form is faster on MI355X (decoder, rotate, SCA's projected
+    sampler) stay fp16 -- a mixed engine, as TensorRT builds them.
     N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and the
     frame runs eagerly with the RCCL exchange inside."""
 
@@ -377,21 +377,12 @@ class ModelFrames:
             cams = gather.cams
         self.note = None
         if kind == "int8":
-            from bevformer_tensorrt_amd.quantization import Int8PluginOps, quantize_backbone_convs, quantize_dense_layers
-            qops = Int8PluginOps("entropy", channels_last=True, fused_sca=True)
-            model = B.BEVFormer("base", ops=qops, seed=0, backbone_layout="nhwc").to(dev, dtype)
-            qops.attach(model)
-            q = quantize_dense_layers(model, qops.cal, lambda n, m: n.startswith(("encoder.", "decoder.")))
-            q += quantize_backbone_convs(model, qops.cal)
-            for m in q:
-                m.calibrate()
-            r = B.FrameRunner(model, dev, dtype, cams=cams, gather=gather)
-            for i in range(calib):
-                r.step(self.img, self.can(i), self.l2i, "calib")
-            scales = qops.freeze()
-            for m in q:
-                m.freeze()
-            self.note = {"int8_plugin_sites": len(scales), "int8_dense_layers": len(q), "calibration_frames": calib}
+            if cams is not None:
+                raise SystemExit("the INT8 build is a single-GPU engine (camera sharding runs the fp16 model)")
+            from bevformer_tensorrt_amd.quantization import build_int8_engine
+            frames = [(self.img, self.can(i), self.l2i) for i in range(calib)]
+            model, _, self.note = build_int8_engine(B, "base", dev, frames, "entropy",
+                                                    chain=os.environ.get("BEVOPS_INT8_CHAIN", "1") != "0")
         else:
             model = B.BEVFormer("base", seed=0).to(dev, dtype)
         self.graph = world == 1 and graph

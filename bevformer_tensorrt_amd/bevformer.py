@@ -229,6 +229,14 @@ class DCNv2Pack(nn.Module):
         return self.ops.modulated_deformable_conv2d(x, offset, torch.sigmoid(mask), self.weight,
                                                     self.bias, self.stride, 1, 1, 1, 1)
 
+    def _chain_collect(self, om):
+        """Calibration of the INT8 engine's activation chain (quantization.Int8ChainBackbone): the offsets and the
+        mask (sigmoid of the logits) this pack hands its DCNv2 operator, as the INT8 plugin's two int8 inputs."""
+        cal = getattr(self, "chain_cal", None)
+        if cal is not None:
+            cal.collect(self.chain_site + ".offset", om[:, :18])
+            cal.collect(self.chain_site + ".mask", torch.sigmoid(om[:, 18:27]))
+
     def forward_nhwc(self, x, relu):
         # MIOpen's NHWC kernels are 3-8x slower at 27 output channels than at 32 (170 vs 52 us at
         # stage 3): run the offset conv with the filters zero-padded to 32 and drop the extra planes
@@ -237,6 +245,7 @@ class DCNv2Pack(nn.Module):
             # own implicit-GEMM kernel: all 9 x Cin x 32 weights LDS-resident, bias in the epilogue
             try:
                 out = fn(x, self.conv_offset.weight, self.conv_offset.bias)
+                self._chain_collect(out)
                 return self.ops.modulated_deformable_conv2d_nhwc(x, None, None, self.weight, self.bias, self.stride,
                                                                  1, 1, 1, 1, relu=relu, offset_mask_nhwc=out)
             except _lib.BevopsError as exc:
@@ -254,6 +263,7 @@ class DCNv2Pack(nn.Module):
         if not out.is_contiguous(memory_format=torch.channels_last):
             out = out.contiguous(memory_format=torch.channels_last)
         out = self.ops.bias_act_nhwc_(out, self._w32[1], None, False)
+        self._chain_collect(out)
         # the raw [B, H, W, 32] tensor goes to the operator: (o1, o2) are its first 18 channels in the
         # order cat((o1, o2)) gives, the mask logits the next 9; sigmoid fused
         return self.ops.modulated_deformable_conv2d_nhwc(x, None, None, self.weight, self.bias, self.stride, 1, 1,
@@ -281,6 +291,11 @@ class Bottleneck(nn.Module):
     def forward_nhwc(self, x, ops):
         idt = x if self.downsample is None else _conv1x1_nhwc(ops, x, self.downsample, False)
         out = _conv1x1_nhwc(ops, x, self.conv1, True)
+        cal = getattr(self, "chain_cal", None)     # calibration of the INT8 engine's activation chain
+        if cal is not None:
+            cal.collect(self.chain_site + ".t1", out)
+            if self.downsample is not None:
+                cal.collect(self.chain_site + ".idt", idt)
         if isinstance(self.conv2, DCNv2Pack):
             out = self.conv2.forward_nhwc(out, True)
         else:
@@ -351,7 +366,10 @@ class FPN(nn.Module):
         return outs
 
     def forward_nhwc(self, feats, ops):
-        lat = [_conv1x1_nhwc(ops, f, l, False) for l, f in zip(self.lateral, feats)]
+        return self.topdown_nhwc([_conv1x1_nhwc(ops, f, l, False) for l, f in zip(self.lateral, feats)], ops)
+
+    def topdown_nhwc(self, lat, ops):
+        """Everything behind the lateral 1x1 convolutions (the INT8 engine's chain evaluates those itself)."""
         up_add = getattr(ops, "upsample_add_nhwc_", None)
         for i in range(len(lat) - 1, 0, -1):
             a, b = lat[i - 1], lat[i]
@@ -676,6 +694,9 @@ class BEVFormer(nn.Module):
         if cams is not None:
             img = img[cams]
         nhwc = self.backbone_layout == "nhwc" or (self.backbone_layout == "auto" and self.ops is _hip_ops)
+        chain = getattr(self, "int8_chain", None)     # quantization.Int8ChainBackbone, after its freeze()
+        if chain is not None and chain.ready and img.dtype == torch.float16 and img.is_cuda:
+            return chain(img)
         if nhwc and img.dtype == torch.float16 and img.is_cuda:
             if not self._nhwc_ready:   # MIOpen picks its NHWC kernels when the filters are channels-last too
                 for m in list(self.backbone.modules()) + list(self.neck.modules()):

@@ -73,6 +73,11 @@ const Entry kTable[] = {
     {"bevops_tile_gemm_f16", (void *)&bevops_tile_gemm_f16},
     {"bevops_conv_tile_f16", (void *)&bevops_conv_tile_f16},
     {"bevops_conv_tile_int8_fused", (void *)&bevops_conv_tile_int8_fused},
+    {"bevops_linear_int8_chain", (void *)&bevops_linear_int8_chain},
+    {"bevops_conv_tile_int8", (void *)&bevops_conv_tile_int8},
+    {"bevops_bias_relu_maxpool_nhwc_int8", (void *)&bevops_bias_relu_maxpool_nhwc_int8},
+    {"bevops_mdconv_int8_nhwc_workspace_size", (void *)&bevops_mdconv_int8_nhwc_workspace_size},
+    {"bevops_mdconv_forward_int8_nhwc", (void *)&bevops_mdconv_forward_int8_nhwc},
     {"bevops_image_normalize_pad", (void *)&bevops_image_normalize_pad},
     {"bevops_msda_packed_size", (void *)&bevops_msda_packed_size},
     {"bevops_msda_pack_value", (void *)&bevops_msda_pack_value},

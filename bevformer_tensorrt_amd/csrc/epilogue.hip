@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256) void bias_act_f16_kernel(__half *__restrict__ 
 // convolution's raw output (resnet.py: conv1 -> norm1 (folded) -> relu -> maxpool).  A thread owns 8 channels of
 // one output pixel: up to nine 16-byte loads, max in fp32 of the shifted values, ReLU, one rounding -- rounding is
 // monotonic, so this IS max over the fp16 values relu(x + bias) the two-pass form pools.
+// OUT8: the pooled value leaves as int8, q = clamp(rne(v * (1 / s_out)), -127, 127) -- the first tensor of the INT8
+// engine's int8 activation chain (the requantisation of tile_gemm.hip's OUT8 epilogue).
+template <bool OUT8>
 __global__ __launch_bounds__(256) void bias_relu_maxpool_f16_kernel(const __half *__restrict__ x,
                                                                     const __half *__restrict__ bias,
-                                                                    __half *__restrict__ out, int B, int H, int W,
-                                                                    int C, int Ho, int Wo) {
+                                                                    void *__restrict__ out_, int B, int H, int W,
+                                                                    int C, int Ho, int Wo, float inv_s_out) {
   const int cv = C / 8;
   const size_t total = (size_t)B * Ho * Wo * cv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -85,9 +88,18 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_f16_kernel(const __half
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k] + bb[k], 0.f);   // max(x) + b = max(x + b): the shift is per channel
-  uint4 o;
-  o.x = pack_h2(m[0], m[1]); o.y = pack_h2(m[2], m[3]); o.z = pack_h2(m[4], m[5]); o.w = pack_h2(m[6], m[7]);
-  *reinterpret_cast<uint4 *>(out + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8) = o;
+  const size_t o_at = (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8;
+  if constexpr (OUT8) {
+    unsigned pk[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      pk[k >> 2] |= ((unsigned)(int)fminf(fmaxf(rintf(m[k] * inv_s_out), -127.f), 127.f) & 0xffu) << (8 * (k & 3));
+    *reinterpret_cast<uint2 *>(static_cast<int8_t *>(out_) + o_at) = make_uint2(pk[0], pk[1]);
+  } else {
+    uint4 o;
+    o.x = pack_h2(m[0], m[1]); o.y = pack_h2(m[2], m[3]); o.z = pack_h2(m[4], m[5]); o.w = pack_h2(m[6], m[7]);
+    *reinterpret_cast<uint4 *>(static_cast<__half *>(out_) + o_at) = o;
+  }
 }
 
 // layer_norm over the last dimension of x[rows, C], C = 8 * L with L in {8, 16, 32, 64} lanes per
@@ -295,8 +307,22 @@ extern "C" int bevops_bias_relu_maxpool_nhwc(int dtype, const void *x, const voi
     return BEVOPS_NOT_SUPPORTED;
   const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;     // floor((h + 2 - 3) / 2) + 1
   const size_t total = (size_t)n * ho * wo * (channels / 8);
-  hipLaunchKernelGGL(bias_relu_maxpool_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const __half *)x, (const __half *)bias, (__half *)out, n, h, w,
-                     channels, ho, wo);
+  hipLaunchKernelGGL(bias_relu_maxpool_f16_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const __half *)x, (const __half *)bias, out, n, h, w,
+                     channels, ho, wo, 0.f);
+  return launch_status();
+}
+
+extern "C" int bevops_bias_relu_maxpool_nhwc_int8(int dtype, const void *x, const void *bias, void *out_q,
+                                                  float scale_out, int n, int h, int w, int channels, void *stream) {
+  if (!x || !out_q || n <= 0 || h <= 0 || w <= 0 || channels <= 0 || !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16 || channels % 8 != 0 || !aligned16(x) || (reinterpret_cast<uintptr_t>(out_q) & 7u) ||
+      !aligned16(bias))
+    return BEVOPS_NOT_SUPPORTED;
+  const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+  const size_t total = (size_t)n * ho * wo * (channels / 8);
+  hipLaunchKernelGGL(bias_relu_maxpool_f16_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const __half *)x, (const __half *)bias, out_q, n, h, w,
+                     channels, ho, wo, 1.0f / scale_out);
   return launch_status();
 }

@@ -531,11 +531,43 @@ __device__ __forceinline__ unsigned s8_mask4(const int (&x)[4], float m) {
 
 // ABL (timing experiments; 1..8 give wrong results): 1 no gathers, 2 no producer VALU, 4 no weight DMA, 8 no MFMA,
 // 16 wave halves in opposite phase order (correct results; measured no faster: the kernel is VALU-bound)
-template <int WN, int ABL>
+// ENG (the INT8 engine's channels-last block, bevops_mdconv_forward_int8_nhwc): `xt` is the caller's SIGNED int8
+// [B, H, W, Cin] activation itself (no copy: the +128 bias of the unsigned dot is one v_xor per gathered dword),
+// `offset` is the raw fp16 [B, Ho, Wo, om_channels] output of the pack's offset convolution -- its offsets and the
+// sigmoid of its mask logits are quantised with s_off / s_mask while they are staged (what TensorRT's Q node in
+// front of the plugin does), so the arithmetic below is the plugin's on exactly those int8 operands -- and the
+// output leaves as int8 [B, Ho, Wo, Cout] with the ReLU folded into the requantisation.
+struct S8Eng { int om_channels, relu; };
+
+// 4 consecutive output channels m..m+3 of output pixel n: requantise (ReLU first when asked), one dword store
+__device__ __forceinline__ void s8_store4_nhwc(int8_t *__restrict__ out, const float *__restrict__ bias,
+                                               const int (&a)[4], int n, int m, int g, int cout_g, int Cout,
+                                               float s_iw, float s_out, int relu) {
+  int8_t *p = out + (size_t)n * Cout + g * cout_g + m;
+  unsigned pk = 0u;
+  int q[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+    float v = ((float)a[e] * s_iw + ((bias && m + e < cout_g) ? bias[g * cout_g + m + e] : 0.f)) / s_out;
+    if (relu) v = fmaxf(v, 0.f);
+    q[e] = q_away(v);
+    pk |= ((unsigned)q[e] & 0xffu) << (8 * e);
+  }
+  if (m + 3 < cout_g && (((g * cout_g + m) | Cout) & 3) == 0) {
+    *reinterpret_cast<unsigned *>(p) = pk;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (m + e < cout_g) p[e] = (int8_t)q[e];
+  }
+}
+
+template <int WN, int ABL, bool ENG = false>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
     const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
     const int8_t *__restrict__ wt, const float *__restrict__ bias, int8_t *__restrict__ out, ConvDims d, int g,
-    int Kp, float s_off, float s_mask, float s_iw, float s_out, TailPlan tp) {
+    int Kp, float s_off, float s_mask, float s_iw, float s_out, TailPlan tp, S8Eng eng) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1][Om]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -593,6 +625,23 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
     for (int r = 0; r < 16; ++r) acc[i][r] = 0;
 
   // offsets / mask of the tile's pixels -> LDS, once
+  if constexpr (ENG) {
+    const __half *om = reinterpret_cast<const __half *>(offset);
+    for (int idx = tid; idx < 3 * KK * kN; idx += kTh) {
+      const int p = idx / (3 * KK), t = idx - p * (3 * KK);   // a pixel's 3 KK values are contiguous
+      const int n = n0 + p;
+      int q = 0;
+      if (n < N) {
+        float v = __half2float(om[(size_t)n * eng.om_channels + (size_t)dg * 3 * KK + t]), sc = s_off;
+        if (t >= 2 * KK) {   // mask = sigmoid(logit), rounded to fp16 as the fp16 block's tensor is
+          v = __half2float(__float2half_rn(1.f / (1.f + __expf(-v))));
+          sc = s_mask;
+        }
+        q = (int)fminf(fmaxf(rintf(v / sc), -127.f), 127.f);
+      }
+      Om[t * kN + p] = (int8_t)q;
+    }
+  } else
   for (int idx = tid; idx < 3 * KK * kN; idx += kTh) {
     const int p = idx % kN, t = idx / kN;
     const int n = n0 + p;
@@ -682,8 +731,11 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   // corners in rb (footprint c_*) -> the pixel's 16 column bytes in buffer `buf`: per group of 4 channels the
   // byte transposes, the dots with the first requantisation (top byte), the mask multiply + rounding
   auto produce = [&](int buf) {
-    const unsigned c0w[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, c1w[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
-    const unsigned c2w[4] = {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, c3w[4] = {rb[3].x, rb[3].y, rb[3].z, rb[3].w};
+    constexpr unsigned kX = ENG ? 0x80808080u : 0u;   // signed activation bytes -> the u8-biased form of the dot
+    const unsigned c0w[4] = {rb[0].x ^ kX, rb[0].y ^ kX, rb[0].z ^ kX, rb[0].w ^ kX};
+    const unsigned c1w[4] = {rb[1].x ^ kX, rb[1].y ^ kX, rb[1].z ^ kX, rb[1].w ^ kX};
+    const unsigned c2w[4] = {rb[2].x ^ kX, rb[2].y ^ kX, rb[2].z ^ kX, rb[2].w ^ kX};
+    const unsigned c3w[4] = {rb[3].x ^ kX, rb[3].y ^ kX, rb[3].z ^ kX, rb[3].w ^ kX};
     unsigned res[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -780,6 +832,17 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   }
   const int n = n0 + wn * 32 + (lane & 31);
   if (n >= N) return;
+  if constexpr (ENG) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int av[4] = {acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]};
+        s8_store4_nhwc(out, bias, av, n, m0 + wm * 64 + i * 32 + 8 * rq + 4 * (lane >> 5), g, cout_g, d.Cout, s_iw,
+                       s_out, eng.relu);
+      }
+    return;
+  }
   const int b = n / HoWo, pix = n - b * HoWo;
   int8_t *ob = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
 #pragma unroll
@@ -796,10 +859,10 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
 }
 
 // grid (tail tiles, Cout tiles, 8): block z sums accumulator quad z = i*4 + rq of every thread, then requantises
-template <int WN>
+template <int WN, bool ENG = false>
 __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_s8_kernel(const float *__restrict__ bias,
                                                                  int8_t *__restrict__ out, ConvDims d, int g,
-                                                                 float s_iw, float s_out, TailPlan tp) {
+                                                                 float s_iw, float s_out, TailPlan tp, S8Eng eng) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int cout_g = d.Cout / d.G, HoWo = d.Ho * d.Wo, N = d.B * HoWo;
@@ -817,6 +880,11 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_s8_kernel(const floa
   if (n >= N) return;
   const int b = n / HoWo, pix = n - b * HoWo;
   const int av[4] = {a.x, a.y, a.z, a.w};
+  if constexpr (ENG) {
+    s8_store4_nhwc(out, bias, av, n, m0 + wm * 64 + i * 32 + 8 * rq + 4 * (lane >> 5), g, cout_g, d.Cout, s_iw, s_out,
+                   eng.relu);
+    return;
+  }
   int8_t *ob = out + ((size_t)b * d.Cout + g * cout_g) * HoWo + pix;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -829,16 +897,16 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_s8_kernel(const floa
   }
 }
 
-template <int WN, int ABL>
+template <int WN, int ABL, bool ENG = false>
 int glds_s8_resident_blocks() {
   static thread_local int cached_dev = -1, cached = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev == cached_dev) return cached;
   int per_cu = 0, cus = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_s8_kernel<WN, ABL>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_s8_kernel<WN, ABL, ENG>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, GldsS8<WN>::kLds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_s8_kernel<WN, ABL>, Glds<WN>::kThreads,
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_s8_kernel<WN, ABL, ENG>, Glds<WN>::kThreads,
                                                    GldsS8<WN>::kLds) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
@@ -848,14 +916,14 @@ int glds_s8_resident_blocks() {
 }
 
 // launch of the int8 LDS-DMA kernel with its tail plan (same plan as launch_glds; int32 partials)
-template <int WN, int ABL>
+template <int WN, int ABL, bool ENG = false>
 int launch_glds_s8(const int8_t *xt, const void *offset, const void *mask, const int8_t *wt, const void *bias,
                    void *output, const ConvDims &d, int g, int Kp, char *part_ws, size_t part_room, bool allow_tail,
-                   float s_off, float s_mask, float s_iw, float s_out, hipStream_t st) {
+                   float s_off, float s_mask, float s_iw, float s_out, hipStream_t st, S8Eng eng = S8Eng{0, 0}) {
   const int KK = d.Kh * d.Kw, cout_g = d.Cout / d.G;
   const size_t N = (size_t)d.B * d.Ho * d.Wo;
   const dim3 grid((unsigned)((N + Glds<WN>::kN - 1) / Glds<WN>::kN), (cout_g + kFM - 1) / kFM);
-  const int slots = glds_s8_resident_blocks<WN, ABL>();
+  const int slots = glds_s8_resident_blocks<WN, ABL, ENG>();
   if (slots <= 0) return BEVOPS_FAILURE;
   TailPlan tp{0, 1, (int)grid.x, nullptr, 0, 0, 0, 0};
   const int blocks = (int)(grid.x * grid.y);
@@ -873,12 +941,13 @@ int launch_glds_s8(const int8_t *xt, const void *offset, const void *mask, const
     }
   }
   const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
-  hipLaunchKernelGGL((dcn_glds_s8_kernel<WN, ABL>), grid2, dim3(Glds<WN>::kThreads), GldsS8<WN>::kLds, st, xt,
+  hipLaunchKernelGGL((dcn_glds_s8_kernel<WN, ABL, ENG>), grid2, dim3(Glds<WN>::kThreads), GldsS8<WN>::kLds, st, xt,
                      (const int8_t *)offset, (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g,
-                     Kp, s_off, s_mask, s_iw, s_out, tp);
+                     Kp, s_off, s_mask, s_iw, s_out, tp, eng);
   if (tp.tail_tiles)
-    hipLaunchKernelGGL(dcn_tail_finish_s8_kernel<WN>, dim3((unsigned)tp.tail_tiles, grid.y, 8),
-                       dim3(Glds<WN>::kThreads), 0, st, (const float *)bias, (int8_t *)output, d, g, s_iw, s_out, tp);
+    hipLaunchKernelGGL((dcn_tail_finish_s8_kernel<WN, ENG>), dim3((unsigned)tp.tail_tiles, grid.y, 8),
+                       dim3(Glds<WN>::kThreads), 0, st, (const float *)bias, (int8_t *)output, d, g, s_iw, s_out, tp,
+                       eng);
   return launch_status();
 }
 
@@ -1042,4 +1111,69 @@ extern "C" int bevops_mdconv_forward_int8_packed(const void *input, float scale_
     return BEVOPS_BAD_PARAM;
   return run_s8(input, offset, mask, packed_weight, bias, output, workspace, d, scale_in, scale_offset,
                 scale_mask, scale_weight, scale_out, static_cast<hipStream_t>(stream), true);
+}
+
+// The INT8 engine's channels-last DCNv2 block (not a reference plugin; its arithmetic is the INT8 plugin's,
+// modulatedDeformableConv2dKernel.cu:463-607,897-978, on the operands a TensorRT INT8 engine hands it): the
+// activation int8 [B, H, W, Cin] in and int8 [B, Ho, Wo, Cout] out, offsets / mask logits the raw fp16
+// [B, Ho, Wo, om_channels] output of the pack's offset convolution (quantised with scale_offset / scale_mask
+// while staged), weights packed by bevops_mdconv_pack_weight(BEVOPS_I8), ReLU folded into the requantisation.
+// Domain of the LDS-DMA kernel: (Cin / groups) % 128 == 0, one deform group per conv group, 3 Kh Kw <= 32.
+extern "C" int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float scale_in, const void *offset_mask_nhwc,
+                                               int offset_mask_channels, float scale_offset, float scale_mask,
+                                               const void *packed_weight, float scale_weight, const float *bias,
+                                               void *output_nhwc, float scale_out, int relu, void *workspace,
+                                               size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
+                                               int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                                               int dil_w, int groups, int deform_groups, void *stream) {
+  if (!input_nhwc || !offset_mask_nhwc || !packed_weight || !output_nhwc) return BEVOPS_BAD_PARAM;
+  if (!(scale_in > 0.f) || !(scale_offset > 0.f) || !(scale_mask > 0.f) || !(scale_weight > 0.f) || !(scale_out > 0.f))
+    return BEVOPS_BAD_PARAM;
+  ConvDims d;
+  if (!make_dims(d, B, Cin, H, W, Cout, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups, deform_groups))
+    return BEVOPS_BAD_PARAM;
+  const int KK = Kh * Kw, cin_g = Cin / groups, cout_g = Cout / groups;
+  if (offset_mask_channels < deform_groups * 3 * KK) return BEVOPS_BAD_PARAM;
+  if (!aligned16(input_nhwc) || !aligned16(packed_weight) || (reinterpret_cast<uintptr_t>(output_nhwc) & 3u) ||
+      (reinterpret_cast<uintptr_t>(offset_mask_nhwc) & 1u))
+    return BEVOPS_BAD_PARAM;
+  const size_t N = (size_t)B * d.Ho * d.Wo;
+  const int Kp = (int)kpad(d, 1);
+  bool one_dg = cin_g <= Cin / deform_groups;
+  for (int g = 0; g < groups && one_dg; ++g)
+    one_dg = (g * cin_g) / (Cin / deform_groups) == (g * cin_g + cin_g - 1) / (Cin / deform_groups);
+  const bool fits32 = (size_t)B * H * W * Cin < 0xFFFFFF00ull && (size_t)cout_g * Kp < 0xFFFFFF00ull;
+  if (N > 0x7FFFFFFFull || !fits32 || !one_dg || cin_g % 128 != 0 || 3 * KK > kSOmRows || Kp != KK * cin_g ||
+      cout_g % 4 != 0)
+    return BEVOPS_NOT_SUPPORTED;
+  // the split-K tail's int32 partials live in the caller's workspace (none lent: every tile runs its whole k-loop)
+  char *pw = static_cast<char *>(workspace);
+  const size_t room = (workspace && aligned16(workspace)) ? workspace_bytes : 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t wide_blocks = ((N + Glds<4>::kN - 1) / Glds<4>::kN) * ((cout_g + kFM - 1) / kFM);
+  const bool w4 = wide_blocks * 2 >= (size_t)cus || g_mdconv_wide;
+  const S8Eng eng{offset_mask_channels, relu ? 1 : 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int g = 0; g < groups; ++g) {
+    const int rc = w4 ? launch_glds_s8<4, 0, true>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr,
+                                                   (const int8_t *)packed_weight, bias, output_nhwc, d, g, Kp, pw, room,
+                                                   !g_mdconv_no_tail, scale_offset, scale_mask, scale_in * scale_weight,
+                                                   scale_out, st, eng)
+                      : launch_glds_s8<2, 0, true>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr,
+                                                   (const int8_t *)packed_weight, bias, output_nhwc, d, g, Kp, pw, room,
+                                                   !g_mdconv_no_tail, scale_offset, scale_mask, scale_in * scale_weight,
+                                                   scale_out, st, eng);
+    if (rc != BEVOPS_SUCCESS) return rc;
+  }
+  return launch_status();
+}
+
+// bytes of workspace bevops_mdconv_forward_int8_nhwc can use for its split-K tail (nothing lent = no tail split):
+// the plan of launch_glds_s8 keeps split x tail tiles within the resident block slots (<= 1024 threads per CU),
+// each thread parks 32 int32 partial sums
+extern "C" size_t bevops_mdconv_int8_nhwc_workspace_size(void) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return (size_t)(cus > 0 ? cus : 256) * 1024 * 32 * sizeof(int);
 }

@@ -28,7 +28,10 @@
 // through LDS per wave (32 rows x 64 columns at a time) so that a thread owns 8 consecutive columns of a row:
 // scale, bias, identity, ReLU in fp32 on 16-byte accesses, ONE rounding to fp16 (or the requantisation to int8
 // for a following int8 layer).
-// Convolution mode (bevops_conv_tile_f16, bevops_conv_tile_int8_fused): the same kernel as an implicit GEMM over
+// INT8 chain (bevops_linear_int8_chain, bevops_conv_tile_int8): activations that already ARE int8 (the producer's
+// epilogue requantised them with this layer's input scale), the identity rows int8 with their own scale, the
+// output int8 with the consumer's scale -- one byte per element in and out of every layer of a ResNet bottleneck.
+// Convolution mode (bevops_conv_tile_f16, bevops_conv_tile_int8_fused, bevops_conv_tile_int8): the same kernel as an implicit GEMM over
 // channels-last activations --
 // output row m is pixel (b, yo, xo), its k-values are [tap][Cin]; a tap moves the row's base address by a
 // block-uniform delta and a per-row validity bit (zero padding) selects the beyond-the-buffer address; a stride
@@ -79,6 +82,7 @@ struct TileArgs {
   const float *wscale;              // per output channel (S8 / F16Q) or null
   void *out;
   float inv_sa, s_aw, inv_s_out;
+  float s_res;                      // RES8: scale of the int8 identity rows
   int M, N, K, relu, tiles_n, tiles_total;
   unsigned a_bytes;                 // size of the activation buffer (range check of its loads)
   // conv_cin > 0: implicit convolution over channels-last [B, Hin, Win, Cin] activations: kernel ks x ks
@@ -88,7 +92,8 @@ struct TileArgs {
 
 // NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
 // matrix work on columns that do not exist)
-template <int MODE, bool OUT8, int NI, bool CONV>
+// RES8: the identity rows are int8 [M, N] (real = q * s_res) instead of fp16
+template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false>
 __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   constexpr int kTN = 64 * NI;
   __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + 128) * kTLd];   // 40 KB: [image][A rows | W rows][80]
@@ -204,14 +209,21 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   const bool col_ok = ncol < N;
   const bool vec = (N & 7) == 0;                 // rows 16-byte aligned and the chunk all in or all out; else per element
   const __half *res = static_cast<const __half *>(p.res);
+  constexpr int kRB = RES8 ? 1 : 2;              // bytes per identity element
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__half *>(res), 0, res ? (unsigned)((size_t)M * N * 2) : 0u, 0x00020000);
+      const_cast<__half *>(res), 0, res ? (unsigned)((size_t)M * N * kRB) : 0u, 0x00020000);
   uint4 rres[2][kIT];
   auto res_request = [&](int j) {
 #pragma unroll
     for (int it = 0; it < kIT; ++it) {
       const int m = m0 + wm * 64 + j * 32 + it * (64 / kCH) + lane / kCH;
-      rres[j][it] = bload(rs_r, (m < M && col_ok) ? (unsigned)(((size_t)m * N + ncol) * 2) : kOob, 0);
+      const unsigned off = (m < M && col_ok) ? (unsigned)(((size_t)m * N + ncol) * kRB) : kOob;
+      if constexpr (RES8) {   // 8 identity bytes of this lane's 8 columns
+        const uint2 q = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, (int)off, 0, 0));
+        rres[j][it] = make_uint4(q.x, q.y, 0u, 0u);
+      } else {
+        rres[j][it] = bload(rs_r, off, 0);
+      }
     }
   };
   const bool res_vec = res != nullptr && vec;
@@ -317,7 +329,20 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
         }
       }
       if (res) {
-        if (vec) {
+        if constexpr (RES8) {
+          if (vec) {
+            const uint4 q = rres[j][it];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] += (float)(int)(signed char)((q.x >> (8 * c)) & 0xffu) * p.s_res;
+              v[4 + c] += (float)(int)(signed char)((q.y >> (8 * c)) & 0xffu) * p.s_res;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (ncol + c < N) v[c] += (float)reinterpret_cast<const int8_t *>(res)[(size_t)m * N + ncol + c] * p.s_res;
+          }
+        } else if (vec) {
           const uint4 q = rres[j][it];
           v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
           v[4] += h2f_lo(q.z); v[5] += h2f_hi(q.z); v[6] += h2f_lo(q.w); v[7] += h2f_hi(q.w);
@@ -367,11 +392,17 @@ struct ConvGeom { int cin = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1,
 template <int MODE>
 int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w_scales, float scale_w,
                      const void *bias, const void *residual, int out_dtype, void *out, float scale_out, long long M,
-                     int N, int K, int relu, void *stream, const ConvGeom &cg = ConvGeom()) {
+                     int N, int K, int relu, void *stream, const ConvGeom &cg = ConvGeom(), int res_dtype = BEVOPS_F16,
+                     float scale_res = 1.f) {
   if (!a || !w || !out || M < 0 || N <= 0 || K <= 0) return BEVOPS_BAD_PARAM;
   if (MODE != kF16 && (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f)))) return BEVOPS_BAD_PARAM;
   constexpr int kChunk = MODE == kF16 ? 8 : 16;   // k-values a staging thread handles per step
-  if (K % kChunk != 0 || !aligned16(a) || !aligned16(w) || !aligned16(residual) ||
+  const bool res8 = residual != nullptr && res_dtype == BEVOPS_I8;
+  if (residual && res_dtype != BEVOPS_I8 && res_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (res8 && (MODE != kS8 || cg.cin > 0)) return BEVOPS_NOT_SUPPORTED;   // int8 identity rows: the int8-chain GEMM only
+  if (res8 && !(scale_res > 0.f)) return BEVOPS_BAD_PARAM;
+  if (K % kChunk != 0 || !aligned16(a) || !aligned16(w) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & (res8 ? 7u : 15u))) ||
       (reinterpret_cast<uintptr_t>(out) & (out_dtype == BEVOPS_I8 ? 7u : 15u)) || M > 0x7fffffffLL)
     return BEVOPS_NOT_SUPPORTED;
   if (out_dtype == BEVOPS_I8 && (MODE == kF16 || !(scale_out > 0.f))) return BEVOPS_BAD_PARAM;
@@ -380,7 +411,7 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const unsigned long long a_bytes = (cg.cin > 0 ? (unsigned long long)cg.in_elems : (unsigned long long)M * K) *
                                      (MODE == kS8 ? 1 : 2);
   if (a_bytes >= kOob || (unsigned long long)N * K * (MODE == kF16 ? 2 : 1) >= kOob ||
-      (residual && (unsigned long long)M * N * 2 >= kOob))
+      (residual && (unsigned long long)M * N * (res8 ? 1 : 2) >= kOob))
     return BEVOPS_NOT_SUPPORTED;
   if (M == 0) return BEVOPS_SUCCESS;
   TileArgs p;
@@ -388,6 +419,7 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   p.inv_sa = MODE == kF16 ? 1.f : 1.0f / scale_a;
   p.s_aw = MODE == kF16 ? 1.f : (w_scales ? scale_a : scale_a * scale_w);
   p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
+  p.s_res = scale_res;
   p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
   p.a_bytes = (unsigned)a_bytes;
   p.conv_cin = cg.cin; p.conv_hin = cg.hin; p.conv_win = cg.win; p.conv_hout = cg.hout; p.conv_wout = cg.wout;
@@ -400,23 +432,30 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   p.tiles_total = (int)tiles;
   const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (out_dtype == BEVOPS_F16) {
-    if constexpr (MODE == kF16 || MODE == kF16Q) {
-      if (cg.cin > 0) {
-        if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2, true>), grid, dim3(256), 0, st, p);
-        return launch_status();
-      }
-    }
-    if (cg.cin > 0) return BEVOPS_NOT_SUPPORTED;
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 1, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, false, 2, false>), grid, dim3(256), 0, st, p);
-  } else if constexpr (MODE != kF16) {
-    if (cg.cin > 0) return BEVOPS_NOT_SUPPORTED;
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 1, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, true, 2, false>), grid, dim3(256), 0, st, p);
+  const bool conv = cg.cin > 0, out8 = out_dtype == BEVOPS_I8;
+#define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                              \
+  do {                                                                                                              \
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_>), grid, dim3(256), 0, st, p);   \
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_>), grid, dim3(256), 0, st, p);          \
+    return launch_status();                                                                                         \
+  } while (0)
+  if constexpr (MODE == kF16) {
+    if (conv) BEVOPS_TG(false, true, false);
+    BEVOPS_TG(false, false, false);
+  } else if constexpr (MODE == kF16Q) {
+    if (conv && out8) return BEVOPS_NOT_SUPPORTED;
+    if (conv) BEVOPS_TG(false, true, false);
+    if (out8) BEVOPS_TG(true, false, false);
+    BEVOPS_TG(false, false, false);
+  } else {   // kS8: the int8 chain -- every combination of convolution mode, int8 output and int8 identity rows it uses
+    if (conv && out8) BEVOPS_TG(true, true, false);
+    if (conv) BEVOPS_TG(false, true, false);
+    if (out8 && res8) BEVOPS_TG(true, false, true);
+    if (out8) BEVOPS_TG(true, false, false);
+    if (res8) BEVOPS_TG(false, false, true);
+    BEVOPS_TG(false, false, false);
   }
-  return launch_status();
+#undef BEVOPS_TG
 }
 
 }  // namespace
@@ -473,4 +512,28 @@ extern "C" int bevops_conv_tile_f16(const void *x, const void *weight_taps, cons
   if (rc != BEVOPS_SUCCESS) return rc;
   return launch_tile_gemm<kF16>(x, 1.f, weight_taps, nullptr, 1.f, bias, residual, BEVOPS_F16, out, 1.f,
                                 (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
+}
+
+extern "C" int bevops_linear_int8_chain(const void *a, int a_dtype, float scale_a, const void *w_q, const float *w_scales,
+                                        float scale_w, const float *bias, const void *residual, int res_dtype,
+                                        float scale_res, int out_dtype, void *out, float scale_out, long long M, int N,
+                                        int K, int relu, void *stream) {
+  if (a_dtype == BEVOPS_I8)
+    return launch_tile_gemm<kS8>(a, scale_a, w_q, w_scales, scale_w, bias, residual, out_dtype, out, scale_out, M, N, K,
+                                 relu, stream, ConvGeom(), res_dtype, scale_res);
+  if (a_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (residual && res_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  return launch_tile_gemm<kF16Q>(a, scale_a, w_q, w_scales, scale_w, bias, residual, out_dtype, out, scale_out, M, N, K,
+                                 relu, stream);
+}
+
+extern "C" int bevops_conv_tile_int8(const void *x_q, float scale_a, const void *w_q_taps, const float *w_scales,
+                                     float scale_w, const float *bias, const void *residual, int out_dtype, void *out,
+                                     float scale_out, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                     int relu, void *stream) {
+  ConvGeom cg;
+  const int rc = conv_geometry(cg, B, H, W, Cin, Cout, ksize, stride, 64);
+  if (rc != BEVOPS_SUCCESS) return rc;
+  return launch_tile_gemm<kS8>(x_q, scale_a, w_q_taps, w_scales, scale_w, bias, residual, out_dtype, out, scale_out,
+                               (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
 }

@@ -15,7 +15,9 @@ device the data lives on):
                           S. Migacz, GTC 2017): 2048-bin histogram of |x|; for every candidate
                           clip bin i in [128, 2048): reference P = hist[:i] with the outliers
                           folded into the last bin, candidate Q = P merged into 128 levels and
-                          expanded back over P's non-empty bins; threshold = argmin KL(P || Q).
+                          expanded back over P's non-empty bins; threshold = argmin KL(P || Q).  The
+                          zero bin is given its neighbour's count first (the spike of exact zeros behind
+                          a ReLU carries no information about the clip point).
 
 `get_calibrator(name)` mirrors the reference's factory; `Calibrator.collect(name, tensor)` is
 called per boundary tensor per calibration frame; `scales()` returns {name: scale}.
@@ -109,7 +111,12 @@ class EntropyCalibrator(_Histogram):
 def entropy_threshold_bin(hist, num_levels=_NUM_LEVELS):
     """Clip bin minimising KL(P || Q) as described in the module docstring.  All candidate clip
     bins are evaluated at once (a [candidates, bins] batch) instead of one Python iteration each."""
-    hist = hist.double().cpu()
+    hist = hist.double().cpu().clone()
+    # the bin at zero takes the count of its neighbour (pytorch_quantization's histogram calibrator does the same,
+    # `bins[0] = bins[1]` in _compute_amax_entropy): the exact zeros a ReLU emits -- half of the tensor or more --
+    # are represented exactly at ANY threshold, yet as one spike they dominate KL(P || Q) and drag the threshold
+    # towards it (a ReLU of a unit Gaussian: T = 1.8 sigma, 17 % rms error; with a shifted ReLU 66 %)
+    hist[0] = hist[1]
     n = hist.numel()
     cand = torch.arange(num_levels, n + 1)                       # i = number of bins kept
     k = torch.arange(n)
@@ -173,9 +180,15 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "image_normalize_pad")
+             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc",
+             "image_normalize_pad", "upsample_add_nhwc_", "feat_embed_nhwc")
+    # `engine=True` (the build bench.py times, build_int8_engine below) additionally passes the entries whose fp16
+    # form is FASTER than any int8 form on MI355X: the channels-last nearest-neighbour rotate of prev_bev (pure data
+    # movement: rotating commutes with quantising, the int8 plugin would only add a quantise and a de-quantise pass
+    # around it) and the value projection that writes the SCA sampler's planes itself.
+    _ENGINE_PASS = ("rotate_hwc", "spatial_cross_attention_projected")
 
-    def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False):
+    def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False, engine=False):
         from . import functions as _f
         self.fp = fp_ops if fp_ops is not None else _f
         self.cal = get_calibrator(calibrator)() if isinstance(calibrator, str) else calibrator
@@ -184,6 +197,12 @@ class Int8PluginOps:
         self._n = {}
         self._wq = _TensorCache()      # float weight tensor -> (int8 weight, scale)
         self._pass = self._PASS + (("spatial_cross_attention_sample",) if fused_sca else ()) if channels_last else ()
+        if engine:
+            self._pass = self._pass + self._ENGINE_PASS
+        self._site_bs = {}             # msda site -> batch dimension of its call (2: TSA, cameras: SCA, 1: decoder)
+        # optional predicate site -> bool: in the int8 phase a site it rejects keeps its fp operator (a layer-precision
+        # fallback, as a TensorRT build allows per layer; tools/int8_attribution.py switches groups of sites with it)
+        self.site_filter = None
 
     def __getattr__(self, name):       # only reached for names this class does not define
         if name in self.__dict__.get("_pass", ()) and hasattr(self.fp, name):
@@ -210,6 +229,13 @@ class Int8PluginOps:
         self._n[op] = i + 1
         return f"{op}#{i}"
 
+    def site_batch(self, site):
+        """Batch dimension the MSDA site was calibrated with (None: not an MSDA site / never seen)."""
+        return self._site_bs.get(site)
+
+    def _fp_site(self, site):
+        return self.mode == "int8" and self.site_filter is not None and not self.site_filter(site)
+
     def _q(self, name, t):
         s = self._scales[name]
         if t.is_cuda and t.dtype == torch.float16 and t.numel() % 8 == 0 and hasattr(self.fp, "quantize_rows"):
@@ -228,10 +254,13 @@ class Int8PluginOps:
     def multi_scale_deformable_attn(self, value, shapes, ref, off, w):
         site = self._site("msda")
         if self.mode == "calibrate":
+            self._site_bs[site] = int(value.shape[0])
             out = self.fp.multi_scale_deformable_attn(value, shapes, ref, off, w)
             for k, t in (("value", value), ("offsets", off), ("weights", w), ("out", out)):
                 self.cal.collect(f"{site}.{k}", t)
             return out
+        if self._fp_site(site):
+            return self.fp.multi_scale_deformable_attn(value, shapes, ref, off, w)
         (qv, sv), (qo, so), (qw, sw) = (self._q(f"{site}.{k}", t) for k, t in
                                         (("value", value), ("offsets", off), ("weights", w)))
         s_out = self._scales[f"{site}.out"]
@@ -248,6 +277,8 @@ class Int8PluginOps:
             out = self.fp.rotate(img, angle, center, interpolation)
             self.cal.collect(f"{site}.img", img)
             return out
+        if self._fp_site(site):
+            return self.fp.rotate(img, angle, center, interpolation)
         q, s = self._q(f"{site}.img", img)
         out = self.fp.rotate_int8(q.contiguous(), angle, center, s, s, interpolation)
         return self._dq(out, s, img.dtype)
@@ -263,6 +294,9 @@ class Int8PluginOps:
             for k, t in (("x", x), ("offset", offset), ("mask", mask), ("weight", weight), ("out", out)):
                 self.cal.collect(f"{site}.{k}", t)
             return out
+        if self._fp_site(site):
+            return self.fp.modulated_deformable_conv2d(x, offset, mask, weight, bias, stride, padding, dilation,
+                                                       groups, deform_groups)
         (qx, sx), (qo, so), (qm, sm) = (self._q(f"{site}.{k}", t) for k, t in
                                         (("x", x), ("offset", offset), ("mask", mask)))
         hit = self._wq.get(weight)           # the weights of a deployed model are quantised (and packed) once
@@ -496,3 +530,205 @@ def quantize_backbone_convs(model, calibrator, select=lambda name, mod: True, co
                 setattr(mod, child_name, q)
                 swapped.append(q)
     return swapped
+
+
+class Int8ChainBackbone:
+    """The backbone + FPN laterals of the INT8 engine as an int8 ACTIVATION CHAIN (what TensorRT builds from the
+    reference's `Conv2dQ` backbone, configs/bevformer/plugin/bevformer_base_trt_p2_q.py, when it keeps the tensors
+    between the layers in int8): the stem's pooled output is quantised once; from there every 1x1 / 3x3 / DCNv2
+    layer of every bottleneck reads int8 and writes int8 with its consumer's calibrated input scale -- the identity
+    rows included -- until the FPN lateral convolutions de-quantise into the fp16 neck.  One byte per element in and
+    out of every layer instead of two; no quantise / de-quantise passes.
+
+    Build (like a TensorRT PTQ build, three steps):
+        chain = Int8ChainBackbone(model, calibrator)   # swaps the 1x1 convolutions for Conv2dQ, arms the taps
+        ... calibration frames through the fp16 model ...
+        chain.freeze()                                 # scales + int8 weights; model.extract_feat now runs the chain
+
+    Layer arithmetic: `functions/int8_chain.py` (int8 x int8 -> int32 on the matrix cores, requantising epilogues;
+    the DCNv2 block is the INT8 plugin's arithmetic on channels-last int8 tensors)."""
+
+    def __init__(self, model, calibrator, weight_calibrator=None):
+        self.model, self.cal, self.ready = model, calibrator, False
+        self.wcal = weight_calibrator or MinMaxCalibrator
+        self.convs = quantize_backbone_convs(model, calibrator)
+        for m in self.convs:
+            m.calibrate()
+        for si, stage in enumerate(model.backbone.stages):
+            for bi, blk in enumerate(stage):
+                blk.chain_cal, blk.chain_site = calibrator, f"chain:{si}.{bi}"
+                if hasattr(blk.conv2, "conv_offset"):
+                    blk.conv2.chain_cal, blk.conv2.chain_site = calibrator, f"chain:{si}.{bi}"
+        model.int8_chain = self
+
+    # ---- build
+    def _wq(self, w):
+        wc = self.wcal()
+        wc.collect("w", w.detach())
+        s = float(wc.scale("w"))
+        return _Base.quantize(w.detach(), s), s
+
+    def _scale(self, name):
+        return float(self.cal.scale(name)) if self.cal.has(name) else 1.0
+
+    def freeze(self):
+        m = self.model
+        for c in self.convs:
+            c.freeze()
+        for stage in m.backbone.stages:
+            for blk in stage:
+                blk.chain_cal = None
+                if hasattr(blk.conv2, "conv_offset"):
+                    blk.conv2.chain_cal = None
+        dev = m.backbone.stem.weight.device
+        plan = []
+        stages = m.backbone.stages
+        lat_of = {}                     # stage index -> lateral convolution reading its output
+        for l, si in zip(m.neck.lateral, m.backbone.out_indices):
+            lat_of[si] = l
+        for si, stage in enumerate(stages):
+            blocks = []
+            for bi, blk in enumerate(stage):
+                site = f"chain:{si}.{bi}"
+                e = {"s_x": blk.conv1.lin.scale_in, "s_1": self._scale(site + ".t1"), "s_2": blk.conv3.lin.scale_in,
+                     "c1": blk.conv1, "c3": blk.conv3, "down": blk.downsample, "s_idt": None}
+                if blk.downsample is not None:
+                    e["s_idt"] = self._scale(site + ".idt")
+                c2 = blk.conv2
+                if hasattr(c2, "conv_offset"):       # DCNv2 pack
+                    wq, sw = self._wq(c2.weight)
+                    ow = torch.zeros((32,) + tuple(c2.conv_offset.weight.shape[1:]), dtype=torch.float32, device=dev)
+                    ow[:27] = c2.conv_offset.weight.detach().float()
+                    amax = ow.abs().flatten(1).amax(1).clamp(min=1e-12)        # per output channel (zero rows: any scale)
+                    osc = (amax / 127.0)
+                    oq = torch.clamp(torch.round(ow / osc.view(-1, 1, 1, 1)), -127, 127).to(torch.int8)
+                    ob = torch.zeros(32, dtype=torch.float32, device=dev)
+                    ob[:27] = c2.conv_offset.bias.detach().float()
+                    e["dcn"] = dict(wq=wq.contiguous(), sw=sw, bias=c2.bias.detach().float().contiguous(),
+                                    oq=oq.permute(0, 2, 3, 1).contiguous(), osc=osc.contiguous(), ob=ob,
+                                    s_off=self._scale(site + ".offset"), s_mask=self._scale(site + ".mask"),
+                                    stride=c2.stride)
+                else:
+                    wq, sw = self._wq(c2.weight)
+                    e["conv"] = dict(wq=wq.permute(0, 2, 3, 1).contiguous(), sw=sw,
+                                     bias=c2.bias.detach().float().contiguous(), stride=c2.stride[0])
+                blocks.append(e)
+            plan.append(blocks)
+        # output scale of a block = input scale of what reads it: the next block, the next stage, or the lateral
+        for si, blocks in enumerate(plan):
+            for bi, e in enumerate(blocks):
+                if bi + 1 < len(blocks):
+                    e["s_out"] = blocks[bi + 1]["s_x"]
+                elif si + 1 < len(plan):
+                    e["s_out"] = plan[si + 1][0]["s_x"]
+                else:
+                    e["s_out"] = lat_of[si].lin.scale_in
+        self.plan, self.lat_of = plan, lat_of
+        self.s_stem = plan[0][0]["s_x"]
+        self.ready = True
+        return self
+
+    # ---- run
+    @staticmethod
+    def _conv1x1(x, s_x, conv, relu, out_dtype, s_out, residual=None, s_res=1.0):
+        """x int8 channels-last -> conv (a Conv2dQ, frozen) as the int8 GEMM over its rows; a stride goes into the
+        implicit GEMM's row addressing."""
+        from .functions import int8_chain as C
+        lin = conv.lin
+        if conv.stride[0] > 1:
+            assert residual is None
+            w = lin.weight_q.view(conv.out_channels, 1, 1, conv.in_channels)
+            return C.conv_int8_chain_nhwc(x, s_x, w, lin.scale_w, lin.bias_f32, relu, conv.stride[0], out_dtype, s_out)
+        n, c, h, w_ = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(-1, c)
+        res = None if residual is None else residual.permute(0, 2, 3, 1).reshape(-1, residual.shape[1])
+        y = C.linear_int8_chain(rows, s_x, lin.weight_q, lin.scale_w, lin.bias_f32, res, s_res, relu, out_dtype, s_out)
+        return y.view(n, h, w_, -1).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def __call__(self, img):
+        """img [cams, 3, H, W] fp16 -> the FPN's outputs (fp16, channels-last), as model.neck.forward_nhwc gives."""
+        import torch.nn.functional as F
+        from .functions import int8_chain as C
+        m = self.model
+        ops = m.ops
+        bb = m.backbone
+        x = img.contiguous(memory_format=torch.channels_last)
+        y = F.conv2d(x, bb.stem.weight, None, bb.stem.stride, bb.stem.padding)       # 7x7 stem: library convolution
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        x = C.bias_relu_maxpool_nhwc_int8(y, bb.stem.bias, self.s_stem)
+        i8 = torch.int8
+        lats = []
+        for si, blocks in enumerate(self.plan):
+            for e in blocks:
+                if e["down"] is not None:
+                    idt, s_idt = self._conv1x1(x, e["s_x"], e["down"], False, i8, e["s_idt"]), e["s_idt"]
+                else:
+                    idt, s_idt = x, e["s_x"]
+                t = self._conv1x1(x, e["s_x"], e["c1"], True, i8, e["s_1"])
+                if "dcn" in e:
+                    d = e["dcn"]
+                    om = C.conv_int8_chain_nhwc(t, e["s_1"], d["oq"], d["osc"], d["ob"], False, d["stride"],
+                                                torch.float16)
+                    t = C.modulated_deformable_conv2d_int8_nhwc(t, e["s_1"], om, d["s_off"], d["s_mask"], d["wq"],
+                                                                d["sw"], d["bias"], e["s_2"], True, d["stride"], 1, 1,
+                                                                1, 1)
+                else:
+                    c = e["conv"]
+                    t = C.conv_int8_chain_nhwc(t, e["s_1"], c["wq"], c["sw"], c["bias"], True, c["stride"], i8,
+                                               e["s_2"])
+                x = self._conv1x1(t, e["s_2"], e["c3"], True, i8, e["s_out"], idt, s_idt)
+            if si in self.lat_of:
+                lats.append(self._conv1x1(x, blocks[-1]["s_out"], self.lat_of[si], False, torch.float16, 1.0))
+        return m.neck.topdown_nhwc(lats, ops)
+
+
+def engine_dense_select(name, mod):
+    """Which nn.Linear layers of the re-hosted BEVFormer the INT8 engine runs as LinearQ: the encoder's dense layers
+    except (a) TSA's sampling_offsets / attention_weights, whose fp16 form is the split projection (two K = 256 GEMMs
+    on the un-concatenated operands, 40 us) where the int8 form needs the [nq, 512] concatenation copy first (50 us
+    + 2 x 17 us), and (b) SCA's value_proj, which in fp16 writes the sampler's planes itself.  The decoder (900
+    queries: every layer is launch-bound, INT8 buys no time) stays fp16 -- the layer-precision choice a TensorRT
+    builder makes by timing; tools/int8_attribution.py has the error side of it."""
+    if not name.startswith("encoder."):
+        return False
+    return not name.endswith(("tsa.sampling_offsets", "tsa.attention_weights", "sca.value_proj"))
+
+
+def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, dense_select=None, decoder_int8=False):
+    """The PTQ build of the re-hosted model that bench.py times (`B` = the bevformer module, `frames` = an iterable
+    of (image, can_bus, lidar2img) calibration frames of one scene): int8 activation chain through the backbone
+    (Int8ChainBackbone; chain=False: Conv2dQ layers with fp16 tensors between them, the round-3 build), encoder
+    dense layers as LinearQ, TSA's MSDA on the INT8 plugin, everything else on the fp16 operators.
+    Returns (model, qops, note)."""
+    dtype = torch.float16
+    qops = Int8PluginOps(calibrator, channels_last=True, fused_sca=True, engine=True)
+    model = B.BEVFormer(name, ops=qops, seed=0, backbone_layout="nhwc").to(dev, dtype)
+    qops.attach(model)
+    sel = dense_select or ((lambda n, m: n.startswith(("encoder.", "decoder."))) if decoder_int8 else engine_dense_select)
+    q = quantize_dense_layers(model, qops.cal, sel)
+    ch = None
+    if chain:
+        ch = Int8ChainBackbone(model, qops.cal)
+    else:
+        q += quantize_backbone_convs(model, qops.cal)
+    for m in q:
+        m.calibrate()
+    r = B.FrameRunner(model, dev, dtype)
+    n = 0
+    for img, can, l2i in frames:
+        r.step(img, can, l2i, "calib")
+        n += 1
+    scales = qops.freeze()
+    for m in q:
+        m.freeze()
+    if ch is not None:
+        ch.freeze()
+    if not decoder_int8:
+        qops.site_filter = lambda site: qops.site_batch(site) != 1      # the decoder's MSDA (batch 1) stays fp16
+    note = {"int8_plugin_sites": sum(1 for k in scales if k.endswith(".out") and k.startswith("msda")
+                                     and (decoder_int8 or qops.site_batch(k[:-4]) != 1)),
+            "int8_dense_layers": len(q), "int8_backbone_layers": (len(ch.convs) + sum(len(b) for b in ch.plan)) if ch else 0,
+            "activation_chain": bool(ch), "calibration_frames": n}
+    return model, qops, note

@@ -391,6 +391,48 @@ int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bia
 int bevops_conv_tile_int8_fused(const void *x_f16, float scale_a, const void *w_q_taps, const float *w_scales,
                                 float scale_w, const float *bias, const void *residual, void *out, int B, int H,
                                 int W, int Cin, int Cout, int ksize, int stride, int relu, void *stream);
+/* The INT8 engine's int8 ACTIVATION CHAIN (not plugins -- what TensorRT builds from the
+ * reference's `Conv2dQ` / `LinearQ` layers, det2trt/models/utils/register.py:78-84, selected by
+ * configs/bevformer/plugin/bevformer_base_trt_p2_q.py, when it keeps the tensors BETWEEN the layers of a ResNet
+ * bottleneck in int8): every producer requantises with its consumer's calibrated input scale, so a layer moves one
+ * byte per element in and one out.
+ *   bevops_linear_int8_chain: bevops_linear_int8 / _fused behind one entry, plus int8 identity rows:
+ *                         a [M, K] BEVOPS_I8 (quantised with scale_a) or BEVOPS_F16 (quantised in the operand load);
+ *                         residual [M, N] BEVOPS_F16, or BEVOPS_I8 with scale_res (int8 `a` only); out fp16, or int8
+ *                         requantised with scale_out: q = clamp(rne(v * (1 / scale_out)), -127, 127).
+ *   bevops_conv_tile_int8:   bevops_conv_tile_int8_fused on an activation that already IS int8 [B, H, W, Cin]
+ *                         (ksize in {1, 3}, pad ksize / 2, any stride, Cin % 64 == 0), fp16 or int8 out [B, Ho, Wo,
+ *                         Cout]; `residual` must be NULL.
+ *   bevops_bias_relu_maxpool_nhwc_int8: bevops_bias_relu_maxpool_nhwc leaving as int8 with scale_out (the stem
+ *                         epilogue: first tensor of the chain).
+ *   bevops_mdconv_forward_int8_nhwc: the DCNv2 block of the chain.  Its arithmetic is the INT8 plugin's
+ *                         (modulatedDeformableConv2dKernel.cu:463-607,897-978: u8 x255 area weights, dot4 blend,
+ *                         T2int8(t / 255), T2int8(val * mask), s8 x s8 -> i32 GEMM, one requantisation) on
+ *                         input int8 [B, H, W, Cin] and on the offsets / sigmoid(mask logits) of the raw fp16
+ *                         [B, Ho, Wo, offset_mask_channels] output of the pack's offset convolution (cnn/dcn.py:
+ *                         70-86), quantised with scale_offset / scale_mask while they are staged (the Q node
+ *                         TensorRT places in front of the plugin); weights packed by bevops_mdconv_pack_weight(
+ *                         BEVOPS_I8); output int8 [B, Ho, Wo, Cout] with the ReLU folded into the requantisation.
+ *                         `workspace` (optional, bevops_mdconv_int8_nhwc_workspace_size() bytes) holds the int32
+ *                         partial sums of the split-K tail.  NOT_SUPPORTED outside (Cin / groups) % 128 == 0, one
+ *                         deform group per conv group, 3 Kh Kw <= 32. */
+int bevops_linear_int8_chain(const void *a, int a_dtype, float scale_a, const void *w_q, const float *w_scales,
+                             float scale_w, const float *bias, const void *residual, int res_dtype, float scale_res,
+                             int out_dtype, void *out, float scale_out, long long M, int N, int K, int relu,
+                             void *stream);
+int bevops_conv_tile_int8(const void *x_q, float scale_a, const void *w_q_taps, const float *w_scales, float scale_w,
+                          const float *bias, const void *residual, int out_dtype, void *out, float scale_out, int B,
+                          int H, int W, int Cin, int Cout, int ksize, int stride, int relu, void *stream);
+int bevops_bias_relu_maxpool_nhwc_int8(int dtype, const void *x, const void *bias, void *out_q, float scale_out,
+                                       int n, int h, int w, int channels, void *stream);
+size_t bevops_mdconv_int8_nhwc_workspace_size(void);
+int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float scale_in, const void *offset_mask_nhwc,
+                                    int offset_mask_channels, float scale_offset, float scale_mask,
+                                    const void *packed_weight, float scale_weight, const float *bias,
+                                    void *output_nhwc, float scale_out, int relu, void *workspace,
+                                    size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh, int Kw,
+                                    int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                    int groups, int deform_groups, void *stream);
 /* Camera-image front end of the frame loop (not a plugin): the reference's test
  * pipeline NormalizeMultiviewImage + PadMultiViewImage(size_divisor=32) + DefaultFormatBundle3D
  * (configs/bevformer/bevformer_base.py:11,228-231; third_party/bev_mmdet3d/datasets/pipelines/

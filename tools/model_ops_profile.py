@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Operator-level (with input shapes) device-time breakdown of one steady-state eager frame of the
 re-hosted model: which framework element-wise / copy ops are worth fusing next.
-usage: model_ops_profile.py [model] [rows]"""
+usage: model_ops_profile.py [model] [rows] [--int8]   (--int8: the PTQ build bench.py times, base only)"""
 import os
 import sys
 
@@ -11,11 +11,17 @@ from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "base"
-rows = int(sys.argv[2]) if len(sys.argv) > 2 else 70
+int8 = "--int8" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--int8"]
+name = argv[0] if len(argv) > 0 else "base"
+rows = int(argv[1]) if len(argv) > 1 else 70
 dev, dtype = torch.device("cuda"), torch.float16
-model = B.BEVFormer(name).to(dev, dtype)
-runner = B.FrameRunner(model, dev, dtype, graph=False)
+if int8:
+    import bench
+    runner = bench.ModelFrames(dev, "int8", 1, 0, None, None, graph=False).runner
+else:
+    model = B.BEVFormer(name).to(dev, dtype)
+    runner = B.FrameRunner(model, dev, dtype, graph=False)
 H, W = B.CONFIGS[name]["image"]
 l2i = G.synthetic_lidar2img((H, W)).to(dev)
 img = torch.randn(1, 6, 3, H, W).to(dev, dtype)
