@@ -361,12 +361,12 @@ class ModelFrames:
     N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and the
     frame runs eagerly with the RCCL exchange inside."""
 
-    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True):
+    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True, name="base"):
         from bevformer_tensorrt_amd import bevformer as B, geometry as G
-        self.B, self.dev, self.kind = B, dev, kind
+        self.B, self.dev, self.kind, self.name = B, dev, kind, name
         dtype = torch.float16
         torch.cuda.empty_cache()
-        H, W = B.CONFIGS["base"]["image"]
+        H, W = B.CONFIGS[name]["image"]
         gen = torch.Generator().manual_seed(0)
         self.img = torch.randn(1, 6, 3, H, W, generator=gen).to(dev, dtype)
         self.l2i = G.synthetic_lidar2img((H, W)).to(dev)
@@ -381,12 +381,19 @@ class ModelFrames:
                 raise SystemExit("the INT8 build is a single-GPU engine (camera sharding runs the fp16 model)")
             from bevformer_tensorrt_amd.quantization import build_int8_engine
             frames = [(self.img, self.can(i), self.l2i) for i in range(calib)]
-            model, _, self.note = build_int8_engine(B, "base", dev, frames, "entropy",
+            model, _, self.note = build_int8_engine(B, name, dev, frames, "entropy",
                                                     chain=os.environ.get("BEVOPS_INT8_CHAIN", "1") != "0")
         else:
-            model = B.BEVFormer("base", seed=0).to(dev, dtype)
-        self.graph = world == 1 and graph
-        self.runner = B.FrameRunner(model, dev, dtype, cams=cams, gather=gather, graph=self.graph)
+            model = B.BEVFormer(name, seed=0).to(dev, dtype)
+        # N > 1: the "reduce" exchange (fused sampler on the local cameras, ONE all-reduce per encoder layer) is
+        # captured with its RCCL collectives; the per-camera pipelined all-gathers run eagerly
+        self.graph = graph and (world == 1 or exchange == "reduce")
+        self._shard = (cams, gather)
+        # the graph's own output buffers are handed out (no per-frame clones), and the synthetic camera images sit in
+        # the frame's static input buffer, where a serving caller's normalise pass (FrameRunner.step_raw) writes them
+        self.runner = B.FrameRunner(model, dev, dtype, cams=cams, gather=gather, graph=self.graph, clone_outputs=False)
+        self.runner.image_buffer.copy_(self.img)
+        self.img = self.runner.image_buffer
         self.i = 0
         # priming, part of the build and outside every timed region whatever --warmup says: the first frame of a
         # scene and the frames after it replay two different graphs (each captured on first use, after the measured
@@ -409,7 +416,11 @@ class ModelFrames:
                 raise
             # graph capture refused (an operator that synchronises during capture): eager frames
             self.graph = False
-            self.runner = self.B.FrameRunner(self.runner.model, self.dev, torch.float16)
+            img = self.img.clone()
+            self.runner = self.B.FrameRunner(self.runner.model, self.dev, torch.float16, cams=self._shard[0],
+                                             gather=self._shard[1], clone_outputs=False)
+            self.runner.image_buffer.copy_(img)
+            self.img = self.runner.image_buffer
             return self.runner.step(self.img, self.can(self.i), self.l2i, "scene")
 
 
@@ -434,6 +445,52 @@ def run_frames(frames, steps, warmup, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def run_frames_protocol(frames, steps):
+    """The reference's own FPS protocol (det2trt/utils/tensorrt.py:72-76, tools/bevformer/evaluate_trt.py:166-168):
+    the device forward of ONE frame between two stream synchronisations, first and last frame dropped,
+    FPS = 1000 / mean ms.  (`value` of the line is back-to-back throughput, as bench.py's contract defines a step;
+    this is the latency-style figure next to it.)"""
+    ts = []
+    for _ in range(steps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames.step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    core = ts[1:-1]
+    ms = sum(core) / len(core)
+    return {"value": round(1000.0 / ms, 3), "unit": "frames/s", "ms_per_frame": round(ms, 4), "frames": len(core),
+            "protocol": "per-frame stream sync, first and last frame dropped, 1000 / mean ms (tensorrt.py:72-76)"}
+
+
+def bevdet_frames(dev, steps, warmup):
+    """BASELINE config 5: the whole BEVDet-R50 (6 x 3x256x704 -> R50 + FPN -> depth_net -> bev_pool_v2 -> bev encoder ->
+    CenterHead; det2trt/models/detector/bevdet.py:29-82) in fp16, random weights, synthetic rig, HIP-graph replay;
+    back-to-back frames/s and the reference's per-frame-synchronised protocol."""
+    from bevformer_tensorrt_amd import bevdet as D
+    model = D.BEVDet(seed=0).to(dev, torch.float16)
+    ranks = [r.to(dev) for r in model.view.get_bev_pool_input(*D.synthetic_rig(model.view))]
+    img = torch.randn(1, 6, 3, *D.view_input_size(model.view), generator=torch.Generator().manual_seed(0)).to(dev, torch.float16)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            model(img, *ranks)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        model(img, *ranks)
+
+    class _F:
+        step = staticmethod(graph.replay)
+
+    el = run_frames(_F, steps, warmup, dev, None)
+    return {"config": "BEVDet-R50 fp16: 6x(3x256x704) -> ResNet-50 + FPN -> depth_net -> bev_pool_v2 (%d points, %d intervals) "
+                      "-> bev encoder + FPN_LSS -> CenterHead" % (ranks[0].numel(), ranks[3].numel()),
+            "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "hip_graph": True,
+            "protocol_sync": run_frames_protocol(_F, steps)}
 
 
 def self_launch(args):
@@ -464,14 +521,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "int8"],
                     help="which build of the model the headline `value` times (the other one is a sub-record at N=1)")
-    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
-                    help="N>1: per-camera all-gathers of the camera features (BASELINE config 4) or all-reduce of "
-                         "each rank's masked camera sum (SURVEY 8e alternative, 6x less data)")
+    ap.add_argument("--exchange", default="reduce", choices=["gather", "reduce"],
+                    help="N>1: all-reduce of each rank's masked camera sum (default: the fused sampler runs on the local "
+                         "cameras, one 20.5 MB collective per encoder layer, the frame replays from a HIP graph with its "
+                         "RCCL collectives inside) or the per-camera pipelined all-gathers of the camera features "
+                         "(BASELINE config 4's exchange: 6x the data, eager frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="profiling runs: time the sampling hot path only (the line's value is then the hot-path rate)")
     ap.add_argument("--no-int8", action="store_true", help="skip the INT8 sub-records of the default fp16 run")
     ap.add_argument("--no-hot-path", action="store_true", help="skip the hot-path / roofline sub-records")
+    ap.add_argument("--no-small", action="store_true", help="skip the BEVFormer-small end-to-end sub-record")
     ap.add_argument("--no-geometry-extra", action="store_true",
                     help="skip the extra SCA timings on the model's own reference points (profiling runs: keeps "
                          "the rocprofv3 per-kernel averages to the contract workload)")
@@ -500,7 +560,9 @@ def main():
     if not args.no_end_to_end:
         frames = ModelFrames(dev, args.dtype, world, rank, dist, args.exchange)
         elapsed = run_frames(frames, args.steps, args.warmup, dev, dist)
-        headline = {"elapsed": elapsed, "hip_graph": frames.graph, "note": frames.note}
+        headline = {"elapsed": elapsed, "hip_graph": frames.graph, "note": frames.note, "protocol_sync": None}
+        if world == 1:
+            headline["protocol_sync"] = run_frames_protocol(frames, args.steps)
         del frames
         torch.cuda.empty_cache()
 
@@ -548,11 +610,35 @@ def main():
                 e8 = run_frames(f8, args.steps, args.warmup, dev, None)
                 other["end_to_end"] = {"value": round(args.steps / e8, 3), "unit": "frames/s",
                                        "ms_per_step": round(e8 / args.steps * 1e3, 4), "hip_graph": f8.graph,
-                                       "build": f8.note}
+                                       "build": f8.note, "protocol_sync": run_frames_protocol(f8, args.steps)}
                 del f8
                 torch.cuda.empty_cache()
             except Exception as exc:
                 other["end_to_end"] = {"error": repr(exc)[:300]}
+
+    # BASELINE config 3: BEVFormer-small fp16 / INT8 end to end (same protocol pair)
+    small = None
+    if world == 1 and not args.no_end_to_end and not args.no_small:
+        small = {"config": "BEVFormer-small: 6x(3x736x1280) -> ResNet-101-DCN (C5) + FPN level -> 3 encoder layers "
+                           "(150x150 BEV queries) -> 6 decoder layers -> heads"}
+        for kind in ("fp16",) + (() if args.no_int8 else ("int8",)):
+            try:
+                fs = ModelFrames(dev, kind, 1, 0, None, args.exchange, name="small")
+                es = run_frames(fs, args.steps, args.warmup, dev, None)
+                small[kind] = {"value": round(args.steps / es, 3), "unit": "frames/s",
+                               "ms_per_step": round(es / args.steps * 1e3, 4), "hip_graph": fs.graph, "build": fs.note,
+                               "protocol_sync": run_frames_protocol(fs, args.steps)}
+                del fs
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                small[kind] = {"error": repr(exc)[:300]}
+
+    bevdet = None
+    if world == 1 and not args.no_end_to_end and not args.no_small:
+        try:
+            bevdet = bevdet_frames(dev, args.steps, args.warmup)
+        except Exception as exc:
+            bevdet = {"error": repr(exc)[:300]}
 
     if rank == 0:
         cpu = None
@@ -594,7 +680,8 @@ def main():
                        "parallelism": f"cameras/{world}+all-{args.exchange}" if world > 1 else "single"},
             "ranks_seen": dist.get_world_size() if dist is not None else 1,
             "roofline": roofline, "cpu_baseline": cpu, "hot_path": hot if headline is not None else None,
-            "int8": other,
+            "protocol_sync": headline["protocol_sync"] if headline else None,
+            "int8": other, "small": small, "bevdet_r50": bevdet,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

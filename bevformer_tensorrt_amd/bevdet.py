@@ -114,3 +114,159 @@ class LSSViewTransformer(nn.Module):
         out = self.ops.bev_pool_v2_2(depth, tran_feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
                                      interval_lengths, bev_h, bev_w)
         return out.permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------- the whole detector (BASELINE config 5)
+# BEVDetTRT.forward_trt (det2trt/models/detector/bevdet.py:29-82) re-hosted without mmcv / mmdet, frozen BatchNorm
+# folded into the convolution in front of it:
+#   image [1, 6, 3, 256, 704] -> ResNet-50 (style "pytorch", out_indices (2, 3); configs/bevdet/bevdet-r50-cbgs.py:73-84)
+#   -> CustomFPN (1024 / 2048 -> 256, top-down add, ONE 3x3 output convolution on the stride-16 level;
+#      third_party/bev_mmdet3d/models/necks/fpn.py) -> depth_net -> depth softmax -> bev_pool_v2 (the plugin)
+#   -> CustomResNet bev encoder (basic blocks, 64 -> 128 / 256 / 512, strides 2; models/backbone/bev_resnet.py)
+#   -> FPN_LSS (bilinear x4 of the stride-8 level, concatenation with the stride-2 level, two 3x3 convolutions,
+#      bilinear x2, 3x3 + 1x1; models/necks/lss_fpn.py) -> CenterHead.forward_trt (shared 3x3 convolution, one task,
+#      six two-convolution heads with final_kernel 3; det2trt/models/dense_heads/centerpoint_head.py:42-53).
+# Two data paths through the same weights, as in bevformer.py: `forward` (NCHW, library convolutions -- the reference
+# op sequence, any device / dtype) and the channels-last fp16 path on this package's convolution / GEMM kernels.
+from . import bevformer as _B   # noqa: E402  (ResNet and the channels-last convolution helpers)
+import torch.nn.functional as F   # noqa: E402
+
+HEADS_R50 = (("reg", 2), ("height", 1), ("dim", 3), ("rot", 2), ("vel", 2), ("heatmap", 10))
+
+
+def _conv(ops, x, conv, relu=False, residual=None):
+    """act(conv(x) + bias + residual) for a BN-folded nn.Conv2d: channels-last fp16 tensors take this package's
+    kernels (1x1: GEMM over the pixel rows; 3x3: implicit GEMM), everything else the library convolution."""
+    fast = x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(memory_format=torch.channels_last) \
+        and hasattr(ops, "conv3x3_auto")
+    if fast and conv.kernel_size == (1, 1):
+        return _B._conv1x1_nhwc(ops, x, conv, relu, residual)
+    if fast and conv.kernel_size == (3, 3) and conv.in_channels % 32 == 0:
+        return _B._conv_nhwc(ops, x, conv, relu, residual)
+    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+class BasicBlock(nn.Module):
+    """mmdet BasicBlock with the 3x3 downsample convolution CustomResNet gives the first block of a stage."""
+
+    def __init__(self, cin, cout, stride, downsample):
+        super().__init__()
+        self.conv1, self.conv2 = nn.Conv2d(cin, cout, 3, stride, 1), nn.Conv2d(cout, cout, 3, 1, 1)
+        self.downsample = nn.Conv2d(cin, cout, 3, stride, 1) if downsample else None
+
+    def forward(self, x, ops):
+        idt = x if self.downsample is None else _conv(ops, x, self.downsample)
+        return _conv(ops, _conv(ops, x, self.conv1, True), self.conv2, True, idt)
+
+
+class BEVDet(nn.Module):
+    """forward(image [1, 6, 3, H, W], ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths)
+    -> (reg, height, dim, rot, vel, heatmap), each [1, c, 128, 128] -- BEVDetTRT.forward_trt."""
+
+    def __init__(self, cfg=None, ops=None, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        cfg = cfg or BEVDET_R50
+        self.cfg = cfg
+        self.ops = ops = ops if ops is not None else _hip_ops
+        self.backbone = _B.ResNet(50, (False,) * 4, (2, 3), ops, "pytorch")
+        self.lateral = nn.ModuleList([nn.Conv2d(1024, 256, 1), nn.Conv2d(2048, 256, 1)])
+        self.fpn_conv = nn.Conv2d(256, 256, 3, 1, 1)
+        self.view = LSSViewTransformer(**{k: cfg[k] for k in ("grid_config", "input_size", "downsample", "in_channels",
+                                                              "out_channels")}, ops=ops, seed=seed)
+        c = cfg["out_channels"]
+        chans, cin, stages = [2 * c, 4 * c, 8 * c], c, []
+        for ch in chans:
+            stages.append(nn.ModuleList([BasicBlock(cin, ch, 2, True), BasicBlock(ch, ch, 1, False)]))
+            cin = ch
+        self.bev_stages = nn.ModuleList(stages)
+        self.neck_conv = nn.ModuleList([nn.Conv2d(chans[2] + chans[0], 512, 3, 1, 1), nn.Conv2d(512, 512, 3, 1, 1)])
+        self.up2_conv = nn.ModuleList([nn.Conv2d(512, 256, 3, 1, 1), nn.Conv2d(256, 256, 1)])
+        self.shared_conv = nn.Conv2d(256, 64, 3, 1, 1)
+        self.heads = nn.ModuleDict({k: nn.ModuleList([nn.Conv2d(64, 64, 3, 1, 1), nn.Conv2d(64, n, 3, 1, 1)])
+                                    for k, n in HEADS_R50})
+        self.eval()
+
+    def image_features(self, image):
+        """img_backbone + img_neck: [6, 3, H, W] -> [6, 256, H / 16, W / 16]."""
+        ops = self.ops
+        nhwc = image.is_cuda and image.dtype == torch.float16 and hasattr(ops, "conv3x3_auto")
+        if nhwc:
+            if not getattr(self, "_nhwc_ready", False):
+                for m in self.modules():
+                    if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+                self._nhwc_ready = True
+            c4, c5 = self.backbone.forward_nhwc(image, ops)
+        else:
+            c4, c5 = self.backbone(image)
+        l4, l5 = _conv(ops, c4, self.lateral[0]), _conv(ops, c5, self.lateral[1])
+        up_add = getattr(ops, "upsample_add_nhwc_", None)
+        if nhwc and up_add is not None and l4.is_contiguous(memory_format=torch.channels_last) \
+                and l5.is_contiguous(memory_format=torch.channels_last):
+            up_add(l4, l5)
+        else:
+            l4 = l4 + F.interpolate(l5, size=l4.shape[2:], mode="nearest")
+        return _conv(ops, l4, self.fpn_conv)
+
+    def bev_encoder(self, x):
+        ops = self.ops
+        if x.is_cuda and x.dtype == torch.float16:
+            x = x.contiguous(memory_format=torch.channels_last)
+        feats = []
+        for stage in self.bev_stages:
+            for blk in stage:
+                x = blk(x, ops)
+            feats.append(x)
+        x1 = F.interpolate(feats[2], scale_factor=4, mode="bilinear", align_corners=True)
+        x = torch.cat([feats[0], x1], dim=1)
+        if feats[0].is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = _conv(ops, _conv(ops, x, self.neck_conv[0], True), self.neck_conv[1], True)
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        return _conv(ops, _conv(ops, x, self.up2_conv[0], True), self.up2_conv[1])
+
+    @torch.no_grad()
+    def forward(self, image, ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths):
+        x = self.image_features(image.flatten(0, 1))
+        bev = self.view.view_transform(x, ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths)
+        feat = self.bev_encoder(bev)
+        ops = self.ops
+        s = _conv(ops, feat, self.shared_conv, True)
+        return tuple(_conv(ops, _conv(ops, s, h[0], True), h[1]) for h in (self.heads[k] for k, _ in HEADS_R50))
+
+
+def synthetic_rig(view, n_cams=6, seed=0):
+    """A plausible six-camera calibration for timing and tests (no nuScenes data here): cameras on a ring, 60 degrees
+    apart, looking outwards, the resize / crop augmentation of the test pipeline as post_rots / post_trans.
+    Returns the six tensors of LSSViewTransformer.get_bev_pool_input."""
+    import math
+    H, W = view_input_size(view)
+    s2e = torch.zeros(1, n_cams, 4, 4)
+    for i in range(n_cams):
+        yaw = math.radians(60.0 * i)
+        # camera axes (x right, y down, z forward) in the ego frame (x forward, y left, z up)
+        fwd = torch.tensor([math.cos(yaw), math.sin(yaw), 0.0])
+        right = torch.tensor([math.sin(yaw), -math.cos(yaw), 0.0])
+        down = torch.tensor([0.0, 0.0, -1.0])
+        s2e[0, i, :3, 0], s2e[0, i, :3, 1], s2e[0, i, :3, 2] = right, down, fwd
+        s2e[0, i, :3, 3] = torch.tensor([1.5 * math.cos(yaw), 1.5 * math.sin(yaw), 1.6])
+        s2e[0, i, 3, 3] = 1.0
+    e2g = torch.eye(4).view(1, 1, 4, 4).repeat(1, n_cams, 1, 1)
+    K = torch.tensor([[1266.0, 0.0, 800.0], [0.0, 1266.0, 450.0], [0.0, 0.0, 1.0]]).view(1, 1, 3, 3).repeat(1, n_cams, 1, 1)
+    scale = W / 1600.0
+    post_rots = (torch.eye(3) * scale).view(1, 1, 3, 3).repeat(1, n_cams, 1, 1)
+    post_rots[..., 2, 2] = 1.0
+    post_trans = torch.zeros(1, n_cams, 3)
+    post_trans[..., 1] = -(900.0 * scale - H)
+    bda = torch.eye(3).view(1, 3, 3)
+    return s2e, e2g, K, post_rots, post_trans, bda
+
+
+def view_input_size(view):
+    """(H, W) of the camera images the frustum of `view` was built for."""
+    x, y = view.frustum[0, 0, :, 0], view.frustum[0, :, 0, 1]
+    return int(round(float(y[-1]))) + 1, int(round(float(x[-1]))) + 1

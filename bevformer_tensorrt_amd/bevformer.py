@@ -408,7 +408,7 @@ class TemporalSelfAttention(nn.Module):
     def _split_projection(self, query, prev0, bev_pos):
         """sampling_offsets and attention_weights of cat([prev_bev, query + bev_pos]) as ONE stacked
         [192, 512] weight split along K:  prev_bev @ Wa.T + query @ Wb.T + (bev_pos @ Wb.T + b), the last
-        term frame-independent (cached per bev_pos tensor).  Two K=256 GEMMs with the running sum as
+        term frame-independent (cached per bev_pos storage / version).  Two K=256 GEMMs with the running sum as
         their epilogue's identity replace the add, the [nq, 512] concatenation and two K=512 GEMMs.
         None -> the caller's module-by-module path (quantised build, fp32, CPU, no algorithm)."""
         fn = _gemm_entry(self.ops)
@@ -424,8 +424,11 @@ class TemporalSelfAttention(nn.Module):
                                torch.cat([so.bias, aw.bias]).detach().contiguous())
                 self._pos_term = None
             _, wa, wb, b = self._split
-            if self._pos_term is None or self._pos_term[0] is not bev_pos:
-                self._pos_term = (bev_pos, fn(bev_pos.reshape(-1, EMBED), wb, b, None, False))
+            # keyed on the tensor's storage, not its Python identity: the model passes a fresh VIEW of the cached
+            # positional encoding every frame
+            pkey = (bev_pos.data_ptr(), bev_pos._version, tuple(bev_pos.shape), bev_pos.dtype)
+            if self._pos_term is None or self._pos_term[0] != pkey:
+                self._pos_term = (pkey, fn(bev_pos.reshape(-1, EMBED), wb, b, None, False))
             t = fn(prev0.reshape(-1, EMBED), wa, None, self._pos_term[1], False)
             return fn(query.reshape(-1, EMBED), wb, None, t, False)
         except _lib.BevopsError as exc:
@@ -467,55 +470,57 @@ class SpatialCrossAttention(nn.Module):
     def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None):
         inp_residual = query
         ncam, nk, nq = value.shape[0], value.shape[1], query.shape[1]   # ncam may be 0 (rank without cameras)
+        mode = getattr(gather, "mode", None)
+        if cams is None and gather is not None and hasattr(gather, "cams"):
+            cams = gather.cams   # the exchange object knows this rank's cameras
+        ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
+        # camera-sharded: `value` holds this rank's cameras only; their reference points / visibility weights
+        ref_l, mask_l = (ref, bev_mask) if cams is None else (ref[cams], bev_mask[cams])
+        # The fused forms produce the MASKED CAMERA SUM of the cameras they are given, so they serve a single GPU
+        # (all cameras) and the "reduce" exchange (this rank's cameras, then ONE all-reduce of [1, nq, 256]) alike.
+        local_sum = gather is None or mode == "reduce"
         projected = getattr(self.ops, "spatial_cross_attention_projected", None)
-        if projected is not None and gather is None and cams is None and _R3["enabled"] and self._proj_ok \
-                and value.dtype == torch.float16 and value.is_cuda and not hasattr(self.value_proj, "fake_quant_reference"):
+        fused = getattr(self.ops, "spatial_cross_attention_sample", None)
+        fp16_gpu = value.dtype == torch.float16 and value.is_cuda
+        slots = None
+        if local_sum and ncam == 0:
+            slots = torch.zeros((1, nq, EMBED), dtype=value.dtype, device=value.device)
+        elif projected is not None and local_sum and _R3["enabled"] and self._proj_ok and fp16_gpu \
+                and not hasattr(self.value_proj, "fake_quant_reference"):
             # value_proj's GEMM writes the sampler's planes itself; the fused sampling reads them
             off = _dense(self.ops, self.sampling_offsets, query).view(1, nq, HEADS, -1)
             w = _dense(self.ops, self.attention_weights, query).view(1, nq, HEADS, -1)
-            ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
             try:
                 slots = projected(value.reshape(ncam, nk, EMBED), self.value_proj.weight, self.value_proj.bias,
-                                  spatial_shapes, ref, off, w, bev_mask, HEADS)
-                return _dense(self.ops, self.output_proj, slots, inp_residual, False)
+                                  spatial_shapes, ref_l.contiguous(), off, w, mask_l.contiguous(), HEADS)
             except _lib.BevopsError as exc:
                 if exc.status != _lib.NOT_SUPPORTED:
                     raise
                 self._proj_ok = False   # another pyramid (tiny / small: one level): the separate projection below
-        value = _dense(self.ops, self.value_proj, value.reshape(ncam, nk, EMBED)).view(ncam, nk, HEADS, EMBED // HEADS)
-        # the per-camera copies of `query` are identical: project once, expand (stride 0)
-        off = _dense(self.ops, self.sampling_offsets, query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
-        w = _dense(self.ops, self.attention_weights, query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
-        ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
-        if cams is None and gather is not None and hasattr(gather, "cams"):
-            cams = gather.cams   # the exchange object knows this rank's cameras
-        if cams is not None:  # camera-sharded: this rank's cameras only
-            ref = ref[cams]
-        fused = getattr(self.ops, "spatial_cross_attention_sample", None)
-        msda = self.ops.multi_scale_deformable_attn
-        if getattr(gather, "mode", None) == "gather":
-            # camera-sharded, pipelined: camera i's all-gather overlaps the sampling of camera i + 1
-            ref = ref.contiguous()
-            queries = gather.gather(
-                lambda i: msda(value[i:i + 1], spatial_shapes, ref[i:i + 1], off[:1], w[:1]).flatten(2),
-                (nq, EMBED), value.dtype, value.device)
-            slots = (queries * bev_mask).sum(0, keepdim=True)
-        elif getattr(gather, "mode", None) == "reduce":
-            # camera-sharded, cheaper exchange: this rank's masked camera sum, then ONE all-reduce
-            if ncam:
-                queries = msda(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
-                slots = (queries * bev_mask[cams]).sum(0, keepdim=True)
-            else:
-                slots = torch.zeros((1, nq, EMBED), dtype=value.dtype, device=value.device)
-            slots = gather.reduce(slots)
-        elif fused is not None and gather is None and value.dtype == torch.float16:
-            # one call: camera-shared offsets, invisible (camera, query) pairs skipped, masked sum
-            slots = fused(value, spatial_shapes, ref, off[:1], w[:1], bev_mask)
-        else:
-            queries = msda(value, spatial_shapes, ref.contiguous(), off, w).flatten(2)
-            if gather is not None:  # [cams_local, nq, 256] -> [6, nq, 256] on every rank
-                queries = gather(queries)
-            slots = (queries * bev_mask).sum(0, keepdim=True)
+        if slots is None:
+            value = _dense(self.ops, self.value_proj, value.reshape(ncam, nk, EMBED)).view(ncam, nk, HEADS, EMBED // HEADS)
+            # the per-camera copies of `query` are identical: project once, expand (stride 0)
+            off = _dense(self.ops, self.sampling_offsets, query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
+            w = _dense(self.ops, self.attention_weights, query).view(1, nq, HEADS, -1).expand(ncam, -1, -1, -1)
+            msda = self.ops.multi_scale_deformable_attn
+            if mode == "gather":
+                # camera-sharded, pipelined: camera i's all-gather overlaps the sampling of camera i + 1
+                ref_c = ref_l.contiguous()
+                queries = gather.gather(
+                    lambda i: msda(value[i:i + 1], spatial_shapes, ref_c[i:i + 1], off[:1], w[:1]).flatten(2),
+                    (nq, EMBED), value.dtype, value.device)
+                slots = (queries * bev_mask).sum(0, keepdim=True)
+            elif local_sum and fused is not None and (fp16_gpu or getattr(fused, "any_device", False)):
+                # one call: camera-shared offsets, invisible (camera, query) pairs skipped, masked sum
+                slots = fused(value, spatial_shapes, ref_l, off[:1], w[:1], mask_l)
+            elif local_sum:
+                queries = msda(value, spatial_shapes, ref_l.contiguous(), off, w).flatten(2)
+                slots = (queries * mask_l).sum(0, keepdim=True)
+            else:   # a plain callable: [cams_local, nq, 256] -> [6, nq, 256] on every rank
+                queries = gather(msda(value, spatial_shapes, ref_l.contiguous(), off, w).flatten(2))
+                slots = (queries * bev_mask).sum(0, keepdim=True)
+        if mode == "reduce":
+            slots = gather.reduce(slots)      # this rank's masked camera sum -> everyone's
         return _dense(self.ops, self.output_proj, slots, inp_residual, False)
 
 
@@ -888,19 +893,35 @@ class FrameRunner:
     first frame of a scene replays the "no history" graph, every other frame the "history" graph, and
     neither carries the per-layer select between prev_bev and the repeated query."""
 
-    def __init__(self, model, device, dtype, graph=False, cams=None, gather=None):
-        self.model, self.device, self.dtype = model, device, dtype
+    def __init__(self, model, device, dtype, graph=False, cams=None, gather=None, clone_outputs=True):
+        """clone_outputs=False: under graph replay `step` hands out the graph's own output buffers (valid until the
+        next `step`, like the output bindings of a TensorRT execution context) instead of copies."""
+        self.model, self.device, self.dtype, self.clone_outputs = model, device, dtype, clone_outputs
         self.cams, self.gather = cams, gather
+        if gather is not None and device.type == "cuda":
+            # camera-sharded: every rank must evaluate the replicated layers with the same kernels (functions/linear.py)
+            from .functions.linear import DETERMINISTIC
+            DETERMINISTIC["enabled"] = True
         self.tuned_gemms = use_tuned_gemms() if device.type == "cuda" else False
         nq = model.bev_h * model.bev_w
         self.prev_bev = torch.zeros(nq, 1, EMBED, device=device, dtype=dtype)
         self.prev = {"scene": None, "pos": None, "angle": None}
         self.use_graph, self._graphs, self._use = graph, {}, 0.0
         H, W = model.cfg["image"]
+        # the frame's small host-side inputs travel as ONE upload: [can_bus (18) | bev shift (2)]
+        small = torch.zeros(20, device=device)
+        self._host_small = torch.zeros(20)
         self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
-                        can_bus=torch.zeros(18, device=device), lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
-                        use=torch.zeros((), device=device, dtype=dtype),
-                        shift=torch.zeros(1, 2, device=device))
+                        small=small, can_bus=small[:18], shift=small[18:].view(1, 2),
+                        lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
+                        use=torch.zeros((), device=device, dtype=dtype))
+        self._l2i_seen = None
+
+    @property
+    def image_buffer(self):
+        """The static [1, cams, 3, H, W] input buffer of the frame: a caller that writes its (normalised) camera
+        images here -- as `step_raw` does -- and passes this very tensor to `step` saves the per-frame copy."""
+        return self._in["image"]
 
     @property
     def _graph(self):   # the graph of the current use_prev_bev value (None: not captured yet)
@@ -922,7 +943,11 @@ class FrameRunner:
                 self._forward()
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # camera-sharded frames capture their RCCL collectives too (the process group's stream joins the capture
+        # through the events torch records around every collective); the group's watchdog thread polls events
+        # meanwhile, which only the thread-local capture mode tolerates
+        kw = {"capture_error_mode": "thread_local"} if self.gather is not None else {}
+        with torch.cuda.graph(graph, **kw):
             bev, cls, crd = self._forward()
             self.prev_bev.copy_(bev)     # state update is part of the graph
         self._graphs[self._use] = (graph, (cls, crd))
@@ -951,13 +976,20 @@ class FrameRunner:
             can_bus[-1] = 0
         self.prev.update(scene=scene_token, pos=pos, angle=angle)
         i = self._in
-        i["image"].copy_(image, non_blocking=True)
-        i["can_bus"].copy_(can_bus, non_blocking=True)
-        i["lidar2img"].copy_(lidar2img, non_blocking=True)
+        if image.data_ptr() != i["image"].data_ptr():      # (the caller may have filled the static buffer itself)
+            i["image"].copy_(image, non_blocking=True)
+        l2i_key = (lidar2img.data_ptr(), lidar2img._version)
+        if l2i_key != self._l2i_seen:                       # calibration matrices change per scene, not per frame
+            i["lidar2img"].copy_(lidar2img, non_blocking=True)
+            self._l2i_seen = l2i_key
         m = self.model
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / m.bev_h, (PC_RANGE[3] - PC_RANGE[0]) / m.bev_w)
-        i["shift"].copy_(G.bev_shift(can_bus.cpu(), m.bev_h, m.bev_w, grid_length), non_blocking=True)
-        i["use"].fill_(use_prev)
+        can_host = can_bus.cpu()
+        self._host_small[:18] = can_host
+        self._host_small[18:] = G.bev_shift(can_host, m.bev_h, m.bev_w, grid_length)[0]
+        i["small"].copy_(self._host_small)                  # one upload (pageable source: staged before the call returns)
+        if not _R3["enabled"]:
+            i["use"].fill_(use_prev)
         self._use = use_prev
         if self.use_graph:
             if self._graph is None:
@@ -967,8 +999,9 @@ class FrameRunner:
             graph, outs = self._graphs[self._use]
             graph.replay()
             # the capture's output buffers are overwritten by the next replay: hand out copies
-            # (2 x 54 000 values), as the eager path hands out fresh tensors
-            return tuple(t.clone() for t in outs)
+            # (2 x 54 000 values), as the eager path hands out fresh tensors -- unless the caller asked for the
+            # buffers themselves
+            return tuple(t.clone() for t in outs) if self.clone_outputs else outs
         bev_embed, cls, crd = self._forward()
         self.prev_bev = bev_embed                                               # stays on device (:144)
         return cls, crd

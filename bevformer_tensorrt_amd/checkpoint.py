@@ -151,6 +151,11 @@ def load_reference_state_dict(model, state_dict, strict=True):
                     continue
                 used.add(src)
                 val = sd[src]
+            if name == "level_embeds" and val.dim() == 2 and val.shape[0] > p.shape[0] and val.shape[1:] == p.shape[1:]:
+                # tiny / small configs never pass num_feature_levels, so PerceptionTransformer allocates its default
+                # 4 rows (modules/transformer.py:15,55) although only level_embeds[lvl] for lvl < the FPN's levels is
+                # ever read (:313-321): take the rows that are used
+                val = val[:p.shape[0]]
             if tuple(val.shape) != tuple(p.shape):
                 raise ValueError(f"{name}: shape {tuple(p.shape)} vs reference {tuple(val.shape)}")
             p.copy_(val.to(p.dtype))

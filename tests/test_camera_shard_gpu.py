@@ -66,3 +66,31 @@ def test_model_with_exchange_equals_plain_model(nccl_group, mode):
         assert (cs.float() - cp.float()).abs().max().item() <= 5e-2
         # box parameters are unbounded regressions (|values| up to ~25 here): relative bar
         assert (bs.float() - bp.float()).abs().max().item() <= 2e-2 * max(1.0, bp.float().abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_sharded_frame_replays_from_a_hip_graph_with_its_collectives(nccl_group, name):
+    """The "reduce" exchange under graph replay: the fused sampler on this rank's cameras, ONE all-reduce per encoder
+    layer, the RCCL collectives captured together with the kernels (FrameRunner(graph=True, gather=...)) -- against
+    the plain single-GPU graph runner on the same frames."""
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    from bevformer_tensorrt_amd.camera_shard import CameraExchange
+    dev, dtype = torch.device("cuda"), torch.float16
+    model = B.BEVFormer(name, seed=0).to(dev, dtype)
+    ex = CameraExchange(nccl_group, 6, "reduce")
+    H, W = B.CONFIGS[name]["image"]
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    g = torch.Generator().manual_seed(0)
+    run_s = B.FrameRunner(model, dev, dtype, graph=True, cams=list(ex.cams), gather=ex)
+    run_p = B.FrameRunner(model, dev, dtype, graph=True)
+    for i in range(3):
+        img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+        can = torch.zeros(18)
+        can[0], can[-1] = 0.3 * i, 0.5 * i
+        cs, bs = run_s.step(img, can, l2i, "s")
+        cp, bp = run_p.step(img, can, l2i, "s")
+        torch.cuda.synchronize()
+        assert run_s._graph is not None            # captured, not an eager fallback
+        scale = run_p.prev_bev.float().std().item()
+        assert (run_s.prev_bev.float() - run_p.prev_bev.float()).abs().max().item() <= 3e-2 * max(1.0, scale)
+        assert (cs.float() - cp.float()).abs().max().item() <= 5e-2

@@ -139,6 +139,26 @@ def test_round_trip_tiny():
     assert missing == ["level_embeds"] and unexpected == ["pts_bbox_head.some_new_buffer"]
 
 
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_reference_shaped_level_embeds_load(name):
+    """The reference's tiny / small configs never pass num_feature_levels, so their checkpoints carry a [4, 256]
+    level_embeds (modules/transformer.py:15,55) although one FPN level is used: the rows that are read are taken."""
+    a = B.BEVFormer(name, ops=object(), seed=1)
+    sd = synthetic_reference_state_dict(a)
+    key = "pts_bbox_head.transformer.level_embeds"
+    assert sd[key].shape == (1, 256)
+    ref = torch.randn(4, 256)
+    ref[0] = sd[key][0]
+    sd[key] = ref                                   # the reference's shape
+    b = B.BEVFormer(name, ops=object(), seed=2)
+    missing, unexpected = C.load_reference_state_dict(b, sd)
+    assert missing == [] and unexpected == []
+    assert torch.equal(b.level_embeds.detach(), ref[:1])
+    sd[key] = torch.randn(4, 128)                   # a genuinely different shape still fails loudly
+    with pytest.raises(ValueError):
+        C.load_reference_state_dict(b, sd)
+
+
 def test_tiny_backbone_is_pytorch_style_and_base_caffe():
     """configs/bevformer/bevformer_tiny.py:62 (style="pytorch": stride on the 3x3), bevformer_base.py:50."""
     t = B.BEVFormer("tiny", ops=object()).backbone.stages[1][0]

@@ -90,25 +90,26 @@ def test_stem_pool_int8():
     _close_int8(q, torch.clamp(torch.round(want / s), -127, 127))
 
 
-@pytest.mark.parametrize("B,C,H,W,relu", [(6, 256, 58, 100, True), (2, 128, 20, 30, False), (6, 512, 29, 50, True)])
-def test_dcn_int8_nhwc_is_the_int8_plugin_on_channels_last(B, C, H, W, relu):
+@pytest.mark.parametrize("B,Ch,H,W,relu", [(6, 256, 58, 100, True), (2, 128, 20, 30, False), (6, 512, 29, 50, True)])
+def test_dcn_int8_nhwc_is_the_int8_plugin_on_channels_last(B, Ch, H, W, relu):
     """bevops_mdconv_forward_int8_nhwc against bevops_mdconv_forward_int8 (the INT8 plugin entry) fed the operands
     the channels-last entry quantises internally: offsets / sigmoid(mask logits) with rne, input as is."""
     import bevformer_tensorrt_amd as bev
     from bevformer_tensorrt_amd.functions import int8_chain as C
-    g = torch.Generator().manual_seed(B * C + H)
-    x = torch.randint(-127, 128, (B, C, H, W), generator=g, dtype=torch.int8).cuda()
-    w = torch.randint(-127, 128, (C, C, 3, 3), generator=g, dtype=torch.int8).cuda()
-    bias = torch.randn(C, generator=g).cuda()
+    g = torch.Generator().manual_seed(B * Ch + H)
+    x = torch.randint(-127, 128, (B, Ch, H, W), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-127, 128, (Ch, Ch, 3, 3), generator=g, dtype=torch.int8).cuda()
+    bias = torch.randn(Ch, generator=g).cuda()
     om = torch.zeros(B, 32, H, W)
     om[:, :18] = torch.randn(B, 18, H, W, generator=g) * 2.0
     om[:, 18:27] = torch.randn(B, 9, H, W, generator=g) * 1.5
     om = om.half().cuda().contiguous(memory_format=torch.channels_last)
-    s_in, s_off, s_mask, s_w, s_out = 0.02, 6.0 / 127, 1.0 / 127, 0.01 / (C * 9) ** 0.5, 0.06
+    s_in, s_off, s_mask, s_w, s_out = 0.02, 6.0 / 127, 1.0 / 127, 0.01 / (Ch * 9) ** 0.5, 0.06
     got = C.modulated_deformable_conv2d_int8_nhwc(x.contiguous(memory_format=torch.channels_last), s_in, om, s_off,
                                                   s_mask, w, s_w, bias, s_out, relu)
-    off_q = _q(om[:, :18], s_off).contiguous()
-    mask_q = _q(torch.sigmoid(om[:, 18:27]), s_mask).contiguous()           # fp16 sigmoid, as the fp16 block's tensor
+    # (the divisions on the HOST: the device's tensor / python-scalar division multiplies by the rounded reciprocal)
+    off_q = _q(om[:, :18].cpu(), s_off).contiguous().cuda()
+    mask_q = _q(torch.sigmoid(om[:, 18:27]).cpu(), s_mask).contiguous().cuda()   # fp16 sigmoid, as the fp16 block's tensor
     want = bev.modulated_deformable_conv2d_int8(x.contiguous(), off_q, mask_q, w, bias, s_in, s_off, s_mask, s_w, s_out,
                                                 1, 1, 1, 1, 1)
     if relu:

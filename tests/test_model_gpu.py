@@ -270,8 +270,13 @@ def test_tsa_split_projection_equals_concatenated_linear():
     shapes = torch.tensor([[64, 64]])
     with torch.no_grad():
         (a1, a2), (b1, _) = _r3_ab(lambda: (tsa(q, prev, pos, ref, shapes), tsa(q, prev, pos, ref, shapes)))
-    assert tsa._split is not None and tsa._pos_term is not None and tsa._pos_term[0] is pos
+    assert tsa._split is not None and tsa._pos_term is not None and tsa._pos_term[0][0] == pos.data_ptr()
     assert torch.equal(a1, a2)                      # the cached term is reused, not recomputed differently
+    # ... also through a fresh VIEW of the same storage (the model passes bev_pos.view(1, nq, 256) every frame)
+    term = tsa._pos_term[1]
+    with torch.no_grad():
+        a3 = tsa(q, prev, pos.view(1, nq, 256), ref, shapes)
+    assert tsa._pos_term[1] is term and torch.equal(a1, a3)
     assert (a1.float() - b1.float()).abs().max().item() <= 2e-2 * max(1.0, b1.float().abs().max().item())
     assert (a1.float() - b1.float()).abs().mean().item() <= 2e-3
 

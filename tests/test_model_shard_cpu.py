@@ -46,6 +46,27 @@ def _run_frames(model, B, G, cams, gather):
     return outs
 
 
+class _FusedRefOps:
+    """RefOps plus a torch statement of the fused SCA sampling op (spatial_cross_attention_sample: the masked
+    camera sum of the cameras it is given), so that the "reduce" exchange runs its product dataflow on the CPU:
+    fused sampling on the LOCAL cameras -> one all-reduce of [1, nq, 256]."""
+    calls = 0
+
+    def __getattr__(self, name):
+        from util_refops import RefOps
+        return getattr(RefOps, name)
+
+    def spatial_cross_attention_sample(self, value, shapes, ref, off, w, bev_mask):
+        from util_refops import RefOps
+        type(self).calls += 1
+        n = value.shape[0]
+        q = RefOps.multi_scale_deformable_attn(value, shapes, ref.contiguous(), off.expand(n, -1, -1, -1),
+                                               w.expand(n, -1, -1, -1)).flatten(2)
+        return (q * bev_mask.reshape(n, -1, 1)).sum(0, keepdim=True)
+
+    spatial_cross_attention_sample.any_device = True
+
+
 def _worker(rank, world, port, mode, q):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
@@ -57,19 +78,23 @@ def _worker(rank, world, port, mode, q):
     from bevformer_tensorrt_amd.camera_shard import CameraExchange
     from util_refops import RefOps
     B.CONFIGS["unit"] = dict(B.CONFIGS["tiny"], image=(96, 160), bev=(12, 12))
-    model = B.BEVFormer("unit", ops=RefOps, seed=0)
+    fused = mode == "reduce-fused"
+    mode = "reduce" if fused else mode
+    model = B.BEVFormer("unit", ops=_FusedRefOps() if fused else RefOps, seed=0)
     ex = CameraExchange(dist, 6, mode)
     sharded = _run_frames(model, B, G, ex.cams, ex)
     whole = _run_frames(model, B, G, None, None)
     err = max(float((a[0] - b[0]).abs().max()) for a, b in zip(sharded, whole))
     equal = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(sharded, whole))
+    if fused:      # every encoder layer of both runs took the fused op (a rank without cameras contributes zeros)
+        assert _FusedRefOps.calls == (6 if len(ex.cams) else 0) + 6, _FusedRefOps.calls
     q.put((rank, equal, err, len(ex.cams)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("mode", ["gather", "reduce"])
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather"), (8, "gather"), (2, "reduce"), (4, "reduce"),
+                                        (8, "reduce"), (2, "reduce-fused"), (8, "reduce-fused")])
 def test_sharded_model_equals_single_process(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
