@@ -465,32 +465,49 @@ def run_frames_protocol(frames, steps):
             "protocol": "per-frame stream sync, first and last frame dropped, 1000 / mean ms (tensorrt.py:72-76)"}
 
 
-def bevdet_frames(dev, steps, warmup):
+def bevdet_frames(dev, steps, warmup, int8=True):
     """BASELINE config 5: the whole BEVDet-R50 (6 x 3x256x704 -> R50 + FPN -> depth_net -> bev_pool_v2 -> bev encoder ->
-    CenterHead; det2trt/models/detector/bevdet.py:29-82) in fp16, random weights, synthetic rig, HIP-graph replay;
-    back-to-back frames/s and the reference's per-frame-synchronised protocol."""
+    CenterHead; det2trt/models/detector/bevdet.py:29-82), random weights, synthetic rig, HIP-graph replay: fp16, and
+    the PTQ build (int8 activation chain through the backbone, INT8 bev_pool_v2); back-to-back frames/s and the
+    reference's per-frame-synchronised protocol for each."""
     from bevformer_tensorrt_amd import bevdet as D
+
+    def graphed(model, img, ranks):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                model(img, *ranks)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            model(img, *ranks)
+
+        class _F:
+            step = staticmethod(graph.replay)
+
+        el = run_frames(_F, steps, warmup, dev, None)
+        return {"value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4),
+                "hip_graph": True, "protocol_sync": run_frames_protocol(_F, steps)}
+
     model = D.BEVDet(seed=0).to(dev, torch.float16)
     ranks = [r.to(dev) for r in model.view.get_bev_pool_input(*D.synthetic_rig(model.view))]
-    img = torch.randn(1, 6, 3, *D.view_input_size(model.view), generator=torch.Generator().manual_seed(0)).to(dev, torch.float16)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            model(img, *ranks)
-    torch.cuda.current_stream().wait_stream(s)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        model(img, *ranks)
-
-    class _F:
-        step = staticmethod(graph.replay)
-
-    el = run_frames(_F, steps, warmup, dev, None)
-    return {"config": "BEVDet-R50 fp16: 6x(3x256x704) -> ResNet-50 + FPN -> depth_net -> bev_pool_v2 (%d points, %d intervals) "
-                      "-> bev encoder + FPN_LSS -> CenterHead" % (ranks[0].numel(), ranks[3].numel()),
-            "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "hip_graph": True,
-            "protocol_sync": run_frames_protocol(_F, steps)}
+    gen = torch.Generator().manual_seed(0)
+    hw = D.view_input_size(model.view)
+    img = torch.randn(1, 6, 3, *hw, generator=gen).to(dev, torch.float16)
+    out = {"config": "BEVDet-R50: 6x(3x256x704) -> ResNet-50 + FPN -> depth_net -> bev_pool_v2 (%d points, %d intervals) "
+                     "-> bev encoder + FPN_LSS -> CenterHead" % (ranks[0].numel(), ranks[3].numel()),
+           "fp16": graphed(model, img, ranks)}
+    del model
+    if int8:
+        try:
+            from bevformer_tensorrt_amd.quantization import build_int8_bevdet
+            cal = [(torch.randn(1, 6, 3, *hw, generator=gen).to(dev, torch.float16), *ranks) for _ in range(4)]
+            m8, _, note = build_int8_bevdet(D, dev, cal)
+            out["int8"] = dict(graphed(m8, img, ranks), build=note)
+        except Exception as exc:
+            out["int8"] = {"error": repr(exc)[:300]}
+    return out
 
 
 def self_launch(args):
@@ -636,7 +653,7 @@ def main():
     bevdet = None
     if world == 1 and not args.no_end_to_end and not args.no_small:
         try:
-            bevdet = bevdet_frames(dev, args.steps, args.warmup)
+            bevdet = bevdet_frames(dev, args.steps, args.warmup, not args.no_int8)
         except Exception as exc:
             bevdet = {"error": repr(exc)[:300]}
 

@@ -138,7 +138,7 @@ def _conv(ops, x, conv, relu=False, residual=None):
     """act(conv(x) + bias + residual) for a BN-folded nn.Conv2d: channels-last fp16 tensors take this package's
     kernels (1x1: GEMM over the pixel rows; 3x3: implicit GEMM), everything else the library convolution."""
     fast = x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(memory_format=torch.channels_last) \
-        and hasattr(ops, "conv3x3_auto")
+        and hasattr(ops, "conv3x3_auto") and conv.out_channels % 8 == 0    # (the heads' 1 / 2 / 3-channel outputs: library)
     if fast and conv.kernel_size == (1, 1):
         return _B._conv1x1_nhwc(ops, x, conv, relu, residual)
     if fast and conv.kernel_size == (3, 3) and conv.in_channels % 32 == 0:
@@ -162,6 +162,31 @@ class BasicBlock(nn.Module):
         return _conv(ops, _conv(ops, x, self.conv1, True), self.conv2, True, idt)
 
 
+class CustomFPN(nn.Module):
+    """CustomFPN(in_channels=[1024, 2048], out_channels=256, num_outs=1, out_ids=[0]) of the BEVDet-R50 config
+    (third_party/bev_mmdet3d/models/necks/fpn.py:158-183): two lateral 1x1 convolutions, nearest top-down add, one
+    3x3 output convolution on the finer level."""
+
+    def __init__(self, cins=(1024, 2048), cout=256):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, cout, 1) for c in cins)
+        self.fpn_conv = nn.Conv2d(cout, cout, 3, 1, 1)
+
+    def topdown_nhwc(self, lats, ops):
+        """everything behind the lateral convolutions (the INT8 chain evaluates those itself); any layout"""
+        l4, l5 = lats
+        up_add = getattr(ops, "upsample_add_nhwc_", None)
+        if up_add is not None and l4.is_cuda and l4.dtype == torch.float16 \
+                and l4.is_contiguous(memory_format=torch.channels_last) and l5.is_contiguous(memory_format=torch.channels_last):
+            up_add(l4, l5)
+        else:
+            l4 = l4 + F.interpolate(l5, size=l4.shape[2:], mode="nearest")
+        return _conv(ops, l4, self.fpn_conv)
+
+    def forward(self, feats, ops):
+        return self.topdown_nhwc([_conv(ops, f, l) for l, f in zip(self.lateral, feats)], ops)
+
+
 class BEVDet(nn.Module):
     """forward(image [1, 6, 3, H, W], ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths)
     -> (reg, height, dim, rot, vel, heatmap), each [1, c, 128, 128] -- BEVDetTRT.forward_trt."""
@@ -173,8 +198,7 @@ class BEVDet(nn.Module):
         self.cfg = cfg
         self.ops = ops = ops if ops is not None else _hip_ops
         self.backbone = _B.ResNet(50, (False,) * 4, (2, 3), ops, "pytorch")
-        self.lateral = nn.ModuleList([nn.Conv2d(1024, 256, 1), nn.Conv2d(2048, 256, 1)])
-        self.fpn_conv = nn.Conv2d(256, 256, 3, 1, 1)
+        self.neck = CustomFPN()
         self.view = LSSViewTransformer(**{k: cfg[k] for k in ("grid_config", "input_size", "downsample", "in_channels",
                                                               "out_channels")}, ops=ops, seed=seed)
         c = cfg["out_channels"]
@@ -200,17 +224,13 @@ class BEVDet(nn.Module):
                     if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
                         m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
                 self._nhwc_ready = True
-            c4, c5 = self.backbone.forward_nhwc(image, ops)
+            chain = getattr(self, "int8_chain", None)     # quantization.Int8ChainBackbone, after its freeze()
+            if chain is not None and chain.ready:
+                return chain(image)
+            feats = self.backbone.forward_nhwc(image, ops)
         else:
-            c4, c5 = self.backbone(image)
-        l4, l5 = _conv(ops, c4, self.lateral[0]), _conv(ops, c5, self.lateral[1])
-        up_add = getattr(ops, "upsample_add_nhwc_", None)
-        if nhwc and up_add is not None and l4.is_contiguous(memory_format=torch.channels_last) \
-                and l5.is_contiguous(memory_format=torch.channels_last):
-            up_add(l4, l5)
-        else:
-            l4 = l4 + F.interpolate(l5, size=l4.shape[2:], mode="nearest")
-        return _conv(ops, l4, self.fpn_conv)
+            feats = self.backbone(image)
+        return self.neck(feats, ops)
 
     def bev_encoder(self, x):
         ops = self.ops

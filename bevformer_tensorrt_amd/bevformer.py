@@ -898,10 +898,6 @@ class FrameRunner:
         next `step`, like the output bindings of a TensorRT execution context) instead of copies."""
         self.model, self.device, self.dtype, self.clone_outputs = model, device, dtype, clone_outputs
         self.cams, self.gather = cams, gather
-        if gather is not None and device.type == "cuda":
-            # camera-sharded: every rank must evaluate the replicated layers with the same kernels (functions/linear.py)
-            from .functions.linear import DETERMINISTIC
-            DETERMINISTIC["enabled"] = True
         self.tuned_gemms = use_tuned_gemms() if device.type == "cuda" else False
         nq = model.bev_h * model.bev_w
         self.prev_bev = torch.zeros(nq, 1, EMBED, device=device, dtype=dtype)
@@ -928,6 +924,18 @@ class FrameRunner:
         return self._graphs.get(self._use, (None, None))[0]
 
     def _forward(self):
+        if self.gather is not None and self.device.type == "cuda":
+            # camera-sharded: every rank must evaluate the replicated layers with the same kernels, so the measured
+            # per-process dispatch (functions/linear.py) is off for the duration of this runner's forwards
+            from .functions.linear import DETERMINISTIC
+            prev, DETERMINISTIC["enabled"] = DETERMINISTIC["enabled"], True
+            try:
+                return self._forward_impl()
+            finally:
+                DETERMINISTIC["enabled"] = prev
+        return self._forward_impl()
+
+    def _forward_impl(self):
         i = self._in
         if not _R3["enabled"]:   # A/B: the device-side flag (one graph, per-layer select)
             return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,

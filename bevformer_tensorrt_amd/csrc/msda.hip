@@ -852,7 +852,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
         }
         // hm5 (msda_hm5.hip): hm3's planes, re-scheduled, plus the exact visibility pre-pass; default
         // for the 4-level x 8-point SCA shape.  Variants 1000 + flags select its A/B builds
-        if (spatial_shapes_host && ((g_variant >= 1000 && g_variant < 3048) || (g_variant == 0 && pays))) {
+        if (spatial_shapes_host && ((g_variant >= 1000 && g_variant < 9192) || (g_variant == 0 && pays))) {
           const int rc = msda_hm5_forward_f16(
               (const __half *)value, spatial_shapes_host, (const __half *)reference_points,
               (const __half *)sampling_offsets, (const __half *)attention_weights, (__half *)output,

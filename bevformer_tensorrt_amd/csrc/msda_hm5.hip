@@ -168,8 +168,10 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 // time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
 // every lane the record of slot (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot
 // and dword does the rest (26 more VALU instructions per phase, no LDS traffic).
+// (512-thread blocks are the level-class split probe's: two of them -- one per level class -- share a CU, so each
+// is compiled for 4 waves per SIMD, i.e. <= 128 registers, like the 1024-thread block)
 template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX, bool PERSIST>
-__global__ __launch_bounds__(THREADS) void msda_hm5_kernel(
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
     __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
@@ -646,6 +648,23 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
                        n_pair);
   }
   const int chunk = (flags & 128) ? 2 * kH5Chunk : kH5Chunk;
+  // Level-class split probe (round-3 review, item 2: "overlap across blocks, not inside a wave"): the call as TWO
+  // kernels that can share a CU -- A takes the big levels' samples through L2 with NO plane image in LDS, B the
+  // staged levels' samples from its LDS image -- timed alone and concurrently on two streams by
+  // tools/sca_split_probe.py.  These are TIMING builds (each leaves the other class's samples out, so the output is
+  // not the operator's); whether a correct pair with a partial-sum hand-off is worth building is what they measure.
+  //   2048: A (no staged taps, no LDS image); 4096: B (no big-level taps); + 2: 1024-thread blocks instead of 512
+  if (flags & (2048 | 4096)) {
+    Hm3Plan pa = pl;
+    if (flags & 2048) pa.stage_bytes = 0;
+    const bool wide = (flags & 2) != 0;
+    if (flags & 2048) {
+      if (wide) return h5_go<2, 1024, 2, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
+      return h5_go<2, 512, 2, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
+    }
+    if (wide) return h5_go<2, 1024, 1, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
+    return h5_go<2, 512, 1, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
+  }
 #define BEVOPS_H5(KERN_, THREADS_, ABL_, LISTED_) \
   return KERN_<2, THREADS_, ABL_, LISTED_ ? 1 : 0>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
   if (!(flags & 256)) {   // default: records through DPP

@@ -93,10 +93,16 @@ struct TileArgs {
 // NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
 // matrix work on columns that do not exist)
 // RES8: the identity rows are int8 [M, N] (real = q * s_res) instead of fp16
-template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false>
-__global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
+// MJ: 32-row MFMA blocks per wave: 2 -> 128-row tiles (three blocks per CU), 1 -> 64-row tiles (FOUR blocks per CU and
+// twice the tiles): the layers whose 128-row tiling is a single sparse round of long k-chains (M <= 40 000: ResNet
+// stages 3 / 4, every encoder layer) are bound by the latency of a chain, not by bytes -- more, smaller chains in
+// flight per CU hide it better (dense layers).
+template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false, int MJ = 2>
+__global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArgs p) {
   constexpr int kTN = 64 * NI;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (kTM + 128) * kTLd];   // 40 KB: [image][A rows | W rows][80]
+  constexpr int TM = 64 * MJ;                    // rows per tile
+  constexpr int kImg = 2 * (TM + 128) * kTLd, kEpi = 4 * 32 * kEpiStride;
+  __shared__ __attribute__((aligned(16))) char smem[kImg > kEpi ? kImg : kEpi];   // [image][A rows | W rows][80]; 40 / 34 KB
   constexpr int kAB = MODE == kS8 ? 1 : 2;     // bytes per activation element in memory
   constexpr int kWB = MODE == kF16 ? 2 : 1;    // bytes per weight element
   constexpr int kAV = MODE == kF16Q ? 2 : 1;   // 16-byte loads per activation row and step
@@ -108,14 +114,14 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   const int per_xcd = (p.tiles_total + 7) >> 3;
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= p.tiles_total) return;
-  const int m0 = (logical / p.tiles_n) * kTM, n0 = (logical % p.tiles_n) * kTN;
+  const int m0 = (logical / p.tiles_n) * TM, n0 = (logical % p.tiles_n) * kTN;
   const int r0 = tid >> 2, r1 = r0 + 64;       // 128 rows x 4 chunks of 16 bytes of k
   const int kce = (tid & 3) * (kStepK / 4);    // this thread's first k-value inside a step
-  typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[NI][2];
+  typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[NI][MJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
   const int nk = (K + kStepK - 1) / kStepK;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   const int cin = p.conv_cin;
   constexpr bool conv = CONV;
   const int taps = p.conv_ks * p.conv_ks, pad = p.conv_ks >> 1;
-  unsigned a_off0, a_off1, tapmask0 = 0, tapmask1 = 0;
+  unsigned a_off0, a_off1 = kOob, tapmask0 = 0, tapmask1 = 0;   // (the second row of a staging thread: 128-row tiles only)
   if (conv) {
     auto place = [&](int m, unsigned &off, unsigned &mk) {
       off = kOob; mk = 0;
@@ -146,10 +152,10 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
       }
     };
     place(m0 + r0, a_off0, tapmask0);
-    place(m0 + r1, a_off1, tapmask1);
+    if constexpr (MJ == 2) place(m0 + r1, a_off1, tapmask1);
   } else {
     a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * K + kce) * kAB) : kOob;
-    a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
+    if constexpr (MJ == 2) a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
   }
   int g_tap = 0, g_c = 0;                      // conv mode: the (tap, channel) position of the NEXT gload
   const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
         ra0[S][h] = bload(rs_a, v0 + 16u * h, g_c * kAB);
-        ra1[S][h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
+        if constexpr (MJ == 2) ra1[S][h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
       }
       g_c += kStepK;
       if (g_c >= cin) { g_c = 0; ++g_tap; }
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
         ra0[S][h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
-        ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+        if constexpr (MJ == 2) ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
       }
     }
     rb0[S] = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
@@ -190,13 +196,13 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   const int lchunk = (tid & 3) * 16;           // byte position of the thread's chunk in an LDS row
   auto lstore = [&](int buf, auto setc) {
     constexpr int S = decltype(setc)::value;
-    char *As = smem + buf * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
+    char *As = smem + buf * (TM + 128) * kTLd, *Ws = As + TM * kTLd;
     if constexpr (MODE == kF16Q) {
       *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[S][0], ra0[S][1], p.inv_sa);
-      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
+      if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
     } else {
       *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = ra0[S][0];
-      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[S][0];
+      if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[S][0];
     }
     *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0[S];
     if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1[S];
@@ -212,11 +218,11 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   constexpr int kRB = RES8 ? 1 : 2;              // bytes per identity element
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__half *>(res), 0, res ? (unsigned)((size_t)M * N * kRB) : 0u, 0x00020000);
-  uint4 rres[2][kIT];
+  uint4 rres[MJ][kIT];
   auto res_request = [&](int j) {
 #pragma unroll
     for (int it = 0; it < kIT; ++it) {
-      const int m = m0 + wm * 64 + j * 32 + it * (64 / kCH) + lane / kCH;
+      const int m = m0 + wm * 32 * MJ + j * 32 + it * (64 / kCH) + lane / kCH;
       const unsigned off = (m < M && col_ok) ? (unsigned)(((size_t)m * N + ncol) * kRB) : kOob;
       if constexpr (RES8) {   // 8 identity bytes of this lane's 8 columns
         const uint2 q = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, (int)off, 0, 0));
@@ -233,23 +239,23 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   // step s is staged in set s % kDepth; with two sets the loads of step s + 2 are issued as soon as set s % 2
   // has been written to LDS, i.e. two steps of multiply ahead of their use
   auto compute = [&](int kt) {
-    const char *As = smem + (kt & 1) * (kTM + 128) * kTLd, *Ws = As + kTM * kTLd;
+    const char *As = smem + (kt & 1) * (TM + 128) * kTLd, *Ws = As + TM * kTLd;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 32 + (lane >> 5) * 16;
       // MFMA operand A = the weight rows (output columns n), B = the activation rows (m): a lane's 4
       // consecutive accumulator rows are then 4 consecutive n of one output row m
-      i32x4_t a[NI], b[2];
+      i32x4_t a[NI], b[MJ];
 #pragma unroll
       for (int i = 0; i < NI; ++i)
         a[i] = *reinterpret_cast<const i32x4_t *>(Ws + (wn * 32 * NI + i * 32 + (lane & 31)) * kTLd + kk);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b[j] = *reinterpret_cast<const i32x4_t *>(As + (wm * 64 + j * 32 + (lane & 31)) * kTLd + kk);
+      for (int j = 0; j < MJ; ++j)
+        b[j] = *reinterpret_cast<const i32x4_t *>(As + (wm * 32 * MJ + j * 32 + (lane & 31)) * kTLd + kk);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < MJ; ++j) {
           if constexpr (MODE == kF16)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i]),
                                                                __builtin_bit_cast(f16x8_t, b[j]), acc[i][j], 0, 0, 0);
@@ -282,9 +288,11 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   } else {
     for (int kt = 0; kt < nk; ++kt) step(kt, Set0{});
   }
-  // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*32*NI + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*64 + j*32 + (lane & 31)
+  // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*32*NI + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*32*MJ + j*32 + (lane & 31)
   // (the barrier that ended the last step also freed both LDS images)
-  if (res_vec) res_request(1);
+  if constexpr (MJ == 2) {
+    if (res_vec) res_request(1);
+  }
   char *stage = smem + wave * 32 * kEpiStride;
   float sc[8], bs[8];
 #pragma unroll
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < MJ; ++j) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
 #pragma unroll
     for (int it = 0; it < kIT; ++it) {
       const int row = it * (64 / kCH) + lane / kCH;
-      const int m = m0 + wm * 64 + j * 32 + row;
+      const int m = m0 + wm * 32 * MJ + j * 32 + row;
       const i32x4_t lo = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32);
       const i32x4_t hi = *reinterpret_cast<const i32x4_t *>(stage + row * kEpiStride + c8 * 32 + 16);
       if (m >= M || !col_ok) continue;
@@ -387,6 +395,8 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
   }
 }
 
+thread_local int g_tile_rows = 0;   // bevops_tile_gemm_set_variant: 0 measured policy, 64 / 128 force the tile height (A/B)
+
 struct ConvGeom { int cin = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, ks = 1; size_t in_elems = 0; };
 
 template <int MODE>
@@ -427,17 +437,28 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool narrow = N <= 64;                    // 64-column tiles: no matrix work on columns that do not exist
   const int tn = narrow ? 64 : 128;
   p.tiles_n = (N + tn - 1) / tn;
-  const long long tiles = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
+  // 64-row tiles when the 128-row tiling would not even fill two rounds of the chip's resident blocks (3 per CU):
+  // then the launch is a few long dependent chains per CU and more, shorter-lived tiles hide their latency better
+  // (bevops_tile_gemm_set_variant: 64 / 128 force one tiling for A/B)
+  const long long tiles128 = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
+  const bool rows64 = g_tile_rows == 64 || (g_tile_rows == 0 && tiles128 <= 2 * 768);
+  const int tm = rows64 ? 64 : kTM;
+  const long long tiles = (long long)p.tiles_n * ((M + tm - 1) / tm);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
   p.tiles_total = (int)tiles;
   const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool conv = cg.cin > 0, out8 = out_dtype == BEVOPS_I8;
-#define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                              \
-  do {                                                                                                              \
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_>), grid, dim3(256), 0, st, p);   \
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_>), grid, dim3(256), 0, st, p);          \
-    return launch_status();                                                                                         \
+#define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                                 \
+  do {                                                                                                                 \
+    if (rows64) {                                                                                                      \
+      if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p);        \
+    } else {                                                                                                           \
+      if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);        \
+    }                                                                                                                  \
+    return launch_status();                                                                                            \
   } while (0)
   if constexpr (MODE == kF16) {
     if (conv) BEVOPS_TG(false, true, false);
@@ -536,4 +557,12 @@ extern "C" int bevops_conv_tile_int8(const void *x_q, float scale_a, const void 
   if (rc != BEVOPS_SUCCESS) return rc;
   return launch_tile_gemm<kS8>(x_q, scale_a, w_q_taps, w_scales, scale_w, bias, residual, out_dtype, out, scale_out,
                                (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
+}
+
+// A/B switch of the tile height (thread-local): 0 = the policy of launch_tile_gemm, 64 / 128 = force.  Returns the
+// previous value.
+extern "C" int bevops_tile_gemm_set_variant(int rows) {
+  const int prev = g_tile_rows;
+  g_tile_rows = (rows == 64 || rows == 128) ? rows : 0;
+  return prev;
 }

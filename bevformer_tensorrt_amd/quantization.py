@@ -311,6 +311,25 @@ class Int8PluginOps:
 
     modulated_deformable_conv2d2 = modulated_deformable_conv2d
 
+    def bev_pool_v2(self, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
+                    out_height=128, out_width=128):
+        """BEVPoolV2TRT[2] (bevPoolKernel.cu:115-149 in its INT8 flavour): depth and features int8, int32 sums,
+        one requantisation with the output's calibrated scale."""
+        site = self._site("bev_pool")
+        args = (ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths)
+        if self.mode == "calibrate" or self._fp_site(site):
+            out = self.fp.bev_pool_v2_2(depth, feat, *args, out_height, out_width)
+            if self.mode == "calibrate":
+                for k, t in (("depth", depth), ("feat", feat), ("out", out)):
+                    self.cal.collect(f"{site}.{k}", t)
+            return out
+        (qd, sd), (qf, sf) = self._q(f"{site}.depth", depth), self._q(f"{site}.feat", feat)
+        s_out = self._scales[f"{site}.out"]
+        out = self.fp.bev_pool_v2_int8(qd.contiguous(), qf.contiguous(), *args, sd, sf, s_out, out_height, out_width)
+        return self._dq(out, s_out, depth.dtype)
+
+    bev_pool_v2_2 = bev_pool_v2
+
 
 FUSED_QUANT = {"enabled": os.environ.get("BEVOPS_FUSED_QUANT", "1") != "0"}   # A/B: LinearQ hands the fp16 activation to bevops_linear_int8_fused
 
@@ -731,4 +750,26 @@ def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, de
                                      and (decoder_int8 or qops.site_batch(k[:-4]) != 1)),
             "int8_dense_layers": len(q), "int8_backbone_layers": (len(ch.convs) + sum(len(b) for b in ch.plan)) if ch else 0,
             "activation_chain": bool(ch), "calibration_frames": n}
+    return model, qops, note
+
+
+def build_int8_bevdet(D, dev, frames, calibrator="entropy"):
+    """The PTQ build of the re-hosted BEVDet-R50 (BASELINE config 5; `D` = the bevdet module, `frames` = an iterable
+    of (image, ranks...) calibration inputs): ResNet-50 + FPN laterals as the int8 activation chain, bev_pool_v2 on
+    its INT8 plugin flavour; the small BEV encoder / head convolutions stay fp16.  Returns (model, qops, note)."""
+    qops = Int8PluginOps(calibrator, channels_last=True)
+    model = D.BEVDet(ops=qops, seed=0).to(dev, torch.float16)
+    model.view.ops = qops
+    ch = Int8ChainBackbone(model, qops.cal)
+    n = 0
+    for f in frames:
+        qops.begin_frame()
+        model(*f)
+        n += 1
+    scales = qops.freeze()
+    ch.freeze()
+    model.register_forward_pre_hook(lambda m, args: qops.begin_frame())
+    note = {"int8_plugin_sites": sum(1 for k in scales if k.startswith("bev_pool") and k.endswith(".out")),
+            "int8_backbone_layers": len(ch.convs) + sum(len(b) for b in ch.plan), "activation_chain": True,
+            "calibration_frames": n}
     return model, qops, note

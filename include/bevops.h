@@ -375,6 +375,10 @@ int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, 
  * next to bevops_tsgemm_f16 and bevops_linear_bias_act. */
 int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                          void *out, long long M, int N, int K, int relu, void *stream);
+/* A/B switch of the tiled GEMM family's tile height (thread-local; affects bevops_tile_gemm_f16, bevops_linear_int8*,
+ * bevops_conv_tile_*): 0 = the launcher's policy (64-row tiles when 128-row tiles would not fill two rounds of
+ * resident blocks), 64 / 128 = force.  Both tilings give bit-identical results.  Returns the previous value. */
+int bevops_tile_gemm_set_variant(int rows);
 /* Convolution on channels-last fp16 activations as an implicit GEMM on the same tiled skeleton (no column
  * buffer, no strided copy): kernel ksize x ksize in {1, 3}, pad ksize / 2, any stride.  x [B, H, W, Cin],
  * weight_taps [Cout][ksize][ksize][Cin] (= weight.permute(0, 2, 3, 1)), out [B, Hout, Wout, Cout] =

@@ -79,3 +79,22 @@ def test_whole_detector_frame_matches_the_reference_path():
     torch.cuda.synchronize()
     for a, b in zip(outs, got):
         assert (a.float() - b.float()).abs().max().item() <= 1e-2 * max(1.0, b.float().abs().max().item())
+
+
+def test_int8_bevdet_engine_tracks_fp16():
+    """The PTQ build of the whole BEVDet-R50 (quantization.build_int8_bevdet: ResNet-50 + FPN laterals as the int8
+    activation chain, bev_pool_v2 on its INT8 plugin flavour) against the fp16 detector on an unseen frame."""
+    from bevformer_tensorrt_amd import bevdet as D
+    from bevformer_tensorrt_amd.quantization import build_int8_bevdet
+    dev = torch.device("cuda")
+    ref = D.BEVDet(seed=0).to(dev, torch.float16)
+    ranks = [r.to(dev) for r in ref.view.get_bev_pool_input(*D.synthetic_rig(ref.view))]
+    g = torch.Generator().manual_seed(2)
+    frames = [(torch.randn(1, 6, 3, 256, 704, generator=g).to(dev, torch.float16), *ranks) for _ in range(3)]
+    model, qops, note = build_int8_bevdet(D, dev, frames[:2])
+    assert note["activation_chain"] and note["int8_plugin_sites"] == 1 and model.int8_chain.ready
+    got, want = model(*frames[2]), ref(*frames[2])
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.isfinite(a.float()).all()
+        rel = ((a.float() - b.float()).abs().mean() / b.float().abs().mean().clamp(min=1e-3)).item()
+        assert rel <= 0.25, rel          # 8-bit noise of a random-weight network with unnormalised residual streams

@@ -29,7 +29,9 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         per[k][f"dispatches_{counter}"] = len(v)
 if per:
     json.dump(per, open(os.path.join(dst, "rocprofv3_pmc_fetch_write_per_kernel.json"), "w"), indent=1)
-for name, out in (("bench.json", "bench_n1.json"), ("sweep.jsonl", "msda_sweep.jsonl"),
+for name, out in (("bench.json", "bench_n1.json"), ("bench_n1.json", "bench_n1.json"), ("pytest_gpu_tail.log", "pytest_gpu_tail.log"),
+                  ("shard_amdahl.jsonl", "shard_amdahl.jsonl"), ("sca_split_probe.jsonl", "sca_split_probe.jsonl"),
+                  ("int8_attribution.jsonl", "int8_attribution.jsonl"), ("tile_rows_ab.jsonl", "tile_rows_ab.jsonl"), ("sweep.jsonl", "msda_sweep.jsonl"),
                   ("model_bench.jsonl", "model_bench.jsonl"), ("dcn_time.jsonl", "dcn_time.jsonl"),
                   ("pytest.log", "pytest_gpu_tail.log"), ("smoke.log", "smoke.log"),
                   ("ops_timing.jsonl", "ops_timing.jsonl"), ("bevdet_slice.jsonl", "bevdet_slice.jsonl"),

@@ -3,7 +3,8 @@
 -DDCN_PROFILE: make -C bevformer_tensorrt_amd/csrc EXTRA=-DDCN_PROFILE)."""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tools/ (msda_sweep)
 import bevformer_tensorrt_amd as bev
 from bevformer_tensorrt_amd.functions import multi_scale_deformable_attn as M
 from bevformer_tensorrt_amd.utils import load_library

@@ -7,7 +7,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tools/ (msda_sweep)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bevformer_tensorrt_amd as bev  # noqa: E402
 from bevformer_tensorrt_amd.utils import load_library  # noqa: E402

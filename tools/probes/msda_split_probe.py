@@ -2,7 +2,8 @@
 """How the base SCA call's time splits over pyramid levels (kernel-design probe)."""
 import json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tools/ (msda_sweep)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bevformer_tensorrt_amd as bev
 from bevformer_tensorrt_amd.utils import load_library

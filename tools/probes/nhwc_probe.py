@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is an NHWC (channels_last) backbone faster than NCHW on this stack?  conv / linear micro-timings."""
 import sys, os, json, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from msda_sweep import time_call
 dev = "cuda"
 def t(fn): return round(time_call(fn, iters=20, warm=5)[0], 1)
