@@ -66,6 +66,23 @@ inverse_sigmoid = G.inverse_sigmoid   # the head's (mmdet) form; the decoder's i
 #    run MIOpen's NHWC kernels without layout transposes, every remaining shift / residual / ReLU
 #    chain is ONE bevops_bias_act_nhwc pass, DCNv2 reads and writes NHWC directly, and the FPN
 #    outputs already are the [cams, keys, 256] value layout of the encoder.
+_CAM_IDX = {}
+
+
+def _take_cams(t, cams):
+    """t[cams] along dim 0 for a Python list of camera ids, through a cached DEVICE index tensor: indexing with the
+    list itself uploads a fresh index tensor every call, which a stream capture does not permit (the camera-sharded
+    frame is captured into a HIP graph)."""
+    cams = tuple(cams)
+    if cams == tuple(range(t.shape[0])):
+        return t
+    key = (cams, str(t.device))
+    idx = _CAM_IDX.get(key)
+    if idx is None:
+        idx = _CAM_IDX[key] = torch.tensor(cams, dtype=torch.long, device=t.device)
+    return t.index_select(0, idx)
+
+
 def _rows(x):
     """[N, C, H, W] channels-last -> [N*H*W, C] view."""
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
@@ -475,7 +492,7 @@ class SpatialCrossAttention(nn.Module):
             cams = gather.cams   # the exchange object knows this rank's cameras
         ref = reference_points_cam.reshape(reference_points_cam.shape[0], nq, 1, -1)
         # camera-sharded: `value` holds this rank's cameras only; their reference points / visibility weights
-        ref_l, mask_l = (ref, bev_mask) if cams is None else (ref[cams], bev_mask[cams])
+        ref_l, mask_l = (ref, bev_mask) if cams is None else (_take_cams(ref, cams), _take_cams(bev_mask, cams))
         # The fused forms produce the MASKED CAMERA SUM of the cameras they are given, so they serve a single GPU
         # (all cameras) and the "reduce" exchange (this rank's cameras, then ONE all-reduce of [1, nq, 256]) alike.
         local_sum = gather is None or mode == "reduce"
@@ -697,7 +714,7 @@ class BEVFormer(nn.Module):
         B, N, C, H, W = image.shape
         img = image.view(B * N, C, H, W)
         if cams is not None:
-            img = img[cams]
+            img = _take_cams(img, cams)
         nhwc = self.backbone_layout == "nhwc" or (self.backbone_layout == "auto" and self.ops is _hip_ops)
         chain = getattr(self, "int8_chain", None)     # quantization.Int8ChainBackbone, after its freeze()
         if chain is not None and chain.ready and img.dtype == torch.float16 and img.is_cuda:
@@ -718,10 +735,28 @@ class BEVFormer(nn.Module):
         return pos.permute(2, 0, 1).unsqueeze(0).to(dtype)   # [1, 256, h, w]
 
     @torch.no_grad()
-    def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None, shift=None):
+    def _geometry(self, dev):
+        if self._static is None or self._static[0].device != dev:   # frame-independent geometry
+            # evaluated on the HOST once (linspace / scalar divisions are not bit-stable across
+            # devices) and uploaded: the anchors are then the reference's CPU values bit for bit
+            ref_3d = G.reference_points_3d(self.bev_h, self.bev_w, PC_RANGE[5] - PC_RANGE[2], 4, device="cpu", dtype=torch.float)
+            self._static = tuple(t.to(dev) for t in (ref_3d, G.reference_points_2d(ref_3d),
+                                                     G.pillar_points(ref_3d, PC_RANGE)))
+        return self._static
+
+    @torch.no_grad()
+    def project(self, lidar2img, image_shape, dtype):
+        """point_sampling_trt (encoder.py:197-259) of the BEV pillars for one rig: (reference_points_cam, bev_mask) in
+        the model's dtype.  It depends on the calibration matrices only -- they change per scene, not per frame -- so
+        the frame loop evaluates it when `lidar2img` changes and hands the result to `forward(proj=...)`."""
+        _, _, pillars = self._geometry(lidar2img.device)
+        ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
+        return ref_cam.to(dtype), bev_mask.to(dtype)
+
+    def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None, shift=None, proj=None):
         """`shift` [1, 2]: optional precomputed G.bev_shift(can_bus) -- the frame loop evaluates it
         on the host (atan / sin / cos differ in the last ulp between host and device libraries;
-        the host value is the reference's CPU path bit for bit)."""
+        the host value is the reference's CPU path bit for bit).  `proj`: optional precomputed `project(lidar2img)`."""
         dev, dtype = image.device, image.dtype
         image_shape = image.shape[-2:]
         mlvl = self.extract_feat(image, cams)
@@ -750,7 +785,7 @@ class BEVFormer(nn.Module):
             prev_bev = prev_bev.permute(1, 2, 0).reshape(nq, 1, -1)
         bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
         feats, level_hw = [], []
-        cam_embed = self.cams_embeds if cams is None else self.cams_embeds[cams]
+        cam_embed = self.cams_embeds if cams is None else _take_cams(self.cams_embeds, cams)
         embed_fn = getattr(self.ops, "feat_embed_nhwc", None)
         fused_embed = embed_fn is not None and _FUSED_LINEAR["enabled"] and _R3["enabled"] and dtype == torch.float16 and image.is_cuda \
             and all(f.is_contiguous(memory_format=torch.channels_last) for f in mlvl) and mlvl[0].shape[0] > 0
@@ -778,16 +813,9 @@ class BEVFormer(nn.Module):
         bev_shapes = torch.tensor([[bev_h, bev_w]])
 
         # ---- encoder.forward_trt (:261-334)
-        if self._static is None or self._static[0].device != dev:   # frame-independent geometry
-            # evaluated on the HOST once (linspace / scalar divisions are not bit-stable across
-            # devices) and uploaded: the anchors are then the reference's CPU values bit for bit
-            ref_3d = G.reference_points_3d(bev_h, bev_w, PC_RANGE[5] - PC_RANGE[2], 4, device="cpu", dtype=torch.float)
-            self._static = tuple(t.to(dev) for t in (ref_3d, G.reference_points_2d(ref_3d),
-                                                     G.pillar_points(ref_3d, PC_RANGE)))
-        ref_3d, ref_2d, pillars = self._static
-        ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
+        ref_3d, ref_2d, pillars = self._geometry(dev)
+        ref_cam, bev_mask = proj if proj is not None else self.project(lidar2img, image_shape, dtype)
         hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
-        ref_cam, bev_mask = ref_cam.to(dtype), bev_mask.to(dtype)
         q = bev_queries.view(1, nq, EMBED)
         pos = bev_pos.view(1, nq, EMBED)
         prev = torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
@@ -912,6 +940,7 @@ class FrameRunner:
                         lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
                         use=torch.zeros((), device=device, dtype=dtype))
         self._l2i_seen = None
+        self._proj = None               # (reference_points_cam, bev_mask) of the current rig, static buffers
 
     @property
     def image_buffer(self):
@@ -941,7 +970,7 @@ class FrameRunner:
             return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,
                               shift=i["shift"])
         return self.model(i["image"], self.prev_bev, self._use, i["can_bus"], i["lidar2img"], self.cams, self.gather,
-                          shift=i["shift"])
+                          shift=i["shift"], proj=self._proj)
 
     def _capture(self):
         s = torch.cuda.Stream()
@@ -990,6 +1019,13 @@ class FrameRunner:
         if l2i_key != self._l2i_seen:                       # calibration matrices change per scene, not per frame
             i["lidar2img"].copy_(lidar2img, non_blocking=True)
             self._l2i_seen = l2i_key
+            if _R3["enabled"]:      # ... and so does the projection of the BEV pillars into the cameras: evaluated here,
+                proj = self.model.project(i["lidar2img"], i["image"].shape[-2:], self.dtype)   # not once per frame
+                if self._proj is None:
+                    self._proj = tuple(t.clone() for t in proj)
+                else:
+                    for dst, src in zip(self._proj, proj):
+                        dst.copy_(src)
         m = self.model
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / m.bev_h, (PC_RANGE[3] - PC_RANGE[0]) / m.bev_w)
         can_host = can_bus.cpu()

@@ -537,6 +537,12 @@ __device__ __forceinline__ unsigned s8_mask4(const int (&x)[4], float m) {
 // sigmoid of its mask logits are quantised with s_off / s_mask while they are staged (what TensorRT's Q node in
 // front of the plugin does), so the arithmetic below is the plugin's on exactly those int8 operands -- and the
 // output leaves as int8 [B, Ho, Wo, Cout] with the ReLU folded into the requantisation.
+// FAST (ENG only; the engine's default): ONE requantisation per column element instead of the plugin's two -- the
+// mask is folded into the four area weights before they are quantised, a_q = u8(area_q * mask * 255), so the column
+// byte is T2int8(sum_q a_q v_q / 255) straight out of the dot + saturating multiply-add; the plugin's second step
+// (float multiply by the mask, round half away: ~ 20 VALU operations per 4 channels, the bulk of what makes the
+// plugin kernel VALU-bound) disappears.  Same 8-bit weight resolution, one rounding less: NOT bit-identical to the
+// plugin (tests compare it within a step), which the exact flavour (FAST = false) remains.
 struct S8Eng { int om_channels, relu; };
 
 // 4 consecutive output channels m..m+3 of output pixel n: requantise (ReLU first when asked), one dword store
@@ -563,7 +569,7 @@ __device__ __forceinline__ void s8_store4_nhwc(int8_t *__restrict__ out, const f
   }
 }
 
-template <int WN, int ABL, bool ENG = false>
+template <int WN, int ABL, bool ENG = false, bool FAST = false>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
     const int8_t *__restrict__ xt, const int8_t *__restrict__ offset, const int8_t *__restrict__ mask,
     const int8_t *__restrict__ wt, const float *__restrict__ bias, int8_t *__restrict__ out, ConvDims d, int g,
@@ -691,7 +697,8 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
       const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
       const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w0 + 1 < d.W, h0 + 1 < d.H && w0 >= 0,
                           h0 + 1 < d.H && w0 + 1 < d.W};
-      const int a4[4] = {u8w(hh * hw), u8w(hh * lw), u8w(lh * hw), u8w(lh * lw)};
+      const float mf = FAST ? f_m : 1.f;
+      const int a4[4] = {u8w(hh * hw * mf), u8w(hh * lw * mf), u8w(lh * hw * mf), u8w(lh * lw * mf)};
       const int hq[4] = {h0, h0, h0 + 1, h0 + 1}, wq[4] = {w0, w0 + 1, w0, w0 + 1};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -746,7 +753,12 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
         s8_transpose(c0w[v], c1w[v], c2w[v], c3w[v], tr);
         int xq[4];
         s8_quad(tr, c_aw, c_neg, magic, half, xq);
-        res[v] = s8_mask4(xq, c_m);
+        if constexpr (FAST) {   // the requantised value sits in the top byte of each xq[c]
+          res[v] = __builtin_amdgcn_perm((unsigned)xq[1], (unsigned)xq[0], 0x0c0c0703u) |
+                   __builtin_amdgcn_perm((unsigned)xq[3], (unsigned)xq[2], 0x07030c0cu);
+        } else {
+          res[v] = s8_mask4(xq, c_m);
+        }
       }
     }
     // hand-written store: behind a compiler-visible LDS store the waitcnt pass drains vmcnt to 0 (it cannot
@@ -897,16 +909,16 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_s8_kernel(const floa
   }
 }
 
-template <int WN, int ABL, bool ENG = false>
+template <int WN, int ABL, bool ENG = false, bool FAST = false>
 int glds_s8_resident_blocks() {
   static thread_local int cached_dev = -1, cached = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev == cached_dev) return cached;
   int per_cu = 0, cus = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_s8_kernel<WN, ABL, ENG>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_s8_kernel<WN, ABL, ENG, FAST>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, GldsS8<WN>::kLds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_s8_kernel<WN, ABL, ENG>, Glds<WN>::kThreads,
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn_glds_s8_kernel<WN, ABL, ENG, FAST>, Glds<WN>::kThreads,
                                                    GldsS8<WN>::kLds) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
@@ -916,14 +928,14 @@ int glds_s8_resident_blocks() {
 }
 
 // launch of the int8 LDS-DMA kernel with its tail plan (same plan as launch_glds; int32 partials)
-template <int WN, int ABL, bool ENG = false>
+template <int WN, int ABL, bool ENG = false, bool FAST = false>
 int launch_glds_s8(const int8_t *xt, const void *offset, const void *mask, const int8_t *wt, const void *bias,
                    void *output, const ConvDims &d, int g, int Kp, char *part_ws, size_t part_room, bool allow_tail,
                    float s_off, float s_mask, float s_iw, float s_out, hipStream_t st, S8Eng eng = S8Eng{0, 0}) {
   const int KK = d.Kh * d.Kw, cout_g = d.Cout / d.G;
   const size_t N = (size_t)d.B * d.Ho * d.Wo;
   const dim3 grid((unsigned)((N + Glds<WN>::kN - 1) / Glds<WN>::kN), (cout_g + kFM - 1) / kFM);
-  const int slots = glds_s8_resident_blocks<WN, ABL, ENG>();
+  const int slots = glds_s8_resident_blocks<WN, ABL, ENG, FAST>();
   if (slots <= 0) return BEVOPS_FAILURE;
   TailPlan tp{0, 1, (int)grid.x, nullptr, 0, 0, 0, 0};
   const int blocks = (int)(grid.x * grid.y);
@@ -941,7 +953,7 @@ int launch_glds_s8(const int8_t *xt, const void *offset, const void *mask, const
     }
   }
   const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
-  hipLaunchKernelGGL((dcn_glds_s8_kernel<WN, ABL, ENG>), grid2, dim3(Glds<WN>::kThreads), GldsS8<WN>::kLds, st, xt,
+  hipLaunchKernelGGL((dcn_glds_s8_kernel<WN, ABL, ENG, FAST>), grid2, dim3(Glds<WN>::kThreads), GldsS8<WN>::kLds, st, xt,
                      (const int8_t *)offset, (const int8_t *)mask, wt, (const float *)bias, (int8_t *)output, d, g,
                      Kp, s_off, s_mask, s_iw, s_out, tp, eng);
   if (tp.tail_tiles)
@@ -1122,7 +1134,7 @@ extern "C" int bevops_mdconv_forward_int8_packed(const void *input, float scale_
 extern "C" int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float scale_in, const void *offset_mask_nhwc,
                                                int offset_mask_channels, float scale_offset, float scale_mask,
                                                const void *packed_weight, float scale_weight, const float *bias,
-                                               void *output_nhwc, float scale_out, int relu, void *workspace,
+                                               void *output_nhwc, float scale_out, int relu, int exact, void *workspace,
                                                size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh,
                                                int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                                                int dil_w, int groups, int deform_groups, void *stream) {
@@ -1156,14 +1168,12 @@ extern "C" int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float sca
   const S8Eng eng{offset_mask_channels, relu ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int g = 0; g < groups; ++g) {
-    const int rc = w4 ? launch_glds_s8<4, 0, true>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr,
-                                                   (const int8_t *)packed_weight, bias, output_nhwc, d, g, Kp, pw, room,
-                                                   !g_mdconv_no_tail, scale_offset, scale_mask, scale_in * scale_weight,
-                                                   scale_out, st, eng)
-                      : launch_glds_s8<2, 0, true>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr,
-                                                   (const int8_t *)packed_weight, bias, output_nhwc, d, g, Kp, pw, room,
-                                                   !g_mdconv_no_tail, scale_offset, scale_mask, scale_in * scale_weight,
-                                                   scale_out, st, eng);
+#define BEVOPS_S8E(WN_, FAST_)                                                                                       \
+  launch_glds_s8<WN_, 0, true, FAST_>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr, (const int8_t *)packed_weight, \
+                                      bias, output_nhwc, d, g, Kp, pw, room, !g_mdconv_no_tail, scale_offset, scale_mask,   \
+                                      scale_in * scale_weight, scale_out, st, eng)
+    const int rc = exact ? (w4 ? BEVOPS_S8E(4, false) : BEVOPS_S8E(2, false)) : (w4 ? BEVOPS_S8E(4, true) : BEVOPS_S8E(2, true));
+#undef BEVOPS_S8E
     if (rc != BEVOPS_SUCCESS) return rc;
   }
   return launch_status();

@@ -93,10 +93,8 @@ struct TileArgs {
 // NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
 // matrix work on columns that do not exist)
 // RES8: the identity rows are int8 [M, N] (real = q * s_res) instead of fp16
-// MJ: 32-row MFMA blocks per wave: 2 -> 128-row tiles (three blocks per CU), 1 -> 64-row tiles (FOUR blocks per CU and
-// twice the tiles): the layers whose 128-row tiling is a single sparse round of long k-chains (M <= 40 000: ResNet
-// stages 3 / 4, every encoder layer) are bound by the latency of a chain, not by bytes -- more, smaller chains in
-// flight per CU hide it better (dense layers).
+// MJ: 32-row MFMA blocks per wave: 2 -> 128-row tiles (three blocks per CU, the default), 1 -> 64-row tiles (four
+// blocks per CU and twice the tiles; an A/B build, measured slower on every layer -- see launch_tile_gemm).
 template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false, int MJ = 2>
 __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArgs p) {
   constexpr int kTN = 64 * NI;
@@ -437,11 +435,12 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool narrow = N <= 64;                    // 64-column tiles: no matrix work on columns that do not exist
   const int tn = narrow ? 64 : 128;
   p.tiles_n = (N + tn - 1) / tn;
-  // 64-row tiles when the 128-row tiling would not even fill two rounds of the chip's resident blocks (3 per CU):
-  // then the launch is a few long dependent chains per CU and more, shorter-lived tiles hide their latency better
-  // (bevops_tile_gemm_set_variant: 64 / 128 force one tiling for A/B)
-  const long long tiles128 = (long long)p.tiles_n * ((M + kTM - 1) / kTM);
-  const bool rows64 = g_tile_rows == 64 || (g_tile_rows == 0 && tiles128 <= 2 * 768);
+  // 64-row tiles (four blocks per CU, twice the tiles) are an A/B build only (bevops_tile_gemm_set_variant(64)): the
+  // idea -- layers whose 128-row tiling is one sparse round of long k-chains would hide the chain latency better with
+  // more, smaller tiles in flight -- measured 3-10 % SLOWER on every base-model layer and flavour
+  // (profiles/r04/tile_rows_ab.jsonl: e.g. ResNet stage-3 conv1 fp16 43.7 vs 39.3 us, FFN fc2 32.2 vs 28.0, int8 conv1
+  // 25.8 vs 24.9): half the matrix work per staged weight byte and per barrier costs more than the extra chains hide.
+  const bool rows64 = g_tile_rows == 64;
   const int tm = rows64 ? 64 : kTM;
   const long long tiles = (long long)p.tiles_n * ((M + tm - 1) / tm);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;

@@ -108,13 +108,14 @@ _PACKED_S8 = _TensorCache()     # int8 DCNv2 weight [Cout, Cin / groups, Kh, Kw]
 
 def modulated_deformable_conv2d_int8_nhwc(x_q, scale_in, offset_mask_nhwc, scale_offset, scale_mask, weight_q,
                                           scale_weight, bias, scale_out, relu=False, stride=1, padding=1, dilation=1,
-                                          groups=1, deform_groups=1):
+                                          groups=1, deform_groups=1, exact=False):
     """The DCNv2 block of the int8 chain (bevops_mdconv_forward_int8_nhwc): x_q int8 channels-last [B, Cin, H, W],
     offset_mask_nhwc the raw fp16 channels-last output [B, OC >= 3 K K, Ho, Wo] of the pack's offset convolution
     (2 K K offsets, then K K mask logits -- quantised with scale_offset / scale_mask inside the kernel, the
     sigmoid fused), weight_q int8 [Cout, Cin / groups, K, K] (packed once per tensor), bias fp32 -> int8
-    channels-last [B, Cout, Ho, Wo] quantised with scale_out, ReLU folded in.  The arithmetic is the INT8
-    plugin's (modulatedDeformableConv2dKernel.cu:463-607) on those int8 operands."""
+    channels-last [B, Cout, Ho, Wo] quantised with scale_out, ReLU folded in.  exact=True: the arithmetic is the INT8
+    plugin's (modulatedDeformableConv2dKernel.cu:463-607) on those int8 operands, bit for bit; exact=False (default):
+    the mask is folded into the quantised area weights, one requantisation per column element instead of two."""
     assert x_q.is_cuda and x_q.dtype == torch.int8 and x_q.dim() == 4 and weight_q.dtype == torch.int8
     assert x_q.is_contiguous(memory_format=torch.channels_last)
     assert offset_mask_nhwc.dtype == torch.float16 and offset_mask_nhwc.is_contiguous(memory_format=torch.channels_last)
@@ -145,7 +146,8 @@ def modulated_deformable_conv2d_int8_nhwc(x_q, scale_in, offset_mask_nhwc, scale
         st = handle.bevops_mdconv_forward_int8_nhwc(
             x_q.data_ptr(), float(scale_in), offset_mask_nhwc.data_ptr(), int(offset_mask_nhwc.shape[1]),
             float(scale_offset), float(scale_mask), packed.data_ptr(), float(scale_weight),
-            b.data_ptr() if b is not None else None, out.data_ptr(), float(scale_out), int(bool(relu)), ws.data_ptr(),
+            b.data_ptr() if b is not None else None, out.data_ptr(), float(scale_out), int(bool(relu)), int(bool(exact)),
+            ws.data_ptr(),
             ws_bytes, B, Cin, H, W, Cout, Kh, Kw, stride, stride, padding, padding, dilation, dilation, groups,
             deform_groups, stream)
     _lib.check(st, "bevops_mdconv_forward_int8_nhwc")

@@ -100,7 +100,7 @@ SIGNATURES = {
                                                    c_void_p]),
     "bevops_mdconv_int8_nhwc_workspace_size": (c_size_t, []),
     "bevops_mdconv_forward_int8_nhwc": (c_int, [c_void_p, c_float, c_void_p, c_int, c_float, c_float, c_void_p, c_float,
-                                                c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t] + [c_int] * 15 +
+                                                c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t] + [c_int] * 15 +
                                         [c_void_p]),
     "bevops_linear_tune": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
                                                               c_void_p, c_size_t, c_void_p]),

@@ -376,8 +376,9 @@ int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, 
 int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                          void *out, long long M, int N, int K, int relu, void *stream);
 /* A/B switch of the tiled GEMM family's tile height (thread-local; affects bevops_tile_gemm_f16, bevops_linear_int8*,
- * bevops_conv_tile_*): 0 = the launcher's policy (64-row tiles when 128-row tiles would not fill two rounds of
- * resident blocks), 64 / 128 = force.  Both tilings give bit-identical results.  Returns the previous value. */
+ * bevops_conv_tile_*): 0 / 128 = the default 128-row tiles, 64 = 64-row tiles (four blocks per CU; measured 3-10 %
+ * slower on the base-model layers, profiles/r04/tile_rows_ab.jsonl).  Both tilings give bit-identical results.
+ * Returns the previous value. */
 int bevops_tile_gemm_set_variant(int rows);
 /* Convolution on channels-last fp16 activations as an implicit GEMM on the same tiled skeleton (no column
  * buffer, no strided copy): kernel ksize x ksize in {1, 3}, pad ksize / 2, any stride.  x [B, H, W, Cin],
@@ -417,6 +418,11 @@ int bevops_conv_tile_int8_fused(const void *x_f16, float scale_a, const void *w_
  *                         70-86), quantised with scale_offset / scale_mask while they are staged (the Q node
  *                         TensorRT places in front of the plugin); weights packed by bevops_mdconv_pack_weight(
  *                         BEVOPS_I8); output int8 [B, Ho, Wo, Cout] with the ReLU folded into the requantisation.
+ *                         exact != 0: exactly that arithmetic (bit-identical to the plugin on those operands);
+ *                         exact == 0 (the engine's default): the mask is folded into the four area weights before
+ *                         they are quantised, a_q = u8(area_q mask 255), so a column element is requantised ONCE,
+ *                         T2int8(sum a_q v_q / 255) -- the plugin's float mask multiply + second rounding, which
+ *                         makes its kernel VALU-bound, disappears; within a step of the exact flavour.
  *                         `workspace` (optional, bevops_mdconv_int8_nhwc_workspace_size() bytes) holds the int32
  *                         partial sums of the split-K tail.  NOT_SUPPORTED outside (Cin / groups) % 128 == 0, one
  *                         deform group per conv group, 3 Kh Kw <= 32. */
@@ -433,7 +439,7 @@ size_t bevops_mdconv_int8_nhwc_workspace_size(void);
 int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float scale_in, const void *offset_mask_nhwc,
                                     int offset_mask_channels, float scale_offset, float scale_mask,
                                     const void *packed_weight, float scale_weight, const float *bias,
-                                    void *output_nhwc, float scale_out, int relu, void *workspace,
+                                    void *output_nhwc, float scale_out, int relu, int exact, void *workspace,
                                     size_t workspace_bytes, int B, int Cin, int H, int W, int Cout, int Kh, int Kw,
                                     int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                                     int groups, int deform_groups, void *stream);

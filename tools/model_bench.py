@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd import bevformer as B, geometry as G  # noqa: E402
 
 
-def run(name, frames, dtype, graph=False, int8=False):
+def run(name, frames, dtype, graph=False, int8=False, clone=True, static_image=False):
     dev = torch.device("cuda")
     if int8:    # the PTQ build of bench.py (base only): int8 plugin sites + LinearQ / Conv2dQ dense layers
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,11 +24,14 @@ def run(name, frames, dtype, graph=False, int8=False):
         runner = bench.ModelFrames(dev, "int8", 1, 0, None, None, graph=graph).runner
     else:
         model = B.BEVFormer(name).to(dev, dtype)
-        runner = B.FrameRunner(model, dev, dtype, graph=graph)
+        runner = B.FrameRunner(model, dev, dtype, graph=graph, clone_outputs=clone)
     H, W = B.CONFIGS[name]["image"]
     l2i = G.synthetic_lidar2img((H, W)).to(dev)
     g = torch.Generator().manual_seed(0)
     img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+    if static_image:      # the caller fills the frame's static input buffer itself (what FrameRunner.step_raw does)
+        runner.image_buffer.copy_(img)
+        img = runner.image_buffer
     ts = []
     for i in range(frames):
         can = torch.zeros(18)
@@ -40,7 +43,8 @@ def run(name, frames, dtype, graph=False, int8=False):
         ts.append((time.perf_counter() - t0) * 1e3)
     core = ts[1:-1]
     ms = sum(core) / len(core)
-    return dict(model=name, dtype="int8 build" if int8 else str(dtype)[6:], graph=graph, frames=frames, ms_per_frame=round(ms, 3),
+    return dict(model=name, dtype="int8 build" if int8 else str(dtype)[6:], graph=graph, clone_outputs=clone,
+                static_image=static_image, frames=frames, ms_per_frame=round(ms, 3),
                 fps=round(1000.0 / ms, 2), first_frame_ms=round(ts[0], 1))
 
 
@@ -53,11 +57,17 @@ if __name__ == "__main__":
     ap.add_argument("--int8", action="store_true", help="the INT8 (PTQ) build of the base model, as bench.py makes it")
     ap.add_argument("--conv-variant", type=int, default=0, help="bevops_conv3x3_c32_set_variant (A/B)")
     ap.add_argument("--mdconv-variant", type=int, default=0, help="bevops_mdconv_set_variant (A/B)")
+    ap.add_argument("--no-clone", action="store_true", help="hand out the graph's output buffers instead of copies")
+    ap.add_argument("--static-image", action="store_true", help="images already in the frame's static input buffer")
+    ap.add_argument("--tile-rows", type=int, default=0, help="bevops_tile_gemm_set_variant: 64 / 128 force the tile height (A/B)")
     a = ap.parse_args()
     if a.conv_variant or a.mdconv_variant:
         from bevformer_tensorrt_amd.utils import load_library
         load_library().bevops_conv3x3_c32_set_variant(a.conv_variant)
         load_library().bevops_mdconv_set_variant(a.mdconv_variant)
+    if a.tile_rows:
+        from bevformer_tensorrt_amd.utils import load_library
+        load_library().bevops_tile_gemm_set_variant(a.tile_rows)
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
-        print(json.dumps(run(m, a.frames, dt, a.graph, a.int8)), flush=True)
+        print(json.dumps(run(m, a.frames, dt, a.graph, a.int8, not a.no_clone, a.static_image)), flush=True)
