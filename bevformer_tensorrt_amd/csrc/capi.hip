@@ -71,6 +71,7 @@ const Entry kTable[] = {
     {"bevops_linear_int8", (void *)&bevops_linear_int8},
     {"bevops_linear_int8_fused", (void *)&bevops_linear_int8_fused},
     {"bevops_tile_gemm_f16", (void *)&bevops_tile_gemm_f16},
+    {"bevops_small_gemm_f16", (void *)&bevops_small_gemm_f16},
     {"bevops_conv_tile_f16", (void *)&bevops_conv_tile_f16},
     {"bevops_conv_tile_int8_fused", (void *)&bevops_conv_tile_int8_fused},
     {"bevops_linear_int8_chain", (void *)&bevops_linear_int8_chain},
@@ -91,6 +92,7 @@ const Entry kTable[] = {
     {"bevops_conv3x3_c32_pack_weight", (void *)&bevops_conv3x3_c32_pack_weight},
     {"bevops_conv3x3_c32_packed_weight_size", (void *)&bevops_conv3x3_c32_packed_weight_size},
     {"bevops_layer_norm", (void *)&bevops_layer_norm},
+    {"bevops_refine_reference_points", (void *)&bevops_refine_reference_points},
 };
 }  // namespace
 

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kCPT = 8;  // channel planes per thread
+thread_local bool g_rotate_narrow = false;   // bevops_rotate_set_variant(1): per-lane stores (the round 1-3 kernel; A/B)
 
 template <typename A> __device__ __forceinline__ float scalar_at(const void *p, int i);
 template <> __device__ __forceinline__ float scalar_at<float>(const void *p, int i) {
@@ -97,61 +98,90 @@ __global__ __launch_bounds__(kBlock) void rotate_hwc_kernel(const T *__restrict_
   *op = res;
 }
 
-template <typename T, typename A>
+// WIDE: a thread's kCPT values do not leave as kCPT stores of sizeof(T) bytes per lane (2-byte stores for fp16: the
+// launch was store-ISSUE-bound, 26 % of the HBM roofline) but through a [kCPT][kBlock] LDS tile read back in 16-byte
+// runs of consecutive pixels of one plane: one 16-byte store per thread (fp16) instead of eight 2-byte ones.  Needs
+// plane starts 16-byte aligned (H W sizeof(T) % 16 == 0, aligned `out`): the host picks the flavour.
+template <typename T, typename A, bool WIDE>
 __global__ __launch_bounds__(kBlock) void rotate_kernel(const T *__restrict__ img,
                                                         const void *__restrict__ angle,
                                                         const void *__restrict__ center,
                                                         T *__restrict__ out, int C, int H, int W,
                                                         int interp, float s_in, float s_out) {
-  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) T tile[WIDE ? kCPT : 1][WIDE ? kBlock : 1];
+  const int p0 = blockIdx.x * kBlock;
+  const int pix = p0 + threadIdx.x;
   const int HW = H * W;
-  if (pix >= HW) return;
-  const int w = pix % W, h = pix / W;
-  float ix, iy;
-  rotate_source<A>(angle, center, w, h, H, W, ix, iy);
+  const bool valid = pix < HW;
+  if (!WIDE && !valid) return;
   const int c0 = blockIdx.y * kCPT;
   const int c1 = min(c0 + kCPT, C);
-  const T *ip = img + (size_t)c0 * HW;
-  T *op = out + (size_t)c0 * HW + pix;
   constexpr bool kInt8 = sizeof(T) == 1;
-  if (interp == BEVOPS_NEAREST) {
-    const int o = footprint_nearest(ix, iy, H, W);
-    const float os = kInt8 ? s_in / s_out : 1.f;
-    for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
-      if (o >= 0) {
-        if constexpr (kInt8) st<T>(op, ld<T>(ip + o), os);
-        else *op = ip[o];  // pure copy: bit-exact for fp16/fp32
-      } else {
-        st<T>(op, 0.f, 1.f);
-      }
-    }
-  } else {
-    Footprint2D<4> f;
-    footprint_bilinear(ix, iy, H, W, f);
-    if constexpr (kInt8) {
-      // rotateKernel.cu:463-540: int8 area weights x127, int32 dot, requantise
-      int wq[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) wq[k] = q127_rne(f.w[k]);
-      const float os = (1.f / 127.f) * s_in / s_out;
-      for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
-        int t = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (f.off[k] >= 0) t += (int)ip[f.off[k]] * wq[k];
-        *op = t2int8((float)t * os);
+  if (valid) {
+    const int w = pix % W, h = pix / W;
+    float ix, iy;
+    rotate_source<A>(angle, center, w, h, H, W, ix, iy);
+    const T *ip = img + (size_t)c0 * HW;
+    T *op = out + (size_t)c0 * HW + pix;
+    auto emit = [&](int c, T v) {
+      if constexpr (WIDE) tile[c - c0][threadIdx.x] = v;
+      else op[(size_t)(c - c0) * HW] = v;
+    };
+    if (interp == BEVOPS_NEAREST) {
+      const int o = footprint_nearest(ix, iy, H, W);
+      const float os = kInt8 ? s_in / s_out : 1.f;
+      for (int c = c0; c < c1; ++c, ip += HW) {
+        T v;
+        if (o >= 0) {
+          if constexpr (kInt8) st<T>(&v, ld<T>(ip + o), os);
+          else v = ip[o];  // pure copy: bit-exact for fp16/fp32
+        } else {
+          st<T>(&v, 0.f, 1.f);
+        }
+        emit(c, v);
       }
     } else {
-      for (int c = c0; c < c1; ++c, ip += HW, op += HW) {
-        float o = 0.f;
+      Footprint2D<4> f;
+      footprint_bilinear(ix, iy, H, W, f);
+      if constexpr (kInt8) {
+        // rotateKernel.cu:463-540: int8 area weights x127, int32 dot, requantise
+        int wq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (f.off[k] >= 0) {
+        for (int k = 0; k < 4; ++k) wq[k] = q127_rne(f.w[k]);
+        const float os = (1.f / 127.f) * s_in / s_out;
+        for (int c = c0; c < c1; ++c, ip += HW) {
+          int t = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (f.off[k] >= 0) t += (int)ip[f.off[k]] * wq[k];
+          emit(c, t2int8((float)t * os));
+        }
+      } else {
+        for (int c = c0; c < c1; ++c, ip += HW) {
+          float o = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (f.off[k] >= 0) {
 #pragma clang fp contract(off)
-            o += ld<T>(ip + f.off[k]) * f.w[k];
-          }
-        st<T>(op, o, 1.f);
+              o += ld<T>(ip + f.off[k]) * f.w[k];
+            }
+          T v;
+          st<T>(&v, o, 1.f);
+          emit(c, v);
+        }
       }
+    }
+  }
+  if constexpr (WIDE) {
+    __syncthreads();
+    constexpr int VPX = 16 / sizeof(T);             // pixels per 16-byte run
+    constexpr int kChunks = kBlock / VPX;           // runs per plane of this block's pixel range
+    for (int idx = threadIdx.x; idx < kCPT * kChunks; idx += kBlock) {
+      const int plane = idx / kChunks, chunk = idx - plane * kChunks;
+      const int px = p0 + chunk * VPX;
+      if (c0 + plane < c1 && px < HW)               // (H W % VPX == 0: a run is all in or all out)
+        *reinterpret_cast<uint4 *>(out + (size_t)(c0 + plane) * HW + px) =
+            *reinterpret_cast<const uint4 *>(&tile[plane][chunk * VPX]);
     }
   }
 }
@@ -160,12 +190,19 @@ template <typename T>
 int launch(const void *img, const void *angle, const void *center, int angle_dtype, void *out,
            int C, int H, int W, int interp, float s_in, float s_out, hipStream_t st) {
   const dim3 grid((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)((C + kCPT - 1) / kCPT));
-  if (angle_dtype == BEVOPS_F32)
-    hipLaunchKernelGGL((rotate_kernel<T, float>), grid, dim3(kBlock), 0, st, (const T *)img, angle,
-                       center, (T *)out, C, H, W, interp, s_in, s_out);
-  else
-    hipLaunchKernelGGL((rotate_kernel<T, __half>), grid, dim3(kBlock), 0, st, (const T *)img, angle,
-                       center, (T *)out, C, H, W, interp, s_in, s_out);
+  // wide (LDS-transposed) stores when every plane starts on a 16-byte boundary; variant 1 keeps the per-lane stores (A/B)
+  const bool wide = !g_rotate_narrow && ((size_t)H * W * sizeof(T)) % 16 == 0 && aligned16(out);
+#define BEVOPS_ROT(A_, WIDE_)                                                                                   \
+  hipLaunchKernelGGL((rotate_kernel<T, A_, WIDE_>), grid, dim3(kBlock), 0, st, (const T *)img, angle, center, \
+                     (T *)out, C, H, W, interp, s_in, s_out)
+  if (angle_dtype == BEVOPS_F32) {
+    if (wide) BEVOPS_ROT(float, true);
+    else BEVOPS_ROT(float, false);
+  } else {
+    if (wide) BEVOPS_ROT(__half, true);
+    else BEVOPS_ROT(__half, false);
+  }
+#undef BEVOPS_ROT
   return launch_status();
 }
 
@@ -230,4 +267,12 @@ extern "C" int bevops_rotate_forward_hwc(int dtype, const void *img, const void 
     hipLaunchKernelGGL((rotate_hwc_kernel<__half, __half>), grid, blk, 0, st, (const __half *)img, angle, center,
                        (__half *)output, channels, height, width, interpolation);
   return launch_status();
+}
+
+// A/B switch (thread-local): 1 = the per-lane stores of rounds 1-3, 0 = LDS-transposed 16-byte stores where the
+// plane alignment allows.  Returns the previous value.
+extern "C" int bevops_rotate_set_variant(int variant) {
+  const int prev = g_rotate_narrow ? 1 : 0;
+  g_rotate_narrow = variant == 1;
+  return prev;
 }

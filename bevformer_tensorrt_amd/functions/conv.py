@@ -104,8 +104,14 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
     if B == 0 and Cin % 32 == 0:
         return conv_nhwc(x, weight, bias, relu, residual, stride)      # (empty result, nothing to measure)
     key = (str(x.device), B, H, W, Cin, weight.shape[0], weight.shape[2], stride, bool(relu), residual is not None)
-    from .linear import DETERMINISTIC
+    from .linear import DETERMINISTIC, _problem, _table
     name = "tile" if (DETERMINISTIC["enabled"] and Cin % 32 == 0) else _CHOICE.get(key)
+    if name is None:      # shipped choice (dispatch_gfx950.json): no measurement, the same kernel on every box
+        name = _table()["conv"].get(_problem(key))
+        if name in ("tile", "library") and (name == "library" or Cin % 32 == 0):
+            _CHOICE[key] = name
+        else:
+            name = None
     if name is None:
         if Cin % 32 != 0:
             name = _CHOICE[key] = "library"

@@ -101,6 +101,28 @@ def layer_norm(x, weight=None, bias=None, eps=1e-5, out=None):
     return out.view(x.shape)
 
 
+def refine_reference_points(tmp, reference_points, eps=1e-5):
+    """geometry.refine_reference_points (decoder.py:93-103) as one launch (bevops_refine_reference_points): tmp
+    [1, nq, C >= 5] fp16 (the regression branch's output), reference_points [1, nq, 3] fp16 -> (new reference points
+    [1, nq, 3], their (x, y) as the next layer's sampling reference [1, nq, 1, 2]).  Bit-identical to the framework's
+    op sequence."""
+    assert tmp.is_cuda and tmp.dtype == torch.float16 and reference_points.dtype == torch.float16
+    nq, C = tmp.shape[-2], tmp.shape[-1]
+    t2, r2 = tmp.reshape(nq, C), reference_points.reshape(nq, 3)
+    if not t2.is_contiguous():
+        t2 = t2.contiguous()
+    if not r2.is_contiguous():
+        r2 = r2.contiguous()
+    out = torch.empty((1, nq, 3), dtype=tmp.dtype, device=tmp.device)
+    xy = torch.empty((1, nq, 1, 2), dtype=tmp.dtype, device=tmp.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(tmp.device):
+        st = handle.bevops_refine_reference_points(_lib.F16, t2.data_ptr(), r2.data_ptr(), out.data_ptr(), xy.data_ptr(),
+                                                   nq, C, float(eps), _lib.current_stream_ptr(tmp.device))
+    _lib.check(st, "bevops_refine_reference_points")
+    return out, xy
+
+
 def quantize_rows(x, scale, out=None):
     """fp16 tensor -> int8 with one per-tensor scale: clamp(rne(x / scale), -127, 127) (bevops_quantize_rows)."""
     assert x.is_cuda and x.dtype == torch.float16
@@ -236,6 +258,46 @@ def tile_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
     return out.view(*x.shape[:-1], N)
 
 
+def small_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
+    """act(x @ weight.T + bias + residual) for layers with FEW rows (the decoder's 900 queries) on the
+    no-pipeline MFMA GEMM (bevops_small_gemm_f16, csrc/small_gemm.hip: 32 x 64 tiles, split-K inside the block, every
+    operand fragment requested before the first matrix instruction -- one memory round trip per launch instead of a
+    chain of dependent k-steps).  x [..., K] fp16, weight [N, K]; K % 64 == 0, K <= 1024; offered up to 8192 rows."""
+    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
+    K, N = x.shape[-1], weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {K}]")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M > 8192:
+        raise _lib.BevopsError("small_gemm: more than 8192 rows (the tiled GEMMs' domain)", _lib.NOT_SUPPORTED)
+    weight = weight.contiguous()
+    r2 = None
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.numel() != M * N:
+            raise ValueError("residual must be fp16 with M*N elements")
+        r2 = residual.reshape(M, N)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == M * N and out.dtype == x.dtype
+    if M == 0:
+        return out.view(*x.shape[:-1], N)
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_small_gemm_f16(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K,
+                                          int(bool(relu)), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_small_gemm_f16")
+    return out.view(*x.shape[:-1], N)
+
+
 # ---- measured choice between the dense-layer implementations -------------------------------------------------
 def _torch_dense(x, weight, bias, residual, relu):
     if residual is not None or bias is None:
@@ -245,7 +307,7 @@ def _torch_dense(x, weight, bias, residual, relu):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
-_DENSE = {"tsgemm": tsgemm, "tile": tile_gemm, "blaslt": linear_bias_act, "torch": _torch_dense}
+_DENSE = {"tsgemm": tsgemm, "tile": tile_gemm, "small": small_gemm, "blaslt": linear_bias_act, "torch": _torch_dense}
 _DENSE_CHOICE = {}     # problem -> name of the fastest implementation measured in this process
 DENSE_LOG = []         # (problem, {name: us}) of every measurement, for tools / profiles
 # Reproducible mode: no per-process timing, the choice is a function of the problem alone and falls on the two
@@ -255,7 +317,35 @@ DENSE_LOG = []         # (problem, {name: us}) of every measurement, for tools /
 DETERMINISTIC = {"enabled": False}
 
 
-def _dense_deterministic(N, K):
+# Shipped choices (bevformer_tensorrt_amd/dispatch_gfx950.json, written by tools/dump_dispatch.py from one MI355X's
+# measurements): a problem found there takes its recorded winner WITHOUT a measurement, so the kernel that runs is the
+# same on every box and in every process; only problems the table has never seen are timed (BEVOPS_DENSE_TUNE=1: time
+# everything, i.e. regenerate; =0: no table, no timing -- the reproducible defaults).
+_TABLE = {"loaded": False, "dense": {}, "conv": {}}
+
+
+def _table():
+    import json
+    import os
+    if not _TABLE["loaded"]:
+        _TABLE["loaded"] = True
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dispatch_gfx950.json")
+        if os.path.exists(path) and os.environ.get("BEVOPS_DENSE_TUNE", "") not in ("0", "1"):
+            try:
+                t = json.load(open(path))
+                _TABLE["dense"], _TABLE["conv"] = t.get("dense", {}), t.get("conv", {})
+            except (OSError, ValueError):
+                pass
+    return _TABLE
+
+
+def _problem(key):
+    return ",".join(str(int(v)) if isinstance(v, bool) else str(v) for v in key[1:])   # without the device name
+
+
+def _dense_deterministic(N, K, M=1 << 30):
+    if M <= 4096 and K % 64 == 0 and K <= 1024:
+        return "small"
     return "tsgemm" if (N % 256 == 0 and K % 64 == 0 and K >= 256) else "tile"
 
 
@@ -279,10 +369,16 @@ def dense_auto(x, weight, bias=None, residual=None, relu=False):
     if M == 0:          # a rank of the camera-sharded path that owns no camera
         return x.new_empty((*x.shape[:-1], N))
     key = (str(x.device), M, N, K, bool(relu), bias is not None, residual is not None)
-    name = _dense_deterministic(N, K) if (DETERMINISTIC["enabled"] and K % 8 == 0) else _DENSE_CHOICE.get(key)
+    name = _dense_deterministic(N, K, M) if (DETERMINISTIC["enabled"] and K % 8 == 0) else _DENSE_CHOICE.get(key)
+    if name is None:
+        name = _table()["dense"].get(_problem(key))
+        if name is not None and name in _DENSE:
+            _DENSE_CHOICE[key] = name
+        else:
+            name = None
     if name is None:
         if torch.cuda.is_current_stream_capturing() or os.environ.get("BEVOPS_DENSE_TUNE", "1") == "0" or M < 64:
-            name = _dense_default(N, K, residual is not None)
+            name = "small" if (M <= 4096 and K % 64 == 0 and K <= 1024) else _dense_default(N, K, residual is not None)
         else:
             name = _DENSE_CHOICE[key] = _dense_measure(key, x, weight, bias, residual, relu)
     try:

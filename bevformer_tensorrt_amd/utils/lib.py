@@ -72,8 +72,10 @@ SIGNATURES = {
     "bevops_conv3x3_c32_pack_weight": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bevops_conv3x3_c32_forward_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_void_p]),
+    "bevops_rotate_set_variant": (c_int, [c_int]),
     "bevops_rotate_forward_hwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                           c_int, c_int, c_int, c_int, c_void_p]),
+    "bevops_refine_reference_points": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "bevops_layer_norm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "bevops_linear_workspace_size": (c_size_t, []),
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,
@@ -87,6 +89,7 @@ SIGNATURES = {
     "bevops_linear_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                          c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tile_gemm_set_variant": (c_int, [c_int]),
+    "bevops_small_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "bevops_bias_relu_maxpool_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -333,6 +333,10 @@ int bevops_conv3x3_c32_set_variant(int variant);
 int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const void *packed_weight,
                                     const void *bias32, void *output_nhwc, int B, int H, int W, int Cin,
                                     void *stream);
+/* A/B switch of bevops_rotate_forward's store path (thread-local): 0 = 16-byte stores through an LDS transpose of
+ * 8-pixel runs where every plane starts 16-byte aligned, 1 = one store per lane and plane (rounds 1-3).  Same values
+ * either way.  Returns the previous setting. */
+int bevops_rotate_set_variant(int variant);
 /* bevops_rotate_forward on channels-last data: img / output are [height, width, channels] (fp32 /
  * fp16, channels a multiple of 4 / 8) -- the layout prev_bev [H*W, 1, C] already has in the model,
  * so the permute-copy to [C, H, W] and back around the plugin (transformer.py:296-303) disappears.
@@ -346,6 +350,13 @@ int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, con
  * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
 int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                       size_t rows, int channels, float eps, void *stream);
+/* Decoder reference-point refinement (det2trt/models/modules/decoder.py:93-103, inverse_sigmoid of :24-40) as one
+ * launch: out[q, :] = sigmoid((tmp[q, 0], tmp[q, 1], tmp[q, 4]) + log(c / (1 - c))), c = clamp(reference_points[q, :],
+ * eps, 1 - eps); tmp [num_query, tmp_channels] (the regression branch's output), reference_points / out
+ * [num_query, 3], out_xy (optional) [num_query, 2] = out[:, :2] (the next layer's sampling reference).  fp16; every
+ * intermediate rounded to binary16 where the framework's op sequence rounds it: bit-identical to that sequence. */
+int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points, void *out, void *out_xy,
+                                   int num_query, int tmp_channels, float eps, void *stream);
 /* INT8 dense layers: what TensorRT builds from the reference's `LinearQ` /
  * `Conv2dQ` (= pytorch_quantization QuantLinear / QuantConv2d, det2trt/models/utils/register.py:78-84):
  * per-tensor symmetric quantisation of the layer input, int8 x int8 -> int32 GEMM on the matrix cores,
@@ -516,6 +527,14 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
  * (the caller keeps its library GEMM). */
 int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
                       long long m, int n, int k, int relu, void *stream);
+
+/* The same dense layer for problems with FEW rows (the decoder's 900 object queries: decoder.py:381-471,
+ * bevformer_head.py:247-282; csrc/small_gemm.hip): 32 x 64 output tiles, split-K over the four waves of a block, every
+ * operand fragment requested before the first matrix instruction -- one memory round trip per launch instead of a
+ * chain of dependent k-steps.  fp16 in / out, fp32 sums, bias / residual fp16, optional.  BEVOPS_NOT_SUPPORTED outside
+ * K % 64 == 0, K <= 1024, M <= 65536. */
+int bevops_small_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
+                          long long m, int n, int k, int relu, void *stream);
 
 /* OPTIONAL, BLOCKING: pick the hipBLASLt algorithm for one bevops_linear_bias_act problem (same
  * arguments) by timing every supporting algorithm on `stream` with the caller's buffers, and cache

@@ -274,3 +274,32 @@ def test_grid_sampler_staged_path_is_bit_identical(dtype):
                     assert st == 0
                     torch.cuda.synchronize()
                     assert torch.equal(staged, planar), (N, C, H, W, mode, pad, align)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.int8])
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+@pytest.mark.parametrize("shape", [(256, 200, 200), (20, 50, 52), (9, 31, 40), (5, 7, 9)])
+def test_rotate_wide_stores_equal_per_lane_stores(dtype, interp, shape):
+    """bevops_rotate_forward stores through an LDS transpose of 8-pixel runs (16-byte stores) where every plane
+    starts 16-byte aligned; `bevops_rotate_set_variant(1)` keeps the per-lane stores of rounds 1-3.  Same values
+    bit for bit -- full and partial pixel blocks, partial channel chunks, plane sizes that fall back."""
+    import bevformer_tensorrt_amd as bevm
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    g = torch.Generator().manual_seed(sum(shape))
+    C, H, W = shape
+    ang, ctr = torch.tensor(17.5).cuda(), torch.tensor([W * 0.45, H * 0.55]).cuda()
+    if dtype == torch.int8:
+        img = torch.randint(-127, 128, shape, generator=g, dtype=torch.int8).cuda()
+        run = lambda: bevm.rotate_int8(img, ang, ctr, 0.03, 0.04, interp)
+    else:
+        img = torch.randn(shape, generator=g).to(dtype).cuda()
+        run = lambda: bevm.rotate(img, ang, ctr, interp)
+    outs = []
+    for variant in (0, 1):
+        prev = lib.bevops_rotate_set_variant(variant)
+        try:
+            outs.append(run())
+        finally:
+            lib.bevops_rotate_set_variant(prev)
+    assert torch.equal(outs[0], outs[1])

@@ -20,7 +20,10 @@ SHAPES = [("s1.conv1", 556800, 64, 256, False, True), ("s1.conv3", 556800, 256, 
           ("tsa.split", 40000, 192, 256, True, False), ("enc.output_proj", 40000, 256, 256, True, False),
           ("sca.offsets", 40000, 512, 256, False, False), ("sca.weights", 40000, 256, 256, False, False),
           ("ffn.fc1", 40000, 512, 256, False, True), ("ffn.fc2", 40000, 256, 512, True, False),
-          ("dec.value_proj", 40000, 256, 256, False, False), ("dec.in_proj", 900, 768, 256, True, False)]
+          ("dec.value_proj", 40000, 256, 256, False, False), ("dec.in_proj", 900, 768, 256, True, False),
+          ("dec.out_proj", 900, 256, 256, True, False), ("dec.offsets", 900, 64, 256, True, False),
+          ("dec.ffn.fc1", 900, 512, 256, False, True), ("dec.ffn.fc2", 900, 256, 512, True, False),
+          ("head.reg", 900, 256, 256, False, True)]
 
 B.use_tuned_gemms()
 for name, M, N, K, has_res, relu in SHAPES:

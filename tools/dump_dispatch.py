@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Regenerates bevformer_tensorrt_amd/dispatch_gfx950.json: the measured choice between the dense-layer / convolution
+implementations (functions/linear.py: dense_auto, functions/conv.py: conv3x3_auto) for every problem the re-hosted
+models pose -- BEVFormer tiny / small / base in fp16, the INT8 engines (their fp16 layers) and BEVDet-R50 --
+measured on THIS box with BEVOPS_DENSE_TUNE=1 semantics (every problem timed).  The shipped table makes the kernel
+selection the same on every box; timings are kept next to the choices for the record.
+usage: dump_dispatch.py [out.json]"""
+import json
+import os
+import sys
+
+os.environ["BEVOPS_DENSE_TUNE"] = "1"
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bevformer_tensorrt_amd import bevdet as D, bevformer as B, geometry as G  # noqa: E402
+from bevformer_tensorrt_amd.functions import conv as CV, linear as L  # noqa: E402
+from bevformer_tensorrt_amd.quantization import build_int8_bevdet, build_int8_engine  # noqa: E402
+
+dev, dtype = torch.device("cuda"), torch.float16
+
+
+def frames_of(name, n):
+    H, W = B.CONFIGS[name]["image"]
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 6, 3, H, W, generator=g).to(dev, dtype)
+    out = []
+    for i in range(n):
+        can = torch.zeros(18)
+        can[0], can[-1] = 0.5 * i, 0.8 * i
+        out.append((img, can, l2i))
+    return out
+
+
+for name in ("tiny", "small", "base"):
+    fr = frames_of(name, 3)
+    r = B.FrameRunner(B.BEVFormer(name, seed=0).to(dev, dtype), dev, dtype)
+    for f in fr:
+        r.step(*f, "s")
+    model, _, _ = build_int8_engine(B, name, dev, fr[:2])
+    r = B.FrameRunner(model, dev, dtype)
+    for f in fr:
+        r.step(*f, "s")
+    del r, model
+    torch.cuda.empty_cache()
+m = D.BEVDet(seed=0).to(dev, dtype)
+ranks = [t.to(dev) for t in m.view.get_bev_pool_input(*D.synthetic_rig(m.view))]
+img = torch.randn(1, 6, 3, 256, 704).to(dev, dtype)
+m(img, *ranks)
+m8, _, _ = build_int8_bevdet(D, dev, [(img, *ranks)] * 2)
+m8(img, *ranks)
+table = {"dense": {L._problem(k): v for k, v in L._DENSE_CHOICE.items()},
+         "conv": {L._problem(k): v for k, v in CV._CHOICE.items()},
+         "measured_us": {"dense": {L._problem(k): t for k, t in L.DENSE_LOG}, "conv": {L._problem(k): t for k, t in CV.CONV_LOG}},
+         "device": torch.cuda.get_device_name(0)}
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "bevformer_tensorrt_amd", "dispatch_gfx950.json")
+json.dump(table, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps({"dense_problems": len(table["dense"]), "conv_problems": len(table["conv"]), "out": out}))

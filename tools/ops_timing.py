@@ -33,10 +33,16 @@ def main():  # noqa: C901
         # rotate: prev_bev [256,200,200]
         img = torch.randn(256, 200, 200, generator=g).to(dt).cuda()
         ang, ctr = torch.tensor(1.5).cuda(), torch.tensor([100.0, 100.0]).cuda()
+        from bevformer_tensorrt_amd.utils import load_library
         for interp in ("nearest", "bilinear"):
-            us = time_call(lambda: bev.rotate(img, ang, ctr, interp))
-            rows.append(dict(op=f"rotate_{interp}", dtype=str(dt)[6:], us=round(us, 1),
-                             GBs=round(2 * img.numel() * es / us / 1e3, 1)))
+            for variant, tag in ((0, ""), (1, "_per_lane_stores_r03")):     # LDS-transposed 16-byte stores vs rounds 1-3
+                load_library().bevops_rotate_set_variant(variant)
+                try:
+                    us = time_call(lambda: bev.rotate(img, ang, ctr, interp))
+                finally:
+                    load_library().bevops_rotate_set_variant(0)
+                rows.append(dict(op=f"rotate_{interp}{tag}", dtype=str(dt)[6:], us=round(us, 1),
+                                 GBs=round(2 * img.numel() * es / us / 1e3, 1), frac_of_8TBs=round(2 * img.numel() * es / us / 8e6, 3)))
         # DCN stage 3 / 4 of R101 at base: 6 cams
         for name, (C, H, W) in {"dcn_s3": (256, 58, 100), "dcn_s4": (512, 29, 50)}.items():
             x = torch.randn(6, C, H, W, generator=g).to(dt).cuda()
