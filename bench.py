@@ -5,12 +5,19 @@ A "step" is ONE MODEL FRAME: six 3x928x1600 camera images -> ResNet-101-DCN + FP
 self-attention, spatial cross-attention, FFN over 200x200 BEV queries) -> 6 decoder layers -> heads, through the
 reference's stateful frame loop with prev_bev kept on the device (bevformer_tensorrt_amd/bevformer.py: the
 mmcv-free re-host of the reference's *TRTP wrappers; random weights and synthetic frames -- no datasets or
-checkpoints here).  `value` = frames/s of that step in fp16 (`--dtype int8`: the PTQ build).  N = 1 replays the
-frame from a HIP graph; N > 1 shards the six cameras over the ranks (backbone, FPN, value_proj and the SCA
-sampler per camera; RCCL exchange of the per-camera BEV features once per encoder layer, BASELINE config 4)
--- strong scaling: the job is still one frame.
+checkpoints here).  `value` = frames/s of that step in fp16 (`--dtype int8`: the PTQ engine), replayed from a HIP
+graph.  N > 1 shards the six cameras over the ranks (backbone, FPN, value projection and the fused SCA sampler on the
+local cameras; ONE RCCL all-reduce of the masked camera sums per encoder layer, captured into the graph;
+`--exchange gather`: BASELINE config 4's per-camera all-gathers, eager) -- strong scaling: the job is still one frame.
 
 Sub-records of the same JSON line (N = 1):
+  protocol_sync : the reference's own FPS protocol for the same frames (one frame between two stream syncs, first and
+                 last dropped, 1000 / mean ms; det2trt/utils/tensorrt.py:72-76) -- also inside every other
+                 end-to-end record below;
+  int8         : the INT8 counterparts: end_to_end = the PTQ engine (int8 activation chain through the backbone,
+                 encoder LinearQ layers, TSA MSDA on the INT8 plugin; quantization.build_int8_engine), hot path, roofline;
+  small        : BEVFormer-small fp16 / INT8 end to end (BASELINE config 3);
+  bevdet_r50   : BEVDet-R50 fp16 / INT8 end to end (BASELINE config 5);
   hot_path     : one frame's pass over the SAMPLING operators alone at the BEVFormer-base shapes, inputs drawn
                  like the reference's op tests (seed 0; value / offsets / logits ~ N(0,1), reference points
                  ~ U[0,1): the worst case for the sampler; test_multi_scale_deformable_attn.py:25-33):
@@ -22,7 +29,6 @@ Sub-records of the same JSON line (N = 1):
                  fp16) from HIP events around every such call of the hot-path step, vs the 8 TB/s
                  HBM peak; .model_geometry / .fused_sca: the same call on the reference points a 6-camera rig
                  produces, as the drop-in op and as the fused SCA op;
-  int8         : the INT8 counterparts (hot path, its roofline, end-to-end PTQ build);
   cpu_baseline : the sampling operators of a frame on this host's cores through the oracle (kind "port"), and
                  the whole BEVFormer-tiny in fp32 on the host (BASELINE config 1).
 """

@@ -118,20 +118,14 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
         elif torch.cuda.is_current_stream_capturing() or os.environ.get("BEVOPS_DENSE_TUNE", "1") == "0":
             name = "library"
         else:
+            from .linear import graph_time_us
             times = {}
             for cand, fn in (("tile", conv_nhwc), ("library", _library)):
                 for _ in range(2):
                     fn(x, weight, bias, relu, residual, stride)
-                best = float("inf")
-                for _ in range(3):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(3):
-                        fn(x, weight, bias, relu, residual, stride)
-                    b.record()
-                    b.synchronize()
-                    best = min(best, a.elapsed_time(b) * 1e3 / 3)
-                times[cand] = round(best, 1)
+                torch.cuda.synchronize()
+                # (under HIP-graph replay: an eager loop would time the host for the small late-stage convolutions)
+                times[cand] = round(graph_time_us(lambda: fn(x, weight, bias, relu, residual, stride), 4, 3), 1)
             CONV_LOG.append((key, times))
             name = _CHOICE[key] = min(times, key=times.get)
     return (conv_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual, stride)
