@@ -836,20 +836,15 @@ class BEVFormer(nn.Module):
         init_reference = reference_points
         inter, inter_refs, regs = [], [], []
         out = query
-        # one launch per layer for the refinement (bit-identical to the op sequence of geometry.refine_reference_points;
-        # tests/test_geometry_gpu.py) where the operator set has it; it also hands back the next layer's (x, y) reference
-        refine = getattr(self.ops, "refine_reference_points", None)
-        if not (_R3["enabled"] and _FUSED_LINEAR["enabled"] and dtype == torch.float16 and image.is_cuda):
-            refine = None
+        # (a one-launch fused refinement was built in round 4 and REMOVED: index generation must stay bit-exact, and the
+        # device's exp / log inside a hand-written kernel did not reproduce the framework's op sequence on every element
+        # -- 1 binary16 ulp on a handful of 19 000; the seven small launches per layer stay)
         ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
         for lid, layer in enumerate(self.decoder):
             out = layer(out, bev_embed, query_pos, ref_xy, bev_shapes)
             tmp = _mlp(self.ops, self.reg_branches[lid], out).view(1, -1, 10)
-            if refine is not None:
-                reference_points, ref_xy = refine(tmp, reference_points)
-            else:
-                reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
-                ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
+            reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
+            ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
             inter.append(out)
             inter_refs.append(reference_points)
             regs.append(tmp)

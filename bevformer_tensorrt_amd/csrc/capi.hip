@@ -92,7 +92,6 @@ const Entry kTable[] = {
     {"bevops_conv3x3_c32_pack_weight", (void *)&bevops_conv3x3_c32_pack_weight},
     {"bevops_conv3x3_c32_packed_weight_size", (void *)&bevops_conv3x3_c32_packed_weight_size},
     {"bevops_layer_norm", (void *)&bevops_layer_norm},
-    {"bevops_refine_reference_points", (void *)&bevops_refine_reference_points},
 };
 }  // namespace
 

@@ -219,49 +219,10 @@ __global__ __launch_bounds__(256) void feat_embed_f16_kernel(const __half *__res
   *reinterpret_cast<uint4 *>(dst + n * dst_stride + k * 8) = o;
 }
 
-// Decoder reference-point refinement (det2trt/models/modules/decoder.py:93-103 with the decoder's own
-// inverse_sigmoid, :24-40) as ONE launch instead of the framework's seven element-wise kernels per decoder layer:
-//   new = sigmoid( (tmp[..., 0], tmp[..., 1], tmp[..., 4]) + log(c / (1 - c)) ),  c = clamp(ref, eps, 1 - eps)
-// on fp16 tensors.  Index / grid generation must stay bit-exact, so every intermediate is rounded
-// to binary16 exactly where the framework's op sequence rounds it (each op computes in fp32 and stores fp16) and the
-// same device math functions are used (expf / logf, IEEE division): tests compare it bit for bit with the op sequence.
-__device__ __forceinline__ float r16(float v) { return __half2float(__float2half_rn(v)); }
-
-__global__ __launch_bounds__(256) void refine_reference_points_f16_kernel(const __half *__restrict__ tmp,
-                                                                         const __half *__restrict__ ref,
-                                                                         __half *__restrict__ out,
-                                                                         __half *__restrict__ out_xy, int n,
-                                                                         int tmp_stride, float eps) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n * 3) return;
-  const int q = i / 3, k = i - q * 3;
-  const float x = __half2float(ref[i]);
-  const float t = __half2float(tmp[(size_t)q * tmp_stride + (k < 2 ? k : 4)]);
-  const float c = r16(fminf(fmaxf(x, eps), 1.f - eps));     // clamp(min = eps, max = 1 - eps)
-  const float d = r16(1.f - c);                              // 1 - x
-  const float qd = r16(c / d);                               // x / (1 - x)
-  const float l = r16(logf(qd));                             // log
-  const float s = r16(t + l);                                // cat(tmp) + inverse_sigmoid
-  const __half o = __float2half_rn(1.f / (1.f + expf(-s)));  // sigmoid
-  out[i] = o;
-  if (out_xy && k < 2) out_xy[q * 2 + k] = o;
-}
-
 }  // namespace
 }  // namespace bevops
 
 using namespace bevops;
-
-extern "C" int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points, void *out,
-                                              void *out_xy, int num_query, int tmp_channels, float eps, void *stream) {
-  if (!tmp || !reference_points || !out || num_query < 0 || tmp_channels < 5 || !(eps > 0.f)) return BEVOPS_BAD_PARAM;
-  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
-  if (num_query == 0) return BEVOPS_SUCCESS;
-  hipLaunchKernelGGL(refine_reference_points_f16_kernel, dim3((unsigned)((num_query * 3 + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const __half *)tmp, (const __half *)reference_points,
-                     (__half *)out, (__half *)out_xy, num_query, tmp_channels, eps);
-  return launch_status();
-}
 
 extern "C" int bevops_upsample_add_nhwc(int dtype, void *a, const void *b, int n, int h, int w, int hb, int wb,
                                         int channels, void *stream) {

@@ -101,28 +101,6 @@ def layer_norm(x, weight=None, bias=None, eps=1e-5, out=None):
     return out.view(x.shape)
 
 
-def refine_reference_points(tmp, reference_points, eps=1e-5):
-    """geometry.refine_reference_points (decoder.py:93-103) as one launch (bevops_refine_reference_points): tmp
-    [1, nq, C >= 5] fp16 (the regression branch's output), reference_points [1, nq, 3] fp16 -> (new reference points
-    [1, nq, 3], their (x, y) as the next layer's sampling reference [1, nq, 1, 2]).  Bit-identical to the framework's
-    op sequence."""
-    assert tmp.is_cuda and tmp.dtype == torch.float16 and reference_points.dtype == torch.float16
-    nq, C = tmp.shape[-2], tmp.shape[-1]
-    t2, r2 = tmp.reshape(nq, C), reference_points.reshape(nq, 3)
-    if not t2.is_contiguous():
-        t2 = t2.contiguous()
-    if not r2.is_contiguous():
-        r2 = r2.contiguous()
-    out = torch.empty((1, nq, 3), dtype=tmp.dtype, device=tmp.device)
-    xy = torch.empty((1, nq, 1, 2), dtype=tmp.dtype, device=tmp.device)
-    handle = _lib.load_library()
-    with torch.cuda.device(tmp.device):
-        st = handle.bevops_refine_reference_points(_lib.F16, t2.data_ptr(), r2.data_ptr(), out.data_ptr(), xy.data_ptr(),
-                                                   nq, C, float(eps), _lib.current_stream_ptr(tmp.device))
-    _lib.check(st, "bevops_refine_reference_points")
-    return out, xy
-
-
 def quantize_rows(x, scale, out=None):
     """fp16 tensor -> int8 with one per-tensor scale: clamp(rne(x / scale), -127, 127) (bevops_quantize_rows)."""
     assert x.is_cuda and x.dtype == torch.float16

@@ -75,7 +75,6 @@ SIGNATURES = {
     "bevops_rotate_set_variant": (c_int, [c_int]),
     "bevops_rotate_forward_hwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                           c_int, c_int, c_int, c_int, c_void_p]),
-    "bevops_refine_reference_points": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "bevops_layer_norm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "bevops_linear_workspace_size": (c_size_t, []),
     "bevops_linear_bias_act": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int,

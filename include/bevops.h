@@ -350,13 +350,6 @@ int bevops_rotate_forward_hwc(int dtype, const void *img, const void *angle, con
  * blocks of the re-hosted encoder / decoder (encoder.py:510-636) as one streaming pass. */
 int bevops_layer_norm(int dtype, const void *x, const void *gamma, const void *beta, void *out,
                       size_t rows, int channels, float eps, void *stream);
-/* Decoder reference-point refinement (det2trt/models/modules/decoder.py:93-103, inverse_sigmoid of :24-40) as one
- * launch: out[q, :] = sigmoid((tmp[q, 0], tmp[q, 1], tmp[q, 4]) + log(c / (1 - c))), c = clamp(reference_points[q, :],
- * eps, 1 - eps); tmp [num_query, tmp_channels] (the regression branch's output), reference_points / out
- * [num_query, 3], out_xy (optional) [num_query, 2] = out[:, :2] (the next layer's sampling reference).  fp16; every
- * intermediate rounded to binary16 where the framework's op sequence rounds it: bit-identical to that sequence. */
-int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points, void *out, void *out_xy,
-                                   int num_query, int tmp_channels, float eps, void *stream);
 /* INT8 dense layers: what TensorRT builds from the reference's `LinearQ` /
  * `Conv2dQ` (= pytorch_quantization QuantLinear / QuantConv2d, det2trt/models/utils/register.py:78-84):
  * per-tensor symmetric quantisation of the layer input, int8 x int8 -> int32 GEMM on the matrix cores,
