@@ -718,7 +718,7 @@ class BEVFormer(nn.Module):
         nhwc = self.backbone_layout == "nhwc" or (self.backbone_layout == "auto" and self.ops is _hip_ops)
         chain = getattr(self, "int8_chain", None)     # quantization.Int8ChainBackbone, after its freeze()
         if chain is not None and chain.ready and img.dtype == torch.float16 and img.is_cuda:
-            return chain(img)
+            return chain(img)       # (img is already this rank's camera subset when `cams` is given)
         if nhwc and img.dtype == torch.float16 and img.is_cuda:
             if not self._nhwc_ready:   # MIOpen picks its NHWC kernels when the filters are channels-last too
                 for m in list(self.backbone.modules()) + list(self.neck.modules()):

@@ -465,6 +465,10 @@ class ConvTapsQ(torch.nn.Conv2d):
         self.scale_in = self.scale_w = None
         self.register_buffer("weight_q", None, persistent=False)
         self.bias_f32 = None
+        # prequant: quantise the fp16 input ONCE (one pass over it) and run the int8 implicit GEMM on the int8 copy,
+        # instead of quantising inside the operand load -- there every input pixel is re-read and RE-QUANTISED once
+        # per tap (nine times for a 3x3), which is what made the fused form lose to the fp16 kernel in round 3
+        self.prequant = False
 
     def calibrate(self):
         self.qmode = "calibrate"
@@ -485,6 +489,11 @@ class ConvTapsQ(torch.nn.Conv2d):
 
     def int8_nhwc(self, x, residual=None, relu=False):
         from . import functions as _f
+        if self.prequant and residual is None:
+            from .functions import int8_chain as C
+            q = _f.quantize_rows(x.permute(0, 2, 3, 1), self.scale_in)      # [n, h, w, c]: the channels-last bytes as they lie
+            return C.conv_int8_chain_nhwc(q.permute(0, 3, 1, 2), self.scale_in, self.weight_q, self.scale_w, self.bias_f32,
+                                          relu, self.stride[0], torch.float16)
         return _f.conv_int8_nhwc(x, self.scale_in, self.weight_q, self.scale_w, self.bias_f32, relu, residual,
                                  self.stride[0])
 
@@ -730,6 +739,15 @@ def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, de
     ch = None
     if chain:
         ch = Int8ChainBackbone(model, qops.cal)
+        if os.environ.get("BEVOPS_INT8_FPN", "1") != "0":
+            # the FPN's 3x3 output convolutions as int8 implicit GEMMs on a pre-quantised copy of their fp16 input
+            # (Conv2dQ of the reference's INT8 config; 2x the matrix rate of the fp16 kernel on the frame's largest
+            # convolution, 6 x 256 x 116 x 200)
+            taps = [m for m in quantize_backbone_convs(model, qops.cal, lambda n, m: n.startswith("neck."), conv3x3=True)
+                    if isinstance(m, ConvTapsQ)]
+            for m in taps:
+                m.prequant = True
+            q += taps
     else:
         q += quantize_backbone_convs(model, qops.cal)
     for m in q:

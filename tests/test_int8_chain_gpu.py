@@ -183,3 +183,34 @@ def test_int8_engine_tiny_runs_and_tracks_fp16():
     a = rg.step(*f, "g")
     b = rg.step(*f, "g")
     assert torch.isfinite(a[0].float()).all() and torch.isfinite(b[0].float()).all()
+
+
+def test_conv_taps_q_on_a_prequantised_input():
+    """ConvTapsQ(prequant=True) -- the FPN's 3x3 convolutions in the INT8 engine: one quantise pass over the fp16 input,
+    then the int8 implicit GEMM on the int8 copy -- against its own fake-quant reference (QuantConv2d's formula) and
+    against the fused-quantise form (same integers up to rounding ties of x / s vs x * (1 / s))."""
+    from bevformer_tensorrt_amd.quantization import ConvTapsQ, MinMaxCalibrator
+    g = torch.Generator().manual_seed(4)
+    conv = torch.nn.Conv2d(256, 256, 3, 1, 1).cuda().half()
+    cal = MinMaxCalibrator()
+    m = ConvTapsQ(conv, cal, "site").cuda().half()
+    x = torch.randn(2, 256, 29, 50, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    m.calibrate()
+    m(x)
+    m.freeze()
+    ref = m.fake_quant_reference(x)
+    m.prequant = True
+    y_pre = m.int8_nhwc(x)
+    m.prequant = False
+    y_fused = m.int8_nhwc(x)
+    assert y_pre.shape == ref.shape and y_pre.is_contiguous(memory_format=torch.channels_last)
+    assert (y_pre.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert (y_pre.float() - y_fused.float()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    # stride 2 (the FPN's extra level)
+    conv2 = torch.nn.Conv2d(256, 256, 3, 2, 1).cuda().half()
+    m2 = ConvTapsQ(conv2, cal, "site2").cuda().half()
+    m2.calibrate(); m2(x); m2.freeze()
+    m2.prequant = True
+    y2 = m2.int8_nhwc(x)
+    r2 = m2.fake_quant_reference(x)
+    assert y2.shape == r2.shape and (y2.float() - r2).abs().max().item() <= 4e-3 * max(1.0, r2.abs().max().item())

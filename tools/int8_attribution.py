@@ -72,9 +72,14 @@ def main():
     # every dense layer of the encoder / decoder is calibrated (also the ones the engine keeps in fp16), so that
     # each group can be switched on its own
     dense_q = quantize_dense_layers(model_q, qops.cal, lambda n, m: n.startswith(("encoder.", "decoder.")))
-    chain = None
+    chain, taps = None, []
     if a.chain:       # the int8 activation chain through the backbone, as bench.py's engine runs it (one group)
         chain = Int8ChainBackbone(model_q, qops.cal)
+        taps = [m for m in quantize_backbone_convs(model_q, qops.cal, lambda n, m: n.startswith("neck."), conv3x3=True)
+                if not hasattr(m, "lin")]          # the FPN's 3x3 convolutions (ConvTapsQ on a pre-quantised input)
+        for m in taps:
+            m.prequant = True
+            m.calibrate()
     else:
         dense_q += quantize_backbone_convs(model_q, qops.cal)
     for m in dense_q:
@@ -89,6 +94,8 @@ def main():
         m.freeze()
     if chain is not None:
         chain.freeze()
+    for m in taps:
+        m.freeze()
     lin_of = lambda m: getattr(m, "lin", m)          # Conv2dQ keeps its LinearQ in .lin
     dense_sites = {lin_of(m).site: lin_of(m) for m in dense_q}
     plugin_sites = sorted({k.rsplit(".", 1)[0] for k in qops._scales if k.split("#")[0] in ("msda", "rotate", "dcn")})
@@ -119,6 +126,8 @@ def main():
 
     if chain is not None:
         groups["chain.backbone"] = ["chain.backbone"]
+    if taps:
+        groups["conv.neck.fpn3x3"] = ["conv.neck.fpn3x3"]
 
     def with_sites(on):
         on = set(on)
@@ -128,6 +137,8 @@ def main():
             chain.ready = "chain.backbone" in on
             for c in chain.convs:
                 c.lin.mode = "float"
+        for m in taps:
+            m.qmode = "int8" if "conv.neck.fpn3x3" in on else "float"
         qops.site_filter = lambda site: site in on
         return delta(evaluate(B.FrameRunner(model_q, dev, dtype)))
 
@@ -145,11 +156,13 @@ def main():
             torch.cuda.empty_cache()
         except Exception as exc:
             print(json.dumps(dict(head, row="noise_floor", error=repr(exc)[:200])), flush=True)
-    everything = list(dense_sites) + plugin_sites + (["chain.backbone"] if chain is not None else [])
+    everything = list(dense_sites) + plugin_sites + (["chain.backbone"] if chain is not None else []) + \
+        (["conv.neck.fpn3x3"] if taps else [])
     engine = None
     if chain is not None:     # the subset bench.py's engine switches on (quantization.build_int8_engine)
         from bevformer_tensorrt_amd.quantization import engine_dense_select
         engine = [s for s in dense_sites if engine_dense_select(s.split(":", 1)[1], None)] + ["chain.backbone"] + \
+                 (["conv.neck.fpn3x3"] if taps else []) + \
                  [s for s in plugin_sites if s.startswith("msda#") and qops.site_batch(s) != 1]
     if dev.type != "cuda":
         print(json.dumps(dict(head, row="all int8 sites off", groups={g: len(v) for g, v in groups.items()}, **with_sites([]))))
