@@ -94,6 +94,7 @@ def _from_rows(y, n, h, w):
 
 _FUSED_LINEAR = {"enabled": os.environ.get("BEVOPS_FUSED_LINEAR", "1") != "0"}   # A/B switch
 _R3 = {"enabled": os.environ.get("BEVOPS_R3_FUSIONS", "1") != "0"}   # A/B switch of the round-3 launch-count work
+_TSA_LOCAL = {"enabled": os.environ.get("BEVOPS_TSA_LOCAL", "0") == "1"}   # A/B switch: TSA's MSDA on the quad kernel (round 4)
 
 
 def _fused_linear(ops, x, weight, bias, residual, relu):
@@ -468,7 +469,11 @@ class TemporalSelfAttention(nn.Module):
         value = _dense(self.ops, self.value_proj, value).view(2, nq, HEADS, EMBED // HEADS)
         w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
         off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
-        out = self.ops.multi_scale_deformable_attn(value, spatial_shapes, ref_2d, off, w).flatten(2)
+        # the BEV grid's reference points have locality (neighbouring queries, neighbouring pixels): the operator set's
+        # layout-preserving entry skips the head-major re-layout the default dispatch needs for random points
+        msda = (getattr(self.ops, "multi_scale_deformable_attn_local", None) if _TSA_LOCAL["enabled"] else None) \
+            or self.ops.multi_scale_deformable_attn
+        out = msda(value, spatial_shapes, ref_2d, off, w).flatten(2)
         out = torch.mean(out, keepdim=True, dim=0)
         return _dense(self.ops, self.output_proj, out, identity, False)
 

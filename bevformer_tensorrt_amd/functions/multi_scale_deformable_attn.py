@@ -157,6 +157,21 @@ def multi_scale_deformable_attn(value, value_spatial_shapes, reference_points, s
     return _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights)
 
 
+def multi_scale_deformable_attn_local(value, value_spatial_shapes, reference_points, sampling_offsets,
+                                      attention_weights):
+    """The same operator for callers that KNOW their reference points have locality -- neighbouring queries sample
+    neighbouring pixels, as the BEV grid of temporal self-attention does (encoder.py:170-195): it runs the
+    layout-preserving quad kernel directly on `value` (no head-major re-layout pass), whatever the size of the maps.
+    The default dispatch must assume the op test's uniform-random points, for which maps beyond an XCD's L2 want the
+    head-major form.  Same values (tests); not a reference name."""
+    handle = _lib.load_library()
+    prev = handle.bevops_msda_set_variant(10)          # thread-local: "never the head-major kernels"
+    try:
+        return _msda(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights)
+    finally:
+        handle.bevops_msda_set_variant(prev)
+
+
 def multi_scale_deformable_attn2(value, value_spatial_shapes, reference_points, sampling_offsets,
                                  attention_weights):
     """Same op under the reference's `half2` plugin name (MultiScaleDeformableAttnTRT2,

@@ -200,3 +200,27 @@ def test_runs_on_side_stream(bev, oracle_mod):
         out = bev.multi_scale_deformable_attn(*args)
     s.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), oracle_of(oracle_mod, args), rtol=1e-5, atol=2e-5)
+
+
+def test_local_entry_equals_default_on_a_bev_grid():
+    """multi_scale_deformable_attn_local (the layout-preserving quad kernel for callers whose reference points have
+    locality: TSA's BEV grid) against the default dispatch (head-major kernels at this map size) and the oracle."""
+    import bevformer_tensorrt_amd as bev
+    import oracle
+    g = torch.Generator().manual_seed(2)
+    hw, heads, C, P = 96, 8, 32, 4
+    nq = hw * hw
+    value = torch.randn(2, nq, heads, C, generator=g).half().cuda()
+    off = torch.randn(2, nq, heads, P * 2, generator=g).half().cuda()
+    logit = torch.randn(2, nq, heads, P, generator=g).half().cuda()
+    shapes = torch.tensor([[hw, hw]])
+    ys, xs = torch.meshgrid(torch.linspace(0.5, hw - 0.5, hw) / hw, torch.linspace(0.5, hw - 0.5, hw) / hw, indexing="ij")
+    grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).view(1, nq, 1, 2)
+    ref = torch.cat([grid + 0.01, grid]).half().cuda()
+    a = bev.multi_scale_deformable_attn_local(value, shapes, ref, off, logit)
+    b = bev.multi_scale_deformable_attn(value, shapes, ref, off, logit)
+    want = oracle.msda_f32(value.float().cpu().numpy(), shapes.int().numpy(), ref.float().cpu().numpy(),
+                           off.float().cpu().numpy(), logit.float().cpu().numpy())
+    assert a.shape == b.shape == (2, nq, heads, C)
+    assert np.abs(a.float().cpu().numpy() - want).max() <= 1e-2
+    assert (a.float() - b.float()).abs().max().item() <= 1e-2
