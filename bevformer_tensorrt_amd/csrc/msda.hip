@@ -603,9 +603,12 @@ using namespace bevops;
 
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant;
-  // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan
-  msda_hm4_set_no_occ(variant == 19 || (variant >= 200 && variant < 1000));
-  g_variant = variant == 19 ? 17 : variant;
+  // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan.  21 .. 24 (A/B, forced
+  // hm4): int8 big set as pixel-pair entries (21, 22) or as 2x2 footprints (23, 24), on the two-blocks (21, 23) or
+  // the one-block plan (22, 24); any other value restores the default entry format
+  msda_hm4_set_no_occ(variant == 19 || variant == 22 || variant == 24 || (variant >= 200 && variant < 1000));
+  msda_hm4_set_pair(variant == 21 || variant == 22 ? 1 : (variant == 23 || variant == 24 ? 0 : -1));
+  g_variant = (variant == 19 || (variant >= 21 && variant <= 24)) ? 17 : variant;
   return prev;
 }
 

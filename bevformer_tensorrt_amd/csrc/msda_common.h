@@ -231,6 +231,7 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
                      void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st);
 bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
 void msda_hm4_set_no_occ(bool v);
+void msda_hm4_set_pair(int v);
 int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, int bs, int nk,
                   int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st);
 int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, size_t packed_bytes,

@@ -77,9 +77,10 @@ __device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int p
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                 int nk, int heads, unsigned bias) {
+                                                                 int nk, int heads, unsigned bias, int pair) {
   // `bias` = 0x80808080 for the x255 flavour: its planes hold v + 128 as u8 (pads included: they
-  // stand for the value 0), see i8_sample_u
+  // stand for the value 0), see i8_sample_u.  `pair`: the big set holds 64-byte pixel-pair entries too (the staged
+  // format) -- half the bytes per plane, two 8-byte loads per sample (H4Plan::pair)
   const int c8 = threadIdx.x & 7;
   const RepackPos p = repack_pos(t, blockIdx.x, 32, (int)(threadIdx.x >> 3));
   if (p.f < 0) return;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *_
     };
     px[0] = at(p.yp, p.x);
     px[1] = at(p.yp, p.x + 1);
-    if (p.big) { px[2] = at(p.yp + 1, p.x); px[3] = at(p.yp + 1, p.x + 1); }
+    if (p.big && !pair) { px[2] = at(p.yp + 1, p.x); px[3] = at(p.yp + 1, p.x + 1); }
   }
-  if (p.big) {
+  if (p.big && !pair) {
     unsigned o[4];
     transpose4x4(px[0], px[1], px[2], px[3], o);
     *reinterpret_cast<uint4 *>(gset + ((size_t)bh * t.g_entries + p.f) * kEntBytes + c8 * 16) =
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *_
     uint2 o;
     o.x = __builtin_amdgcn_perm(px[1], px[0], 0x05010400u) ^ bias;  // c0(x0), c0(x1), c1(x0), c1(x1)
     o.y = __builtin_amdgcn_perm(px[1], px[0], 0x07030602u) ^ bias;  // c2(x0), c2(x1), c3(x0), c3(x1)
-    *reinterpret_cast<uint2 *>(sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes + c8 * 8) = o;
+    char *dst = p.big ? gset + ((size_t)bh * t.g_entries + p.f) * kLdsPixBytes
+                      : sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes;
+    *reinterpret_cast<uint2 *>(dst + c8 * 8) = o;
   }
 }
 
@@ -183,6 +186,10 @@ __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
 // 0 .. D-1, only the later batches wait for it, after most of the iteration's own work).
 // 1024: compiled for 4 waves per SIMD (<= 128 VGPRs) so that TWO 512-thread blocks share a CU when the staged
 // planes are small (experiment: only the last level staged, variant 18).
+// 2048 (int8 only, results unchanged): the big set holds 64-byte pixel-pair entries (the staged format) instead of
+// 128-byte 2x2 footprints: a sample is two 8-byte loads per lane (row 0, row 1) + the four v_perm of the LDS path,
+// and a (batch, head) plane is half as large -- the base SCA planes (3.96 MB as footprints: as large as an XCD's L2,
+// 63 % hit rate, 2.2 GB fetched per call) become 1.98 MB.
 template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
 __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel(const H4Args a) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
@@ -193,6 +200,8 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
   constexpr int D = (NBIG >= 2 && !(ABL & 64)) ? 2 : 1;    // big batches in flight
   constexpr int kBox = LP * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
   constexpr int ESZ = I8 ? 1 : 2;         // bytes per logit / offset component
+  constexpr bool PAIR = I8 && (ABL & 2048) != 0;
+  constexpr unsigned kBigEnt = PAIR ? (unsigned)kLdsPixBytes : (unsigned)kEntBytes;
   static_assert(NBIG >= 0 && NBIG <= NB, "NBIG");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const MsdaDims &d = a.d;
@@ -212,8 +221,8 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
   if (threadIdx.x < (unsigned)t.L) {
     const int l = threadIdx.x;
     const bool staged = l >= t.ls;
-    const unsigned sh = staged ? 6u : 7u;
-    const unsigned base = staged ? (unsigned)kTab : bh * (unsigned)t.g_entries * kEntBytes;
+    const unsigned sh = (staged || PAIR) ? 6u : 7u;
+    const unsigned base = staged ? (unsigned)kTab : bh * (unsigned)t.g_entries * kBigEnt;
     float4 f;
     f.x = (float)t.W[l];
     f.y = (float)t.H[l];
@@ -498,14 +507,20 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
     if (__any(any_cur)) {
       uint4 bp[D][BT];
       u32x4 r0[D][BT], r1[D][BT];
+      u32x2 p0[D][BT], p1[D][BT];   // PAIR: rows 0 / 1 of the pixel-pair entries
       auto issue = [&](int tb) {
         const int sl = tb % D;
 #pragma unroll
         for (int j = 0; j < BT; ++j) bp[sl][j] = *reinterpret_cast<const uint4 *>(box + (tb * BT + j) * 16);
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
-          r0[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].z + lane16), 0, 0);
-          if constexpr (!I8) r1[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].w + lane16), 0, 0);
+          if constexpr (PAIR) {
+            p0[sl][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(bp[sl][j].z + lane8b), 0, 0);
+            p1[sl][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(bp[sl][j].w + lane8b), 0, 0);
+          } else {
+            r0[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].z + lane16), 0, 0);
+            if constexpr (!I8) r1[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].w + lane16), 0, 0);
+          }
         }
       };
       // int8: 4 samples x 4 channels -> requantised samples, gathered per channel, one dot4 each
@@ -541,7 +556,17 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
       };
       auto consume = [&](int tb) {
         const int sl = tb % D;
-        if constexpr (I8) {
+        if constexpr (PAIR) {
+          unsigned v[BT][4];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) {   // channel c: (v00, v01) of row 0, (v10, v11) of row 1 -> one dot4 operand
+            v[j][0] = __builtin_amdgcn_perm(p1[sl][j].x, p0[sl][j].x, 0x05040100u);
+            v[j][1] = __builtin_amdgcn_perm(p1[sl][j].x, p0[sl][j].x, 0x07060302u);
+            v[j][2] = __builtin_amdgcn_perm(p1[sl][j].y, p0[sl][j].y, 0x05040100u);
+            v[j][3] = __builtin_amdgcn_perm(p1[sl][j].y, p0[sl][j].y, 0x07060302u);
+          }
+          i8_batch(v, bp[sl]);
+        } else if constexpr (I8) {
           unsigned v[BT][4];
 #pragma unroll
           for (int j = 0; j < BT; ++j) { v[j][0] = r0[sl][j].x; v[j][1] = r0[sl][j].y; v[j][2] = r0[sl][j].z; v[j][3] = r0[sl][j].w; }
@@ -706,29 +731,43 @@ inline int h4_box_bytes(int LP) { return (kH4Threads / 8) * (LP * 16 + 16); }
 // under the 128-register cap) takes 950 us instead of 565: fp16 keeps the one-block plan.
 constexpr int kOccStageCap = 40 * 1024;
 thread_local bool g_h4_no_occ = false;   // variant 19 / the ablation variants: the one-block plan for int8 too
+// int8, L*P = 32: pixel-pair entries in the big set (kernel flag 2048).  A/B switch (bevops_msda_set_variant 21 / 22 on,
+// 23 / 24 off); the default is what profiles/r04/msda_i8_pair_ab.jsonl measured faster
+constexpr int kH4PairDefault = 0;
+thread_local int g_h4_pair = kH4PairDefault;
 
 struct H4Plan {
   Hm3Plan p;
   int nbig;   // tap batches served by L1/L2
   bool occ2;  // the two-blocks-per-CU plan
+  bool pair;  // int8: 64-byte pixel-pair entries in the big set (g_bytes is adjusted)
 };
 
 bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl, bool i8) {
   const int LP = L * P;
   const int bt = LP >= 4 ? 4 : LP;
   pl.occ2 = false;
+  pl.pair = false;
+  auto pair_mode = [&]() {
+    if (i8 && g_h4_pair && LP == 32 && (pl.nbig == 4 || pl.nbig == 6 || pl.nbig == 8)) {
+      pl.pair = true;
+      pl.p.g_bytes = (size_t)bs * heads * pl.p.t.g_entries * kLdsPixBytes;
+    }
+  };
   if (i8 && !g_h4_no_occ && LP == 32) {
     // (hm3_plan budgets the staged planes as kLdsLimit - kTab - box bytes: a cap is a larger pretended box)
     if (hm3_plan(shapes_host, bs, heads, L, nq, kLdsLimit - kTab - kOccStageCap, pl.p) && pl.p.t.ls < L &&
         (pl.p.t.ls * P) % bt == 0 && pl.p.t.ls * P / bt == 6) {
       pl.nbig = 6;
       pl.occ2 = true;
+      pair_mode();
       return true;
     }
   }
   if (!hm3_plan(shapes_host, bs, heads, L, nq, h4_box_bytes(LP), pl.p)) return false;
   if ((pl.p.t.ls * P) % bt) return false;  // a batch never straddles the big / staged boundary
   pl.nbig = pl.p.t.ls * P / bt;
+  pair_mode();
   return true;
 }
 
@@ -747,7 +786,7 @@ int h4_go(const H4Args &a, hipStream_t st) {
 // instantiated (L*P, big batches) combinations: the model's calls.  Anything else -> NOT_SUPPORTED
 // (the caller keeps its older kernels for those).
 template <bool I8, bool U8W, typename RefT, bool MASKED>
-int h4_dispatch(int LP, int nbig, bool occ2, const H4Args &a, int ablate, hipStream_t st) {
+int h4_dispatch(int LP, int nbig, bool occ2, bool pair, const H4Args &a, int ablate, hipStream_t st) {
   if (ablate) {  // timing ablations, base SCA shape only (tools/hm4_probe.py)
     if constexpr (!MASKED && !U8W) {
       if (LP == 32 && nbig == 4 && a.d.ppg == 4 && a.d.P % 4 == 0) {
@@ -774,7 +813,24 @@ int h4_dispatch(int LP, int nbig, bool occ2, const H4Args &a, int ablate, hipStr
     }                                                                                     \
     return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false, PROD>(a, st);                  \
   }
-  if constexpr (I8 && !MASKED) {   // the two-blocks-per-CU plan (h4_plan): <= 128 VGPRs, one big batch in flight
+  if constexpr (I8 && !MASKED) {
+    if (pair) {   // pixel-pair entries in the big set (h4_plan: L*P = 32 only)
+      if (LP != 32) return BEVOPS_NOT_SUPPORTED;
+      if (occ2) {
+        if (nbig != 6) return BEVOPS_NOT_SUPPORTED;
+        if (rr) return h4_go<32, 6, I8, U8W, RefT, MASKED, true, PROD | 1024 | 64 | 2048>(a, st);
+        return h4_go<32, 6, I8, U8W, RefT, MASKED, false, PROD | 1024 | 64 | 2048>(a, st);
+      }
+#define BEVOPS_H4_PAIR(NBIG_)                                                                  \
+  if (nbig == NBIG_) {                                                                         \
+    if (rr) return h4_go<32, NBIG_, I8, U8W, RefT, MASKED, true, PROD | 2048>(a, st);          \
+    return h4_go<32, NBIG_, I8, U8W, RefT, MASKED, false, PROD | 2048>(a, st);                 \
+  }
+      BEVOPS_H4_PAIR(4) BEVOPS_H4_PAIR(6) BEVOPS_H4_PAIR(8)
+#undef BEVOPS_H4_PAIR
+      return BEVOPS_NOT_SUPPORTED;
+    }
+    // the two-blocks-per-CU plan (h4_plan): <= 128 VGPRs, one big batch in flight
     if (occ2) {
       if (LP != 32 || nbig != 6) return BEVOPS_NOT_SUPPORTED;
       if (rr) return h4_go<32, 6, I8, U8W, RefT, MASKED, true, PROD | 1024 | 64>(a, st);
@@ -805,6 +861,7 @@ int h4_chunk(const Hm3Plan &p, int nq, int variant_chunk) {
 }  // namespace
 
 void msda_hm4_set_no_occ(bool v) { g_h4_no_occ = v; }
+void msda_hm4_set_pair(int v) { g_h4_pair = v < 0 ? kH4PairDefault : v; }   // < 0: back to the default
 
 size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, bool i8) {
   H4Plan pl;
@@ -840,7 +897,7 @@ int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *sh
     if (bs * heads > 65535) return BEVOPS_NOT_SUPPORTED;
     const dim3 grid((unsigned)(((t.g_entries + 31) >> 5) + ((t.s_entries + 31) >> 5)), (unsigned)(bs * heads));
     hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
-                       heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
+                       heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u, pl.pair ? 1 : 0);
   } else {
     msda_hm3_repack_launch(value, gset, sset, &t, bs, nk, heads, st);
   }
@@ -873,9 +930,9 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
   a.qmask = nullptr;
   a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
   const bool i8 = dtype == BEVOPS_I8;
-  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, pl.occ2, a, ablate, st);
+  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, pl.occ2, false, a, ablate, st);
+  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, pl.occ2, pl.pair, a, ablate, st);
+  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, pl.occ2, pl.pair, a, ablate, st);
   return BEVOPS_NOT_SUPPORTED;
 }
 

@@ -118,6 +118,37 @@ def test_int8_bit_identical_to_layout_preserving_kernel(ctx, oracle_mod, name, r
         assert d.max() <= 1 and (d > 0).mean() <= 0.01
 
 
+@pytest.mark.parametrize("name", ["base_sca_q4k", "base_sca_q1k", "sca_3lvl_q3k", "ragged_tail"])
+@pytest.mark.parametrize("ref_dtype", [torch.float32, torch.float16], ids=["s8w_f32ref", "u8w_f16ref"])
+def test_int8_entry_formats_bit_identical(ctx, name, ref_dtype):
+    """int8, L*P = 32: the big set as 64-byte pixel-pair entries (variants 21 two blocks per CU, 22 one block) against
+    128-byte 2x2 footprints (23, 24): same arithmetic in the same order -> equal bits; and against the
+    layout-preserving kernel (10).  Saturating inputs on the ragged shape."""
+    value, sh, ref, off, logit = make(SHAPES[name][0])
+    if name == "ragged_tail":
+        value = value * 3.0
+    qv, s_v = quantize(value); qo, s_o = quantize(off); qw, s_w = quantize(logit)
+    if name == "ragged_tail":
+        qv = torch.where(torch.rand(qv.shape) < 0.3, torch.full_like(qv, 127), qv)
+        qv = torch.where(torch.rand(qv.shape) < 0.2, torch.full_like(qv, -128), qv)
+    args = (qv.cuda(), sh.cuda(), ref.to(ref_dtype).cuda(), qo.cuda(), qw.cuda())
+    scales = (s_v, s_o, s_w, 0.02)
+    quad = run(ctx, args, 10, scales)
+    for pair, foot in ((21, 23), (22, 24)):
+        a, b = run(ctx, args, pair, scales), run(ctx, args, foot, scales)
+        assert torch.equal(a, b), (name, pair, (a != b).float().mean().item())
+        same_as_quad(a, quad, ref_dtype, name)
+    # a packed value made under one entry format is sampled under the same one (the plan is part of the variant)
+    bev, lib = ctx
+    lib.bevops_msda_set_variant(21)
+    try:
+        packed = bev.msda_pack_value(args[0], args[1], SHAPES[name][0][2], SHAPES[name][0][3], reference_dtype=ref_dtype)
+        c = bev.multi_scale_deformable_attn_prepacked(packed, args[2], args[3], args[4], scales)
+    finally:
+        lib.bevops_msda_set_variant(0)
+    assert torch.equal(c, run(ctx, args, 21, scales))
+
+
 @pytest.mark.parametrize("ref_dtype", [torch.float32, torch.float16], ids=["s8w_f32ref", "u8w_f16ref"])
 def test_int8_default_choice_at_full_base_size(ctx, ref_dtype):
     """6 x 40 000 queries: the default dispatch (hm4) against the layout-preserving kernel."""
