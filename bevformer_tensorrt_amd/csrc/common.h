@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/bevops.h"
 
 namespace bevops {
@@ -87,5 +89,22 @@ inline int launch_status() {
   return hipGetLastError() == hipSuccess ? BEVOPS_SUCCESS : BEVOPS_FAILURE;
 }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (kernel instance, device) and raised
+// only when a launch needs more than what was set before -- not on every launch
+template <auto Kern>
+inline bool ensure_dynamic_lds(size_t lds) {
+  static std::atomic<int> have[16];
+  if (lds <= 64 * 1024) return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::atomic<int> &slot = have[dev & 15];
+  if ((int)lds <= slot.load(std::memory_order_acquire)) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return false;
+  slot.store((int)lds, std::memory_order_release);
+  return true;
+}
 
 }  // namespace bevops

@@ -6,8 +6,6 @@
 // "big" set read through L1/L2 (128-byte entries) and a "staged" tail that a block keeps in LDS
 // (64-byte entries); what an entry holds is the kernel family's business.
 #pragma once
-#include <atomic>
-
 #include "msda_common.h"
 
 namespace bevops {
@@ -120,23 +118,6 @@ __device__ __forceinline__ void add_h2(float &a0, float &a1, h2_t v) {
   const unsigned u = __builtin_bit_cast(unsigned, v);
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(u));
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(u));
-}
-
-// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (kernel instance, device) and raised
-// only when a launch needs more than what was set before -- not on every launch
-template <auto Kern>
-inline bool ensure_dynamic_lds(size_t lds) {
-  static std::atomic<int> have[16];
-  if (lds <= 64 * 1024) return true;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  std::atomic<int> &slot = have[dev & 15];
-  if ((int)lds <= slot.load(std::memory_order_acquire)) return true;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return false;
-  slot.store((int)lds, std::memory_order_release);
-  return true;
 }
 
 }  // namespace

@@ -50,7 +50,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 enum { kS8 = 0, kF16Q = 1, kF16 = 2 };
 
-constexpr int kTM = 128, kTKB = 64, kTLd = kTKB + 16;  // 64 bytes of k per row and step; +16: conflict-free b128 reads
+constexpr int kTM = 128;   // (bytes of k per row and step: template parameter KB; LDS rows are KB + 16: conflict-free b128 reads)
 constexpr float kQMagic = 12582912.f;          // 1.5 * 2^23: bits 0x4B400000, low byte 0
 constexpr int kQMagicBits = 0x4B400000;
 constexpr int kEpiStride = 64 * 4 + 16;        // staging row: 64 x 4 bytes + pad
@@ -95,16 +95,30 @@ struct TileArgs {
 // RES8: the identity rows are int8 [M, N] (real = q * s_res) instead of fp16
 // MJ: 32-row MFMA blocks per wave: 2 -> 128-row tiles (three blocks per CU, the default), 1 -> 64-row tiles (four
 // blocks per CU and twice the tiles; an A/B build, measured slower on every layer -- see launch_tile_gemm).
-template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false, int MJ = 2>
-__global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArgs p) {
+// KB: bytes of k per row and step.  64 everywhere; 128 ("wide steps", int8 chain GEMMs without convolution mode): the
+// long-K layers of ResNet stages 3 / 4 are ONE sparse round of tiles whose time is their chain of dependent steps
+// (load -> LDS -> barrier -> multiply, ~1.5 us each whatever the step holds) -- a step that holds twice the bytes
+// halves the chain and doubles the bytes a block keeps in flight (two register sets of 32 KB).  72 KB of LDS: two blocks
+// per CU (these layers pose ~2 tiles per CU anyway), dynamic shared memory.
+template <int KB>
+constexpr int tile_lds_bytes(int tm) {
+  return 2 * (tm + 128) * (KB + 16) > 4 * 32 * kEpiStride ? 2 * (tm + 128) * (KB + 16) : 4 * 32 * kEpiStride;
+}
+extern __shared__ __attribute__((aligned(16))) char tile_dyn_smem[];
+template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false, int MJ = 2, int KB = 64>
+__global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_gemm_kernel(TileArgs p) {
+  static_assert(KB == 64 || (KB == 128 && MODE == kS8 && !CONV && MJ == 2), "wide steps: the int8 chain's plain GEMMs");
   constexpr int kTN = 64 * NI;
   constexpr int TM = 64 * MJ;                    // rows per tile
-  constexpr int kImg = 2 * (TM + 128) * kTLd, kEpi = 4 * 32 * kEpiStride;
-  __shared__ __attribute__((aligned(16))) char smem[kImg > kEpi ? kImg : kEpi];   // [image][A rows | W rows][80]; 40 / 34 KB
+  constexpr int kTLd = KB + 16;                  // LDS row: the step's bytes + 16 (conflict-free 16-byte fragment reads)
+  constexpr int kHalves = KB / 64;               // 64-byte halves of a step: a staging thread takes one 16-byte chunk of each
+  // [image][A rows | W rows][KB + 16]; 40 / 34 KB static, 72 KB dynamic (wide steps)
+  __shared__ __attribute__((aligned(16))) char smem_static[KB == 64 ? tile_lds_bytes<64>(TM) : 16];
+  char *const smem = KB == 64 ? smem_static : tile_dyn_smem;
   constexpr int kAB = MODE == kS8 ? 1 : 2;     // bytes per activation element in memory
   constexpr int kWB = MODE == kF16 ? 2 : 1;    // bytes per weight element
   constexpr int kAV = MODE == kF16Q ? 2 : 1;   // 16-byte loads per activation row and step
-  constexpr int kStepK = MODE == kF16 ? kTKB / 2 : kTKB;   // k-values per step
+  constexpr int kStepK = MODE == kF16 ? KB / 2 : KB;       // k-values per step
   const int M = p.M, N = p.N, K = p.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
   if (logical >= p.tiles_total) return;
   const int m0 = (logical / p.tiles_n) * TM, n0 = (logical % p.tiles_n) * kTN;
   const int r0 = tid >> 2, r1 = r0 + 64;       // 128 rows x 4 chunks of 16 bytes of k
-  const int kce = (tid & 3) * (kStepK / 4);    // this thread's first k-value inside a step
+  const int kce = (tid & 3) * (MODE == kF16 ? 8 : 16);   // this thread's first k-value inside a (64-byte half of a) step
   typename std::conditional<MODE == kF16, f32x16_t, i32x16_t>::type acc[NI][MJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
   // block (the step's latency is what bounds the long-K layers); the fused-quantise flavour stages twice the
   // activation bytes per step and stays at one set (168 VGPRs = three blocks per CU)
   constexpr int kDepth = MODE == kF16Q ? 1 : 2;
-  uint4 ra0[kDepth][kAV], ra1[kDepth][kAV], rb0[kDepth], rb1[kDepth];
+  uint4 ra0[kDepth][kAV * kHalves], ra1[kDepth][kAV * kHalves], rb0[kDepth][kHalves], rb1[kDepth][kHalves];
   auto bload = [](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, int soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
   };
@@ -170,6 +184,17 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
     constexpr int S = decltype(setc)::value;
     const int ks = kt * kStepK;
     const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
+    if constexpr (KB == 128) {       // wide steps (int8, no convolution mode): the chunk of each 64-byte half
+#pragma unroll
+      for (int hh = 0; hh < kHalves; ++hh) {
+        const bool ok = ks + 64 * hh + kce < K;
+        ra0[S][hh] = bload(rs_a, ok ? a_off0 + 64u * hh : kOob, ks);
+        ra1[S][hh] = bload(rs_a, ok ? a_off1 + 64u * hh : kOob, ks);
+        rb0[S][hh] = bload(rs_w, ok ? w_off0 + 64u * hh : kOob, ks);
+        if constexpr (NI == 2) rb1[S][hh] = bload(rs_w, ok ? w_off1 + 64u * hh : kOob, ks);
+      }
+      return;
+    }
     if constexpr (CONV) {
       const int delta = ((g_tap / p.conv_ks - pad) * p.conv_win + (g_tap % p.conv_ks - pad)) * cin * kAB;
       const unsigned v0 = (tapmask0 >> g_tap) & 1u ? a_off0 + (unsigned)delta : kOob;
@@ -188,8 +213,8 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
         if constexpr (MJ == 2) ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
       }
     }
-    rb0[S] = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
-    if constexpr (NI == 2) rb1[S] = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
+    rb0[S][0] = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
+    if constexpr (NI == 2) rb1[S][0] = bload(rs_w, kok ? w_off1 : kOob, ks * kWB);
   };
   const int lchunk = (tid & 3) * 16;           // byte position of the thread's chunk in an LDS row
   auto lstore = [&](int buf, auto setc) {
@@ -198,12 +223,17 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
     if constexpr (MODE == kF16Q) {
       *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[S][0], ra0[S][1], p.inv_sa);
       if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
+      *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0[S][0];
+      if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1[S][0];
     } else {
-      *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = ra0[S][0];
-      if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = ra1[S][0];
+#pragma unroll
+      for (int hh = 0; hh < kHalves; ++hh) {
+        *reinterpret_cast<uint4 *>(As + r0 * kTLd + 64 * hh + lchunk) = ra0[S][hh];
+        if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + 64 * hh + lchunk) = ra1[S][hh];
+        *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + 64 * hh + lchunk) = rb0[S][hh];
+        if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + 64 * hh + lchunk) = rb1[S][hh];
+      }
     }
-    *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0[S];
-    if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1[S];
   };
   // ---- epilogue roles, fixed before the loop so that the identity rows can be requested early
   constexpr int kCH = 4 * NI;                    // 8-column chunks per row of the wave's 32 NI columns
@@ -239,7 +269,7 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
   auto compute = [&](int kt) {
     const char *As = smem + (kt & 1) * (TM + 128) * kTLd, *Ws = As + TM * kTLd;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KB / 32; ++ks) {
       const int kk = ks * 32 + (lane >> 5) * 16;
       // MFMA operand A = the weight rows (output columns n), B = the activation rows (m): a lane's 4
       // consecutive accumulator rows are then 4 consecutive n of one output row m
@@ -394,6 +424,10 @@ __global__ __launch_bounds__(256, MJ == 1 ? 4 : 3) void tile_gemm_kernel(TileArg
 }
 
 thread_local int g_tile_rows = 0;   // bevops_tile_gemm_set_variant: 0 measured policy, 64 / 128 force the tile height (A/B)
+// wide steps (KB = 128) of the int8 chain's plain GEMMs: -1 the policy of launch_tile_gemm, 0 never, 1 wherever legal
+// (bevops_tile_gemm_set_variant 255 / 256; A/B)
+thread_local int g_tile_wide = -1;
+constexpr int kWidePolicyMinK = 1 << 30;   // policy: wide steps from this K on (set from profiles/r04/tile_wide_ab.jsonl)
 
 struct ConvGeom { int cin = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, ks = 1; size_t in_elems = 0; };
 
@@ -441,6 +475,9 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   // (profiles/r04/tile_rows_ab.jsonl: e.g. ResNet stage-3 conv1 fp16 43.7 vs 39.3 us, FFN fc2 32.2 vs 28.0, int8 conv1
   // 25.8 vs 24.9): half the matrix work per staged weight byte and per barrier costs more than the extra chains hide.
   const bool rows64 = g_tile_rows == 64;
+  // wide steps: int8 activations, no convolution mode, 128-column tiles, whole 128-byte steps
+  const bool wide_ok = MODE == kS8 && cg.cin == 0 && !narrow && !rows64 && K % 128 == 0;
+  const bool wide = wide_ok && (g_tile_wide < 0 ? K >= kWidePolicyMinK : g_tile_wide == 1);
   const int tm = rows64 ? 64 : kTM;
   const long long tiles = (long long)p.tiles_n * ((M + tm - 1) / tm);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
@@ -450,6 +487,14 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool conv = cg.cin > 0, out8 = out_dtype == BEVOPS_I8;
 #define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                                 \
   do {                                                                                                                 \
+    if constexpr (MODE == kS8 && !CONV_) {                                                                             \
+      if (wide) {                                                                                                      \
+        constexpr size_t lds = (size_t)tile_lds_bytes<128>(kTM);                                                       \
+        if (!ensure_dynamic_lds<tile_gemm_kernel<kS8, OUT8_, 2, false, RES8_, 2, 128>>(lds)) return BEVOPS_FAILURE;    \
+        hipLaunchKernelGGL((tile_gemm_kernel<kS8, OUT8_, 2, false, RES8_, 2, 128>), grid, dim3(256), lds, st, p);      \
+        return launch_status();                                                                                        \
+      }                                                                                                                \
+    }                                                                                                                  \
     if (rows64) {                                                                                                      \
       if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p); \
       else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p);        \
@@ -558,10 +603,11 @@ extern "C" int bevops_conv_tile_int8(const void *x_q, float scale_a, const void 
                                (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
 }
 
-// A/B switch of the tile height (thread-local): 0 = the policy of launch_tile_gemm, 64 / 128 = force.  Returns the
-// previous value.
+// A/B switch (thread-local): 0 = the policy of launch_tile_gemm, 64 / 128 = force the tile height, 256 / 255 = wide
+// k-steps of the int8 chain's plain GEMMs wherever legal / never.  Returns the previous tile-height value.
 extern "C" int bevops_tile_gemm_set_variant(int rows) {
   const int prev = g_tile_rows;
   g_tile_rows = (rows == 64 || rows == 128) ? rows : 0;
+  g_tile_wide = rows == 256 ? 1 : (rows == 255 ? 0 : -1);   // 256: wide steps wherever legal, 255: never; else the policy
   return prev;
 }
