@@ -31,6 +31,7 @@ Differences from the reference that do not change results:
 """
 import math
 import os
+import time
 
 import torch
 import torch.nn as nn
@@ -994,6 +995,13 @@ class FrameRunner:
         # through the events torch records around every collective); the group's watchdog thread polls events
         # meanwhile, which only the thread-local capture mode tolerates
         kw = {"capture_error_mode": "thread_local"} if self.gather is not None else {}
+        if self.gather is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            # ... and even then NOT a query of the end event of a collective issued BEFORE the capture once the group's
+            # stream has joined it ("operation not permitted when stream is capturing", raised on the watchdog thread =
+            # process abort).  Collectives issued during a capture are not handed to the watchdog; the warm-up's are:
+            # let them finish and give the watchdog (100 ms period) time to retire them before the capture begins.
+            torch.cuda.synchronize()
+            time.sleep(0.35)
         with torch.cuda.graph(graph, **kw):
             bev, cls, crd = self._forward()
             self.prev_bev.copy_(bev)     # state update is part of the graph
