@@ -131,7 +131,11 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
 
 /* Tuning hook: selects an internal MSDA kernel variant for subsequent calls from
  * this thread (0 = automatic).  Results are identical across variants; exists so
- * bench/tuning scripts can A/B them in one process.  Returns the previous value. */
+ * bench/tuning scripts can A/B them in one process (the values are listed where they are decoded:
+ * csrc/msda.hip, bevops_msda_set_variant and bevops_msda_forward_ws; e.g. 10 = layout-preserving kernels, 16 / 17 =
+ * forced head-major generations, 21 .. 24 = the int8 head-major call with pixel-pair / 2x2-footprint entries on the
+ * two-blocks / one-block plan, 1000 + flags = builds of the fp16 SCA sampler).  A packed value
+ * (bevops_msda_pack_value) must be sampled under the variant it was packed under.  Returns the previous value. */
 int bevops_msda_set_variant(int variant);
 
 
@@ -382,7 +386,9 @@ int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, co
 /* A/B switch of the tiled GEMM family's tile height (thread-local; affects bevops_tile_gemm_f16, bevops_linear_int8*,
  * bevops_conv_tile_*): 0 / 128 = the default 128-row tiles, 64 = 64-row tiles (four blocks per CU; measured 3-10 %
  * slower on the base-model layers, profiles/r04/tile_rows_ab.jsonl).  Both tilings give bit-identical results.
- * Returns the previous value. */
+ * 256 / 255 = 128-byte k-steps of the int8-chain GEMMs (bevops_linear_int8 / bevops_linear_int8_chain with int8
+ * activations, N > 64, K % 128 == 0) wherever legal / never (also an A/B build, bit-identical, measured slower:
+ * profiles/r04/tile_wide_ab.jsonl); any other value restores the launcher's policy.  Returns the previous tile height. */
 int bevops_tile_gemm_set_variant(int rows);
 /* Convolution on channels-last fp16 activations as an implicit GEMM on the same tiled skeleton (no column
  * buffer, no strided copy): kernel ksize x ksize in {1, 3}, pad ksize / 2, any stride.  x [B, H, W, Cin],
