@@ -364,8 +364,9 @@ class ModelFrames:
     encoder's dense layers as LinearQ, TSA's MSDA on the INT8 plugin; scales from the native entropy calibrator
     over `calib` synthetic frames; layers whose fp16 form is faster on MI355X (decoder, rotate, SCA's projected
     sampler) stay fp16 -- a mixed engine, as TensorRT builds them.
-    N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and the
-    frame runs eagerly with the RCCL exchange inside."""
+    N = 1: the frame is replayed from a HIP graph; N > 1: the cameras are sharded (camera_shard.py) and -- with the
+    default "reduce" exchange -- the frame is replayed from a HIP graph that holds its RCCL all-reduces too (the
+    per-camera all-gather exchange runs eagerly)."""
 
     def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True, name="base"):
         from bevformer_tensorrt_amd import bevformer as B, geometry as G
