@@ -326,6 +326,201 @@ __global__ __launch_bounds__(256) void tsgemm_pad_zero_kernel(TsPacked pk, int p
   }
 }
 
+// ---- the int8 activation chain's flavour (quantization.Int8ChainBackbone: the 1x1 convolutions of ResNet stages 3 / 4):
+//     out = requant( act( (sum_k a[m, k] w[n, k]) * s_a * s_w[n] + bias[n] (+ identity[m, n]) ) )
+// a [M, K], w [N, K] int8 row-major, int32 sums (exact), fp32 bias, identity rows int8 (with their own scale) or fp16,
+// output int8 (requantised with the consumer's scale) or fp16.  The same persistent skeleton as tsgemm_f16_kernel --
+// one block per CU, tiles of up to 160 rows x 256 columns, both operands global -> LDS by DMA in three stages, XOR
+// swizzled 128-byte rows -- with 128 k-values per step instead of 64 (the LDS images, the DMA roles and the 16-byte
+// fragment reads are byte-for-byte the fp16 kernel's: a v_mfma_i32_32x32x32_i8 operand is 16 consecutive bytes of k,
+// lanes 32..63 the second 16 of a 32-value sub-step).  Measured (profiles/r04/tsgemm_s8_ab.jsonl): faster than the
+// tiled int8 GEMM on the 256-column layers with K = 1 024 (stage-3 conv1: 21.5 vs 24.6 us), slower for N > 256 (every
+// 256-column chunk re-reads the activation rows): functions/int8_chain.py picks it for the former only.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+
+struct TsS8Args {
+  const int8_t *a, *w;
+  const float *bias, *wscale;   // fp32 [N] or null
+  const void *res;              // int8 or fp16 [M, N] or null
+  void *out;                    // int8 or fp16 [M, N]
+  float s_aw, s_res, inv_s_out;
+  int M, N, K, relu, units_total, res_i8, out_i8;
+};
+
+__global__ __launch_bounds__(kTsThreads) void tsgemm_s8_kernel(const TsS8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = p.M, N = p.N, K = p.K;
+  const int n0 = blockIdx.y * kTsBN;
+  const int nb = gridDim.x, bi = blockIdx.x;
+  const int per = p.units_total / nb, extra = p.units_total % nb;
+  const int u_begin = bi * per + min(bi, extra);
+  const int u_end = u_begin + per + (bi < extra ? 1 : 0);
+  if (u_begin >= u_end) return;
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.a), 0, (unsigned)((size_t)M * K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.w), 0, (unsigned)((size_t)N * K), 0x00020000);
+  const unsigned prow = (unsigned)(lane >> 3), pchunk = (unsigned)(lane & 7);
+  unsigned w_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned row = (unsigned)((wave * 4 + j) * 8) + prow;
+    w_off[j] = (unsigned)((size_t)(n0 + row) * K) + ((pchunk ^ swz8(row)) << 4);
+  }
+  const unsigned hi = (unsigned)(lane >> 5);
+  const unsigned fa = (unsigned)(wave * 32 + (lane & 31));
+  const int nk = K / 128;
+  // column constants of this lane: acc[g][4 rq + e] is column wave * 32 + 8 rq + 4 hi + e
+  float scol[16], bcol[16];
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = n0 + wave * 32 + 8 * rq + 4 * (int)hi + e;
+      scol[4 * rq + e] = p.wscale ? p.s_aw * p.wscale[col] : p.s_aw;
+      bcol[4 * rq + e] = p.bias ? p.bias[col] : 0.f;
+    }
+  for (int u0 = u_begin; u0 < u_end; u0 += kTsG) {
+    const int G = min(kTsG, u_end - u0);
+    const int r0 = u0 * 32;
+    const int pieces_x = G * 4;
+    unsigned x_off[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const unsigned row = (unsigned)((wave + 8 * j) * 8) + prow;
+      x_off[j] = (unsigned)((size_t)(r0 + row) * K) + ((pchunk ^ swz8(row)) << 4);
+    }
+    const int k_rot = bi % nk;   // (integer sums: the order of the k-slices does not change the result)
+    auto dma = [&](int step, int buf) {
+      char *wd = smem + buf * kTsStage + wave * 4096;
+      int kstep = step + k_rot;
+      if (kstep >= nk) kstep -= nk;
+      const int soff = kstep * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wd + j * 1024), 16, (int)w_off[j], soff, 0, 0);
+      char *xd = smem + buf * kTsStage + kTsW;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (wave + 8 * j < pieces_x)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(xd + (wave + 8 * j) * 1024), 16,
+                                                   (int)x_off[j], soff, 0, 0);
+    };
+    i32x16v acc[kTsG];
+#pragma unroll
+    for (int g = 0; g < kTsG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+    const int my_dma = 4 + (wave < pieces_x ? 1 : 0) + (wave + 8 < pieces_x ? 1 : 0) + (wave + 16 < pieces_x ? 1 : 0);
+    auto wait_keep_one_step = [&]() {
+      switch (my_dma) {
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      }
+    };
+    auto kloop = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int GG = decltype(gc)::value;
+      dma(0, 0);
+      if (nk > 1) dma(1, 1);
+      for (int s = 0; s < nk; ++s) {
+        const int buf = s % kTsStages;
+        if (s + 1 < nk) wait_keep_one_step();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nk) dma(s + 2, (s + 2) % kTsStages);
+        const char *Wb = smem + buf * kTsStage;
+        const char *Xb = Wb + kTsW;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const unsigned c = 2u * ks + hi;
+          const i32x4v a = *reinterpret_cast<const i32x4v *>(Wb + fa * 128 + ((c ^ swz8(fa)) << 4));
+          i32x4v b[GG];
+#pragma unroll
+          for (int g = 0; g < GG; ++g) {
+            const unsigned xr = (unsigned)(g * 32 + (lane & 31));
+            b[g] = *reinterpret_cast<const i32x4v *>(Xb + xr * 128 + ((c ^ swz8(xr)) << 4));
+          }
+#pragma unroll
+          for (int g = 0; g < GG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[g], acc[g], 0, 0, 0);
+        }
+      }
+    };
+    switch (G) {
+      case 1: kloop(std::integral_constant<int, 1>{}); break;
+      case 2: kloop(std::integral_constant<int, 2>{}); break;
+      case 3: kloop(std::integral_constant<int, 3>{}); break;
+      case 4: kloop(std::integral_constant<int, 4>{}); break;
+      default: kloop(std::integral_constant<int, 5>{}); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- epilogue through LDS (fp32: sums already scaled and shifted), two halves of 128 columns
+    const int rows = min(G * 32, M - r0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((wave >> 2) == half) {
+        const int cw = (wave & 3) * 32;
+#pragma unroll
+        for (int g = 0; g < kTsG; ++g) {
+          if (g < G) {
+            char *rowp = smem + (g * 32 + (lane & 31)) * kTsEpiStride;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float4 v = make_float4((float)acc[g][4 * rq] * scol[4 * rq] + bcol[4 * rq],
+                                     (float)acc[g][4 * rq + 1] * scol[4 * rq + 1] + bcol[4 * rq + 1],
+                                     (float)acc[g][4 * rq + 2] * scol[4 * rq + 2] + bcol[4 * rq + 2],
+                                     (float)acc[g][4 * rq + 3] * scol[4 * rq + 3] + bcol[4 * rq + 3]);
+              *reinterpret_cast<float4 *>(rowp + (cw + 8 * rq + 4 * (int)hi) * 4) = v;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      for (int r = tid >> 4; r < rows; r += kTsThreads / 16) {
+        const int c8 = tid & 15;
+        const float4 lo = *reinterpret_cast<const float4 *>(smem + r * kTsEpiStride + c8 * 32);
+        const float4 hi4 = *reinterpret_cast<const float4 *>(smem + r * kTsEpiStride + c8 * 32 + 16);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const int col = n0 + half * 128 + c8 * 8;
+        const size_t m = (size_t)(r0 + r);
+        if (p.res) {
+          if (p.res_i8) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const int8_t *>(p.res) + m * N + col);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] += (float)(int)(signed char)((q.x >> (8 * c)) & 0xffu) * p.s_res;
+              v[4 + c] += (float)(int)(signed char)((q.y >> (8 * c)) & 0xffu) * p.s_res;
+            }
+          } else {
+            const uint4 q = *reinterpret_cast<const uint4 *>(static_cast<const __half *>(p.res) + m * N + col);
+            v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
+            v[4] += h2f_lo(q.z); v[5] += h2f_hi(q.z); v[6] += h2f_lo(q.w); v[7] += h2f_hi(q.w);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (p.out_i8) {
+          unsigned pk[2] = {0, 0};
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            pk[c >> 2] |= ((unsigned)(int)fminf(fmaxf(rintf(v[c] * p.inv_s_out), -127.f), 127.f) & 0xffu) << (8 * (c & 3));
+          *reinterpret_cast<uint2 *>(static_cast<int8_t *>(p.out) + m * N + col) = make_uint2(pk[0], pk[1]);
+        } else {
+          uint4 o;
+          o.x = pack_h2(v[0], v[1]); o.y = pack_h2(v[2], v[3]); o.z = pack_h2(v[4], v[5]); o.w = pack_h2(v[6], v[7]);
+          *reinterpret_cast<uint4 *>(static_cast<__half *>(p.out) + m * N + col) = o;
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
 inline int ts_grid_x(int units, int chunks_n) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -358,6 +553,41 @@ extern "C" int bevops_tsgemm_f16(const void *x, const void *weight, const void *
   hipLaunchKernelGGL(tsgemm_f16_kernel<0>, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
                      (const __half *)x, (const __half *)weight, (const __half *)bias, (const __half *)residual,
                      (__half *)out, (int)m, n, k, relu, units, none);
+  return launch_status();
+}
+
+// int8 chain flavour of the persistent tall-skinny GEMM (see tsgemm_s8_kernel).  a_q [M, K] / w_q [N, K] int8;
+// w_scales fp32 [N] or NULL (then scale_w); bias fp32 [N] or NULL; residual [M, N] int8 (res_dtype BEVOPS_I8, real =
+// q * scale_res) or fp16 or NULL; out [M, N] int8 (requantised with scale_out) or fp16.  Domain: K % 128 == 0,
+// N % 256 == 0, 16-byte aligned operands (8-byte for the int8 identity / output rows).
+extern "C" int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
+                                const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
+                                void *out, float scale_out, long long m, int n, int k, int relu, void *stream) {
+  if (!a_q || !w_q || !out || m <= 0 || n <= 0 || k <= 0) return BEVOPS_BAD_PARAM;
+  if (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f))) return BEVOPS_BAD_PARAM;
+  if (k % 128 != 0 || n % kTsBN != 0) return BEVOPS_NOT_SUPPORTED;
+  if (out_dtype != BEVOPS_I8 && out_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (residual && res_dtype != BEVOPS_I8 && res_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (out_dtype == BEVOPS_I8 && !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
+  if (residual && res_dtype == BEVOPS_I8 && !(scale_res > 0.f)) return BEVOPS_BAD_PARAM;
+  if ((double)m * k >= 4294967040.0 || (double)n * k >= 4294967040.0 || m > 0x7fffffff) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(a_q) || !aligned16(w_q) || (reinterpret_cast<uintptr_t>(out) & (out_dtype == BEVOPS_I8 ? 7u : 15u)) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & (res_dtype == BEVOPS_I8 ? 7u : 15u))) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3u)) || (w_scales && (reinterpret_cast<uintptr_t>(w_scales) & 3u)))
+    return BEVOPS_BAD_PARAM;
+  if (!ensure_dynamic_lds<tsgemm_s8_kernel>(kTsLds)) return BEVOPS_FAILURE;
+  const int units = (int)((m + 31) / 32);
+  const dim3 grid((unsigned)ts_grid_x(units, n / kTsBN), (unsigned)(n / kTsBN));
+  TsS8Args p;
+  p.a = static_cast<const int8_t *>(a_q); p.w = static_cast<const int8_t *>(w_q);
+  p.bias = bias; p.wscale = w_scales; p.res = residual; p.out = out;
+  p.s_aw = w_scales ? scale_a : scale_a * scale_w;
+  p.s_res = scale_res;
+  p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
+  p.M = (int)m; p.N = n; p.K = k; p.relu = relu; p.units_total = units;
+  p.res_i8 = residual && res_dtype == BEVOPS_I8 ? 1 : 0;
+  p.out_i8 = out_dtype == BEVOPS_I8 ? 1 : 0;
+  hipLaunchKernelGGL(tsgemm_s8_kernel, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream), p);
   return launch_status();
 }
 

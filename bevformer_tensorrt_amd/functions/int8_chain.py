@@ -12,6 +12,20 @@ from ..utils import workspace as _ws
 from .multi_scale_deformable_attn import _TensorCache
 
 
+import os
+
+# The persistent int8 GEMM of csrc/tsgemm.hip (bevops_tsgemm_s8; domain N % 256 == 0, K % 128 == 0).  Measured under
+# graph replay against the tiled int8 GEMM (profiles/r04/tsgemm_s8_ab.jsonl): faster on the 256-column layers with a
+# long K (ResNet stage-3 conv1, 34 800 x 256 x 1 024: 21.5 vs 24.6 us; small: 15.6 vs 17.8), slower wherever N > 256
+# (every 256-column chunk re-reads the activation rows).  "enabled": None = that policy (BEVOPS_TSGEMM_S8 unset),
+# True = wherever legal (tests, tools), False = never.
+_TS_S8 = {"enabled": {"1": True, "0": False}.get(os.environ.get("BEVOPS_TSGEMM_S8", ""), None)}
+
+
+def _ts_s8_pays(M, N, K):
+    return N == 256 and K == 1024 and M >= 16384
+
+
 def _code(dtype):
     return {torch.float16: _lib.F16, torch.int8: _lib.I8}[dtype]
 
@@ -42,6 +56,17 @@ def linear_int8_chain(a, scale_a, w_q, scale_w, bias=None, residual=None, scale_
     if M == 0:
         return out.view(*a.shape[:-1], N)
     handle = _lib.load_library()
+    if a2.dtype == torch.int8 and N % 256 == 0 and K % 128 == 0 and \
+            (_TS_S8["enabled"] or (_TS_S8["enabled"] is None and _ts_s8_pays(M, N, K))):
+        with torch.cuda.device(a.device):
+            st = handle.bevops_tsgemm_s8(
+                a2.data_ptr(), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,
+                1.0 if per_channel else float(scale_w), b.data_ptr() if b is not None else None,
+                r.data_ptr() if r is not None else None, _code(r.dtype) if r is not None else _lib.F16, float(scale_res),
+                _code(out_dtype), out.data_ptr(), float(scale_out), M, N, K, int(bool(relu)),
+                _lib.current_stream_ptr(a.device))
+        _lib.check(st, "bevops_tsgemm_s8")
+        return out.view(*a.shape[:-1], N)
     with torch.cuda.device(a.device):
         st = handle.bevops_linear_int8_chain(
             a2.data_ptr(), _code(a2.dtype), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,

@@ -526,6 +526,15 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
  * (the caller keeps its library GEMM). */
 int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
                       long long m, int n, int k, int relu, void *stream);
+/* The int8 activation chain's flavour of the same persistent kernel (the int8 1x1 convolutions of ResNet stages
+ * 3 / 4; arguments as bevops_linear_int8_chain with an int8 activation): a_q [M, K] / w_q [N, K] int8, int32 sums,
+ * fp32 bias, identity rows int8 (res_dtype BEVOPS_I8, real = q * scale_res) or fp16, output int8 (requantised with
+ * scale_out) or fp16.  128 k-values per step.  BEVOPS_NOT_SUPPORTED outside K % 128 == 0, N % 256 == 0.
+ * The host layer uses it for the 256-column layers with K = 1 024 (ResNet stage-3 conv1), where it measured faster
+ * than the tiled int8 GEMM (profiles/r04/tsgemm_s8_ab.jsonl). */
+int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
+                     const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
+                     void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
 
 /* The same dense layer for problems with FEW rows (the decoder's 900 object queries: decoder.py:381-471,
  * bevformer_head.py:247-282; csrc/small_gemm.hip): 32 x 64 output tiles, split-K over the four waves of a block, every

@@ -244,3 +244,47 @@ def test_conv_taps_q_on_a_prequantised_input():
     y2 = m2.int8_nhwc(x)
     r2 = m2.fake_quant_reference(x)
     assert y2.shape == r2.shape and (y2.float() - r2).abs().max().item() <= 4e-3 * max(1.0, r2.abs().max().item())
+
+
+@pytest.mark.parametrize("M,K,N", [(34800, 1024, 256), (34800, 256, 1024), (5000, 128, 512), (8700, 2048, 512), (777, 256, 256)])
+@pytest.mark.parametrize("out8", [False, True])
+@pytest.mark.parametrize("res", ["none", "int8", "fp16"])
+def test_tsgemm_s8_matches_tiled_int8_gemm(M, K, N, out8, res):
+    """bevops_tsgemm_s8 (persistent, LDS-DMA operands, 128 k-values per step; functions/int8_chain._TS_S8) against the
+    tiled int8 GEMM on the same operands: the int32 sums are exact in both, the fp32 epilogues may contract their
+    multiply-adds differently -> int8 outputs equal up to one step on near-ties; and against the integer evaluation in
+    float64 on the first rows."""
+    from bevformer_tensorrt_amd.functions import int8_chain as C
+    if res == "fp16" and out8 is False and M > 30000:
+        pytest.skip("covered by the other combinations at this size")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
+    w = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8)
+    b = torch.randn(N, generator=g)
+    sw = (torch.rand(N, generator=g) + 0.5) * 0.003 / K ** 0.5
+    r = {"none": None, "int8": torch.randint(-127, 128, (M, N), generator=g, dtype=torch.int8),
+         "fp16": torch.randn(M, N, generator=g).half()}[res]
+    s_a, s_r, s_o = 0.021, 0.043, 0.05
+    args = (a.cuda(), s_a, w.cuda(), sw.cuda(), b.cuda(), r.cuda() if r is not None else None, s_r, True,
+            torch.int8 if out8 else torch.float16, s_o)
+    prev = C._TS_S8["enabled"]
+    C._TS_S8["enabled"] = False
+    try:
+        want = C.linear_int8_chain(*args)
+        C._TS_S8["enabled"] = True
+        got = C.linear_int8_chain(*args)
+        torch.cuda.synchronize()
+    finally:
+        C._TS_S8["enabled"] = prev
+    rows = slice(0, min(M, 2000))
+    acc = a[rows].long() @ w.long().t()
+    ref = acc.double() * (np.float32(s_a) * sw.double()) + b.double()
+    if r is not None:
+        ref = ref + (r[rows].double() * np.float32(s_r) if res == "int8" else r[rows].double())
+    ref = torch.relu(ref)
+    if out8:
+        _close_int8(got, want)
+        _close_int8(got[rows], torch.clamp(torch.round(ref / s_o), -127, 127))
+    else:
+        assert (got.float() - want.float()).abs().max().item() <= 2e-3 * max(1.0, want.float().abs().max().item())
+        assert (got[rows].cpu().double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
