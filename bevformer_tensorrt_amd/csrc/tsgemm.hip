@@ -521,6 +521,172 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_s8_kernel(const TsS8Args p)
   }
 }
 
+// ---- A-RESIDENT flavour for the chain's layers with a SHORT K and many columns (ResNet conv3: K = planes <= 256,
+// N = 4 planes): the tiled GEMM poses 2 176 tiles there, each with its fixed ramp / epilogue, and every 128-column tile
+// re-reads its activation rows; tsgemm_s8_kernel above re-reads them once per 256-column chunk (grid.y).  Here a
+// block DMAs its tile's activation rows (up to 160 rows x K <= 256 bytes = 40 KB) into LDS ONCE and walks ALL the
+// 256-column chunks of the weight matrix with them: the flattened (chunk, k-step) sequence is one continuous
+// three-stage DMA pipeline of 32 KB weight slices (L2-resident: N x K <= 512 KB), the activation rows cross the fabric
+// once, and there is no LDS-staged epilogue to drain the pipeline for -- a lane's 4 consecutive columns of a row
+// (acc[g][4 rq .. 4 rq + 3]) are scaled, shifted, given their identity bytes and stored straight from registers
+// (4 bytes per lane and group for int8 output: the L2 merges a row's pieces).  Same arithmetic per element as
+// tsgemm_s8_kernel / the tiled GEMM.  STAGED FOR ROUND 5: compiled and reviewed, not yet run on the device (the
+// round's GPU budget was spent); nothing calls it unless BEVOPS_TSGEMM_S8_ARES=1 (functions/int8_chain.py).
+constexpr int kTsAresMaxSteps = 2;                                   // K <= 256
+constexpr int kTsAresLds = kTsAresMaxSteps * kTsX + kTsStages * kTsW;   // 40 + 96 KB
+
+__global__ __launch_bounds__(kTsThreads) void tsgemm_s8_ares_kernel(const TsS8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // smem: [A: k-step][160 rows x 128 B]  [W stages: 3 x 256 rows x 128 B]
+  char *const a_lds = smem;
+  char *const w_lds = smem + kTsAresMaxSteps * kTsX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nb = gridDim.x, bi = blockIdx.x;
+  const int per = p.units_total / nb, extra = p.units_total % nb;
+  const int u_begin = bi * per + min(bi, extra);
+  const int u_end = u_begin + per + (bi < extra ? 1 : 0);
+  if (u_begin >= u_end) return;
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.a), 0, (unsigned)((size_t)M * K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.w), 0, (unsigned)((size_t)N * K), 0x00020000);
+  const unsigned prow = (unsigned)(lane >> 3), pchunk = (unsigned)(lane & 7);
+  unsigned w_off[4];   // weight rows of chunk 0; chunk c adds c * 256 * K bytes (through the scalar offset)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned row = (unsigned)((wave * 4 + j) * 8) + prow;
+    w_off[j] = (unsigned)((size_t)row * K) + ((pchunk ^ swz8(row)) << 4);
+  }
+  const unsigned hi = (unsigned)(lane >> 5);
+  const unsigned fa = (unsigned)(wave * 32 + (lane & 31));
+  const int nk = K / 128;                 // 1 or 2
+  const int nchunk = N / kTsBN;
+  const int T = nchunk * nk;              // weight slices per tile, in (chunk, k-step) order
+  const int chunk_bytes = kTsBN * K;      // one 256-column chunk of the weight matrix
+  auto dma_w = [&](int t, int buf) {
+    const int c = t / nk, s = t - c * nk;
+    char *wd = w_lds + buf * kTsW + wave * 4096;
+    const int soff = c * chunk_bytes + s * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wd + j * 1024), 16, (int)w_off[j], soff, 0, 0);
+  };
+  for (int u0 = u_begin; u0 < u_end; u0 += kTsG) {
+    const int G = min(kTsG, u_end - u0);
+    const int r0 = u0 * 32;
+    const int pieces_x = G * 4;
+    // the tile's activation rows, all k-steps: pieces of 8 rows, piece wave + 8 j (rows past M read as zero)
+#pragma unroll
+    for (int s = 0; s < kTsAresMaxSteps; ++s) {
+      if (s < nk) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (wave + 8 * j < pieces_x) {
+            const unsigned row = (unsigned)((wave + 8 * j) * 8) + prow;
+            const unsigned off = (unsigned)((size_t)(r0 + row) * K) + ((pchunk ^ swz8(row)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(a_lds + s * kTsX + (wave + 8 * j) * 1024), 16,
+                                                     (int)off, s * 128, 0, 0);
+          }
+        }
+      }
+    }
+    dma_w(0, 0);
+    if (T > 1) dma_w(1, 1);
+    auto tile = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int GG = decltype(gc)::value;
+      i32x16v acc[GG];
+      for (int t = 0; t < T; ++t) {
+        const int c = t / nk, s = t - c * nk;
+        if (s == 0) {
+#pragma unroll
+          for (int g = 0; g < GG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+        }
+        // vmcnt retires in order: the activation pieces were requested before weight slice 0, so waiting for slice t
+        // (all but the 4 pieces of slice t + 1 done) also waits for them
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // slice t visible to all; stage (t + 2) % 3, last read at t - 1, is free
+        if (t + 2 < T) dma_w(t + 2, (t + 2) % kTsStages);
+        const char *Wb = w_lds + (t % kTsStages) * kTsW;
+        const char *Xb = a_lds + s * kTsX;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const unsigned cc = 2u * ks + hi;
+          const i32x4v a = *reinterpret_cast<const i32x4v *>(Wb + fa * 128 + ((cc ^ swz8(fa)) << 4));
+          i32x4v b[GG];
+#pragma unroll
+          for (int g = 0; g < GG; ++g) {
+            const unsigned xr = (unsigned)(g * 32 + (lane & 31));
+            b[g] = *reinterpret_cast<const i32x4v *>(Xb + xr * 128 + ((cc ^ swz8(xr)) << 4));
+          }
+#pragma unroll
+          for (int g = 0; g < GG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[g], acc[g], 0, 0, 0);
+        }
+        if (s + 1 == nk) {
+          // ---- this chunk's sums are complete: epilogue from registers.  acc[g][4 rq + e]: row r0 + 32 g + (lane & 31),
+          // column 256 c + 32 wave + 8 rq + 4 hi + e
+          const int colb = c * kTsBN + wave * 32 + 4 * (int)hi;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int col = colb + 8 * rq;
+            float sc[4], bs[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sc[e] = p.wscale ? p.s_aw * p.wscale[col + e] : p.s_aw;
+              bs[e] = p.bias ? p.bias[col + e] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < GG; ++g) {
+              const int m = r0 + g * 32 + (lane & 31);
+              if (m < M) {
+                const size_t at = (size_t)m * N + col;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)acc[g][4 * rq + e] * sc[e] + bs[e];
+                if (p.res) {
+                  if (p.res_i8) {
+                    const unsigned q = *reinterpret_cast<const unsigned *>(static_cast<const int8_t *>(p.res) + at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)(int)(signed char)((q >> (8 * e)) & 0xffu) * p.s_res;
+                  } else {
+                    const uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const __half *>(p.res) + at);
+                    v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
+                  }
+                }
+                if (p.relu) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.out_i8) {
+                  unsigned pk = 0;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    pk |= ((unsigned)(int)fminf(fmaxf(rintf(v[e] * p.inv_s_out), -127.f), 127.f) & 0xffu) << (8 * e);
+                  *reinterpret_cast<unsigned *>(static_cast<int8_t *>(p.out) + at) = pk;
+                } else {
+                  *reinterpret_cast<uint2 *>(static_cast<__half *>(p.out) + at) =
+                      make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    switch (G) {
+      case 1: tile(std::integral_constant<int, 1>{}); break;
+      case 2: tile(std::integral_constant<int, 2>{}); break;
+      case 3: tile(std::integral_constant<int, 3>{}); break;
+      case 4: tile(std::integral_constant<int, 4>{}); break;
+      default: tile(std::integral_constant<int, 5>{}); break;
+    }
+    __builtin_amdgcn_s_barrier();   // every wave is done with the activation rows and the weight stages of this tile
+  }
+}
+
 inline int ts_grid_x(int units, int chunks_n) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -588,6 +754,40 @@ extern "C" int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q,
   p.res_i8 = residual && res_dtype == BEVOPS_I8 ? 1 : 0;
   p.out_i8 = out_dtype == BEVOPS_I8 ? 1 : 0;
   hipLaunchKernelGGL(tsgemm_s8_kernel, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream), p);
+  return launch_status();
+}
+
+// The A-resident flavour (tsgemm_s8_ares_kernel): same arguments and results as bevops_tsgemm_s8.  Domain: K = 128 or
+// 256, N % 256 == 0, N * K < 2^31.
+extern "C" int bevops_tsgemm_s8_ares(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
+                                     float scale_w, const float *bias, const void *residual, int res_dtype,
+                                     float scale_res, int out_dtype, void *out, float scale_out, long long m, int n, int k,
+                                     int relu, void *stream) {
+  if (!a_q || !w_q || !out || m <= 0 || n <= 0 || k <= 0) return BEVOPS_BAD_PARAM;
+  if (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f))) return BEVOPS_BAD_PARAM;
+  if ((k != 128 && k != 256) || n % kTsBN != 0) return BEVOPS_NOT_SUPPORTED;
+  if (out_dtype != BEVOPS_I8 && out_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (residual && res_dtype != BEVOPS_I8 && res_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (out_dtype == BEVOPS_I8 && !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
+  if (residual && res_dtype == BEVOPS_I8 && !(scale_res > 0.f)) return BEVOPS_BAD_PARAM;
+  if ((double)m * k >= 4294967040.0 || (double)n * k >= 2147483647.0 || m > 0x7fffffff) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(a_q) || !aligned16(w_q) || (reinterpret_cast<uintptr_t>(out) & (out_dtype == BEVOPS_I8 ? 3u : 7u)) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & (res_dtype == BEVOPS_I8 ? 3u : 7u))) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3u)) || (w_scales && (reinterpret_cast<uintptr_t>(w_scales) & 3u)))
+    return BEVOPS_BAD_PARAM;
+  if (!ensure_dynamic_lds<tsgemm_s8_ares_kernel>(kTsAresLds)) return BEVOPS_FAILURE;
+  const int units = (int)((m + 31) / 32);
+  const dim3 grid((unsigned)ts_grid_x(units, 1));
+  TsS8Args p;
+  p.a = static_cast<const int8_t *>(a_q); p.w = static_cast<const int8_t *>(w_q);
+  p.bias = bias; p.wscale = w_scales; p.res = residual; p.out = out;
+  p.s_aw = w_scales ? scale_a : scale_a * scale_w;
+  p.s_res = scale_res;
+  p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
+  p.M = (int)m; p.N = n; p.K = k; p.relu = relu; p.units_total = units;
+  p.res_i8 = residual && res_dtype == BEVOPS_I8 ? 1 : 0;
+  p.out_i8 = out_dtype == BEVOPS_I8 ? 1 : 0;
+  hipLaunchKernelGGL(tsgemm_s8_ares_kernel, grid, dim3(kTsThreads), kTsAresLds, static_cast<hipStream_t>(stream), p);
   return launch_status();
 }
 

@@ -535,6 +535,13 @@ int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const
 int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
                      const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
                      void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
+/* A-resident flavour for short K and many columns (the chain's conv3 layers: K = 128 or 256, N % 256 == 0): a block
+ * keeps its tile's activation rows in LDS and walks all 256-column chunks of the weight matrix with them; epilogue
+ * from registers.  Same arguments and results.  STAGED: compiled and reviewed at the end of round 4, not yet run on
+ * the device; nothing in the package calls it unless BEVOPS_TSGEMM_S8_ARES=1. */
+int bevops_tsgemm_s8_ares(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
+                          const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
+                          void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
 
 /* The same dense layer for problems with FEW rows (the decoder's 900 object queries: decoder.py:381-471,
  * bevformer_head.py:247-282; csrc/small_gemm.hip): 32 x 64 output tiles, split-K over the four waves of a block, every
