@@ -62,7 +62,8 @@ def linear_int8_chain(a, scale_a, w_q, scale_w, bias=None, residual=None, scale_
     if M == 0:
         return out.view(*a.shape[:-1], N)
     handle = _lib.load_library()
-    if _TS_S8_ARES["enabled"] and a2.dtype == torch.int8 and N % 256 == 0 and K in (128, 256):
+    if _TS_S8_ARES["enabled"] and a2.dtype == torch.int8 and N % 256 == 0 and N <= 2048 and K in (128, 256) and \
+            (r is None or r.dtype == torch.int8):
         with torch.cuda.device(a.device):
             st = handle.bevops_tsgemm_s8_ares(
                 a2.data_ptr(), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,

@@ -535,7 +535,8 @@ int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const
 int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
                      const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
                      void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
-/* A-resident flavour for short K and many columns (the chain's conv3 layers: K = 128 or 256, N % 256 == 0): a block
+/* A-resident flavour for short K and many columns (the chain's conv3 layers: K = 128 or 256, N % 256 == 0, N <= 2048,
+ * identity rows int8 or none): a block
  * keeps its tile's activation rows in LDS and walks all 256-column chunks of the weight matrix with them; epilogue
  * from registers.  Same arguments and results.  STAGED: compiled and reviewed at the end of round 4, not yet run on
  * the device; nothing in the package calls it unless BEVOPS_TSGEMM_S8_ARES=1. */

@@ -293,7 +293,7 @@ def test_tsgemm_s8_matches_tiled_int8_gemm(M, K, N, out8, res):
                            "(BEVOPS_STAGED_TESTS=1 runs it)")
 @pytest.mark.parametrize("M,K,N", [(34800, 256, 1024), (139200, 128, 512), (8700, 256, 2048), (777, 128, 256), (161, 256, 512)])
 @pytest.mark.parametrize("out8", [False, True])
-@pytest.mark.parametrize("res", ["none", "int8", "fp16"])
+@pytest.mark.parametrize("res", ["none", "int8"])
 def test_tsgemm_s8_a_resident_matches_tiled_int8_gemm(M, K, N, out8, res):
     """bevops_tsgemm_s8_ares (activation rows resident in LDS, all column chunks in one pass, epilogue from registers)
     against the tiled int8 GEMM: same bar as test_tsgemm_s8_matches_tiled_int8_gemm."""
