@@ -124,3 +124,105 @@ if __name__ == "__main__":
     shapes = [tuple(int(v) for v in sys.argv[1:4])] if len(sys.argv) >= 4 else [(333, 512, 256), (161, 256, 128), (520, 768, 256)]
     for M, N, K in shapes:
         print(M, N, K, "ok" if run(M, N, K) else "MISMATCH", flush=True)
+
+
+def run_f16(M, N, K, stages, units_per_tile, n_blocks=3, seed=0):
+    """tsgemm_f16_ares_kernel<NK, STAGES, UNITS>: the same model with 2-byte elements (small integers, exact in fp16 /
+    fp32), tiles of `units_per_tile` units dealt out per block, `stages` weight stages."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-4, 5, (M, K)).astype(np.float16)
+    w = rng.integers(-4, 5, (N, K)).astype(np.float16)
+    a_flat, w_flat = a.reshape(-1).view(np.uint8), w.reshape(-1).view(np.uint8)
+    KB = K * 2
+    NK = KB // 128
+    UN, kXs = units_per_tile, units_per_tile * 32 * 128
+    nchunk, T, chunk_bytes = N // kTsBN, (N // kTsBN) * NK, kTsBN * KB
+    units = (M + 31) // 32
+    tiles = (units + UN - 1) // UN
+    out = np.full((M, N), -99999.0)
+    tid = np.arange(kThreads)
+    lane, wave = tid & 63, tid >> 6
+    prow, pchunk, hi = lane >> 3, lane & 7, lane >> 5
+    fa = wave * 32 + (lane & 31)
+
+    def load16(flat, nbytes, voff, soff):
+        o = np.zeros((kThreads, 16), np.uint8)
+        ok = voff < nbytes
+        idx = (voff[ok] + soff)[:, None] + np.arange(16)[None, :]
+        o[ok] = flat[idx]
+        return o
+
+    for bi in range(n_blocks):
+        per, extra = tiles // n_blocks, tiles % n_blocks
+        t_begin = bi * per + min(bi, extra)
+        t_end = t_begin + per + (1 if bi < extra else 0)
+        lds_a = np.zeros(4 * kXs, np.uint8)
+        lds_w = np.zeros(stages * kTsW, np.uint8)
+        w_off = [((wave * 4 + j) * 8 + prow) * KB + ((pchunk ^ swz8((wave * 4 + j) * 8 + prow)) << 4) for j in range(4)]
+
+        def dma_w(t, buf):
+            c, s = divmod(t, NK)
+            soff = c * chunk_bytes + s * 128
+            for j in range(4):
+                dst = buf * kTsW + wave * 4096 + j * 1024 + lane * 16
+                lds_w[dst[:, None] + np.arange(16)[None, :]] = load16(w_flat, N * KB, w_off[j], soff)
+
+        for tile_i in range(t_begin, t_end):
+            r0 = tile_i * UN * 32
+            for s in range(NK):
+                for j in range((UN * 4 + 7) // 8):
+                    act = wave + 8 * j < UN * 4
+                    row = (wave + 8 * j) * 8 + prow
+                    off = np.where(r0 + row < M, (r0 + row) * KB + ((pchunk ^ swz8(row)) << 4), kOob)
+                    data = load16(a_flat, M * KB, np.where(act, off, kOob), s * 128)
+                    dst = s * kXs + (wave + 8 * j) * 1024 + lane * 16
+                    lds_a[dst[act][:, None] + np.arange(16)[None, :]] = data[act]
+            dma_w(0, 0)
+            if stages == 3 and T > 1:
+                dma_w(1, 1)
+            t = 0
+            for c in range(nchunk):
+                acc = np.zeros((UN, kThreads, 16))
+                for s in range(NK):
+                    if t + stages - 1 < T:
+                        nxt = (t + stages - 1) % stages
+                        assert nxt != t % stages
+                        dma_w(t + stages - 1, nxt)
+                    Wb, Xb = (t % stages) * kTsW, s * kXs
+                    for ks in range(4):
+                        cc = 2 * ks + hi
+                        a_frag = lds_w[(Wb + fa * 128 + ((cc ^ swz8(fa)) << 4))[:, None] + np.arange(16)[None, :]].view(np.float16)
+                        for g in range(UN):
+                            xr = g * 32 + (lane & 31)
+                            b_frag = lds_a[(Xb + xr * 128 + ((cc ^ swz8(xr)) << 4))[:, None] + np.arange(16)[None, :]].view(np.float16)
+                            for wv in range(8):
+                                sl = slice(wv * 64, wv * 64 + 64)
+                                A, B = np.zeros((32, 16)), np.zeros((32, 16))
+                                for L in range(64):   # v_mfma_f32_32x32x16_f16: lane L supplies row L & 31, k half L >> 5 (8 values)
+                                    A[L & 31, (L >> 5) * 8:(L >> 5) * 8 + 8] = a_frag[sl][L]
+                                    B[L & 31, (L >> 5) * 8:(L >> 5) * 8 + 8] = b_frag[sl][L]
+                                D = A @ B.T
+                                for L in range(64):
+                                    for rq in range(4):
+                                        for e in range(4):
+                                            acc[g, wv * 64 + L, 4 * rq + e] += D[8 * rq + 4 * (L >> 5) + e, L & 31]
+                    t += 1
+                colb = c * kTsBN + wave * 32 + 4 * hi
+                for rq in range(4):
+                    col = colb + 8 * rq
+                    for g in range(UN):
+                        m = r0 + g * 32 + (lane & 31)
+                        row_b = np.where(m < M, m * N * 2, kOob)
+                        off = np.where(row_b == kOob, kOob, row_b + col * 2)
+                        ok = off < M * N * 2
+                        for e in range(4):
+                            mm, nn = np.divmod(off[ok] // 2 + e, N)
+                            out[mm, nn] = acc[g, ok, 4 * rq + e]
+    want = a.astype(np.float64) @ w.astype(np.float64).T
+    assert np.array_equal(out, want), (np.argwhere(out != want)[:5], (out != want).mean())
+    return True
+
+
+if __name__ == "__main__" and len(sys.argv) < 4:
+    for M, N, K, st, un in [(333, 512, 256, 3, 3), (333, 512, 256, 2, 5), (200, 256, 128, 3, 3), (520, 768, 128, 2, 5)]:
+        print("f16", M, N, K, f"stages={st} units={un}", "ok" if run_f16(M, N, K, st, un) else "MISMATCH", flush=True)
