@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevformer_tensorrt_amd.functions import linear as L  # noqa: E402
 
 SHAPES = [("s2.conv3", 139200, 512, 128), ("s3.conv3", 34800, 1024, 256), ("small.s3.conv3", 22080, 1024, 256),
-          ("small.s2.conv3", 88320, 512, 128)]
+          ("small.s2.conv3", 88320, 512, 128),
+          # the encoder's K = 256 layers fit the kernel's domain as well (one 160-row tile per CU at 40 000 rows)
+          ("enc.output_proj", 40000, 256, 256), ("sca.offsets / ffn.fc1", 40000, 512, 256), ("tsa.value_proj", 80000, 256, 256)]
 for name, M, N, K in SHAPES:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(M, K, generator=g).half().cuda()
