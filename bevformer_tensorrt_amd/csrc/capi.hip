@@ -58,9 +58,7 @@ const Entry kTable[] = {
     {"bevops_bias_relu_maxpool_nhwc", (void *)&bevops_bias_relu_maxpool_nhwc},
     {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
-    {"bevops_tsgemm_f16_ares", (void *)&bevops_tsgemm_f16_ares},
     {"bevops_tsgemm_s8", (void *)&bevops_tsgemm_s8},
-    {"bevops_tsgemm_s8_ares", (void *)&bevops_tsgemm_s8_ares},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},
     {"bevops_value_proj_packed", (void *)&bevops_value_proj_packed},
     {"bevops_value_pack_planes", (void *)&bevops_value_pack_planes},

@@ -521,384 +521,6 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_s8_kernel(const TsS8Args p)
   }
 }
 
-// ---- A-RESIDENT flavour for the chain's layers with a SHORT K and many columns (ResNet conv3: K = planes <= 256,
-// N = 4 planes): the tiled GEMM poses 2 176 tiles there, each with its fixed ramp / epilogue, and every 128-column tile
-// re-reads its activation rows; tsgemm_s8_kernel above re-reads them once per 256-column chunk (grid.y).  Here a
-// block DMAs its tile's activation rows (up to 160 rows x K <= 256 bytes = 40 KB) into LDS ONCE and walks ALL the
-// 256-column chunks of the weight matrix with them: the flattened (chunk, k-step) sequence is one continuous
-// three-stage DMA pipeline of 32 KB weight slices (L2-resident: N x K <= 512 KB), the activation rows cross the fabric
-// once, and there is no LDS-staged epilogue to drain the pipeline for -- a lane's 4 consecutive columns of a row
-// (acc[g][4 rq .. 4 rq + 3]) are scaled, shifted, given their identity bytes and stored straight from registers
-// (4 bytes per lane and group for int8 output: the L2 merges a row's pieces).  Same arithmetic per element as
-// tsgemm_s8_kernel / the tiled GEMM.
-// The epilogue is STRAIGHT-LINE code (compile-time identity / output types, rows past M through beyond-the-buffer
-// offsets, per-channel scales and bias from an LDS copy made once per block): a conditional load inside the step loop
-// makes the compiler's wait-count pass assume a pending load at the loop head and drain vmcnt to 0 right behind the
-// weight DMA it has just issued (seen in the first draft's ISA) -- which serialises the pipeline.  The identity rows of
-// a chunk are requested at the chunk's last step AHEAD of that step's weight DMA, so the wait for them does not wait
-// for the slice two steps ahead.
-// STAGED FOR ROUND 5: compiled, reviewed and its ISA inspected, not yet run on the device (the round's GPU budget
-// was spent); nothing calls it unless BEVOPS_TSGEMM_S8_ARES=1 (functions/int8_chain.py).
-constexpr int kTsAresMaxSteps = 2;                                   // K <= 256
-constexpr int kTsAresMaxN = 2048;                                    // scale + bias vectors in LDS: 2 x 8 KB
-constexpr int kTsAresLds = kTsAresMaxSteps * kTsX + kTsStages * kTsW + 2 * kTsAresMaxN * 4;   // 40 + 96 + 16 KB
-
-// NK: k-steps (K / 128); RES: identity rows 0 none, 1 int8 (fp16 identity rows: the other kernels); OUT8: int8 output (else fp16)
-template <int NK, int RES, bool OUT8>
-__global__ __launch_bounds__(kTsThreads) void tsgemm_s8_ares_kernel(const TsS8Args p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // smem: [A: k-step][160 rows x 128 B]  [W stages: 3 x 256 rows x 128 B]  [scale: N fp32]  [bias: N fp32]
-  char *const a_lds = smem;
-  char *const w_lds = smem + kTsAresMaxSteps * kTsX;
-  float *const sc_lds = reinterpret_cast<float *>(smem + kTsAresMaxSteps * kTsX + kTsStages * kTsW);
-  float *const bs_lds = sc_lds + kTsAresMaxN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = p.M, N = p.N;
-  constexpr int K = NK * 128;
-  const int nb = gridDim.x, bi = blockIdx.x;
-  const int per = p.units_total / nb, extra = p.units_total % nb;
-  const int u_begin = bi * per + min(bi, extra);
-  const int u_end = u_begin + per + (bi < extra ? 1 : 0);
-  if (u_begin >= u_end) return;
-  for (int n = tid; n < N; n += kTsThreads) {
-    sc_lds[n] = p.wscale ? p.s_aw * p.wscale[n] : p.s_aw;
-    bs_lds[n] = p.bias ? p.bias[n] : 0.f;
-  }
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.a), 0, (unsigned)((size_t)M * K), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.w), 0, (unsigned)((size_t)N * K), 0x00020000);
-  static_assert(RES == 0 || RES == 1, "identity rows: none or int8");
-  constexpr unsigned kResB = 1u, kOutB = OUT8 ? 1u : 2u;
-  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void *>(p.res), 0, RES ? (unsigned)((size_t)M * N * kResB) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_o =
-      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)M * N * kOutB), 0x00020000);
-  constexpr unsigned kOobOff = 0xFFFFFF00u;   // beyond any buffer: loads read zero, stores are dropped
-  const unsigned prow = (unsigned)(lane >> 3), pchunk = (unsigned)(lane & 7);
-  unsigned w_off[4];   // weight rows of chunk 0; chunk c adds c * 256 * K bytes (through the scalar offset)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned row = (unsigned)((wave * 4 + j) * 8) + prow;
-    w_off[j] = (unsigned)((size_t)row * K) + ((pchunk ^ swz8(row)) << 4);
-  }
-  const unsigned hi = (unsigned)(lane >> 5);
-  const unsigned fa = (unsigned)(wave * 32 + (lane & 31));
-  const int nchunk = N / kTsBN;
-  const int T = nchunk * NK;              // weight slices per tile, in (chunk, k-step) order
-  constexpr int chunk_bytes = kTsBN * K;  // one 256-column chunk of the weight matrix
-  auto dma_w = [&](int t, int buf) {
-    const int c = t / NK, s = t - c * NK;
-    char *wd = w_lds + buf * kTsW + wave * 4096;
-    const int soff = c * chunk_bytes + s * 128;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wd + j * 1024), 16, (int)w_off[j], soff, 0, 0);
-  };
-  for (int u0 = u_begin; u0 < u_end; u0 += kTsG) {
-    const int G = min(kTsG, u_end - u0);
-    const int r0 = u0 * 32;
-    const int pieces_x = G * 4;
-    // the tile's activation rows, all k-steps: pieces of 8 rows, piece wave + 8 j (rows past M read as zero)
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (wave + 8 * j < pieces_x) {
-          const unsigned row = (unsigned)((wave + 8 * j) * 8) + prow;
-          const unsigned off = (unsigned)((size_t)(r0 + row) * K) + ((pchunk ^ swz8(row)) << 4);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(a_lds + s * kTsX + (wave + 8 * j) * 1024), 16,
-                                                   (int)off, s * 128, 0, 0);
-        }
-      }
-    }
-    dma_w(0, 0);
-    if (T > 1) dma_w(1, 1);
-    auto tile = [&](auto gc) __attribute__((always_inline)) {
-      constexpr int GG = decltype(gc)::value;
-      // byte offset of (row of unit g, column 0) in the identity / output rows, or beyond the buffer for rows past M
-      unsigned row_r[GG], row_o[GG];
-#pragma unroll
-      for (int g = 0; g < GG; ++g) {
-        const int m = r0 + g * 32 + (lane & 31);
-        row_r[g] = m < M ? (unsigned)((size_t)m * N * kResB) : kOobOff;
-        row_o[g] = m < M ? (unsigned)((size_t)m * N * kOutB) : kOobOff;
-      }
-      int t = 0;
-      for (int c = 0; c < nchunk; ++c) {
-        i32x16v acc[GG];
-#pragma unroll
-        for (int g = 0; g < GG; ++g)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[g][r] = 0;
-        // this lane's first column of the chunk; group rq adds 8 rq
-        const unsigned colb = (unsigned)(c * kTsBN + wave * 32 + 4 * (int)hi);
-        unsigned idt[RES ? 4 : 1][RES ? GG : 1];   // identity bytes of (rq, g): requested at the chunk's last step
-#pragma unroll
-        for (int s = 0; s < NK; ++s, ++t) {
-          // vmcnt retires loads in order.  First step of a chunk that follows an epilogue: the newest operations are
-          // that epilogue's 4 GG stores behind the 4 pieces of slice t + 1 -- with identity rows the compiler's own wait
-          // for them already implied slice t (requested before them); without, wait down to 4 (safe whatever the
-          // order in which stores retire)
-          if (t + 1 >= T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          } else if (s == 0 && c > 0 && RES != 0) {
-            if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (GG == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (GG == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr (GG == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          }
-          __builtin_amdgcn_s_barrier();     // slice t visible to all; stage (t + 2) % 3, last read at t - 1, is free
-          if constexpr (RES != 0) {
-            if (s == NK - 1) {              // (compile-time: the loop over s is unrolled)
-#pragma unroll
-              for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-                for (int g = 0; g < GG; ++g) {
-                  const unsigned off = row_r[g] == kOobOff ? kOobOff : row_r[g] + (colb + 8u * rq) * kResB;
-                  idt[rq][g] = __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, 0);
-                }
-            }
-          }
-          if (t + 2 < T) dma_w(t + 2, (t + 2) % kTsStages);
-          const char *Wb = w_lds + (t % kTsStages) * kTsW;
-          const char *Xb = a_lds + s * kTsX;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const unsigned cc = 2u * ks + hi;
-            const i32x4v a = *reinterpret_cast<const i32x4v *>(Wb + fa * 128 + ((cc ^ swz8(fa)) << 4));
-            i32x4v b[GG];
-#pragma unroll
-            for (int g = 0; g < GG; ++g) {
-              const unsigned xr = (unsigned)(g * 32 + (lane & 31));
-              b[g] = *reinterpret_cast<const i32x4v *>(Xb + xr * 128 + ((cc ^ swz8(xr)) << 4));
-            }
-#pragma unroll
-            for (int g = 0; g < GG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[g], acc[g], 0, 0, 0);
-          }
-        }
-        // ---- the chunk's sums are complete: epilogue from registers.  acc[g][4 rq + e]: row r0 + 32 g + (lane & 31),
-        // column colb + 8 rq + e
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const unsigned col = colb + 8u * rq;
-          const f32x4 sc = *reinterpret_cast<const f32x4 *>(sc_lds + col);
-          const f32x4 bs = *reinterpret_cast<const f32x4 *>(bs_lds + col);
-#pragma unroll
-          for (int g = 0; g < GG; ++g) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (float)acc[g][4 * rq + e] * sc[e] + bs[e];
-            if constexpr (RES == 1) {
-              const unsigned q = idt[rq][g];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)(int)(signed char)((q >> (8 * e)) & 0xffu) * p.s_res;
-            }
-            if (p.relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            const unsigned off = row_o[g] == kOobOff ? kOobOff : row_o[g] + col * kOutB;
-            if constexpr (OUT8) {
-              unsigned pk = 0;
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                pk |= ((unsigned)(int)fminf(fmaxf(rintf(v[e] * p.inv_s_out), -127.f), 127.f) & 0xffu) << (8 * e);
-              __builtin_amdgcn_raw_buffer_store_b32(pk, rs_o, (int)off, 0, 0);
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])}, rs_o, (int)off, 0, 0);
-            }
-          }
-        }
-      }
-    };
-    switch (G) {
-      case 1: tile(std::integral_constant<int, 1>{}); break;
-      case 2: tile(std::integral_constant<int, 2>{}); break;
-      case 3: tile(std::integral_constant<int, 3>{}); break;
-      case 4: tile(std::integral_constant<int, 4>{}); break;
-      default: tile(std::integral_constant<int, 5>{}); break;
-    }
-    __builtin_amdgcn_s_barrier();   // every wave is done with the activation rows and the weight stages of this tile
-  }
-}
-
-// ---- the fp16 analogue of the A-resident kernel, for the fp16 frame's conv3 layers (K = planes = 128 / 256 fp16 values
-// = 256 / 512 bytes per row, N = 4 planes; 42 us on the library at ResNet stage 3 against a 20 us byte floor).  A row
-// of 512 bytes is four 128-byte k-steps, so the resident activation rows take 16 KB per 32-row unit and the LDS
-// (160 KB) holds either 3 units + THREE weight stages or 5 units + TWO weight stages (next to the fp32 bias copy):
-// template parameters, to be chosen by measurement.  Epilogue from registers as above: acc + bias (+ fp16 identity,
-// 8 bytes per lane and group, requested at the chunk's last step ahead of the DMA), ReLU, one rounding, 8-byte stores.
-// STAGED FOR ROUND 5 like tsgemm_s8_ares_kernel: compiled, index arithmetic modelled on the host, never run on the
-// device; nothing calls it unless BEVOPS_TSGEMM_F16_ARES is set (functions/linear.py).
-struct TsF16AresArgs {
-  const __half *x, *w, *bias, *res;
-  __half *out;
-  int M, N, relu, units_total;
-};
-
-template <int STAGES, int UNITS>
-constexpr int ts_f16_ares_lds() { return 4 * UNITS * 32 * 128 + STAGES * kTsW + kTsAresMaxN * 4; }
-
-// NK: 128-byte k-steps per row (K = 64 NK fp16 values); STAGES: weight stages; UNITS: 32-row units per tile;
-// RES: fp16 identity rows
-template <int NK, int STAGES, int UNITS, bool RES>
-__global__ __launch_bounds__(kTsThreads) void tsgemm_f16_ares_kernel(const TsF16AresArgs p) {
-  static_assert(NK <= 4 && (STAGES == 2 || STAGES == 3) && UNITS >= 1 && UNITS <= 5, "LDS plan");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kXs = UNITS * 32 * 128;                 // one k-step of the resident rows
-  char *const a_lds = smem;                             // [k-step][UNITS * 32 rows x 128 B]
-  char *const w_lds = smem + 4 * kXs;                   // [stage][256 rows x 128 B]
-  float *const bs_lds = reinterpret_cast<float *>(smem + 4 * kXs + STAGES * kTsW);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = p.M, N = p.N;
-  constexpr int KB = NK * 128;                          // bytes per operand row
-  const int nb = gridDim.x, bi = blockIdx.x;
-  // tiles of UNITS units, dealt out contiguously: the first (tiles % grid) blocks take one more
-  const int tiles = (p.units_total + UNITS - 1) / UNITS;
-  const int per = tiles / nb, extra = tiles % nb;
-  const int t_begin = bi * per + min(bi, extra);
-  const int t_end = t_begin + per + (bi < extra ? 1 : 0);
-  if (t_begin >= t_end) return;
-  for (int n = tid; n < N; n += kTsThreads) bs_lds[n] = p.bias ? __half2float(p.bias[n]) : 0.f;
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(p.x), 0, (unsigned)((size_t)M * KB), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(p.w), 0, (unsigned)((size_t)N * KB), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__half *>(p.res), 0, RES ? (unsigned)((size_t)M * N * 2) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)M * N * 2), 0x00020000);
-  constexpr unsigned kOobOff = 0xFFFFFF00u;
-  const unsigned prow = (unsigned)(lane >> 3), pchunk = (unsigned)(lane & 7);
-  unsigned w_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned row = (unsigned)((wave * 4 + j) * 8) + prow;
-    w_off[j] = row * (unsigned)KB + ((pchunk ^ swz8(row)) << 4);
-  }
-  const unsigned hi = (unsigned)(lane >> 5);
-  const unsigned fa = (unsigned)(wave * 32 + (lane & 31));
-  const int nchunk = N / kTsBN;
-  const int T = nchunk * NK;
-  constexpr int chunk_bytes = kTsBN * KB;
-  auto dma_w = [&](int t, int buf) {
-    const int c = t / NK, s = t - c * NK;
-    char *wd = w_lds + buf * kTsW + wave * 4096;
-    const int soff = c * chunk_bytes + s * 128;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wd + j * 1024), 16, (int)w_off[j], soff, 0, 0);
-  };
-  constexpr int kPieceRounds = (UNITS * 4 + 7) / 8;     // pieces of 8 rows per wave and k-step
-  for (int tile_i = t_begin; tile_i < t_end; ++tile_i) {
-    const int r0 = tile_i * UNITS * 32;
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-#pragma unroll
-      for (int j = 0; j < kPieceRounds; ++j) {
-        if (wave + 8 * j < UNITS * 4) {
-          const unsigned row = (unsigned)((wave + 8 * j) * 8) + prow;
-          const unsigned off = (unsigned)(r0 + (int)row) * (unsigned)KB + ((pchunk ^ swz8(row)) << 4);
-          const bool in = r0 + (int)row < M;            // (the product above may wrap for rows far past M)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(a_lds + s * kXs + (wave + 8 * j) * 1024), 16,
-                                                   (int)(in ? off : kOobOff), s * 128, 0, 0);
-        }
-      }
-    }
-    // STAGES - 1 slices in flight ahead of the one being multiplied
-    dma_w(0, 0);
-    if (STAGES == 3 && T > 1) dma_w(1, 1);
-    unsigned row_b[UNITS];   // byte offset of (row of unit g, column 0) in the identity / output rows
-#pragma unroll
-    for (int g = 0; g < UNITS; ++g) {
-      const int m = r0 + g * 32 + (lane & 31);
-      row_b[g] = m < M ? (unsigned)((size_t)m * N * 2) : kOobOff;
-    }
-    int t = 0;
-    for (int c = 0; c < nchunk; ++c) {
-      f32x16 acc[UNITS];
-#pragma unroll
-      for (int g = 0; g < UNITS; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-      const unsigned colb = (unsigned)(c * kTsBN + wave * 32 + 4 * (int)hi);
-      u32x2 idt[RES ? 4 : 1][RES ? UNITS : 1];
-#pragma unroll
-      for (int s = 0; s < NK; ++s, ++t) {
-        // slice t must have landed; slices t + 1 .. t + STAGES - 2 may stay in flight (three stages: the 4 pieces of
-        // slice t + 1, behind them only a previous epilogue's stores; two stages: nothing)
-        if (STAGES == 2 || t + 1 >= T) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (RES && s == 0 && c > 0) {
-          // behind slice t + 1 sit the previous epilogue's 4 UNITS stores; the compiler's wait for that epilogue's
-          // identity rows (requested after slice t) already implied slice t
-          if constexpr (UNITS == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else if constexpr (UNITS == 5) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if constexpr (RES) {
-          if (s == NK - 1) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-              for (int g = 0; g < UNITS; ++g) {
-                const unsigned off = row_b[g] == kOobOff ? kOobOff : row_b[g] + (colb + 8u * rq) * 2u;
-                idt[rq][g] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (int)off, 0, 0);
-              }
-          }
-        }
-        if (t + STAGES - 1 < T) dma_w(t + STAGES - 1, (t + STAGES - 1) % STAGES);
-        const char *Wb = w_lds + (t % STAGES) * kTsW;
-        const char *Xb = a_lds + s * kXs;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const unsigned cc = 2u * ks + hi;
-          const f16x8 a = *reinterpret_cast<const f16x8 *>(Wb + fa * 128 + ((cc ^ swz8(fa)) << 4));
-          f16x8 b[UNITS];
-#pragma unroll
-          for (int g = 0; g < UNITS; ++g) {
-            const unsigned xr = (unsigned)(g * 32 + (lane & 31));
-            b[g] = *reinterpret_cast<const f16x8 *>(Xb + xr * 128 + ((cc ^ swz8(xr)) << 4));
-          }
-#pragma unroll
-          for (int g = 0; g < UNITS; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g], 0, 0, 0);
-        }
-      }
-      // ---- epilogue from registers.  acc[g][4 rq + e]: row r0 + 32 g + (lane & 31), column colb + 8 rq + e
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const unsigned col = colb + 8u * rq;
-        const f32x4 bs = *reinterpret_cast<const f32x4 *>(bs_lds + col);
-#pragma unroll
-        for (int g = 0; g < UNITS; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[g][4 * rq + e] + bs[e];
-          if constexpr (RES) {
-            const u32x2 q = idt[rq][g];
-            v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
-          }
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          const unsigned off = row_b[g] == kOobOff ? kOobOff : row_b[g] + col * 2u;
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])}, rs_o, (int)off, 0, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_s_barrier();   // every wave is done with this tile's resident rows and weight stages
-  }
-}
-
 inline int ts_grid_x(int units, int chunks_n) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -967,93 +589,6 @@ extern "C" int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q,
   p.out_i8 = out_dtype == BEVOPS_I8 ? 1 : 0;
   hipLaunchKernelGGL(tsgemm_s8_kernel, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream), p);
   return launch_status();
-}
-
-// The A-resident flavour (tsgemm_s8_ares_kernel): same arguments and results as bevops_tsgemm_s8.  Domain: K = 128 or
-// 256, N % 256 == 0, N <= 2048, M * N * (bytes per identity / output element) < 2^32 - 256.
-template <int NK, int RES, bool OUT8>
-static int ts_ares_go(const TsS8Args &p, dim3 grid, hipStream_t st) {
-  if (!ensure_dynamic_lds<tsgemm_s8_ares_kernel<NK, RES, OUT8>>(kTsAresLds)) return BEVOPS_FAILURE;
-  hipLaunchKernelGGL((tsgemm_s8_ares_kernel<NK, RES, OUT8>), grid, dim3(kTsThreads), kTsAresLds, st, p);
-  return launch_status();
-}
-
-extern "C" int bevops_tsgemm_s8_ares(const void *a_q, float scale_a, const void *w_q, const float *w_scales,
-                                     float scale_w, const float *bias, const void *residual, int res_dtype,
-                                     float scale_res, int out_dtype, void *out, float scale_out, long long m, int n, int k,
-                                     int relu, void *stream) {
-  if (!a_q || !w_q || !out || m <= 0 || n <= 0 || k <= 0) return BEVOPS_BAD_PARAM;
-  if (!(scale_a > 0.f) || (!w_scales && !(scale_w > 0.f))) return BEVOPS_BAD_PARAM;
-  if ((k != 128 && k != 256) || n % kTsBN != 0 || n > kTsAresMaxN) return BEVOPS_NOT_SUPPORTED;
-  if (out_dtype != BEVOPS_I8 && out_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
-  if (residual && res_dtype != BEVOPS_I8) return BEVOPS_NOT_SUPPORTED;   // fp16 identity rows: the other kernels
-  if (out_dtype == BEVOPS_I8 && !(scale_out > 0.f)) return BEVOPS_BAD_PARAM;
-  if (residual && !(scale_res > 0.f)) return BEVOPS_BAD_PARAM;
-  const double out_b = out_dtype == BEVOPS_I8 ? 1.0 : 2.0, res_b = 1.0;
-  if ((double)m * k >= 4294967040.0 || (double)m * n * out_b >= 4294967040.0 || (double)m * n * res_b >= 4294967040.0 ||
-      m > 0x7fffffff)
-    return BEVOPS_NOT_SUPPORTED;
-  if (!aligned16(a_q) || !aligned16(w_q) || (reinterpret_cast<uintptr_t>(out) & (out_dtype == BEVOPS_I8 ? 3u : 7u)) ||
-      (residual && (reinterpret_cast<uintptr_t>(residual) & 3u)) ||
-      (bias && (reinterpret_cast<uintptr_t>(bias) & 3u)) || (w_scales && (reinterpret_cast<uintptr_t>(w_scales) & 3u)))
-    return BEVOPS_BAD_PARAM;
-  const int units = (int)((m + 31) / 32);
-  const dim3 grid((unsigned)ts_grid_x(units, 1));
-  TsS8Args p;
-  p.a = static_cast<const int8_t *>(a_q); p.w = static_cast<const int8_t *>(w_q);
-  p.bias = bias; p.wscale = w_scales; p.res = residual; p.out = out;
-  p.s_aw = w_scales ? scale_a : scale_a * scale_w;
-  p.s_res = scale_res;
-  p.inv_s_out = out_dtype == BEVOPS_I8 ? 1.0f / scale_out : 0.f;
-  p.M = (int)m; p.N = n; p.K = k; p.relu = relu; p.units_total = units;
-  p.res_i8 = residual && res_dtype == BEVOPS_I8 ? 1 : 0;
-  p.out_i8 = out_dtype == BEVOPS_I8 ? 1 : 0;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool o8 = out_dtype == BEVOPS_I8;
-#define BEVOPS_ARES(NK_)                                                                   \
-  do {                                                                                      \
-    if (!residual) return o8 ? ts_ares_go<NK_, 0, true>(p, grid, st) : ts_ares_go<NK_, 0, false>(p, grid, st); \
-    return o8 ? ts_ares_go<NK_, 1, true>(p, grid, st) : ts_ares_go<NK_, 1, false>(p, grid, st);               \
-  } while (0)
-  if (k == 128) BEVOPS_ARES(1);
-  BEVOPS_ARES(2);
-#undef BEVOPS_ARES
-}
-
-// fp16 A-resident flavour (tsgemm_f16_ares_kernel): arguments and results of bevops_tsgemm_f16; plan 0 = 3 row units +
-// 3 weight stages, 1 = 5 row units + 2 weight stages.  Domain: K = 128 or 256, N % 256 == 0, N <= 2048.
-template <int NK, int STAGES, int UNITS>
-static int ts_f16_ares_go(const TsF16AresArgs &p, hipStream_t st) {
-  constexpr int lds = ts_f16_ares_lds<STAGES, UNITS>();
-  static_assert(lds <= kLdsLimit, "LDS plan");
-  const int tiles = (p.units_total + UNITS - 1) / UNITS;
-  const dim3 grid((unsigned)ts_grid_x(tiles, 1));
-  if (p.res) {
-    if (!ensure_dynamic_lds<tsgemm_f16_ares_kernel<NK, STAGES, UNITS, true>>(lds)) return BEVOPS_FAILURE;
-    hipLaunchKernelGGL((tsgemm_f16_ares_kernel<NK, STAGES, UNITS, true>), grid, dim3(kTsThreads), lds, st, p);
-  } else {
-    if (!ensure_dynamic_lds<tsgemm_f16_ares_kernel<NK, STAGES, UNITS, false>>(lds)) return BEVOPS_FAILURE;
-    hipLaunchKernelGGL((tsgemm_f16_ares_kernel<NK, STAGES, UNITS, false>), grid, dim3(kTsThreads), lds, st, p);
-  }
-  return launch_status();
-}
-
-extern "C" int bevops_tsgemm_f16_ares(const void *x, const void *weight, const void *bias, const void *residual,
-                                      void *out, long long m, int n, int k, int relu, int plan, void *stream) {
-  if (!x || !weight || !out || m <= 0 || n <= 0 || k <= 0) return BEVOPS_BAD_PARAM;
-  if ((k != 128 && k != 256) || n % kTsBN != 0 || n > kTsAresMaxN || (plan != 0 && plan != 1)) return BEVOPS_NOT_SUPPORTED;
-  if ((double)m * k * 2 >= 4294967040.0 || (double)m * n * 2 >= 4294967040.0 || m > 0x7fffffff) return BEVOPS_NOT_SUPPORTED;
-  if (!aligned16(x) || !aligned16(weight) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
-      (residual && (reinterpret_cast<uintptr_t>(residual) & 7u)) || (bias && (reinterpret_cast<uintptr_t>(bias) & 1u)))
-    return BEVOPS_BAD_PARAM;
-  TsF16AresArgs p;
-  p.x = static_cast<const __half *>(x); p.w = static_cast<const __half *>(weight);
-  p.bias = static_cast<const __half *>(bias); p.res = static_cast<const __half *>(residual);
-  p.out = static_cast<__half *>(out);
-  p.M = (int)m; p.N = n; p.relu = relu; p.units_total = (int)((m + 31) / 32);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (k == 128) return plan == 0 ? ts_f16_ares_go<2, 3, 3>(p, st) : ts_f16_ares_go<2, 2, 5>(p, st);
-  return plan == 0 ? ts_f16_ares_go<4, 3, 3>(p, st) : ts_f16_ares_go<4, 2, 5>(p, st);
 }
 
 // The encoder's value projection (spatial_cross_attention.py:754: value = self.value_proj(value)) written

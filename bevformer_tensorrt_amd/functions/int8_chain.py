@@ -26,12 +26,6 @@ def _ts_s8_pays(M, N, K):
     return N == 256 and K == 1024 and M >= 16384
 
 
-# STAGED (end of round 4, compiled and reviewed, NOT yet run on the device): the A-resident flavour for the chain's
-# conv3 layers (K = 128 / 256, N % 256 == 0, csrc/tsgemm.hip: tsgemm_s8_ares_kernel).  Off unless
-# BEVOPS_TSGEMM_S8_ARES=1.
-_TS_S8_ARES = {"enabled": os.environ.get("BEVOPS_TSGEMM_S8_ARES", "0") == "1"}
-
-
 def _code(dtype):
     return {torch.float16: _lib.F16, torch.int8: _lib.I8}[dtype]
 
@@ -62,17 +56,6 @@ def linear_int8_chain(a, scale_a, w_q, scale_w, bias=None, residual=None, scale_
     if M == 0:
         return out.view(*a.shape[:-1], N)
     handle = _lib.load_library()
-    if _TS_S8_ARES["enabled"] and a2.dtype == torch.int8 and N % 256 == 0 and N <= 2048 and K in (128, 256) and \
-            (r is None or r.dtype == torch.int8):
-        with torch.cuda.device(a.device):
-            st = handle.bevops_tsgemm_s8_ares(
-                a2.data_ptr(), float(scale_a), w_q.data_ptr(), ws.data_ptr() if per_channel else None,
-                1.0 if per_channel else float(scale_w), b.data_ptr() if b is not None else None,
-                r.data_ptr() if r is not None else None, _code(r.dtype) if r is not None else _lib.F16, float(scale_res),
-                _code(out_dtype), out.data_ptr(), float(scale_out), M, N, K, int(bool(relu)),
-                _lib.current_stream_ptr(a.device))
-        _lib.check(st, "bevops_tsgemm_s8_ares")
-        return out.view(*a.shape[:-1], N)
     if a2.dtype == torch.int8 and N % 256 == 0 and K % 128 == 0 and \
             (_TS_S8["enabled"] or (_TS_S8["enabled"] is None and _ts_s8_pays(M, N, K))):
         with torch.cuda.device(a.device):

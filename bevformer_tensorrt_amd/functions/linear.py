@@ -199,37 +199,6 @@ def tsgemm(x, weight, bias=None, residual=None, relu=False, out=None):
     return out.view(*x.shape[:-1], N)
 
 
-def tsgemm_ares(x, weight, bias=None, residual=None, relu=False, plan=0):
-    """STAGED (end of round 4, never run on the device): act(x @ weight.T + bias + residual) on the A-resident
-    persistent GEMM (bevops_tsgemm_f16_ares; K = 128 / 256, N % 256 == 0, N <= 2048).  plan 0: 96-row tiles + three
-    weight stages, 1: 160-row tiles + two weight stages.  Not a candidate of dense_auto unless
-    BEVOPS_TSGEMM_F16_ARES=<plan> is set."""
-    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
-    K, N = x.shape[-1], weight.shape[0]
-    x2 = x.reshape(-1, K)
-    if not x2.is_contiguous():
-        x2 = x2.contiguous()
-    weight = weight.contiguous()
-    M = x2.shape[0]
-    r2 = None
-    if residual is not None:
-        r2 = residual.reshape(M, N)
-        if not r2.is_contiguous():
-            r2 = r2.contiguous()
-    if bias is not None:
-        bias = bias.to(torch.float16).contiguous()
-    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    if M == 0:
-        return out.view(*x.shape[:-1], N)
-    handle = _lib.load_library()
-    with torch.cuda.device(x.device):
-        st = handle.bevops_tsgemm_f16_ares(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K,
-                                           int(bool(relu)), int(plan), _lib.current_stream_ptr(x.device))
-    _lib.check(st, "bevops_tsgemm_f16_ares")
-    return out.view(*x.shape[:-1], N)
-
-
 def tile_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
     """act(x @ weight.T + bias + residual) on the tiled MFMA GEMM (bevops_tile_gemm_f16, csrc/tile_gemm.hip:
     128 x 128 tiles, three blocks per CU): x [..., K] fp16 contiguous rows, weight [N, K], bias [N] fp16,
@@ -317,8 +286,6 @@ def _torch_dense(x, weight, bias, residual, relu):
 
 
 _DENSE = {"tsgemm": tsgemm, "tile": tile_gemm, "small": small_gemm, "blaslt": linear_bias_act, "torch": _torch_dense}
-if __import__("os").environ.get("BEVOPS_TSGEMM_F16_ARES") in ("0", "1"):   # staged kernel as a measured candidate, on request
-    _DENSE["ares"] = lambda x, w, b, r, relu: tsgemm_ares(x, w, b, r, relu, int(__import__("os").environ["BEVOPS_TSGEMM_F16_ARES"]))
 _DENSE_CHOICE = {}     # problem -> name of the fastest implementation measured in this process
 DENSE_LOG = []         # (problem, {name: us}) of every measurement, for tools / profiles
 # Reproducible mode: no per-process timing, the choice is a function of the problem alone and falls on the two

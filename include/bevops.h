@@ -526,14 +526,6 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
  * (the caller keeps its library GEMM). */
 int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
                       long long m, int n, int k, int relu, void *stream);
-/* STAGED (end of round 4: compiled, index arithmetic modelled on the host by tools/probes/tsgemm_ares_model.py, never
- * run on the device; nothing in the package calls it unless BEVOPS_TSGEMM_F16_ARES is set): the A-resident flavour for
- * layers with a short K and many columns (the fp16 frame's conv3 layers: K = 128 or 256, N % 256 == 0, N <= 2048): a
- * block keeps its tile's activation rows in LDS and walks all 256-column chunks of the weight matrix with them,
- * epilogue from registers.  plan 0: 96-row tiles + three weight stages, 1: 160-row tiles + two weight stages.
- * Arguments and results of bevops_tsgemm_f16. */
-int bevops_tsgemm_f16_ares(const void *x, const void *weight, const void *bias, const void *residual, void *out,
-                           long long m, int n, int k, int relu, int plan, void *stream);
 /* The int8 activation chain's flavour of the same persistent kernel (the int8 1x1 convolutions of ResNet stages
  * 3 / 4; arguments as bevops_linear_int8_chain with an int8 activation): a_q [M, K] / w_q [N, K] int8, int32 sums,
  * fp32 bias, identity rows int8 (res_dtype BEVOPS_I8, real = q * scale_res) or fp16, output int8 (requantised with
@@ -543,14 +535,6 @@ int bevops_tsgemm_f16_ares(const void *x, const void *weight, const void *bias, 
 int bevops_tsgemm_s8(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
                      const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
                      void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
-/* A-resident flavour for short K and many columns (the chain's conv3 layers: K = 128 or 256, N % 256 == 0, N <= 2048,
- * identity rows int8 or none): a block
- * keeps its tile's activation rows in LDS and walks all 256-column chunks of the weight matrix with them; epilogue
- * from registers.  Same arguments and results.  STAGED: compiled and reviewed at the end of round 4, not yet run on
- * the device; nothing in the package calls it unless BEVOPS_TSGEMM_S8_ARES=1. */
-int bevops_tsgemm_s8_ares(const void *a_q, float scale_a, const void *w_q, const float *w_scales, float scale_w,
-                          const float *bias, const void *residual, int res_dtype, float scale_res, int out_dtype,
-                          void *out, float scale_out, long long m, int n, int k, int relu, void *stream);
 
 /* The same dense layer for problems with FEW rows (the decoder's 900 object queries: decoder.py:381-471,
  * bevformer_head.py:247-282; csrc/small_gemm.hip): 32 x 64 output tiles, split-K over the four waves of a block, every

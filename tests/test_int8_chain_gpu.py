@@ -274,47 +274,19 @@ def test_tsgemm_s8_matches_tiled_int8_gemm(M, K, N, out8, res):
         torch.cuda.synchronize()
     finally:
         C._TS_S8["enabled"] = prev
-    rows = slice(0, min(M, 2000))
-    acc = a[rows].long() @ w.long().t()
-    ref = acc.double() * (np.float32(s_a) * sw.double()) + b.double()
-    if r is not None:
-        ref = ref + (r[rows].double() * np.float32(s_r) if res == "int8" else r[rows].double())
-    ref = torch.relu(ref)
-    if out8:
-        _close_int8(got, want)
-        _close_int8(got[rows], torch.clamp(torch.round(ref / s_o), -127, 127))
-    else:
-        assert (got.float() - want.float()).abs().max().item() <= 2e-3 * max(1.0, want.float().abs().max().item())
-        assert (got[rows].cpu().double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.skipif(__import__("os").environ.get("BEVOPS_STAGED_TESTS", "0") != "1",
-                    reason="staged at the end of round 4: bevops_tsgemm_s8_ares has not run on the device yet "
-                           "(BEVOPS_STAGED_TESTS=1 runs it)")
-@pytest.mark.parametrize("M,K,N", [(34800, 256, 1024), (139200, 128, 512), (8700, 256, 2048), (777, 128, 256), (161, 256, 512)])
-@pytest.mark.parametrize("out8", [False, True])
-@pytest.mark.parametrize("res", ["none", "int8"])
-def test_tsgemm_s8_a_resident_matches_tiled_int8_gemm(M, K, N, out8, res):
-    """bevops_tsgemm_s8_ares (activation rows resident in LDS, all column chunks in one pass, epilogue from registers)
-    against the tiled int8 GEMM: same bar as test_tsgemm_s8_matches_tiled_int8_gemm."""
-    from bevformer_tensorrt_amd.functions import int8_chain as C
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
-    w = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8)
-    b = torch.randn(N, generator=g)
-    sw = (torch.rand(N, generator=g) + 0.5) * 0.003 / K ** 0.5
-    r = {"none": None, "int8": torch.randint(-127, 128, (M, N), generator=g, dtype=torch.int8),
-         "fp16": torch.randn(M, N, generator=g).half()}[res]
-    args = (a.cuda(), 0.021, w.cuda(), sw.cuda(), b.cuda(), r.cuda() if r is not None else None, 0.043, True,
-            torch.int8 if out8 else torch.float16, 0.05)
-    want = C.linear_int8_chain(*args)
-    C._TS_S8_ARES["enabled"] = True
-    try:
-        got = C.linear_int8_chain(*args)
-        torch.cuda.synchronize()
-    finally:
-        C._TS_S8_ARES["enabled"] = False
     if out8:
         _close_int8(got, want)
     else:
         assert (got.float() - want.float()).abs().max().item() <= 2e-3 * max(1.0, want.float().abs().max().item())
+    # exact integer evaluation on the FIRST and on the LAST rows (a persistent kernel's tail partition is where its
+    # row bookkeeping can go wrong)
+    for rows in (slice(0, min(M, 2000)), slice(max(0, M - 2000), M)):
+        acc = a[rows].long() @ w.long().t()
+        ref = acc.double() * (np.float32(s_a) * sw.double()) + b.double()
+        if r is not None:
+            ref = ref + (r[rows].double() * np.float32(s_r) if res == "int8" else r[rows].double())
+        ref = torch.relu(ref)
+        if out8:
+            _close_int8(got[rows], torch.clamp(torch.round(ref / s_o), -127, 127))
+        else:
+            assert (got[rows].cpu().double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())

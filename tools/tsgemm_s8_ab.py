@@ -23,20 +23,15 @@ for name, M, N, K, has_res in SHAPES:
     r8 = torch.randint(-127, 128, (M, N), generator=g, dtype=torch.int8).cuda() if has_res else None
     bf = torch.randn(N, generator=g).cuda()
     fn = lambda: C.linear_int8_chain(a8, 0.02, w8, 0.001, bf, r8, 0.03, True, torch.int8, 0.05)  # noqa: E731
-    res = {False: [], True: [], "ares": []}
+    res = {False: [], True: []}
     for _ in range(3):
-        for v in (False, True, "ares"):
-            if v == "ares" and (K not in (128, 256) or "--ares" not in sys.argv):     # staged kernel: only on request
-                continue
-            C._TS_S8["enabled"] = False if v == "ares" else v
-            C._TS_S8_ARES["enabled"] = v == "ares"
+        for v in (False, True):
+            C._TS_S8["enabled"] = v
             try:
                 res[v].append(round(L.graph_time_us(fn), 2))
             finally:
                 C._TS_S8["enabled"] = None
-                C._TS_S8_ARES["enabled"] = False
     byt = M * K + N * K + M * N * (2 if has_res else 1)
     t, p = sorted(res[False])[1], sorted(res[True])[1]
-    extra = {"us_tsgemm_s8_ares": sorted(res["ares"])[1]} if res["ares"] else {}
-    print(json.dumps({"layer": name, "M": M, "N": N, "K": K, "us_tile": t, "us_tsgemm_s8": p, **extra,
+    print(json.dumps({"layer": name, "M": M, "N": N, "K": K, "us_tile": t, "us_tsgemm_s8": p,
                       "TBs_tile": round(byt / t / 1e6, 2), "TBs_tsgemm_s8": round(byt / p / 1e6, 2)}), flush=True)
