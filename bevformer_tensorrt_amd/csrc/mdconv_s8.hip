@@ -1146,6 +1146,9 @@ extern "C" int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float sca
     return BEVOPS_BAD_PARAM;
   const int KK = Kh * Kw, cin_g = Cin / groups, cout_g = Cout / groups;
   if (offset_mask_channels < deform_groups * 3 * KK) return BEVOPS_BAD_PARAM;
+  // the raw offset-convolution output is read as [2 KK offsets | KK mask logits] of ONE deform group (the layout of
+  // mmcv's cat(o1, o2) | mask for deform_groups == 1, modules/cnn/dcn.py:70-74); several groups interleave differently
+  if (deform_groups != 1) return BEVOPS_NOT_SUPPORTED;
   if (!aligned16(input_nhwc) || !aligned16(packed_weight) || (reinterpret_cast<uintptr_t>(output_nhwc) & 3u) ||
       (reinterpret_cast<uintptr_t>(offset_mask_nhwc) & 1u))
     return BEVOPS_BAD_PARAM;

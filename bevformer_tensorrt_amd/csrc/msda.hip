@@ -601,8 +601,10 @@ int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const
 
 using namespace bevops;
 
+static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19, 21 .. 24 map to 17 + flags below)
 extern "C" int bevops_msda_set_variant(int variant) {
-  const int prev = g_variant;
+  const int prev = g_variant_raw;   // handing this back to set_variant restores the flags too
+  g_variant_raw = variant;
   // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan.  21 .. 24 (A/B, forced
   // hm4): int8 big set as pixel-pair entries (21, 22) or as 2x2 footprints (23, 24), on the two-blocks (21, 23) or
   // the one-block plan (22, 24); any other value restores the default entry format

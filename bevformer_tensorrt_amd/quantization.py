@@ -597,7 +597,12 @@ class Int8ChainBackbone:
         return _Base.quantize(w.detach(), s), s
 
     def _scale(self, name):
-        return float(self.cal.scale(name)) if self.cal.has(name) else 1.0
+        if not self.cal.has(name):
+            if not any(k.startswith("chain:") for k in self.cal._stats):
+                return 1.0          # a rank without cameras fed the backbone empty batches only: placeholder, never used
+            raise RuntimeError(f"int8 chain: no calibration statistics for '{name}' -- calibrate through the "
+                               "channels-last chain path (the NCHW path does not visit the chain's sites)")
+        return float(self.cal.scale(name))
 
     def freeze(self):
         m = self.model
@@ -624,6 +629,10 @@ class Int8ChainBackbone:
                     e["s_idt"] = self._scale(site + ".idt")
                 c2 = blk.conv2
                 if hasattr(c2, "conv_offset"):       # DCNv2 pack
+                    # the chain's offset convolution is the 3x3, one-deform-group form: 18 offsets + 9 mask logits,
+                    # padded to 32 output channels (the channels-last INT8 entry reads exactly that layout)
+                    if c2.conv_offset.out_channels != 27 or getattr(c2, "deform_groups", 1) != 1:
+                        raise NotImplementedError("int8 chain: DCNv2 packs other than 3x3 / deform_groups=1")
                     wq, sw = self._wq(c2.weight)
                     ow = torch.zeros((32,) + tuple(c2.conv_offset.weight.shape[1:]), dtype=torch.float32, device=dev)
                     ow[:27] = c2.conv_offset.weight.detach().float()
