@@ -29,8 +29,17 @@ Sub-records of the same JSON line (N = 1):
                  fp16) from HIP events around every such call of the hot-path step, vs the 8 TB/s
                  HBM peak; .model_geometry / .fused_sca: the same call on the reference points a 6-camera rig
                  produces, as the drop-in op and as the fused SCA op;
-  cpu_baseline : the sampling operators of a frame on this host's cores through the oracle (kind "port"), and
-                 the whole BEVFormer-tiny in fp32 on the host (BASELINE config 1).
+  roofline_frame : the SCA sampling call the model frame ACTUALLY replays (fused sampling on the value projection's
+                 planes over the balanced slices of a visibility plan + the camera reduce: bevops_sca_forward_planned)
+                 on the reference points of the 6-camera rig: its own algorithmic bytes (180.9 MB), HIP-event time,
+                 fraction of 8 TB/s -- `roofline` above is the drop-in op on the op test's uniform points;
+  roofline_mfma : the frame's largest single kernel, the DCNv2 implicit GEMM of ResNet-101 stage 3 (channels-last
+                 entry, 6 x 256 x 58 x 100: 41.05 GFLOP) against the dense fp16 MFMA peak;
+  tiny         : BEVFormer-tiny fp16 / INT8 end to end (BASELINE config 2);
+  dispatch_misses : dense / convolution problems of this run that the shipped dispatch table does not list (they were
+                 measured in-process or defaulted instead);
+  cpu_baseline : the sampling operators of a frame on this host's cores through the oracle (kind "port", the base SCA
+                 call timed WHOLE), and the whole BEVFormer-tiny in fp32 on the host (BASELINE config 1).
 """
 import argparse
 import json
@@ -52,6 +61,7 @@ BASE = dict(
     dcn=[(23, 256, 58, 100), (3, 512, 29, 50)],
 )
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (the task statement's figure; no sparsity)
 
 
 def msda_inputs(cfg, dtype, device, gen, cams=None):
@@ -84,8 +94,9 @@ def msda_bytes(cfg, esize, bs=None):
 
 def cpu_baseline(max_seconds=30.0):
     """The WHOLE hot-path step on the host cores (port), fp32, on a bounded sample scaled to a frame:
-      * MSDA: the reference's PyTorch CPU path (oracle/torch_ref.py) -- one base TSA call + one base
-        decoder call + 1/8 of the queries of the base SCA call (6 x each per frame);
+      * MSDA: the reference's PyTorch CPU path (oracle/torch_ref.py) -- one base TSA call, one base
+        decoder call and one WHOLE base SCA call (6 x each per frame; the SCA call is not run twice: the
+        TSA / decoder calls before it have paged the code in);
       * DCNv2: the C restatement of the reference's im2col + GEMM launcher (oracle/mdconv_ref.c,
         OpenMP) on ONE camera image per ResNet stage (6 images x 23 resp. 3 convolutions per frame);
       * rotate: oracle/sampler_ref.c at 256 x 200 x 200, once per frame.
@@ -97,12 +108,13 @@ def cpu_baseline(max_seconds=30.0):
     t_frame = 0.0
     parts = []
     for name, cfg, frac in (("tsa", BASE["tsa"], 1.0), ("dec", BASE["dec"], 1.0),
-                            ("sca", BASE["sca"], 0.125)):
+                            ("sca", BASE["sca"], 1.0)):
         c = dict(cfg)
         c["nq"] = max(1, int(cfg["nq"] * frac))
         args, _ = msda_inputs(c, torch.float32, "cpu", gen)
         args[1] = args[1].long()
-        torch_ref.msda(*args)  # warm-up
+        if name != "sca":
+            torch_ref.msda(*args)  # warm-up
         t0 = time.perf_counter()
         torch_ref.msda(*args)
         dt = (time.perf_counter() - t0) / frac
@@ -355,6 +367,69 @@ def geometry_rooflines(bev, wl, dev):
     return out
 
 
+def frame_rooflines(bev, dev, iters=20):
+    """roofline_frame + roofline_mfma (see the module docstring): the two kernels the graph-replayed frame spends its
+    sampling time in, each launched as the frame launches it, HIP events around every launch."""
+    from bevformer_tensorrt_amd import geometry as G
+    from bevformer_tensorrt_amd.functions import spatial_cross_attention as S
+    from bevformer_tensorrt_amd.functions.multi_scale_deformable_attn import _host_shapes, _shapes_i32
+    from bevformer_tensorrt_amd.utils import lib as _lib
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    levels = BASE["sca"]["levels"]
+    nk = sum(h * w for h, w in levels)
+    nq, heads, embed = BASE["sca"]["nq"], BASE["heads"], BASE["embed"]
+    try:
+        feats = (torch.randn(6, nk, embed, generator=g) * 0.5).half().to(dev)
+        wgt = (torch.randn(embed, embed, generator=g) / 16).half().to(dev)
+        bias = (torch.randn(embed, generator=g) * 0.1).half().to(dev)
+        ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
+        cam, mask = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img((928, 1600)),
+                                     (928, 1600))
+        ref = cam.reshape(6, nq, 1, 8).half().to(dev)
+        vis = mask.reshape(6, nq, -1).any(-1)
+        bm = (vis.float() / vis.sum(0).clamp(min=1)).half().to(dev)
+        off = torch.randn(1, nq, heads, 64, generator=g).half().to(dev)
+        w = torch.randn(1, nq, heads, 32, generator=g).half().to(dev)
+        handle = _lib.load_library()
+        shapes_dev, shapes_host = _shapes_i32(torch.tensor(levels, dtype=torch.int32), dev)
+        if shapes_host is None:
+            shapes_host = _host_shapes(shapes_dev)
+        geom = (shapes_host, 6, nk, heads, 32, 4, nq, 8, 4)
+        planes = S._project_planes(handle, feats, wgt, bias, geom)
+        plan = S.spatial_cross_attention_plan(bm)
+        us = time_us(lambda: S._sample_planes(handle, planes, geom, ref, off, w, bm, plan), iters=iters)
+        byt = (6 * nk * heads * 32 + nq * heads * 32 * 3 + 6 * nq * 8 + 6 * nq + nq * heads * 32) * 2 + 8 * 4
+        out["roofline_frame"] = {
+            "kernel": "in-frame SCA sampling call = msda_hm5_kernel<2,1024,0,3> (balanced slices of the visibility plan) "
+                      "+ sca_camera_reduce_kernel, on the value projection's planes",
+            "what": "reference points of the 6-camera rig (%.1f %% of the (camera, query) pairs visible), N(0,1) px offsets"
+                    % (100.0 * float(vis.float().mean())),
+            "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters,
+            "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}
+        del feats, planes
+    except Exception as exc:
+        out["roofline_frame"] = {"error": repr(exc)[:200]}
+    try:
+        B, C, H, W = 6, 256, 58, 100
+        x = torch.randn(B, C, H, W, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        om = torch.randn(B, 32, H, W, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().to(dev)
+        bs = torch.randn(C, generator=g).half().to(dev)
+        fn = lambda: bev.modulated_deformable_conv2d_nhwc(x, None, None, wt, bs, 1, 1, 1, 1, 1, True, om)  # noqa: E731
+        us = time_us(fn, iters=iters)
+        flop = 2.0 * B * H * W * C * C * 9
+        out["roofline_mfma"] = {
+            "kernel": "DCNv2 ResNet-101 stage 3, channels-last entry = dcn_glds_f16_kernel<4> (+ dcn_tail_finish_kernel)",
+            "bound": "mfma", "flop_per_launch": flop, "avg_launch_us": round(us, 2), "launches": iters,
+            "achieved": round(flop / us / 1e6, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flop / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)}
+    except Exception as exc:
+        out["roofline_mfma"] = {"error": repr(exc)[:200]}
+    return out
+
+
 class ModelFrames:
     """The whole re-hosted BEVFormer-base (backbone, FPN, encoder, decoder, heads; random weights, synthetic
     6-camera frames) behind the reference's stateful frame loop (tools/bevformer/evaluate_trt.py:76-154).
@@ -384,8 +459,6 @@ class ModelFrames:
             cams = gather.cams
         self.note = None
         if kind == "int8":
-            if cams is not None:
-                raise SystemExit("the INT8 build is a single-GPU engine (camera sharding runs the fp16 model)")
             from bevformer_tensorrt_amd.quantization import build_int8_engine
             frames = [(self.img, self.can(i), self.l2i) for i in range(calib)]
             model, _, self.note = build_int8_engine(B, name, dev, frames, "entropy",
@@ -517,6 +590,17 @@ def bevdet_frames(dev, steps, warmup, int8=True):
     return out
 
 
+def dispatch_misses():
+    """Dense / convolution problems this process posed that bevformer_tensorrt_amd/dispatch_gfx950.json does not list
+    (each was measured in-process, or defaulted under capture): the run-to-run kernel choice is only pinned for listed
+    problems."""
+    try:
+        from bevformer_tensorrt_amd.functions import conv as C, linear as L
+        return {"dense": list(L.DENSE_MISSES), "conv": list(C.CONV_MISSES)}
+    except Exception as exc:
+        return {"error": repr(exc)[:120]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: spawn the N ranks here (one process per GPU,
     RCCL rendezvous on 127.0.0.1) -- the driver's torch.distributed.run launch sets WORLD_SIZE itself
@@ -641,21 +725,29 @@ def main():
                 other["end_to_end"] = {"error": repr(exc)[:300]}
 
     # BASELINE config 3: BEVFormer-small fp16 / INT8 end to end (same protocol pair)
-    small = None
+    small = tiny = None
     if world == 1 and not args.no_end_to_end and not args.no_small:
         small = {"config": "BEVFormer-small: 6x(3x736x1280) -> ResNet-101-DCN (C5) + FPN level -> 3 encoder layers "
                            "(150x150 BEV queries) -> 6 decoder layers -> heads"}
-        for kind in ("fp16",) + (() if args.no_int8 else ("int8",)):
-            try:
-                fs = ModelFrames(dev, kind, 1, 0, None, args.exchange, name="small")
-                es = run_frames(fs, args.steps, args.warmup, dev, None)
-                small[kind] = {"value": round(args.steps / es, 3), "unit": "frames/s",
-                               "ms_per_step": round(es / args.steps * 1e3, 4), "hip_graph": fs.graph, "build": fs.note,
-                               "protocol_sync": run_frames_protocol(fs, args.steps)}
-                del fs
-                torch.cuda.empty_cache()
-            except Exception as exc:
-                small[kind] = {"error": repr(exc)[:300]}
+        tiny = {"config": "BEVFormer-tiny (BASELINE config 2): 6x(3x480x800) -> ResNet-50 (C5) + FPN level -> 3 encoder "
+                          "layers (50x50 BEV queries) -> 6 decoder layers -> heads; custom MSDA / rotate HIP kernels"}
+        for name, rec in (("small", small), ("tiny", tiny)):
+            for kind in ("fp16",) + (() if args.no_int8 else ("int8",)):
+                try:
+                    fs = ModelFrames(dev, kind, 1, 0, None, args.exchange, name=name)
+                    es = run_frames(fs, args.steps, args.warmup, dev, None)
+                    rec[kind] = {"value": round(args.steps / es, 3), "unit": "frames/s",
+                                 "ms_per_step": round(es / args.steps * 1e3, 4), "hip_graph": fs.graph, "build": fs.note,
+                                 "protocol_sync": run_frames_protocol(fs, args.steps)}
+                    del fs
+                    torch.cuda.empty_cache()
+                except Exception as exc:
+                    rec[kind] = {"error": repr(exc)[:300]}
+
+    frame_roof = {}
+    if world == 1 and not args.no_hot_path:
+        frame_roof = frame_rooflines(bev, dev)
+        torch.cuda.empty_cache()
 
     bevdet = None
     if world == 1 and not args.no_end_to_end and not args.no_small:
@@ -672,8 +764,8 @@ def main():
                    "kind": "port",
                    "sample": "the sampling operators of one frame in fp32 on the host (the backbone's dense convolutions, "
                              "GEMMs and norms are NOT in this figure; cpu_baseline.full_model is the whole BEVFormer-tiny): "
-                             "MSDA = reference PyTorch CPU path (oracle/torch_ref.py), base TSA + decoder calls in full "
-                             "and 1/8 of the SCA queries, x 6+6+6 calls; DCNv2 = C restatement of the reference launcher "
+                             "MSDA = reference PyTorch CPU path (oracle/torch_ref.py), base TSA, decoder and SCA calls each "
+                             "timed whole once, x 6+6+6 calls; DCNv2 = C restatement of the reference launcher "
                              "(oracle/mdconv_ref.c, OpenMP) on one camera image per stage, x 6 images x 23+3 convolutions; "
                              "rotate = oracle/sampler_ref.c once; per-call seconds " + sample}
             try:
@@ -703,9 +795,12 @@ def main():
                        "int8_build": headline["note"] if headline else None,
                        "parallelism": f"cameras/{world}+all-{args.exchange}" if world > 1 else "single"},
             "ranks_seen": dist.get_world_size() if dist is not None else 1,
-            "roofline": roofline, "cpu_baseline": cpu, "hot_path": hot if headline is not None else None,
+            "roofline": roofline, "roofline_frame": frame_roof.get("roofline_frame"),
+            "roofline_mfma": frame_roof.get("roofline_mfma"), "cpu_baseline": cpu,
+            "hot_path": hot if headline is not None else None,
             "protocol_sync": headline["protocol_sync"] if headline else None,
-            "int8": other, "small": small, "bevdet_r50": bevdet,
+            "int8": other, "small": small, "tiny": tiny, "bevdet_r50": bevdet,
+            "dispatch_misses": dispatch_misses(),
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

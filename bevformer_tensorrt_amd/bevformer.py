@@ -490,7 +490,9 @@ class SpatialCrossAttention(nn.Module):
         self.attention_weights = nn.Linear(EMBED, HEADS * levels * points)
         self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
 
-    def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None):
+    def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None, plan=None):
+        """`plan`: the visibility plan (functions.spatial_cross_attention_plan) of the bev_mask rows of the cameras
+        sampled here -- all of them, or this rank's -- or None."""
         inp_residual = query
         ncam, nk, nq = value.shape[0], value.shape[1], query.shape[1]   # ncam may be 0 (rank without cameras)
         mode = getattr(gather, "mode", None)
@@ -515,7 +517,8 @@ class SpatialCrossAttention(nn.Module):
             w = _dense(self.ops, self.attention_weights, query).view(1, nq, HEADS, -1)
             try:
                 slots = projected(value.reshape(ncam, nk, EMBED), self.value_proj.weight, self.value_proj.bias,
-                                  spatial_shapes, ref_l.contiguous(), off, w, mask_l.contiguous(), HEADS)
+                                  spatial_shapes, ref_l.contiguous(), off, w, mask_l.contiguous(), HEADS,
+                                  **({"plan": plan} if plan is not None else {}))
             except _lib.BevopsError as exc:
                 if exc.status != _lib.NOT_SUPPORTED:
                     raise
@@ -554,7 +557,7 @@ class BEVFormerLayer(nn.Module):
         self.norms = nn.ModuleList(nn.LayerNorm(EMBED) for _ in range(3))
 
     def forward(self, query, value, bev_pos, ref_2d, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev_bev,
-                use_prev_bev, cams, gather):
+                use_prev_bev, cams, gather, plan=None):
         # encoder.py:586-588: use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1) with
         # use_prev_bev in {0, 1} -- a select (one pass, exact) instead of two scalings, a copy and an add
         if torch.is_tensor(use_prev_bev):
@@ -563,7 +566,7 @@ class BEVFormerLayer(nn.Module):
             prev = prev_bev if use_prev_bev else query.repeat(2, 1, 1)
         ops = self.tsa.ops
         query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
-        query = _layer_norm(ops, self.norms[1], self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather))
+        query = _layer_norm(ops, self.norms[1], self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather, plan))
         return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
 
 
@@ -757,7 +760,18 @@ class BEVFormer(nn.Module):
         the frame loop evaluates it when `lidar2img` changes and hands the result to `forward(proj=...)`."""
         _, _, pillars = self._geometry(lidar2img.device)
         ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
-        return ref_cam.to(dtype), bev_mask.to(dtype)
+        ref_cam, bev_mask = ref_cam.to(dtype), bev_mask.to(dtype)
+        plan = self._sca_plan(bev_mask, None)
+        return (ref_cam, bev_mask) if plan is None else (ref_cam, bev_mask, plan)
+
+    def _sca_plan(self, bev_mask, cams):
+        """Visibility plan of the fused SCA sampling for the cameras sampled on this rank (None: no such operator, or
+        outside its domain).  Depends on the calibration only, like bev_mask itself."""
+        fn = getattr(self.ops, "spatial_cross_attention_plan", None)
+        if fn is None or not _R3["enabled"] or not bev_mask.is_cuda or bev_mask.dtype != torch.float16:
+            return None
+        mask_l = bev_mask if cams is None else _take_cams(bev_mask, cams)
+        return fn(mask_l) if mask_l.shape[0] > 0 else None
 
     def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None, shift=None, proj=None):
         """`shift` [1, 2]: optional precomputed G.bev_shift(can_bus) -- the frame loop evaluates it
@@ -820,14 +834,16 @@ class BEVFormer(nn.Module):
 
         # ---- encoder.forward_trt (:261-334)
         ref_3d, ref_2d, pillars = self._geometry(dev)
-        ref_cam, bev_mask = proj if proj is not None else self.project(lidar2img, image_shape, dtype)
+        ref_cam, bev_mask, *rest = proj if proj is not None else self.project(lidar2img, image_shape, dtype)
+        # the plan that comes with the projection lists all cameras; a camera-sharded rank samples its own only
+        plan = (rest[0] if rest else None) if cams is None else self._sca_plan(bev_mask, cams)
         hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
         q = bev_queries.view(1, nq, EMBED)
         pos = bev_pos.view(1, nq, EMBED)
         prev = torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
         for layer in self.encoder:
             q = layer(q, feat_flatten, pos, hybrid, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev,
-                      use_prev_bev, cams, gather)
+                      use_prev_bev, cams, gather, plan)
         bev_embed = q.view(nq, 1, EMBED)
 
         # ---- decoder (transformer.forward_trt :375-398, decoder.py:52-112)

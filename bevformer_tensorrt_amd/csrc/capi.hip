@@ -64,6 +64,9 @@ const Entry kTable[] = {
     {"bevops_value_pack_planes", (void *)&bevops_value_pack_planes},
     {"bevops_sca_prepacked_workspace_size", (void *)&bevops_sca_prepacked_workspace_size},
     {"bevops_sca_forward_prepacked", (void *)&bevops_sca_forward_prepacked},
+    {"bevops_sca_plan_size", (void *)&bevops_sca_plan_size},
+    {"bevops_sca_plan_build", (void *)&bevops_sca_plan_build},
+    {"bevops_sca_forward_planned", (void *)&bevops_sca_forward_planned},
     {"bevops_feat_embed_nhwc", (void *)&bevops_feat_embed_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},

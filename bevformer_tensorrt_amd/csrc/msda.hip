@@ -605,6 +605,14 @@ static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19, 21
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant_raw;   // handing this back to set_variant restores the flags too
   g_variant_raw = variant;
+  if (variant >= 3100 && variant <= 3104) {   // timing builds of the planned kernel (ablations; outputs not the operator's)
+    msda_hm5_set_plan_ablation(variant - 3100);
+    return prev;
+  }
+  if (variant >= 3001 && variant <= 3008) {   // A/B: slices per CU of the planned fused SCA sampling (default 1)
+    msda_hm5_set_plan_blocks(variant - 3000);
+    return prev;
+  }
   // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan.  21 .. 24 (A/B, forced
   // hm4): int8 big set as pixel-pair entries (21, 22) or as 2x2 footprints (23, 24), on the two-blocks (21, 23) or
   // the one-block plan (22, 24); any other value restores the default entry format
@@ -776,6 +784,44 @@ extern "C" int bevops_sca_forward_prepacked(int dtype, const void *packed, size_
                                          (const __half *)sampling_offsets, (const __half *)attention_weights,
                                          (const __half *)bev_mask, sampled, num_cams, nk, heads, channels, num_levels,
                                          num_query, num_point, points_per_group, st);
+  if (rc != BEVOPS_SUCCESS) return rc;
+  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, st);
+  return launch_status();
+}
+
+extern "C" size_t bevops_sca_plan_size(int num_cams, int num_query) { return msda_hm5_plan_bytes(num_cams, num_query); }
+
+extern "C" int bevops_sca_plan_build(int dtype, const void *bev_mask, int num_cams, int num_query, void *plan,
+                                     size_t plan_bytes, void *stream) {
+  if (!bev_mask || !plan || num_cams <= 0 || num_query <= 0) return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  return msda_hm5_plan_build((const __half *)bev_mask, num_cams, num_query, plan, plan_bytes,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bevops_sca_forward_planned(int dtype, const void *packed, size_t packed_bytes,
+                                          const int32_t *spatial_shapes_host, const void *reference_points_cam,
+                                          const void *sampling_offsets, const void *attention_weights,
+                                          const void *bev_mask, const void *plan, size_t plan_bytes, void *output,
+                                          int num_cams, int nk, int heads, int channels, int num_levels, int num_query,
+                                          int num_point, int points_per_group, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+  if (!packed || !spatial_shapes_host || !reference_points_cam || !sampling_offsets || !attention_weights || !bev_mask ||
+      !plan || !output || !workspace)
+    return BEVOPS_BAD_PARAM;
+  if (num_cams <= 0 || nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0 ||
+      points_per_group <= 0)
+    return BEVOPS_BAD_PARAM;
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (workspace_bytes < bevops_sca_prepacked_workspace_size(num_cams, heads, channels, num_query) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u))
+    return BEVOPS_BAD_PARAM;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  __half *sampled = static_cast<__half *>(workspace);
+  const int rc = msda_hm5_sca_sample_planned_f16(packed, packed_bytes, spatial_shapes_host,
+                                                 (const __half *)reference_points_cam, (const __half *)sampling_offsets,
+                                                 (const __half *)attention_weights, plan, plan_bytes, sampled, num_cams,
+                                                 nk, heads, channels, num_levels, num_query, num_point, points_per_group, st);
   if (rc != BEVOPS_SUCCESS) return rc;
   msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, st);
   return launch_status();

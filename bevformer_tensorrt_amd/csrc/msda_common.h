@@ -249,6 +249,15 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
 int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host, const __half *ref,
                             const __half *off, const __half *logit, const __half *qmask, __half *sampled, int bs,
                             int nk, int heads, int C, int L, int nq, int P, int ppg, hipStream_t st);
+// visibility plan of the fused SCA op (per camera the ascending list of its visible queries) and the sampling on it
+size_t msda_hm5_plan_bytes(int bs, int nq);
+int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t plan_bytes, hipStream_t st);
+int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host,
+                                    const __half *ref, const __half *off, const __half *logit, const void *plan,
+                                    size_t plan_bytes, __half *sampled, int bs, int nk, int heads, int C, int L, int nq,
+                                    int P, int ppg, hipStream_t st);
+void msda_hm5_set_plan_blocks(int k);
+void msda_hm5_set_plan_ablation(int abl);
 void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
                             hipStream_t st);
 bool msda_hm5_layout(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, void *tab,

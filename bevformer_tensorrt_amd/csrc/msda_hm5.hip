@@ -159,10 +159,65 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
   }
 }
 
+// ---- visibility plan of the fused SCA op (LISTED == 3 below): per camera the ascending list of the queries whose
+// bev_mask weight is non-zero.  bev_mask depends on the calibration matrices only (encoder.py:255-258), so a frame loop
+// builds the plan once per rig and every layer of every frame samples with it.  Layout: int32 counts[kPlanCams] (64
+// bytes), then per camera a u16 list of `nq_pad` entries.  One block per camera; a thread takes 8 consecutive queries
+// (one 16-byte load of the fp16 mask) per pass.
+constexpr int kPlanCams = 16;
+inline size_t h5_plan_pad(int nq) { return ((size_t)nq + 63) & ~size_t(63); }
+__device__ __forceinline__ unsigned h5_plan_pad_dev(int nq) { return ((unsigned)nq + 63u) & ~63u; }
+__global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned short *__restrict__ qmask, int nq,
+                                                             unsigned nq_pad, int *__restrict__ counts,
+                                                             unsigned short *__restrict__ lists) {
+  __shared__ unsigned wtot[16];
+  const unsigned cam = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const unsigned short *mk = qmask + (size_t)cam * nq;
+  unsigned short *dst = lists + (size_t)cam * nq_pad;
+  unsigned base = 0;
+  for (unsigned q0 = 0; q0 < (unsigned)nq; q0 += 8192u) {
+    const unsigned q = q0 + threadIdx.x * 8u;
+    unsigned bits = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k)
+      if (q + k < (unsigned)nq && (mk[q + k] & 0x7fffu) != 0) bits |= 1u << k;   // not +-0
+    const unsigned n = (unsigned)__popc(bits);
+    // inclusive prefix over the wave (DPP-free: 6 shuffle steps), then over the block's 16 waves through LDS
+    unsigned incl = n;
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+      const unsigned up = (unsigned)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63u) wtot[wv] = incl;
+    __syncthreads();
+    unsigned before = base, all = 0;
+#pragma unroll
+    for (unsigned w2 = 0; w2 < 16; ++w2) {
+      const unsigned c = wtot[w2];
+      if (w2 < wv) before += c;
+      all += c;
+    }
+    unsigned o = before + incl - n;
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k)
+      if (bits & (1u << k)) dst[o++] = (unsigned short)(q + k);
+    base += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[cam] = (int)base;
+}
+
 // ---- sampling kernel.  ABL: ablation bits for the probes (1: no big-level taps, 2: no staged
 // taps, 4: operands loaded once, 8: no store).  LISTED: 0 every query of the chunk, 1 the items whose
 // visibility byte is set (pre-pass), 2 the (batch, query) pairs with a non-zero `qmask` weight (fused SCA:
-// `vis` then points at the [bs, nq] fp16 bev_mask and the offsets / logits are shared by all batches).
+// `vis` then points at the [bs, nq] fp16 bev_mask and the offsets / logits are shared by all batches), 3 the fused SCA
+// op on a visibility PLAN (`vis` points at it, msda_hm5_plan_kernel): the visible (camera, query) pairs of ALL cameras
+// form one global sequence, and block j of the gridDim.x / heads blocks of a head takes the j-th equal slice of it --
+// every block carries the same number of items whatever the visibility pattern (one block per 1 280-query chunk: 0 ..
+// 830 items per block on the 6-camera rig, 39 % of the blocks empty, the average non-empty block 3 rounds of 128
+// octets behind a 130 KB plane copy), stages the plane of each camera its slice touches (at most two at one block per
+// CU) and needs no in-kernel compaction.
 // MBOX: the 8 records of a phase reach the octet's lanes through an LDS mailbox (one ds_write_b128 per
 // lane, one broadcast ds_read_b128 per record: 36 LDS cycles per phase and wave, ~70 us of LDS-pipe
 // time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
@@ -204,11 +259,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     bh = vb / per_plane;
     ck = vb - bh * per_plane;
   }
-  const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
+  if constexpr (LISTED == 3) {   // head = XCD (d.heads == 8: blockIdx.x & 7); the camera comes with each plan segment
+    h = blockIdx.x % (unsigned)d.heads;
+    b = 0;
+    bh = h;
+  }
   unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + (THREADS / 8) * kBox);
   unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
   auto visible = [&](unsigned q) -> bool {
-    if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
+    if constexpr (LISTED == 3) return true;
+    else if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
     else if constexpr (LISTED == 1) return vis[((size_t)b * d.nq + q) * d.heads + h] != 0;
     else return true;
   };
@@ -220,11 +281,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     }
   };
   unsigned q0 = 0, n_items = 0;
-  if constexpr (!PERSIST) {
+  if constexpr (!PERSIST && LISTED != 3) {
     q0 = ck * (unsigned)chunk;
     const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
     n_items = q_end - q0;
-    if constexpr (LISTED) {
+    if constexpr (LISTED != 0) {
       unsigned base_count = 0;
       for (unsigned t0 = 0; t0 < n_items; t0 += THREADS) {
         const unsigned i = t0 + threadIdx.x;
@@ -264,26 +325,26 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
       out, 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 64u, 0x00020000);
   const unsigned lane8 = threadIdx.x & 7u;
   const unsigned lane16 = lane8 * 16u, lane8b = lane8 * 8u;
-  const unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
+  unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
   const unsigned out_q = (unsigned)d.heads * 64u;
   const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
   const unsigned box = sbase + (unsigned)stage_bytes + (threadIdx.x >> 3) * kBox;
   const unsigned qlist_a = sbase + (unsigned)stage_bytes + (THREADS / 8) * kBox;
-  const H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
+  H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
 
   const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
   const unsigned lg_q = (unsigned)d.heads * 64u;
-  const unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
+  unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
   auto query_of = [&](unsigned i) -> unsigned {
     const unsigned ii = min(i, n_items - 1u);   // octets past the end repeat the last item, unstored
-    return (LISTED || PERSIST) ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
+    return (LISTED != 0 || PERSIST) ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
   };
   auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
     const unsigned q = query_of(i);
     const unsigned o_lg = lg_base + q * lg_q;
     // read-once full lines: non-temporal (shared offsets / logits are re-read by every camera: default policy)
     u32x2 g;
-    if constexpr (LISTED == 2) {
+    if constexpr (LISTED >= 2) {
       g = __builtin_amdgcn_raw_buffer_load_b64(rs_lg, (int)o_lg, 0, 0);
       s.of = __builtin_amdgcn_raw_buffer_load_b128(rs_of, (int)(2u * o_lg), 0, 0);
     } else {
@@ -514,7 +575,41 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
       i += OCT;
     }
   };
-  if constexpr (!PERSIST) {
+  if constexpr (LISTED == 3) {
+    const int *counts = reinterpret_cast<const int *>(vis);
+    const unsigned nq_pad = (unsigned)h5_plan_pad_dev(d.nq);
+    const unsigned short *lists = reinterpret_cast<const unsigned short *>(vis + kPlanCams * 4);
+    const unsigned nb = gridDim.x / (unsigned)d.heads, j = blockIdx.x / (unsigned)d.heads;
+    unsigned total = 0;
+    for (int cam = 0; cam < d.bs; ++cam) total += (unsigned)__builtin_amdgcn_readfirstlane(counts[cam]);
+    // (total <= 16 x 65 535 and nb <= 2 048: the products fit 32 bits; the quotients are wave-uniform -- say so, or the
+    // division's VALU expansion drags every loop bound below into vector registers)
+    const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(total * j / nb));
+    const unsigned p1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(total * (j + 1u) / nb));
+    unsigned pre = 0;
+    for (int cam = 0; cam < d.bs; ++cam) {
+      const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(counts[cam]);
+      const unsigned lo = max(p0, pre), hi = min(p1, pre + cnt);
+      const unsigned first = lo - pre;   // (only meaningful when lo < hi)
+      pre += cnt;
+      if (lo >= hi) continue;
+      b = (unsigned)cam;
+      bh = b * (unsigned)d.heads + h;
+      c = h5_lane_consts(t, lane8, bh, sbase);
+      out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
+      rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
+      const unsigned short *src = lists + (size_t)cam * nq_pad + first;
+      bool staged = false;
+      for (unsigned done = 0; done < hi - lo; done += (unsigned)chunk) {   // pieces of at most `chunk` list entries
+        __syncthreads();   // every wave is through with the previous piece's list (and the previous camera's planes)
+        n_items = min((unsigned)chunk, hi - lo - done);
+        for (unsigned i = threadIdx.x; i < n_items; i += THREADS) wl[i] = src[done + i];
+        if (!staged) { stage_plane(); staged = true; }
+        __syncthreads();
+        run_items();
+      }
+    }
+  } else if constexpr (!PERSIST) {
     run_items();
   } else {
     const unsigned nsub = ((unsigned)d.nq + kSub - 1u) / kSub;
@@ -615,6 +710,73 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
   unsigned *queue = nullptr;
   return h5_go<2, 1024, 0, 2, false, false>(pl, gset, gset + g_room, ref, off, logit, sampled, d,
                                             reinterpret_cast<const unsigned char *>(qmask), kH5Chunk, st, queue);
+}
+
+// ---- the same sampling on a visibility plan (msda_hm5_plan_kernel): balanced slices of the visible (camera, query)
+// pairs, `blocks_per_cu` blocks per CU's worth of slices (1: one slice per CU).
+// (two slices per CU measured best on the 6-camera rig: 108 us per call against 124 for one block per 1 280-query chunk,
+// 112 / 115 with three / four, profiles/r05/sca_plan_ab.jsonl; touching a slice's offset / logit rows ahead of the loop
+// so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
+static thread_local int g_h5_plan_k = 2, g_h5_plan_abl = 0;
+void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
+// TIMING builds of the planned kernel (outputs are not the operator's): 1 no big-level taps, 2 no staged taps, 3 neither,
+// 4 operands loaded once per block
+void msda_hm5_set_plan_ablation(int abl) { g_h5_plan_abl = abl; }
+
+size_t msda_hm5_plan_bytes(int bs, int nq) {
+  if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
+  return (size_t)kPlanCams * 4 + (size_t)bs * h5_plan_pad(nq) * 2;
+}
+
+int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t plan_bytes, hipStream_t st) {
+  const size_t need = msda_hm5_plan_bytes(bs, nq);
+  if (need == 0) return BEVOPS_NOT_SUPPORTED;
+  if (!qmask || !plan || plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
+  hipLaunchKernelGGL(msda_hm5_plan_kernel, dim3((unsigned)bs), dim3(1024), 0, st,
+                     reinterpret_cast<const unsigned short *>(qmask), nq, (unsigned)h5_plan_pad(nq),
+                     static_cast<int *>(plan),
+                     reinterpret_cast<unsigned short *>(static_cast<char *>(plan) + kPlanCams * 4));
+  return launch_status();
+}
+
+constexpr int kH5PlanChunk = 2048;   // list entries of a slice kept in LDS at a time
+int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host,
+                                    const __half *ref, const __half *off, const __half *logit, const void *plan,
+                                    size_t plan_bytes, __half *sampled, int bs, int nk, int heads, int C, int L, int nq,
+                                    int P, int ppg, hipStream_t st) {
+  Hm3Plan pl;
+  if (!h5_shape_ok(C, L, P, ppg) || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) ||
+      !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl) || pl.t.ls != 2)
+    return BEVOPS_NOT_SUPPORTED;
+  if ((double)nq * heads * 32 * 4.0 >= 4294967040.0 || (double)bs * nq * heads * 64.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;
+  const size_t need = msda_hm5_plan_bytes(bs, nq);
+  if (need == 0) return BEVOPS_NOT_SUPPORTED;
+  if (!plan || plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
+  const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
+  if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
+  const char *gset = static_cast<const char *>(packed);
+  const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
+  constexpr int THREADS = 1024;
+  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, kH5PlanChunk);
+  if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
+  auto kern = msda_hm5_kernel<2, THREADS, 0, 3, false, false>;
+  bool ok = false;
+  switch (g_h5_plan_abl) {
+    case 1: kern = msda_hm5_kernel<2, THREADS, 1, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 1, 3, false, false>>(lds); break;
+    case 2: kern = msda_hm5_kernel<2, THREADS, 2, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 2, 3, false, false>>(lds); break;
+    case 3: kern = msda_hm5_kernel<2, THREADS, 3, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 3, 3, false, false>>(lds); break;
+    case 4: kern = msda_hm5_kernel<2, THREADS, 4, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 4, 3, false, false>>(lds); break;
+    default: ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 0, 3, false, false>>(lds); break;
+  }
+  if (!ok) return (int)BEVOPS_FAILURE;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)
+  const unsigned per_head = (unsigned)((cus > 0 ? cus : 256) * g_h5_plan_k + heads - 1) / (unsigned)heads;
+  hipLaunchKernelGGL(kern, dim3(per_head * (unsigned)heads), dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes,
+                     gset + g_room, ref, off, logit, sampled, d, pl.t, kH5PlanChunk, 1, pl.stage_bytes,
+                     static_cast<const unsigned char *>(plan), (unsigned *)nullptr);
+  return launch_status();
 }
 
 // flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;

@@ -17,6 +17,7 @@ from .multi_scale_deformable_attn import _TensorCache
 _PACKED = _TensorCache()   # weight tensor -> taps-major copy (weakly keyed: dies with the model that owns the weight)
 _CHOICE = {}          # problem -> "tile" | "library"
 CONV_LOG = []         # (problem, {name: us})
+CONV_MISSES = []   # problems conv3x3_auto met that dispatch_gfx950.json does not list
 
 
 def pack_taps(weight):
@@ -112,6 +113,8 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
             _CHOICE[key] = name
         else:
             name = None
+            if _problem(key) not in CONV_MISSES:
+                CONV_MISSES.append(_problem(key))   # a problem the shipped table has never seen (bench.py reports them)
     if name is None:
         if Cin % 32 != 0:
             name = _CHOICE[key] = "library"

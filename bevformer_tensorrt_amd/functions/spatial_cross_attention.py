@@ -63,8 +63,33 @@ def spatial_cross_attention_sample(value, value_spatial_shapes, reference_points
     return out
 
 
+PLANNED = {"enabled": __import__("os").environ.get("BEVOPS_SCA_PLAN", "1") != "0"}   # A/B: balanced slices of a visibility plan
+
+
+def spatial_cross_attention_plan(bev_mask):
+    """Visibility plan of the fused SCA sampling for one rig (bevops_sca_plan_build): per camera the ascending list of
+    the queries whose bev_mask weight is non-zero, as opaque device bytes.  bev_mask [num_cams, num_query(, 1)] depends
+    on lidar2img only (modules/encoder.py:255-258), so a frame loop builds this once per calibration and hands it to
+    every spatial_cross_attention_projected call of every layer and frame.  None when the mask is outside the plan's
+    domain (more than 16 cameras or 65 535 queries) -- the caller then runs without a plan."""
+    assert bev_mask.is_cuda
+    handle = _lib.load_library()
+    ncam = bev_mask.shape[0]
+    mask = bev_mask.reshape(ncam, -1).to(torch.float16).contiguous()
+    nq = mask.shape[1]
+    size = handle.bevops_sca_plan_size(ncam, nq) if ncam > 0 else 0
+    if size == 0:
+        return None
+    plan = torch.empty(size, dtype=torch.uint8, device=mask.device)
+    with torch.cuda.device(mask.device):
+        st = handle.bevops_sca_plan_build(_lib.F16, mask.data_ptr(), ncam, nq, plan.data_ptr(), size,
+                                          _lib.current_stream_ptr(mask.device))
+    _lib.check(st, "bevops_sca_plan_build")
+    return plan
+
+
 def spatial_cross_attention_projected(features, weight, bias, value_spatial_shapes, reference_points_cam,
-                                      sampling_offsets, attention_weights, bev_mask, num_heads=8):
+                                      sampling_offsets, attention_weights, bev_mask, num_heads=8, plan=None):
     """value_proj + fused SCA sampling in two launches without the [cams, keys, heads, 32] tensor in between
     (spatial_cross_attention.py:754 followed by :254-270): the value projection runs on the tall-skinny MFMA
     GEMM whose epilogue stores straight into the sampler's padded head-major planes
@@ -73,6 +98,8 @@ def spatial_cross_attention_projected(features, weight, bias, value_spatial_shap
         features: (num_cams, num_keys, embed) fp16 -- the encoder input (FPN levels + camera / level embeddings)
         weight, bias: value_proj parameters [embed, embed], [embed]
         the other arguments as spatial_cross_attention_sample
+        plan: spatial_cross_attention_plan(bev_mask) of THIS bev_mask, or None (the sampling kernel then compacts
+              its own chunk of queries per block: same results, unbalanced blocks)
     Returns (1, num_query, embed).  Raises BevopsError (NOT_SUPPORTED) outside the 4-level x 8-point domain."""
     assert features.is_cuda and features.dtype == torch.float16
     handle = _lib.load_library()
@@ -92,20 +119,46 @@ def spatial_cross_attention_projected(features, weight, bias, value_spatial_shap
     shapes_dev, shapes_host = _shapes_i32(value_spatial_shapes, features.device)
     if shapes_host is None:
         shapes_host = _host_shapes(shapes_dev)
-    out = torch.empty((1, nq, embed), dtype=features.dtype, device=features.device)
-    with torch.cuda.device(features.device):
-        stream = _lib.current_stream_ptr(features.device)
+    geom = (shapes_host, ncam, nk, heads, ch, L, nq, P, ppg)
+    planes = _project_planes(handle, feats, weight, bias, geom)
+    return _sample_planes(handle, planes, geom, ref, off, w, mask, plan)
+
+
+def _project_planes(handle, feats, weight, bias, geom):
+    """bevops_value_proj_packed into a lent workspace: (workspace tensor, plane bytes, offset of the sampler's own
+    workspace, its size)."""
+    shapes_host, ncam, nk, heads, ch, L, nq, P, _ = geom
+    with torch.cuda.device(feats.device):
+        stream = _lib.current_stream_ptr(feats.device)
         pk_bytes = handle.bevops_value_proj_packed_size(shapes_host.data_ptr(), ncam, nk, heads, ch, L, nq, P)
         if pk_bytes == 0:
             raise _lib.BevopsError("bevops_value_proj_packed_size: shape outside the packed-projection domain",
                                    _lib.NOT_SUPPORTED)
         ws_bytes = handle.bevops_sca_prepacked_workspace_size(ncam, heads, ch, nq)
         pk_room = (pk_bytes + 255) & ~255
-        ws = _workspace(pk_room + ws_bytes, features.device, stream)
+        ws = _workspace(pk_room + ws_bytes, feats.device, stream)
         st = handle.bevops_value_proj_packed(feats.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
                                              shapes_host.data_ptr(), ws.data_ptr(), pk_bytes, ncam, nk, heads, ch, L, nq,
                                              P, stream)
-        _lib.check(st, "bevops_value_proj_packed")
+    _lib.check(st, "bevops_value_proj_packed")
+    return ws, pk_bytes, pk_room, ws_bytes
+
+
+def _sample_planes(handle, planes, geom, ref, off, w, mask, plan=None):
+    """The fused sampling on planes `_project_planes` left in the workspace (tools time this half alone)."""
+    shapes_host, ncam, nk, heads, ch, L, nq, P, ppg = geom
+    ws, pk_bytes, pk_room, ws_bytes = planes
+    out = torch.empty((1, nq, heads * ch), dtype=ref.dtype, device=ref.device)
+    with torch.cuda.device(ref.device):
+        stream = _lib.current_stream_ptr(ref.device)
+        if plan is not None and PLANNED["enabled"]:
+            assert plan.is_cuda and plan.dtype == torch.uint8 and plan.is_contiguous()
+            st = handle.bevops_sca_forward_planned(_lib.F16, ws.data_ptr(), pk_bytes, shapes_host.data_ptr(),
+                                                   ref.data_ptr(), off.data_ptr(), w.data_ptr(), mask.data_ptr(),
+                                                   plan.data_ptr(), plan.numel(), out.data_ptr(), ncam, nk, heads, ch, L,
+                                                   nq, P, ppg, ws.data_ptr() + pk_room, ws_bytes, stream)
+            _lib.check(st, "bevops_sca_forward_planned")
+            return out
         st = handle.bevops_sca_forward_prepacked(_lib.F16, ws.data_ptr(), pk_bytes, shapes_host.data_ptr(), ref.data_ptr(),
                                                  off.data_ptr(), w.data_ptr(), mask.data_ptr(), out.data_ptr(), ncam, nk,
                                                  heads, ch, L, nq, P, ppg, ws.data_ptr() + pk_room, ws_bytes, stream)

@@ -63,6 +63,10 @@ SIGNATURES = {
     "bevops_sca_prepacked_workspace_size": (c_size_t, [c_int] * 4),
     "bevops_sca_forward_prepacked": (c_int, [c_int, c_void_p, c_size_t] + [c_void_p] * 6 + [c_int] * 8 +
                                      [c_void_p, c_size_t, c_void_p]),
+    "bevops_sca_plan_size": (c_size_t, [c_int, c_int]),
+    "bevops_sca_plan_build": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "bevops_sca_forward_planned": (c_int, [c_int, c_void_p, c_size_t] + [c_void_p] * 6 + [c_size_t, c_void_p] + [c_int] * 8 +
+                                   [c_void_p, c_size_t, c_void_p]),
     "bevops_tsgemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tsgemm_s8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_int,
                                  c_void_p, c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),

@@ -517,6 +517,23 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
                                  const void *attention_weights, const void *bev_mask, void *output, int num_cams,
                                  int nk, int heads, int channels, int num_levels, int num_query, int num_point,
                                  int points_per_group, void *workspace, size_t workspace_bytes, void *stream);
+/* The same sampling on a VISIBILITY PLAN (round 5).  bev_mask depends on the calibration matrices only
+ * (modules/encoder.py:255-258), so which (camera, query) pairs are sampled is known per rig, not per call:
+ * bevops_sca_plan_build turns the fp16 bev_mask [num_cams, num_query] into per-camera ascending lists of the visible
+ * queries (`plan`: >= bevops_sca_plan_size bytes, 16-byte aligned, device memory the caller keeps for as long as the
+ * mask is valid; num_cams <= 16, num_query <= 65 535), and bevops_sca_forward_planned gives every block of the sampling
+ * kernel an EQUAL slice of the global (camera, query) sequence -- no empty blocks, no per-block compaction, the same
+ * number of rounds on every CU -- with the results of bevops_sca_forward_prepacked (bit-identical: same arithmetic
+ * per pair, same reduction).  `plan` must have been built from the `bev_mask` passed here. */
+size_t bevops_sca_plan_size(int num_cams, int num_query);
+int bevops_sca_plan_build(int dtype, const void *bev_mask, int num_cams, int num_query, void *plan, size_t plan_bytes,
+                          void *stream);
+int bevops_sca_forward_planned(int dtype, const void *packed, size_t packed_bytes, const int32_t *spatial_shapes_host,
+                               const void *reference_points_cam, const void *sampling_offsets,
+                               const void *attention_weights, const void *bev_mask, const void *plan, size_t plan_bytes,
+                               void *output, int num_cams, int nk, int heads, int channels, int num_levels,
+                               int num_query, int num_point, int points_per_group, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* Hand-written tall-skinny fp16 GEMM on the matrix cores (csrc/tsgemm.hip) for the dense layers that wrap the
  * samplers (the reference runs them as cuBLAS / TensorRT layers: spatial_cross_attention.py:694-768,

@@ -167,3 +167,91 @@ def test_packed_projection_planes_are_bit_identical_to_repacking_its_own_gemm():
     planes = nbytes - ((ncam * nq * heads + 255) // 256) * 256
     diff = (a[:planes] != b[:planes])
     assert int(diff.sum()) == 0, (int(diff.sum()), int(diff.nonzero()[0]))
+
+
+def _plan_case(kind, nq, seed):
+    """Inputs of the projected SCA path at the base pyramid with a visibility pattern of the given kind."""
+    from bevformer_tensorrt_amd import geometry as G
+    g = torch.Generator().manual_seed(seed)
+    levels = [[116, 200], [58, 100], [29, 50], [15, 25]]
+    nk = sum(h * w for h, w in levels)
+    heads, embed = 8, 256
+    feats = (torch.randn(6, nk, embed, generator=g) * 0.5).half().cuda()
+    wgt = (torch.randn(embed, embed, generator=g) / 16).half().cuda()
+    bias = (torch.randn(embed, generator=g) * 0.1).half().cuda()
+    off = (torch.randn(1, nq, heads, 64, generator=g) * 2).half().cuda()
+    w = torch.randn(1, nq, heads, 32, generator=g).half().cuda()
+    if kind == "rig":
+        assert nq == 40000
+        ref3d = G.reference_points_3d(200, 200, 8, 4, device="cpu")
+        cam, mask = G.point_sampling(ref3d, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], G.synthetic_lidar2img((928, 1600)), (928, 1600))
+        ref = cam.reshape(6, nq, 1, 8)
+        vis = mask.reshape(6, nq, -1).any(-1)
+    else:
+        ref = torch.rand(6, nq, 1, 8, generator=g) * 1.2 - 0.1
+        if kind == "all":
+            vis = torch.ones(6, nq, dtype=torch.bool)
+        elif kind == "one_camera":          # five cameras see nothing: the slices of all blocks fall into camera 3
+            vis = torch.zeros(6, nq, dtype=torch.bool)
+            vis[3] = torch.rand(nq, generator=g) < 0.7
+        elif kind == "few":                 # fewer visible pairs than blocks: most slices are empty
+            vis = torch.zeros(6, nq, dtype=torch.bool)
+            vis[0, 5] = vis[2, nq - 1] = vis[5, 0] = vis[5, 77] = True
+        elif kind == "none":
+            vis = torch.zeros(6, nq, dtype=torch.bool)
+        else:                               # "random": uneven per-camera counts
+            p = torch.tensor([0.05, 0.9, 0.3, 0.0, 0.5, 0.2]).view(6, 1)
+            vis = torch.rand(6, nq, generator=g) < p
+    bm = (vis.float() / vis.sum(0).clamp(min=1)).half().cuda()
+    sh = torch.tensor(levels, dtype=torch.int32)
+    return feats, wgt, bias, sh, ref.half().cuda(), off, w, bm, heads
+
+
+@pytest.mark.parametrize("kind,nq", [("rig", 40000), ("random", 40000), ("all", 9000), ("one_camera", 12345),
+                                     ("few", 3000), ("none", 2500), ("random", 65535)])
+def test_planned_sampling_is_bit_identical_to_the_chunked_sampling(kind, nq):
+    """bevops_sca_forward_planned (every block an equal slice of the visible (camera, query) pairs of a plan built
+    from bev_mask by bevops_sca_plan_build) against bevops_sca_forward_prepacked (one block per 1 280-query chunk,
+    in-kernel compaction): same arithmetic per pair, same camera reduction -> the same bits, whatever the visibility
+    pattern and the number of slices per CU."""
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd.utils import lib as L
+    args = _plan_case(kind, nq, seed=nq % 97)
+    bm = args[7]
+    want = bev.spatial_cross_attention_projected(*args)
+    plan = bev.spatial_cross_attention_plan(bm)
+    assert plan is not None and plan.dtype == torch.uint8
+    # the plan itself: counts and ascending lists
+    ncam = bm.shape[0]
+    counts = plan[:64].view(torch.int32)[:ncam].cpu()
+    pad = (nq + 63) // 64 * 64
+    lists = plan[64:].view(torch.int16).view(ncam, pad).cpu().to(torch.int32) & 0xffff
+    for c in range(ncam):
+        vis_q = torch.nonzero(bm[c].cpu() != 0).flatten().to(torch.int32)
+        assert int(counts[c]) == vis_q.numel()
+        assert torch.equal(lists[c, :vis_q.numel()], vis_q)
+    handle = L.load_library()
+    try:
+        for k in (1, 2, 3):
+            handle.bevops_msda_set_variant(3000 + k)
+            got = bev.spatial_cross_attention_projected(*args, plan=plan)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (kind, k, (got.float() - want.float()).abs().max().item())
+    finally:
+        handle.bevops_msda_set_variant(3002)      # the default: two slices per CU
+        handle.bevops_msda_set_variant(0)
+
+
+def test_plan_entry_validates_its_arguments():
+    from bevformer_tensorrt_amd.utils import lib as L
+    h = L.load_library()
+    assert h.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 2      # 40 000 is a multiple of 64
+    assert h.bevops_sca_plan_size(17, 100) == 0 and h.bevops_sca_plan_size(6, 65536) == 0
+    m = torch.zeros(6, 100, dtype=torch.half, device="cuda")
+    plan = torch.empty(h.bevops_sca_plan_size(6, 100), dtype=torch.uint8, device="cuda")
+    st = L.current_stream_ptr(m.device)
+    assert h.bevops_sca_plan_build(L.F16, m.data_ptr(), 6, 100, plan.data_ptr(), plan.numel() - 1, st) == L.BAD_PARAM
+    assert h.bevops_sca_plan_build(L.F32, m.data_ptr(), 6, 100, plan.data_ptr(), plan.numel(), st) == L.NOT_SUPPORTED
+    assert h.bevops_sca_plan_build(L.F16, m.data_ptr(), 6, 100, plan.data_ptr(), plan.numel(), st) == 0
+    torch.cuda.synchronize()
+    assert int(plan[:64].view(torch.int32)[:6].abs().sum()) == 0
