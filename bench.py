@@ -467,7 +467,7 @@ class ModelFrames:
             model = B.BEVFormer(name, seed=0).to(dev, dtype)
         # N > 1: the "reduce" exchange (fused sampler on the local cameras, ONE all-reduce per encoder layer) is
         # captured with its RCCL collectives; the per-camera pipelined all-gathers run eagerly
-        self.graph = graph and (world == 1 or exchange == "reduce")
+        self.graph = graph and (world == 1 or exchange in ("reduce", "scatter"))
         self._shard = (cams, gather)
         # the graph's own output buffers are handed out (no per-frame clones), and the synthetic camera images sit in
         # the frame's static input buffer, where a serving caller's normalise pass (FrameRunner.step_raw) writes them
@@ -629,8 +629,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "int8"],
                     help="which build of the model the headline `value` times (the other one is a sub-record at N=1)")
-    ap.add_argument("--exchange", default="reduce", choices=["gather", "reduce"],
-                    help="N>1: all-reduce of each rank's masked camera sum (default: the fused sampler runs on the local "
+    ap.add_argument("--exchange", default="scatter", choices=["gather", "reduce", "scatter"],
+                    help="N>1: scatter (default) = cameras sharded and the rest of the encoder sharded by query range: the "
+                         "fused sampler on the local cameras, per encoder layer one all-gather of the query rows and one "
+                         "reduce-scatter of the masked camera sums (the bytes of one all-reduce), TSA / norms / FFN on a "
+                         "rank's own rows, HIP graph with the RCCL collectives inside; reduce = "
+                         "all-reduce of each rank's masked camera sum (the fused sampler runs on the local "
                          "cameras, one 20.5 MB collective per encoder layer, the frame replays from a HIP graph with its "
                          "RCCL collectives inside) or the per-camera pipelined all-gathers of the camera features "
                          "(BASELINE config 4's exchange: 6x the data, eager frames)")

@@ -455,19 +455,22 @@ class TemporalSelfAttention(nn.Module):
                 raise
             return None
 
-    def forward(self, query, value, bev_pos, ref_2d, spatial_shapes):
+    def forward(self, query, value, bev_pos, ref_2d, spatial_shapes, rows=None):
+        """`rows` = (lo, hi): query-range sharding (camera_shard.py, mode "scatter") -- `query`, `bev_pos` and `ref_2d`
+        hold rows lo .. hi - 1 of the BEV queries only, `value` (the keys: prev_bev | query stack) is whole."""
         identity = query
-        nq = query.shape[1]
-        both = self._split_projection(query, value[0], bev_pos)
+        nq, nk = query.shape[1], value.shape[1]
+        mine = value if rows is None else value[:, rows[0]:rows[1]]      # the value rows that pair with these queries
+        both = self._split_projection(query, mine[0], bev_pos)
         if both is not None:
             n_off = 2 * HEADS * self.points * 2
             off = both[:, :n_off].view(1, nq, HEADS, 2, 1, self.points, 2)
             w = both[:, n_off:].view(1, nq, HEADS, 2, 1, self.points)
         else:
-            query = torch.cat([value[:1], query + bev_pos], -1)
+            query = torch.cat([mine[:1], query + bev_pos], -1)
             off = self.sampling_offsets(query).view(1, nq, HEADS, 2, 1, self.points, 2)
             w = self.attention_weights(query).view(1, nq, HEADS, 2, 1, self.points)
-        value = _dense(self.ops, self.value_proj, value).view(2, nq, HEADS, EMBED // HEADS)
+        value = _dense(self.ops, self.value_proj, value).view(2, nk, HEADS, EMBED // HEADS)
         w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
         off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
         # the BEV grid's reference points have locality (neighbouring queries, neighbouring pixels): the operator set's
@@ -490,10 +493,14 @@ class SpatialCrossAttention(nn.Module):
         self.attention_weights = nn.Linear(EMBED, HEADS * levels * points)
         self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
 
-    def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None, plan=None):
+    def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None, plan=None,
+                residual=None):
         """`plan`: the visibility plan (functions.spatial_cross_attention_plan) of the bev_mask rows of the cameras
-        sampled here -- all of them, or this rank's -- or None."""
-        inp_residual = query
+        sampled here -- all of them, or this rank's -- or None.  `residual`: query-range sharding (exchange mode
+        "scatter") -- `query` is the whole gathered tensor (every camera's sampler needs every query's offsets), the
+        masked camera sum comes back reduce-SCATTERED to this rank's rows, and `residual` holds those rows of the
+        layer input for the output projection."""
+        inp_residual = query if residual is None else residual
         ncam, nk, nq = value.shape[0], value.shape[1], query.shape[1]   # ncam may be 0 (rank without cameras)
         mode = getattr(gather, "mode", None)
         if cams is None and gather is not None and hasattr(gather, "cams"):
@@ -503,7 +510,7 @@ class SpatialCrossAttention(nn.Module):
         ref_l, mask_l = (ref, bev_mask) if cams is None else (_take_cams(ref, cams), _take_cams(bev_mask, cams))
         # The fused forms produce the MASKED CAMERA SUM of the cameras they are given, so they serve a single GPU
         # (all cameras) and the "reduce" exchange (this rank's cameras, then ONE all-reduce of [1, nq, 256]) alike.
-        local_sum = gather is None or mode == "reduce"
+        local_sum = gather is None or mode in ("reduce", "scatter")
         projected = getattr(self.ops, "spatial_cross_attention_projected", None)
         fused = getattr(self.ops, "spatial_cross_attention_sample", None)
         fp16_gpu = value.dtype == torch.float16 and value.is_cuda
@@ -547,6 +554,8 @@ class SpatialCrossAttention(nn.Module):
                 slots = (queries * bev_mask).sum(0, keepdim=True)
         if mode == "reduce":
             slots = gather.reduce(slots)      # this rank's masked camera sum -> everyone's
+        elif mode == "scatter":
+            slots = gather.reduce_scatter_queries(slots, nq)      # ... -> the sum of MY rows only
         return _dense(self.ops, self.output_proj, slots, inp_residual, False)
 
 
@@ -557,14 +566,32 @@ class BEVFormerLayer(nn.Module):
         self.norms = nn.ModuleList(nn.LayerNorm(EMBED) for _ in range(3))
 
     def forward(self, query, value, bev_pos, ref_2d, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev_bev,
-                use_prev_bev, cams, gather, plan=None):
+                use_prev_bev, cams, gather, plan=None, rows=None):
+        ops = self.tsa.ops
+        if rows is not None:
+            # query-range sharding (camera_shard.py, mode "scatter"): `query` holds rows lo .. hi - 1 only.  TSA's
+            # keys are prev_bev | the layer-0 query stack (whole on every rank) -- or, without history, the CURRENT
+            # query repeated, which then has to be gathered first
+            lo, hi = rows
+            nq = bev_pos.shape[1]
+            if torch.is_tensor(use_prev_bev) or not use_prev_bev:
+                full = gather.all_gather_queries(query, nq)
+                prev = torch.where(use_prev_bev.to(torch.bool), prev_bev, full.expand(2, -1, -1)) \
+                    if torch.is_tensor(use_prev_bev) else full.repeat(2, 1, 1)
+            else:
+                prev = prev_bev
+            query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos[:, lo:hi], ref_2d[:, lo:hi].contiguous(),
+                                                             bev_shapes, rows=rows))
+            full = gather.all_gather_queries(query, nq)       # every camera's sampler needs every query's offsets
+            query = _layer_norm(ops, self.norms[1], self.sca(full, value, ref_cam, bev_mask, spatial_shapes, cams, gather,
+                                                             plan, residual=query))
+            return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
         # encoder.py:586-588: use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1) with
         # use_prev_bev in {0, 1} -- a select (one pass, exact) instead of two scalings, a copy and an add
         if torch.is_tensor(use_prev_bev):
             prev = torch.where(use_prev_bev.to(torch.bool), prev_bev, query.expand(2, -1, -1))
         else:
             prev = prev_bev if use_prev_bev else query.repeat(2, 1, 1)
-        ops = self.tsa.ops
         query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
         query = _layer_norm(ops, self.norms[1], self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather, plan))
         return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
@@ -841,9 +868,16 @@ class BEVFormer(nn.Module):
         q = bev_queries.view(1, nq, EMBED)
         pos = bev_pos.view(1, nq, EMBED)
         prev = torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
+        rows = None
+        if getattr(gather, "mode", None) == "scatter":       # the encoder beyond the cameras sharded by query range
+            lo, hi, _ = gather.query_range(nq)
+            rows = (lo, hi)
+            q = q[:, lo:hi].contiguous()
         for layer in self.encoder:
             q = layer(q, feat_flatten, pos, hybrid, ref_cam, bev_mask, spatial_shapes, bev_shapes, prev,
-                      use_prev_bev, cams, gather, plan)
+                      use_prev_bev, cams, gather, plan, rows)
+        if rows is not None:
+            q = gather.all_gather_queries(q, nq)              # the decoder (900 object queries) is replicated
         bev_embed = q.view(nq, 1, EMBED)
 
         # ---- decoder (transformer.forward_trt :375-398, decoder.py:52-112)

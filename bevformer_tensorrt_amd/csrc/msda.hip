@@ -601,24 +601,18 @@ int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const
 
 using namespace bevops;
 
-static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19, 21 .. 24 map to 17 + flags below)
+static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19 maps to 17 + a flag below)
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant_raw;   // handing this back to set_variant restores the flags too
   g_variant_raw = variant;
-  if (variant >= 3100 && variant <= 3104) {   // timing builds of the planned kernel (ablations; outputs not the operator's)
-    msda_hm5_set_plan_ablation(variant - 3100);
-    return prev;
-  }
-  if (variant >= 3001 && variant <= 3008) {   // A/B: slices per CU of the planned fused SCA sampling (default 1)
+  if (variant >= 3001 && variant <= 3008) {   // A/B: slices per CU of the planned fused SCA sampling (default 2)
     msda_hm5_set_plan_blocks(variant - 3000);
     return prev;
   }
-  // 19 (A/B) and the ablation variants (>= 200): int8 hm4 on the one-block-per-CU plan.  21 .. 24 (A/B, forced
-  // hm4): int8 big set as pixel-pair entries (21, 22) or as 2x2 footprints (23, 24), on the two-blocks (21, 23) or
-  // the one-block plan (22, 24); any other value restores the default entry format
-  msda_hm4_set_no_occ(variant == 19 || variant == 22 || variant == 24 || (variant >= 200 && variant < 1000));
-  msda_hm4_set_pair(variant == 21 || variant == 22 ? 1 : (variant == 23 || variant == 24 ? 0 : -1));
-  g_variant = (variant == 19 || (variant >= 21 && variant <= 24)) ? 17 : variant;
+  // 19 (A/B): int8 hm4 on the one-block-per-CU plan (the partner of the default two-blocks plan); g_variant then
+  // reads 17 = "hm4 wherever it is instantiated"
+  msda_hm4_set_no_occ(variant == 19);
+  g_variant = variant == 19 ? 17 : variant;
   return prev;
 }
 
@@ -641,7 +635,7 @@ extern "C" size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int head
     // padded head-major int8 planes (msda_hm4.hip): 128-byte entries, at most (H + 2)(W + 1) <= 3 H W
     // + 2 of them per level -- an upper bound; bevops_msda_workspace_size_shapes gives the exact size
     if (channels != 32 || g_variant == 10 || g_variant == 99) return 0;
-    if (g_variant != 17 && g_variant < 200 && !hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point)) return 0;
+    if (g_variant != 17 && !hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point)) return 0;
     return (size_t)bs * heads * ((size_t)3 * nk + 2 * num_levels + 4) * 128 + 4096;
   }
   if (dtype != BEVOPS_F16) return 0;
@@ -878,32 +872,28 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
     case BEVOPS_F16:
       if (ref_dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
       // head-major path (msda_hm.hip) when the caller lends a workspace and the call is big
-      // enough to amortise the re-layout; variants 10 (never) / 11 (no LDS staging) / 12 (force)
+      // enough to amortise the re-layout; variants 10 (never) / 11 (hm forced) / 15 (hm2 forced)
       if (workspace && g_variant != 10 && g_variant != 99 && g_variant != 1 && g_variant != 2) {
         const bool pays = hm_pays(2, bs, nk, heads, channels, num_levels, num_query, num_point);
         const int LP = num_levels * num_point;
         // hm4 (software-pipelined, msda_hm4.hip): fp16 default where every pyramid level is
         // LDS-resident (tiny / small SCA: 106 vs 142 us at small SCA); for the base SCA call hm3 and
         // hm4 are level (571 vs 579 us kernel, profiles/r02) and hm3 stays.  Variant 17 forces hm4 for
-        // every shape it supports, 170 + k picks a chunk size, 200 + m a schedule / ablation, 16 hm3
+        // every shape it supports, 16 hm3
         const bool staged_all = spatial_shapes_host && g_variant == 0 && num_query >= 8192 &&
                                 msda_hm4_all_staged(spatial_shapes_host, bs, heads, channels, num_levels,
                                                     num_query, num_point);
-        const bool h4 = g_variant == 17 || (g_variant >= 170 && g_variant <= 179) ||
-                        (g_variant >= 200 && g_variant <= 712) || staged_all;
+        const bool h4 = g_variant == 17 || staged_all;
         if (spatial_shapes_host && h4) {
-          static const int kChunks[10] = {0, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 160};
           const int rc = msda_hm4_forward(
               BEVOPS_F16, BEVOPS_F16, value, spatial_shapes_host, reference_points, sampling_offsets,
               attention_weights, output, bs, nk, heads, channels, num_levels, num_query, num_point,
-              points_per_group, shared_offsets ? 1 : 0, 1.f, 1.f, 1.f, 1.f, workspace, workspace_bytes,
-              g_variant >= 170 && g_variant <= 179 ? kChunks[g_variant - 170] : 0,
-              g_variant >= 200 ? g_variant - 200 : 0, st);
+              points_per_group, shared_offsets ? 1 : 0, 1.f, 1.f, 1.f, 1.f, workspace, workspace_bytes, 0, 0, st);
           if (rc != BEVOPS_NOT_SUPPORTED || g_variant != 0) return rc;
         }
         // hm5 (msda_hm5.hip): hm3's planes, re-scheduled, plus the exact visibility pre-pass; default
         // for the 4-level x 8-point SCA shape.  Variants 1000 + flags select its A/B builds
-        if (spatial_shapes_host && ((g_variant >= 1000 && g_variant < 9192) || (g_variant == 0 && pays))) {
+        if (spatial_shapes_host && (g_variant == 1000 || g_variant == 1001 || (g_variant == 0 && pays))) {
           const int rc = msda_hm5_forward_f16(
               (const __half *)value, spatial_shapes_host, (const __half *)reference_points,
               (const __half *)sampling_offsets, (const __half *)attention_weights, (__half *)output,
@@ -919,7 +909,7 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
               shared_offsets ? 1 : 0, workspace, workspace_bytes, st);
           if (rc != BEVOPS_NOT_SUPPORTED || g_variant == 16) return rc;
         }
-        if ((g_variant >= 11 && g_variant <= 15) || pays) {
+        if (g_variant == 11 || g_variant == 15 || pays) {
           const int rc = msda_hm_forward_f16(
               (const __half *)value, spatial_shapes, spatial_shapes_host,
               (const __half *)reference_points, (const __half *)sampling_offsets,
@@ -942,14 +932,12 @@ extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_
       // enough (variant 17 forces it, 10 / 99 keep the layout-preserving kernels)
       if (workspace && spatial_shapes_host && g_variant != 10 && g_variant != 99 &&
           (ref_dtype == BEVOPS_F32 || ref_dtype == BEVOPS_F16) &&
-          (g_variant == 17 || g_variant >= 200 ||
-           hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point))) {
+          (g_variant == 17 || hm_pays(1, bs, nk, heads, channels, num_levels, num_query, num_point))) {
         const int rc = msda_hm4_forward(BEVOPS_I8, ref_dtype, value, spatial_shapes_host, reference_points,
                                         sampling_offsets, attention_weights, output, bs, nk, heads, channels,
                                         num_levels, num_query, num_point, points_per_group,
                                         shared_offsets ? 1 : 0, scale_value, scale_offset, scale_weight,
-                                        scale_out, workspace, workspace_bytes, 0,
-                                        g_variant >= 200 ? g_variant - 200 : 0, st);
+                                        scale_out, workspace, workspace_bytes, 0, 0, st);
         if (rc != BEVOPS_NOT_SUPPORTED) return rc;
       }
       if (ref_dtype == BEVOPS_F32)

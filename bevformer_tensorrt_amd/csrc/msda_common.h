@@ -231,7 +231,6 @@ int msda_hm4_forward(int dtype, int ref_dtype, const void *value, const int32_t 
                      void *workspace, size_t workspace_bytes, int chunk_override, int ablate, hipStream_t st);
 bool msda_hm4_all_staged(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P);
 void msda_hm4_set_no_occ(bool v);
-void msda_hm4_set_pair(int v);
 int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *shapes_host, int bs, int nk,
                   int heads, int C, int L, int nq, int P, void *packed, size_t packed_bytes, hipStream_t st);
 int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, size_t packed_bytes,
@@ -257,7 +256,6 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
                                     size_t plan_bytes, __half *sampled, int bs, int nk, int heads, int C, int L, int nq,
                                     int P, int ppg, hipStream_t st);
 void msda_hm5_set_plan_blocks(int k);
-void msda_hm5_set_plan_ablation(int abl);
 void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
                             hipStream_t st);
 bool msda_hm5_layout(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, void *tab,

@@ -26,7 +26,6 @@ namespace {
 
 constexpr int kPixBytes = 64;       // 32 ch x fp16
 constexpr int kTabBytes = 256;      // level table at the front of dynamic LDS
-constexpr int kStageBudget = 150 * 1024;
 
 __host__ __device__ inline int hm_nkp(int nk, int L) { return (nk + L + 2) & ~1; }
 
@@ -477,35 +476,16 @@ int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __
               const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp,
               int stage_level, size_t stage_bytes, bool threads512, unsigned copy_b,
               hipStream_t st) {
-  const bool stage = stage_level < d.L && stage_bytes > 0;
-  if (stage) {
-    const int chunk = 1024;
-    const int nchunk = (d.nq + chunk - 1) / chunk;
-    const size_t lds = kTabBytes + stage_bytes;
-    auto go = [&](auto kern, int T) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return (int)BEVOPS_FAILURE;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(T), lds, st, vh,
-                         (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk,
-                         stage_level, 0u);
-      return launch_status();
-    };
-    // one block per CU (the staged pyramid tail fills the LDS): 16 waves at <=128 VGPR, or
-    // 8 waves with the full register file (variant 13)
-    if (threads512) return go(msda_hm_kernel<PPL, CH, true, 512>, 512);
-    return go(msda_hm_kernel<PPL, CH, true, 1024>, 1024);
-  } else {
+  // (LDS staging of the pyramid tail with 1024- / 512-thread blocks and the two-copy layout -- variants 12 / 13 / 14
+  // of round 1, measured slower, profiles/r01c -- were removed from the library in round 5; the kernel template keeps
+  // their parameters)
+  (void)stage_level; (void)stage_bytes; (void)threads512;
+  {
     constexpr int T = 256;
     const int chunk = 128;
     const int nchunk = (d.nq + chunk - 1) / chunk;
-    if (copy_b)
-      hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T, true>),
-                         dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(T), kTabBytes, st, vh,
-                         (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk, d.L,
-                         copy_b);
-    else
-      hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
+    (void)copy_b;
+    hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
                          dim3(T), kTabBytes, st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d,
                          nkp, chunk, nchunk, d.L, 0u);
   }
@@ -537,8 +517,8 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
   const int LP = L * P;
   // default: hm2 for the many-point calls (SCA: L*P >= 16), hm for the few-point ones (TSA:
   // only half of an hm2 octet would own a point, and its two-copy re-layout costs more than
-  // it saves); variants 11-14 force hm flavours, 15 forces hm2
-  if ((variant == 15 || LP >= 16) && !(variant >= 11 && variant <= 14)) {
+  // it saves); variant 11 forces hm, 15 forces hm2
+  if ((variant == 15 || LP >= 16) && variant != 11) {
     const size_t need2 = hm2_bytes(bs, nk, heads, L);
     const bool lp_ok = LP == 4 || LP == 8 || LP == 16 || LP == 32 || LP == 64;
     if (workspace && workspace_bytes >= need2 && need2 < 0xFFFFFF00ull && lp_ok &&
@@ -566,7 +546,7 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
   const int nkp = hm_nkp(nk, L);
   __half *vh = static_cast<__half *>(workspace);
   // variant 14: two copies (A: even-start pairs, B: odd-start pairs) -> 2 lines per sample
-  const bool two = variant == 14 && workspace_bytes >= 2 * one + 128 && 2 * one + 128 < 0xFFFFFF00ull;
+  const bool two = false;
   const unsigned copy_b = two ? (unsigned)(one + 64) : 0u;
   const size_t need = two ? 2 * one + 128 : one;
   {
@@ -577,26 +557,8 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
   // LDS staging needs the shapes on the host: stage the longest tail of levels that fits
   int stage_level = L;
   size_t stage_bytes = 0;
-  if (shapes_host && (variant == 12 || variant == 13)) {  // staging is opt-in
-    int dst = 0;
-    int starts[kMaxLevels + 1];
-    for (int l = 0; l < L; ++l) {
-      starts[l] = dst;
-      dst += (shapes_host[2 * l] * shapes_host[2 * l + 1] + 1) & ~1;
-    }
-    for (int l = 0; l < L; ++l) {
-      const size_t bytes = (size_t)(nkp - starts[l]) * kPixBytes;
-      if (bytes <= (size_t)kStageBudget) {
-        stage_level = l;
-        stage_bytes = bytes;
-        break;
-      }
-    }
-    // staging one whole plane per 1024-query block only pays when a plane has many queries
-    if (nq < 2048) { stage_level = L; stage_bytes = 0; }
-  }
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
-  const bool t512 = variant == 13;
+  const bool t512 = false;
   switch (LP / 4) {
     case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
     case 2: return launch_hm<2, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);

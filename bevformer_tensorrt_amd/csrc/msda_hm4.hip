@@ -731,16 +731,11 @@ inline int h4_box_bytes(int LP) { return (kH4Threads / 8) * (LP * 16 + 16); }
 // under the 128-register cap) takes 950 us instead of 565: fp16 keeps the one-block plan.
 constexpr int kOccStageCap = 40 * 1024;
 thread_local bool g_h4_no_occ = false;   // variant 19 / the ablation variants: the one-block plan for int8 too
-// int8, L*P = 32: pixel-pair entries in the big set (kernel flag 2048).  A/B switch (bevops_msda_set_variant 21 / 22 on,
-// 23 / 24 off); the default is what profiles/r04/msda_i8_pair_ab.jsonl measured faster
-constexpr int kH4PairDefault = 0;
-thread_local int g_h4_pair = kH4PairDefault;
-
 struct H4Plan {
   Hm3Plan p;
   int nbig;   // tap batches served by L1/L2
   bool occ2;  // the two-blocks-per-CU plan
-  bool pair;  // int8: 64-byte pixel-pair entries in the big set (g_bytes is adjusted)
+  bool pair;  // (always false since round 5: the pixel-pair entry format of the int8 big set was removed)
 };
 
 bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl, bool i8) {
@@ -748,26 +743,18 @@ bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq
   const int bt = LP >= 4 ? 4 : LP;
   pl.occ2 = false;
   pl.pair = false;
-  auto pair_mode = [&]() {
-    if (i8 && g_h4_pair && LP == 32 && (pl.nbig == 4 || pl.nbig == 6 || pl.nbig == 8)) {
-      pl.pair = true;
-      pl.p.g_bytes = (size_t)bs * heads * pl.p.t.g_entries * kLdsPixBytes;
-    }
-  };
   if (i8 && !g_h4_no_occ && LP == 32) {
     // (hm3_plan budgets the staged planes as kLdsLimit - kTab - box bytes: a cap is a larger pretended box)
     if (hm3_plan(shapes_host, bs, heads, L, nq, kLdsLimit - kTab - kOccStageCap, pl.p) && pl.p.t.ls < L &&
         (pl.p.t.ls * P) % bt == 0 && pl.p.t.ls * P / bt == 6) {
       pl.nbig = 6;
       pl.occ2 = true;
-      pair_mode();
       return true;
     }
   }
   if (!hm3_plan(shapes_host, bs, heads, L, nq, h4_box_bytes(LP), pl.p)) return false;
   if ((pl.p.t.ls * P) % bt) return false;  // a batch never straddles the big / staged boundary
   pl.nbig = pl.p.t.ls * P / bt;
-  pair_mode();
   return true;
 }
 
@@ -787,20 +774,10 @@ int h4_go(const H4Args &a, hipStream_t st) {
 // (the caller keeps its older kernels for those).
 template <bool I8, bool U8W, typename RefT, bool MASKED>
 int h4_dispatch(int LP, int nbig, bool occ2, bool pair, const H4Args &a, int ablate, hipStream_t st) {
-  if (ablate) {  // timing ablations, base SCA shape only (tools/hm4_probe.py)
-    if constexpr (!MASKED && !U8W) {
-      if (LP == 32 && nbig == 4 && a.d.ppg == 4 && a.d.P % 4 == 0) {
-#define BEVOPS_H4_ABL(A) if (ablate == A) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, A>(a, st);
-        BEVOPS_H4_ABL(1) BEVOPS_H4_ABL(2) BEVOPS_H4_ABL(3) BEVOPS_H4_ABL(4) BEVOPS_H4_ABL(8) BEVOPS_H4_ABL(12)
-        BEVOPS_H4_ABL(15) BEVOPS_H4_ABL(16) BEVOPS_H4_ABL(19) BEVOPS_H4_ABL(31) BEVOPS_H4_ABL(11) BEVOPS_H4_ABL(7)
-        if (ablate == 512) return h4_go<32, 4, I8, U8W, RefT, MASKED, true, 0>(a, st);
-        BEVOPS_H4_ABL(256) BEVOPS_H4_ABL(384) BEVOPS_H4_ABL(320)
-        BEVOPS_H4_ABL(32) BEVOPS_H4_ABL(64) BEVOPS_H4_ABL(96) BEVOPS_H4_ABL(128) BEVOPS_H4_ABL(160) BEVOPS_H4_ABL(224)
-#undef BEVOPS_H4_ABL
-      }
-    }
-    return BEVOPS_NOT_SUPPORTED;
-  }
+  // (the schedule / ablation timing builds of round 2 -- profiles/r02/hm4_ablation.jsonl, hm4_schedule_variants.jsonl --
+  // and the pixel-pair entry format of round 4 -- profiles/r04/msda_i8_pair_ab.jsonl: 40 % fewer bytes fetched, 4-16 %
+  // slower -- were removed from the library in round 5; the kernel template keeps their flag bits)
+  if (ablate || pair) return BEVOPS_NOT_SUPPORTED;
   // points of an owner lane (4 of them when L*P = 32) share ONE run of reference points
   const bool rr = LP == 32 && a.d.ppg == 4 && a.d.P % 4 == 0;
   // production schedule (profiles/r02/hm4_variants.jsonl): fp16 requests the next operands at
@@ -814,22 +791,6 @@ int h4_dispatch(int LP, int nbig, bool occ2, bool pair, const H4Args &a, int abl
     return h4_go<LP_, NBIG_, I8, U8W, RefT, MASKED, false, PROD>(a, st);                  \
   }
   if constexpr (I8 && !MASKED) {
-    if (pair) {   // pixel-pair entries in the big set (h4_plan: L*P = 32 only)
-      if (LP != 32) return BEVOPS_NOT_SUPPORTED;
-      if (occ2) {
-        if (nbig != 6) return BEVOPS_NOT_SUPPORTED;
-        if (rr) return h4_go<32, 6, I8, U8W, RefT, MASKED, true, PROD | 1024 | 64 | 2048>(a, st);
-        return h4_go<32, 6, I8, U8W, RefT, MASKED, false, PROD | 1024 | 64 | 2048>(a, st);
-      }
-#define BEVOPS_H4_PAIR(NBIG_)                                                                  \
-  if (nbig == NBIG_) {                                                                         \
-    if (rr) return h4_go<32, NBIG_, I8, U8W, RefT, MASKED, true, PROD | 2048>(a, st);          \
-    return h4_go<32, NBIG_, I8, U8W, RefT, MASKED, false, PROD | 2048>(a, st);                 \
-  }
-      BEVOPS_H4_PAIR(4) BEVOPS_H4_PAIR(6) BEVOPS_H4_PAIR(8)
-#undef BEVOPS_H4_PAIR
-      return BEVOPS_NOT_SUPPORTED;
-    }
     // the two-blocks-per-CU plan (h4_plan): <= 128 VGPRs, one big batch in flight
     if (occ2) {
       if (LP != 32 || nbig != 6) return BEVOPS_NOT_SUPPORTED;
@@ -861,7 +822,6 @@ int h4_chunk(const Hm3Plan &p, int nq, int variant_chunk) {
 }  // namespace
 
 void msda_hm4_set_no_occ(bool v) { g_h4_no_occ = v; }
-void msda_hm4_set_pair(int v) { g_h4_pair = v < 0 ? kH4PairDefault : v; }   // < 0: back to the default
 
 size_t msda_hm4_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, bool i8) {
   H4Plan pl;

@@ -717,11 +717,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 // (two slices per CU measured best on the 6-camera rig: 108 us per call against 124 for one block per 1 280-query chunk,
 // 112 / 115 with three / four, profiles/r05/sca_plan_ab.jsonl; touching a slice's offset / logit rows ahead of the loop
 // so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
-static thread_local int g_h5_plan_k = 2, g_h5_plan_abl = 0;
+static thread_local int g_h5_plan_k = 2;
 void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
-// TIMING builds of the planned kernel (outputs are not the operator's): 1 no big-level taps, 2 no staged taps, 3 neither,
-// 4 operands loaded once per block
-void msda_hm5_set_plan_ablation(int abl) { g_h5_plan_abl = abl; }
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
@@ -760,15 +757,7 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
   auto kern = msda_hm5_kernel<2, THREADS, 0, 3, false, false>;
-  bool ok = false;
-  switch (g_h5_plan_abl) {
-    case 1: kern = msda_hm5_kernel<2, THREADS, 1, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 1, 3, false, false>>(lds); break;
-    case 2: kern = msda_hm5_kernel<2, THREADS, 2, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 2, 3, false, false>>(lds); break;
-    case 3: kern = msda_hm5_kernel<2, THREADS, 3, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 3, 3, false, false>>(lds); break;
-    case 4: kern = msda_hm5_kernel<2, THREADS, 4, 3, false, false>; ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 4, 3, false, false>>(lds); break;
-    default: ok = ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 0, 3, false, false>>(lds); break;
-  }
-  if (!ok) return (int)BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 0, 3, false, false>>(lds)) return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)
@@ -779,10 +768,11 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   return launch_status();
 }
 
-// flags (A/B switches, bevops_msda_set_variant(1000 + flags)): 1 no visibility pre-pass; 2 768-thread blocks;
-// bits 2..5 ablations (4 big taps, 8 staged taps, 16 operand stream, 32 store; they imply "no pre-pass");
-// 128 chunks of 2560 queries; 256 records through the LDS mailbox instead of DPP; 512 32 persistent blocks per plane on strided
-// 256-query sub-chunks instead of one block per 1 280-query chunk (rig geometry 278 vs 271 us); 1024 no raised priority for the load-issuing segment
+// flags (A/B switch of the tests, bevops_msda_set_variant(1000 + flags)): 1 = no visibility pre-pass (every item is
+// sampled; the partner of the default).  The other builds of rounds 3 / 4 -- 768-thread blocks, 2 560-query chunks,
+// records through an LDS mailbox, persistent blocks on strided sub-chunks, no raised priority, the level-class split
+// probe and the ablation (timing) builds -- were measured (design/msda.md, profiles/r03, profiles/r04) and removed from
+// the library in round 5; the kernel template keeps their parameters.
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,
@@ -794,73 +784,18 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   if (pl.t.ls != 2) return BEVOPS_NOT_SUPPORTED;   // two big + two staged levels (the base SCA pyramid)
   if ((double)bs * nq * heads * 32 * 4.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;  // 32-bit offsets
   if (workspace_bytes < msda_hm5_workspace_bytes(shapes_host, bs, heads, C, L, nq, P)) return BEVOPS_NOT_SUPPORTED;
+  if (flags & ~1) return BEVOPS_NOT_SUPPORTED;
   const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
   char *gset = static_cast<char *>(workspace);
   char *sset = gset + g_room;
   unsigned char *vis = reinterpret_cast<unsigned char *>(gset + ((g_room + pl.s_bytes + 255) & ~size_t(255)));
-  unsigned *queue = nullptr;
   if (!prepacked) msda_hm3_repack_launch(value, gset, sset, &pl.t, bs, nk, heads, st);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
-  const int abl = (flags >> 2) & 15;
-  const bool listed = !(flags & 1) && abl == 0;
-  if (listed) {
-    const unsigned n_pair = (unsigned)bs * (unsigned)nq;
-    const unsigned waves = (n_pair + 63u) / 64u;
-    hipLaunchKernelGGL(msda_hm5_vis_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, ref, off, out, vis, d, pl.t,
-                       n_pair);
-  }
-  const int chunk = (flags & 128) ? 2 * kH5Chunk : kH5Chunk;
-  // Level-class split probe (round-3 review, item 2: "overlap across blocks, not inside a wave"): the call as TWO
-  // kernels that can share a CU -- A takes the big levels' samples through L2 with NO plane image in LDS, B the
-  // staged levels' samples from its LDS image -- timed alone and concurrently on two streams by
-  // tools/sca_split_probe.py.  These are TIMING builds (each leaves the other class's samples out, so the output is
-  // not the operator's); whether a correct pair with a partial-sum hand-off is worth building is what they measure.
-  //   2048: A (no staged taps, no LDS image); 4096: B (no big-level taps); + 2: 1024-thread blocks instead of 512
-  if (flags & (2048 | 4096)) {
-    Hm3Plan pa = pl;
-    if (flags & 2048) pa.stage_bytes = 0;
-    const bool wide = (flags & 2) != 0;
-    if (flags & 2048) {
-      if (wide) return h5_go<2, 1024, 2, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-      return h5_go<2, 512, 2, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-    }
-    if (wide) return h5_go<2, 1024, 1, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-    return h5_go<2, 512, 1, 0, false>(pa, gset, sset, ref, off, logit, out, d, vis, chunk, st);
-  }
-#define BEVOPS_H5(KERN_, THREADS_, ABL_, LISTED_) \
-  return KERN_<2, THREADS_, ABL_, LISTED_ ? 1 : 0>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
-  if (!(flags & 256)) {   // default: records through DPP
-#define BEVOPS_H5X(THREADS_, ABL_, LISTED_) \
-  return h5_go<2, THREADS_, ABL_, LISTED_ ? 1 : 0, false>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st)
-    if (flags & 2) {
-      if (abl) return BEVOPS_NOT_SUPPORTED;
-      if (listed) BEVOPS_H5X(768, 0, true);
-      BEVOPS_H5X(768, 0, false);
-    }
-    if ((flags & 1024) && abl == 0) {   // A/B: WITHOUT the raised priority of the load-issuing segment
-      if (listed) BEVOPS_H5X(1024, 16, true);
-      BEVOPS_H5X(1024, 16, false);
-    }
-    if (abl == 0 && (flags & 512) && !(flags & 128)) {   // A/B: 32 persistent blocks per plane on strided sub-chunks
-      if (listed) return h5_go<2, 1024, 0, 1, false, true>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st, queue);
-      return h5_go<2, 1024, 0, 0, false, true>(pl, gset, sset, ref, off, logit, out, d, vis, chunk, st, queue);
-    }
-    switch (abl) {
-      case 0: if (listed) BEVOPS_H5X(1024, 0, true); BEVOPS_H5X(1024, 0, false);
-      case 1: BEVOPS_H5X(1024, 1, false);
-      case 2: BEVOPS_H5X(1024, 2, false);
-      case 4: BEVOPS_H5X(1024, 4, false);
-      case 8: BEVOPS_H5X(1024, 8, false);
-      case 12: BEVOPS_H5X(1024, 12, false);
-      case 14: BEVOPS_H5X(1024, 14, false);
-      default: return BEVOPS_NOT_SUPPORTED;
-    }
-#undef BEVOPS_H5X
-  }
-  if (abl) return BEVOPS_NOT_SUPPORTED;
-  if (listed) BEVOPS_H5(h5_go, 1024, 0, true);
-  BEVOPS_H5(h5_go, 1024, 0, false);
-#undef BEVOPS_H5
+  if (flags & 1) return h5_go<2, 1024, 0, 0, false>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
+  const unsigned n_pair = (unsigned)bs * (unsigned)nq;
+  const unsigned waves = (n_pair + 63u) / 64u;
+  hipLaunchKernelGGL(msda_hm5_vis_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, ref, off, out, vis, d, pl.t, n_pair);
+  return h5_go<2, 1024, 0, 1, false>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
 }
 
 }  // namespace bevops

@@ -423,12 +423,6 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
   }
 }
 
-thread_local int g_tile_rows = 0;   // bevops_tile_gemm_set_variant: 0 measured policy, 64 / 128 force the tile height (A/B)
-// wide steps (KB = 128) of the int8 chain's plain GEMMs: -1 the policy of launch_tile_gemm, 0 never, 1 wherever legal
-// (bevops_tile_gemm_set_variant 255 / 256; A/B)
-thread_local int g_tile_wide = -1;
-constexpr int kWidePolicyMinK = 1 << 30;   // policy: wide steps from this K on (set from profiles/r04/tile_wide_ab.jsonl)
-
 struct ConvGeom { int cin = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, ks = 1; size_t in_elems = 0; };
 
 template <int MODE>
@@ -469,16 +463,11 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool narrow = N <= 64;                    // 64-column tiles: no matrix work on columns that do not exist
   const int tn = narrow ? 64 : 128;
   p.tiles_n = (N + tn - 1) / tn;
-  // 64-row tiles (four blocks per CU, twice the tiles) are an A/B build only (bevops_tile_gemm_set_variant(64)): the
-  // idea -- layers whose 128-row tiling is one sparse round of long k-chains would hide the chain latency better with
-  // more, smaller tiles in flight -- measured 3-10 % SLOWER on every base-model layer and flavour
-  // (profiles/r04/tile_rows_ab.jsonl: e.g. ResNet stage-3 conv1 fp16 43.7 vs 39.3 us, FFN fc2 32.2 vs 28.0, int8 conv1
-  // 25.8 vs 24.9): half the matrix work per staged weight byte and per barrier costs more than the extra chains hide.
-  const bool rows64 = g_tile_rows == 64;
-  // wide steps: int8 activations, no convolution mode, 128-column tiles, whole 128-byte steps
-  const bool wide_ok = MODE == kS8 && cg.cin == 0 && !narrow && !rows64 && K % 128 == 0;
-  const bool wide = wide_ok && (g_tile_wide < 0 ? K >= kWidePolicyMinK : g_tile_wide == 1);
-  const int tm = rows64 ? 64 : kTM;
+  // 128-row tiles, 64-byte k-steps.  Two other builds were measured in round 4 and removed from the library in round
+  // 5 (the kernel template keeps their parameters): 64-row tiles (four blocks per CU: 3-10 % SLOWER on every
+  // base-model layer and flavour, profiles/r04/tile_rows_ab.jsonl) and 128-byte k-steps for the int8 chain's plain
+  // GEMMs (bit-identical, slower: a step costs 0.53 us whatever it holds, profiles/r04/tile_wide_ab.jsonl)
+  const int tm = kTM;
   const long long tiles = (long long)p.tiles_n * ((M + tm - 1) / tm);
   if (tiles > 0x3fffffffLL) return BEVOPS_NOT_SUPPORTED;
   p.tiles_total = (int)tiles;
@@ -487,21 +476,8 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool conv = cg.cin > 0, out8 = out_dtype == BEVOPS_I8;
 #define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                                 \
   do {                                                                                                                 \
-    if constexpr (MODE == kS8 && !CONV_) {                                                                             \
-      if (wide) {                                                                                                      \
-        constexpr size_t lds = (size_t)tile_lds_bytes<128>(kTM);                                                       \
-        if (!ensure_dynamic_lds<tile_gemm_kernel<kS8, OUT8_, 2, false, RES8_, 2, 128>>(lds)) return BEVOPS_FAILURE;    \
-        hipLaunchKernelGGL((tile_gemm_kernel<kS8, OUT8_, 2, false, RES8_, 2, 128>), grid, dim3(256), lds, st, p);      \
-        return launch_status();                                                                                        \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (rows64) {                                                                                                      \
-      if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p); \
-      else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 1>), grid, dim3(256), 0, st, p);        \
-    } else {                                                                                                           \
-      if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p); \
-      else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);        \
-    }                                                                                                                  \
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);   \
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);          \
     return launch_status();                                                                                            \
   } while (0)
   if constexpr (MODE == kF16) {
@@ -601,13 +577,4 @@ extern "C" int bevops_conv_tile_int8(const void *x_q, float scale_a, const void 
   if (rc != BEVOPS_SUCCESS) return rc;
   return launch_tile_gemm<kS8>(x_q, scale_a, w_q_taps, w_scales, scale_w, bias, residual, out_dtype, out, scale_out,
                                (long long)B * cg.hout * cg.wout, Cout, ksize * ksize * Cin, relu, stream, cg);
-}
-
-// A/B switch (thread-local): 0 = the policy of launch_tile_gemm, 64 / 128 = force the tile height, 256 / 255 = wide
-// k-steps of the int8 chain's plain GEMMs wherever legal / never.  Returns the previous tile-height value.
-extern "C" int bevops_tile_gemm_set_variant(int rows) {
-  const int prev = g_tile_rows;
-  g_tile_rows = (rows == 64 || rows == 128) ? rows : 0;
-  g_tile_wide = rows == 256 ? 1 : (rows == 255 ? 0 : -1);   // 256: wide steps wherever legal, 255: never; else the policy
-  return prev;
 }

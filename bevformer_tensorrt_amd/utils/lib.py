@@ -93,7 +93,6 @@ SIGNATURES = {
                                    c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_linear_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                          c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
-    "bevops_tile_gemm_set_variant": (c_int, [c_int]),
     "bevops_small_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),

@@ -131,11 +131,18 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
 
 /* Tuning hook: selects an internal MSDA kernel variant for subsequent calls from
  * this thread (0 = automatic).  Results are identical across variants; exists so
- * bench/tuning scripts can A/B them in one process (the values are listed where they are decoded:
- * csrc/msda.hip, bevops_msda_set_variant and bevops_msda_forward_ws; e.g. 10 = layout-preserving kernels, 16 / 17 =
- * forced head-major generations, 21 .. 24 = the int8 head-major call with pixel-pair / 2x2-footprint entries on the
- * two-blocks / one-block plan, 1000 + flags = builds of the fp16 SCA sampler).  A packed value
- * (bevops_msda_pack_value) must be sampled under the variant it was packed under.  Returns the previous value. */
+ * tests / tuning scripts can A/B a default against its partner in one process.  The complete list (decoded in
+ * csrc/msda.hip: bevops_msda_set_variant, bevops_msda_forward_ws):
+ *    1, 2     other point-splits of the layout-preserving quad kernel;   99  the one-thread-per-output generic kernel
+ *    10       never a head-major kernel (what multi_scale_deformable_attn_local uses)
+ *    11 / 15  head-major generations hm / hm2 forced;  16  hm3;  17  hm4 wherever it is instantiated
+ *    19       int8 hm4 on the one-block-per-CU plan (partner of the default two-blocks plan)
+ *    1000 / 1001  the fp16 SCA sampler hm5 with / without its visibility pre-pass
+ *    3001 .. 3008 slices per CU of the planned fused SCA sampling (default 2; sticky until set again)
+ * (The measured-and-rejected builds of rounds 1-4 -- LDS-staged hm, two-copy hm, hm4 chunk sizes / schedule ablations,
+ * int8 pixel-pair entries, hm5 with 768 threads / mailbox / persistent blocks / level-class split -- are no longer in
+ * the library; their measurements are under profiles/.)  A packed value (bevops_msda_pack_value) must be sampled under
+ * the variant it was packed under.  Returns the previously REQUESTED value. */
 int bevops_msda_set_variant(int variant);
 
 
@@ -383,13 +390,6 @@ int bevops_linear_int8_fused(const void *x_f16, float scale_a, const void *w_q, 
  * next to bevops_tsgemm_f16 and bevops_linear_bias_act. */
 int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                          void *out, long long M, int N, int K, int relu, void *stream);
-/* A/B switch of the tiled GEMM family's tile height (thread-local; affects bevops_tile_gemm_f16, bevops_linear_int8*,
- * bevops_conv_tile_*): 0 / 128 = the default 128-row tiles, 64 = 64-row tiles (four blocks per CU; measured 3-10 %
- * slower on the base-model layers, profiles/r04/tile_rows_ab.jsonl).  Both tilings give bit-identical results.
- * 256 / 255 = 128-byte k-steps of the int8-chain GEMMs (bevops_linear_int8 / bevops_linear_int8_chain with int8
- * activations, N > 64, K % 128 == 0) wherever legal / never (also an A/B build, bit-identical, measured slower:
- * profiles/r04/tile_wide_ab.jsonl); any other value restores the launcher's policy.  Returns the previous tile height. */
-int bevops_tile_gemm_set_variant(int rows);
 /* Convolution on channels-last fp16 activations as an implicit GEMM on the same tiled skeleton (no column
  * buffer, no strided copy): kernel ksize x ksize in {1, 3}, pad ksize / 2, any stride.  x [B, H, W, Cin],
  * weight_taps [Cout][ksize][ksize][Cin] (= weight.permute(0, 2, 3, 1)), out [B, Hout, Wout, Cout] =

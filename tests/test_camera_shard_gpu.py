@@ -25,7 +25,7 @@ def nccl_group():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["gather", "reduce"])
+@pytest.mark.parametrize("mode", ["gather", "reduce", "scatter"])
 def test_exchange_primitives_on_rccl(nccl_group, mode):
     from bevformer_tensorrt_amd.camera_shard import CameraExchange, gather_camera_features, reduce_camera_slots
     dist = nccl_group
@@ -37,9 +37,14 @@ def test_exchange_primitives_on_rccl(nccl_group, mode):
     assert torch.equal(reduce_camera_slots(part.clone(), dist), part)
     ex = CameraExchange(dist, 6, mode)
     assert list(ex.cams) == list(range(6)) and ex.world == 1
+    if mode == "scatter":       # the query-range collectives (one rank: both are identities, through RCCL)
+        q = torch.randn(1, 2500, 256, generator=g).half().cuda()
+        assert ex.query_range(2500) == (0, 2500, 2500)
+        assert torch.equal(ex.all_gather_queries(q, 2500), q)
+        assert torch.equal(ex.reduce_scatter_queries(q, 2500), q)
 
 
-@pytest.mark.parametrize("mode", ["gather", "reduce"])
+@pytest.mark.parametrize("mode", ["gather", "reduce", "scatter"])
 def test_model_with_exchange_equals_plain_model(nccl_group, mode):
     """BEVFormer-tiny (fp16, HIP operators) with cams / CameraExchange wired in -- the sharded code path of
     bevformer.py with its per-camera sampler calls and collectives -- against the plain single-GPU path
@@ -68,16 +73,17 @@ def test_model_with_exchange_equals_plain_model(nccl_group, mode):
         assert (bs.float() - bp.float()).abs().max().item() <= 2e-2 * max(1.0, bp.float().abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["tiny", "base"])
-def test_sharded_frame_replays_from_a_hip_graph_with_its_collectives(nccl_group, name):
-    """The "reduce" exchange under graph replay: the fused sampler on this rank's cameras, ONE all-reduce per encoder
-    layer, the RCCL collectives captured together with the kernels (FrameRunner(graph=True, gather=...)) -- against
-    the plain single-GPU graph runner on the same frames."""
+@pytest.mark.parametrize("name,mode", [("tiny", "reduce"), ("base", "reduce"), ("tiny", "scatter"), ("base", "scatter")])
+def test_sharded_frame_replays_from_a_hip_graph_with_its_collectives(nccl_group, name, mode):
+    """The "reduce" / "scatter" exchanges under graph replay: the fused sampler on this rank's cameras, ONE all-reduce
+    (or one all-gather + one reduce-scatter of the query rows) per encoder layer, the RCCL collectives captured together
+    with the kernels (FrameRunner(graph=True, gather=...)) -- against the plain single-GPU graph runner on the same
+    frames."""
     from bevformer_tensorrt_amd import bevformer as B, geometry as G
     from bevformer_tensorrt_amd.camera_shard import CameraExchange
     dev, dtype = torch.device("cuda"), torch.float16
     model = B.BEVFormer(name, seed=0).to(dev, dtype)
-    ex = CameraExchange(nccl_group, 6, "reduce")
+    ex = CameraExchange(nccl_group, 6, mode)
     H, W = B.CONFIGS[name]["image"]
     l2i = G.synthetic_lidar2img((H, W)).to(dev)
     g = torch.Generator().manual_seed(0)

@@ -11,7 +11,13 @@ backbone and the SCA sampler only for ITS cameras and joins one exchange per enc
       the bar is 2e-5 on values of order 1, with bit equality reported when it holds;
   exchange "reduce" (all-reduce of the masked partial sums): the camera sum is re-associated:
       2e-5 as well.
-Worlds 2 and 4 (uneven shards 2+2+1+1), two frames so that prev_bev and the TSA shift are live."""
+  exchange "scatter" (round 5: cameras sharded as above AND the rest of the encoder by query range -- TSA, norms, FFN
+      and output projections on a rank's own rows, one all-gather + one reduce-scatter per layer): every per-query
+      operator sees the same row with the same operands, the camera sum is re-associated as in "reduce": 2e-5;
+      "scatter-ragged" uses an 11 x 13 BEV grid whose 143 queries do not divide by the world size (short / padded
+      last range), "scatter-fused" the operator set with the fused sampling op.
+Worlds 2 and 4 (uneven shards 2+2+1+1), two frames so that prev_bev and the TSA shift are live (the first frame has no
+history: TSA's keys are the gathered current queries)."""
 import os
 import socket
 
@@ -77,9 +83,9 @@ def _worker(rank, world, port, mode, q):
     from bevformer_tensorrt_amd import bevformer as B, geometry as G
     from bevformer_tensorrt_amd.camera_shard import CameraExchange
     from util_refops import RefOps
-    B.CONFIGS["unit"] = dict(B.CONFIGS["tiny"], image=(96, 160), bev=(12, 12))
-    fused = mode == "reduce-fused"
-    mode = "reduce" if fused else mode
+    B.CONFIGS["unit"] = dict(B.CONFIGS["tiny"], image=(96, 160), bev=(11, 13) if mode.endswith("-ragged") else (12, 12))
+    fused = mode.endswith("-fused")
+    mode = mode.split("-")[0]
     model = B.BEVFormer("unit", ops=_FusedRefOps() if fused else RefOps, seed=0)
     ex = CameraExchange(dist, 6, mode)
     sharded = _run_frames(model, B, G, ex.cams, ex)
@@ -94,7 +100,9 @@ def _worker(rank, world, port, mode, q):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather"), (8, "gather"), (2, "reduce"), (4, "reduce"),
-                                        (8, "reduce"), (2, "reduce-fused"), (8, "reduce-fused")])
+                                        (8, "reduce"), (2, "reduce-fused"), (8, "reduce-fused"),
+                                        (2, "scatter"), (4, "scatter"), (8, "scatter"), (4, "scatter-ragged"),
+                                        (8, "scatter-ragged"), (2, "scatter-fused")])
 def test_sharded_model_equals_single_process(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -102,7 +110,16 @@ def test_sharded_model_equals_single_process(world, mode):
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = []
+    import queue as _queue
+    import time as _time
+    t_end = _time.time() + 600
+    while len(res) < len(procs) and _time.time() < t_end:
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:        # a worker that died reports nothing: fail now, not after the full timeout
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert len(res) == len(procs)
     for p in procs:
         p.join(timeout=120)
     assert sorted(n for *_, n in res) == sorted(len([c for c in range(6) if c % world == r]) for r in range(world))

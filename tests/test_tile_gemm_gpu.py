@@ -163,60 +163,3 @@ def test_narrow_tile_layers():
         acc = q.cpu().long() @ wq.cpu().long().t()
         want8 = torch.relu(acc.double() * (s_x * s_w) + b.cpu().double() + r[rows].cpu().double())
         assert (o8.cpu().double() - want8).abs().max().item() <= 2e-3 * max(1.0, want8.abs().max().item())
-
-
-@pytest.mark.parametrize("M,N,K", [(34800, 256, 1024), (40000, 512, 256), (900, 256, 256), (129, 136, 72), (70, 64, 64)])
-def test_64_and_128_row_tiles_are_bit_identical(M, N, K):
-    """The tile height is a scheduling choice (bevops_tile_gemm_set_variant: 64-row tiles = four blocks per CU for
-    the latency-bound layers): every output element sees the same k-steps in the same order on the same matrix
-    instruction, so both tilings must agree BIT FOR BIT -- fp16, int8 with int8 identity rows and int8 output, the
-    fused-quantise flavour, and the convolution mode."""
-    import bevformer_tensorrt_amd as bev
-    from bevformer_tensorrt_amd.functions import int8_chain as C
-    from bevformer_tensorrt_amd.utils import load_library
-    lib = load_library()
-    g = torch.Generator().manual_seed(M + K)
-    x = torch.randn(M, K, generator=g).half().cuda()
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
-    b = torch.randn(N, generator=g).half().cuda()
-    r = torch.randn(M, N, generator=g).half().cuda()
-    K8 = (K + 15) // 16 * 16
-    a8 = torch.randint(-127, 128, (M, K8), generator=g, dtype=torch.int8).cuda()
-    w8 = torch.randint(-127, 128, (N, K8), generator=g, dtype=torch.int8).cuda()
-    r8 = torch.randint(-127, 128, (M, N), generator=g, dtype=torch.int8).cuda()
-    outs = {}
-    for rows in (64, 128):
-        prev = lib.bevops_tile_gemm_set_variant(rows)
-        try:
-            outs[rows] = (bev.tile_gemm(x, w, b, r, True),
-                          C.linear_int8_chain(a8, 0.02, w8, 0.001, b.float(), r8, 0.03, True, torch.int8, 0.05),
-                          C.linear_int8_chain(a8, 0.02, w8, 0.001, b.float(), r, 1.0, False, torch.float16),
-                          C.linear_int8_chain(x[:, :K // 16 * 16].contiguous(), 0.02, w8[:, :K // 16 * 16].contiguous(), 0.001,
-                                              b.float(), None, 1.0, False, torch.float16) if K >= 16 else None)
-        finally:
-            lib.bevops_tile_gemm_set_variant(prev)
-    for a, c in zip(outs[64], outs[128]):
-        if a is not None:
-            assert torch.equal(a, c)
-    want = _ref(x, w, b, r, True)
-    assert bool(((outs[64][0].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
-
-
-def test_conv_tiles_64_and_128_rows_agree():
-    import bevformer_tensorrt_amd as bev
-    from bevformer_tensorrt_amd.utils import load_library
-    lib = load_library()
-    g = torch.Generator().manual_seed(9)
-    x = torch.randn(2, 64, 29, 50, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(128, 64, 3, 3, generator=g) / 24).half().cuda()
-    b = torch.randn(128, generator=g).half().cuda()
-    outs = []
-    for rows in (64, 128):
-        prev = lib.bevops_tile_gemm_set_variant(rows)
-        try:
-            outs.append(bev.conv_nhwc(x, w, b, True, None, 1))
-        finally:
-            lib.bevops_tile_gemm_set_variant(prev)
-    assert torch.equal(outs[0], outs[1])
-    want = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b.float(), 1, 1))
-    assert (outs[0].float() - want).abs().max().item() <= 2e-2

@@ -66,15 +66,11 @@ if __name__ == "__main__":
     ap.add_argument("--mdconv-variant", type=int, default=0, help="bevops_mdconv_set_variant (A/B)")
     ap.add_argument("--no-clone", action="store_true", help="hand out the graph's output buffers instead of copies")
     ap.add_argument("--static-image", action="store_true", help="images already in the frame's static input buffer")
-    ap.add_argument("--tile-rows", type=int, default=0, help="bevops_tile_gemm_set_variant: 64 / 128 force the tile height (A/B)")
     a = ap.parse_args()
     if a.conv_variant or a.mdconv_variant:
         from bevformer_tensorrt_amd.utils import load_library
         load_library().bevops_conv3x3_c32_set_variant(a.conv_variant)
         load_library().bevops_mdconv_set_variant(a.mdconv_variant)
-    if a.tile_rows:
-        from bevformer_tensorrt_amd.utils import load_library
-        load_library().bevops_tile_gemm_set_variant(a.tile_rows)
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
         print(json.dumps(run(m, a.frames, dt, a.graph, a.int8, not a.no_clone, a.static_image)), flush=True)

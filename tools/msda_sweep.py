@@ -69,7 +69,7 @@ def time_call(fn, iters=30, warm=5):
 def main():
     lib = load_library()
     rows = []
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0,10,11,12,13").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,10,11,15,16,17").split(",")]
     for name, shape in SHAPES.items():
         for dtype in [getattr(torch, d) for d in os.environ.get('DTYPES', 'float16').split(',')]:
             for dist in (("uniform", "rig") if name.endswith("sca") else ("uniform",)):

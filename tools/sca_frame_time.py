@@ -3,7 +3,8 @@
 reference points of the 6-camera rig, WITHOUT the projection GEMM: one block per 1 280-query chunk
 (bevops_sca_forward_prepacked) against the balanced slices of a visibility plan (bevops_sca_forward_planned; k = slices
 per CU), under HIP-graph replay, interleaved.  One JSON line; --offsets S scales the N(0, 1) sampling offsets (pixels).
---once K: K plain launches of every flavour (for rocprofv3 --kernel-trace / --pmc runs)."""
+--once K: K plain launches of every flavour (for rocprofv3 --kernel-trace / --pmc runs).  (The ablation builds whose
+timings are in profiles/r05/sca_plan_ablation.jsonl were removed from the library after that measurement.)"""
 import argparse
 import json
 import os
@@ -22,7 +23,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--offsets", type=float, default=1.0)
 ap.add_argument("--once", type=int, default=0)
 ap.add_argument("--ks", default="1,2,3")
-ap.add_argument("--ablate", action="store_true", help="timing builds of the planned kernel (k = first of --ks): 1 no big-level taps, 2 no staged taps, 3 neither, 4 operands loaded once")
 args = ap.parse_args()
 
 g = torch.Generator().manual_seed(0)
@@ -67,16 +67,6 @@ fns = {"chunked": chunked, **{f"planned_k{k}": planned(k) for k in ks}}
 want = chunked()
 for name, fn in fns.items():
     assert torch.equal(fn(), want), name
-if args.ablate:
-    def ablated(a):
-        def fn():
-            handle.bevops_msda_set_variant(3000 + ks[0])
-            handle.bevops_msda_set_variant(3100 + a)
-            out = S._sample_planes(handle, planes, geom, ref, off, w, bm, plan)
-            handle.bevops_msda_set_variant(3100)
-            return out
-        return fn
-    fns = {f"planned_k{ks[0]}_abl{a}": ablated(a) for a in (0, 1, 2, 3, 4)}
 if args.once:
     for name, fn in fns.items():
         for _ in range(args.once):

@@ -5,6 +5,10 @@ projection + fused SCA sampling of the LOCAL cameras -- timed with 6 / 3 / 2 / 1
 G = 1 / 2 / 4 (max shard) / 8), next to the whole frame (HIP-graph replay).  Replicated time = whole frame - the
 6-camera per-camera part; the all-reduce of the "reduce" exchange is priced from the message size (20.48 MB fp16
 per layer) at the xGMI link rate.  Prints one JSON line per row and the predicted frame time per G.
+Round 5 adds the "scatter" exchange (cameras sharded AND the rest of the encoder sharded by query range): rank 0's
+compute of a G-rank frame is MEASURED as a HIP-graph replay of the real sharded forward with a wire-less stand-in for
+the exchange object (own rows = the first ceil(nq / G), the all-gather a local copy of the right size, the
+reduce-scatter a slice) -- every kernel rank 0 would launch, at the size it would launch it.
 usage: shard_amdahl.py [base] [--iters N]"""
 import argparse
 import json
@@ -39,6 +43,25 @@ class _LocalOnly:
 
     def reduce(self, t):
         return t
+
+
+class _LocalScatter:
+    """rank 0 of a G-rank "scatter" exchange without a wire (timing stand-in: the gathered rows are copies of rank
+    0's rows, so the VALUES of the frame are not the model's -- shapes, kernels and bytes moved locally are)"""
+    mode = "scatter"
+
+    def __init__(self, world, cams):
+        self.world, self.rank, self.cams = world, 0, cams
+
+    def query_range(self, nq):
+        per = -(-nq // self.world)
+        return 0, per, per
+
+    def all_gather_queries(self, local, nq):
+        return local.repeat(1, self.world, 1)[:, :nq].contiguous()
+
+    def reduce_scatter_queries(self, partial, nq):
+        return partial[:, : -(-nq // self.world)].contiguous()
 
 
 def main():
@@ -94,6 +117,25 @@ def main():
     print(json.dumps({"row": "split of the 1-GPU frame", "per_camera_ms": round(shard6, 3), "replicated_ms": round(replicated, 3),
                       "per_camera_share": round(shard6 / whole, 3)}), flush=True)
     msg = nq * B.EMBED * 2
+    # ---- "scatter": rank 0's whole sharded frame, measured (graph replay, wire-less exchange)
+    for Gn, ncam in ((1, 6), (2, 3), (4, 2), (8, 1)):
+        cams = list(range(ncam))
+        r2 = B.FrameRunner(model, dev, dtype, graph=True, cams=cams, gather=_LocalScatter(Gn, cams), clone_outputs=False)
+        r2.image_buffer.copy_(img)
+        for i in range(3):
+            r2.step(r2.image_buffer, can, l2i, "s")
+        t = time_ms(lambda: r2.step(r2.image_buffer, can, l2i, "s"), a.iters)
+        # per layer one all-gather + one reduce-scatter of the query rows = the bytes of one all-reduce; + the final
+        # all-gather.  "ring": every byte over ONE link pair; "direct": the (G - 1) peers' shards over their own links
+        ring = 0.0 if Gn == 1 else (layers * 2 + 1) * ((Gn - 1) / Gn * msg / (a.link_gbs * 1e9)) * 1e3
+        direct = 0.0 if Gn == 1 else (layers * 2 + 1) * (msg / Gn / (a.link_gbs * 1e9)) * 1e3
+        print(json.dumps({"row": f"scatter G={Gn} (rank 0 measured, no wire)", "max_local_cameras": ncam,
+                          "compute_ms": round(t, 3), "wire_ms_ring_one_link": round(ring, 3),
+                          "wire_ms_direct_links": round(direct, 3),
+                          "speedup_compute_only": round(whole / t, 2), "speedup_ring_exposed": round(whole / (t + ring), 2),
+                          "speedup_direct_exposed": round(whole / (t + direct), 2)}), flush=True)
+        del r2
+        torch.cuda.empty_cache()
     for Gn, ncam in ((1, 6), (2, 3), (4, 2), (8, 1)):
         # ring all-reduce on point-to-point links: 2 (G - 1) / G of the message crosses each link, both directions busy
         comm = 0.0 if Gn == 1 else layers * (2 * (Gn - 1) / Gn * msg / (a.link_gbs * 1e9)) * 1e3
