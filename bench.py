@@ -407,7 +407,16 @@ def frame_rooflines(bev, dev, iters=20):
                     % (100.0 * float(vis.float().mean())),
             "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters,
             "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}
+            "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None}
+        try:   # fabric bytes of the two kernels from the newest committed PMC passes (FETCH doubled: gfx950 correction)
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "sca_plan_pmc_fetch_write.json")))[-1]
+            pm = json.load(open(f))
+            tot = sum((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024 for k, v in pm.items()
+                      if isinstance(v, dict) and ("msda_hm5_kernel<2, 1024, 0, 3" in k or "sca_camera_reduce_kernel" in k))
+            out["roofline_frame"]["traffic"], out["roofline_frame"]["traffic_src"] = int(tot), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
         del feats, planes
     except Exception as exc:
         out["roofline_frame"] = {"error": repr(exc)[:200]}
@@ -443,7 +452,7 @@ class ModelFrames:
     default "reduce" exchange -- the frame is replayed from a HIP graph that holds its RCCL all-reduces too (the
     per-camera all-gather exchange runs eagerly)."""
 
-    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True, name="base"):
+    def __init__(self, dev, kind, world, rank, dist, exchange, calib=4, graph=True, name="base", sca_int8=False):
         from bevformer_tensorrt_amd import bevformer as B, geometry as G
         self.B, self.dev, self.kind, self.name = B, dev, kind, name
         dtype = torch.float16
@@ -453,7 +462,7 @@ class ModelFrames:
         self.img = torch.randn(1, 6, 3, H, W, generator=gen).to(dev, dtype)
         self.l2i = G.synthetic_lidar2img((H, W)).to(dev)
         cams = gather = None
-        if world > 1:
+        if world > 1 or dist is not None:     # (dist at world 1: the sharded code path on a one-rank group, --sharded-path)
             from bevformer_tensorrt_amd.camera_shard import CameraExchange
             gather = CameraExchange(dist, 6, exchange)
             cams = gather.cams
@@ -462,12 +471,13 @@ class ModelFrames:
             from bevformer_tensorrt_amd.quantization import build_int8_engine
             frames = [(self.img, self.can(i), self.l2i) for i in range(calib)]
             model, _, self.note = build_int8_engine(B, name, dev, frames, "entropy",
-                                                    chain=os.environ.get("BEVOPS_INT8_CHAIN", "1") != "0")
+                                                    chain=os.environ.get("BEVOPS_INT8_CHAIN", "1") != "0",
+                                                    sca_int8=sca_int8)
         else:
             model = B.BEVFormer(name, seed=0).to(dev, dtype)
         # N > 1: the "reduce" exchange (fused sampler on the local cameras, ONE all-reduce per encoder layer) is
         # captured with its RCCL collectives; the per-camera pipelined all-gathers run eagerly
-        self.graph = graph and (world == 1 or exchange in ("reduce", "scatter"))
+        self.graph = graph and (gather is None or exchange in ("reduce", "scatter"))
         self._shard = (cams, gather)
         # the graph's own output buffers are handed out (no per-frame clones), and the synthetic camera images sit in
         # the frame's static input buffer, where a serving caller's normalise pass (FrameRunner.step_raw) writes them
@@ -638,6 +648,9 @@ def main():
                          "cameras, one 20.5 MB collective per encoder layer, the frame replays from a HIP graph with its "
                          "RCCL collectives inside) or the per-camera pipelined all-gathers of the camera features "
                          "(BASELINE config 4's exchange: 6x the data, eager frames)")
+    ap.add_argument("--sharded-path", action="store_true",
+                    help="run the N > 1 code path (process group, camera / query sharding, collectives inside the frame's "
+                         "HIP graph) even with ONE rank: what the GPU test of this file's multi-GPU path uses on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="profiling runs: time the sampling hot path only (the line's value is then the hot-path rate)")
@@ -659,9 +672,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.sharded_path
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29571"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import bevformer_tensorrt_amd as bev
@@ -673,7 +689,7 @@ def main():
         frames = ModelFrames(dev, args.dtype, world, rank, dist, args.exchange)
         elapsed = run_frames(frames, args.steps, args.warmup, dev, dist)
         headline = {"elapsed": elapsed, "hip_graph": frames.graph, "note": frames.note, "protocol_sync": None}
-        if world == 1:
+        if not sharded:
             headline["protocol_sync"] = run_frames_protocol(frames, args.steps)
         del frames
         torch.cuda.empty_cache()
@@ -681,7 +697,7 @@ def main():
     # ---- sub-records (N = 1 and the hot-path step; at N > 1 the hot path is measured when asked to stand alone)
     my_cams = camera_shards(BASE["sca"]["bs"], world)[rank]
     hot = roofline = None
-    if not args.no_hot_path and (world == 1 or args.no_end_to_end):
+    if not args.no_hot_path and (not sharded or args.no_end_to_end):
         kind = "int8" if args.dtype == "int8" else "fp16"
         wl = build_workload(bev, kind, dev, my_cams)
         el, sca_events = run_hot_path(wl, args.steps, args.warmup, dev, dist, args.exchange, world)
@@ -690,10 +706,10 @@ def main():
                        "+ 6x decoder MSDA, op-test inputs (uniform-random reference points)",
                "value": round(args.steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / args.steps * 1e3, 4),
                "steps": args.steps, "warmup": args.warmup, "dtype": "i8" if kind == "int8" else "f16"}
-        if roofline is not None and world > 1:
+        if roofline is not None and sharded:
             roofline["note"] = ("N>1: rank 0's cameras only (bytes_per_launch counts them); the bracket spans the "
                                 "per-camera sampler calls of one encoder layer and the wait for its exchange")
-        if roofline is not None and world == 1 and kind == "fp16" and not args.no_geometry_extra:
+        if roofline is not None and not sharded and kind == "fp16" and not args.no_geometry_extra:
             try:
                 roofline.update(geometry_rooflines(bev, wl, dev))
             except Exception as exc:  # the contract line must still be printed
@@ -702,7 +718,7 @@ def main():
 
     # the other precision, measured in the SAME default run (the metric is "fp16/INT8")
     other = None
-    if world == 1 and not args.no_int8 and args.dtype == "fp16":
+    if not sharded and not args.no_int8 and args.dtype == "fp16":
         other = {"dtype": "i8"}
         if not args.no_hot_path:
             try:
@@ -727,10 +743,20 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:
                 other["end_to_end"] = {"error": repr(exc)[:300]}
+            try:   # the same engine with the SCA site on the INT8 plugin too (the reference's INT8 configs' choice)
+                f8 = ModelFrames(dev, "int8", 1, 0, None, args.exchange, sca_int8=True)
+                e8 = run_frames(f8, args.steps, args.warmup, dev, None)
+                other["end_to_end_sca_on_int8_plugin"] = {"value": round(args.steps / e8, 3), "unit": "frames/s",
+                                                          "ms_per_step": round(e8 / args.steps * 1e3, 4),
+                                                          "hip_graph": f8.graph, "build": f8.note}
+                del f8
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                other["end_to_end_sca_on_int8_plugin"] = {"error": repr(exc)[:300]}
 
     # BASELINE config 3: BEVFormer-small fp16 / INT8 end to end (same protocol pair)
     small = tiny = None
-    if world == 1 and not args.no_end_to_end and not args.no_small:
+    if not sharded and not args.no_end_to_end and not args.no_small:
         small = {"config": "BEVFormer-small: 6x(3x736x1280) -> ResNet-101-DCN (C5) + FPN level -> 3 encoder layers "
                            "(150x150 BEV queries) -> 6 decoder layers -> heads"}
         tiny = {"config": "BEVFormer-tiny (BASELINE config 2): 6x(3x480x800) -> ResNet-50 (C5) + FPN level -> 3 encoder "
@@ -749,12 +775,12 @@ def main():
                     rec[kind] = {"error": repr(exc)[:300]}
 
     frame_roof = {}
-    if world == 1 and not args.no_hot_path:
+    if not sharded and not args.no_hot_path:
         frame_roof = frame_rooflines(bev, dev)
         torch.cuda.empty_cache()
 
     bevdet = None
-    if world == 1 and not args.no_end_to_end and not args.no_small:
+    if not sharded and not args.no_end_to_end and not args.no_small:
         try:
             bevdet = bevdet_frames(dev, args.steps, args.warmup, not args.no_int8)
         except Exception as exc:
@@ -762,7 +788,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             v, sample = cpu_baseline()
             cpu = {"value": round(v, 5), "unit": "frames/s", "cores": torch.get_num_threads(),
                    "kind": "port",
@@ -797,7 +823,7 @@ def main():
                        "shapes": "SCA(6,30825,40000,4x8) TSA(2,40000,40000,1x4) dec(1,40000,900,1x4)",
                        "hip_graph": headline["hip_graph"] if headline else None,
                        "int8_build": headline["note"] if headline else None,
-                       "parallelism": f"cameras/{world}+all-{args.exchange}" if world > 1 else "single"},
+                       "parallelism": f"cameras/{world}+{args.exchange}" if sharded else "single"},
             "ranks_seen": dist.get_world_size() if dist is not None else 1,
             "roofline": roofline, "roofline_frame": frame_roof.get("roofline_frame"),
             "roofline_mfma": frame_roof.get("roofline_mfma"), "cpu_baseline": cpu,

@@ -733,14 +733,21 @@ def engine_dense_select(name, mod):
     return not name.endswith(("tsa.sampling_offsets", "tsa.attention_weights", "sca.value_proj"))
 
 
-def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, dense_select=None, decoder_int8=False):
+def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, dense_select=None, decoder_int8=False,
+                      sca_int8=False):
     """The PTQ build of the re-hosted model that bench.py times (`B` = the bevformer module, `frames` = an iterable
     of (image, can_bus, lidar2img) calibration frames of one scene): int8 activation chain through the backbone
     (Int8ChainBackbone; chain=False: Conv2dQ layers with fp16 tensors between them, the round-3 build), encoder
     dense layers as LinearQ, TSA's MSDA on the INT8 plugin, everything else on the fp16 operators.
+    sca_int8=True: the SCA site too runs the INT8 plugin (quantise value / offsets / weights, bevops_msda_forward in
+    int8, masked camera sum on the de-quantised result) as the reference's INT8 engines do
+    (configs/bevformer/plugin/bevformer_base_trt_p2_q.py) -- instead of the fp16 projected sampler, which is faster
+    than every int8 form of that site on MI355X; bench.py reports both builds.
     Returns (model, qops, note)."""
     dtype = torch.float16
-    qops = Int8PluginOps(calibrator, channels_last=True, fused_sca=True, engine=True)
+    qops = Int8PluginOps(calibrator, channels_last=True, fused_sca=not sca_int8, engine=True)
+    if sca_int8:
+        qops._pass = tuple(n for n in qops._pass if not n.startswith("spatial_cross_attention"))
     model = B.BEVFormer(name, ops=qops, seed=0, backbone_layout="nhwc").to(dev, dtype)
     qops.attach(model)
     sel = dense_select or ((lambda n, m: n.startswith(("encoder.", "decoder."))) if decoder_int8 else engine_dense_select)
@@ -776,7 +783,7 @@ def build_int8_engine(B, name, dev, frames, calibrator="entropy", chain=True, de
     note = {"int8_plugin_sites": sum(1 for k in scales if k.endswith(".out") and k.startswith("msda")
                                      and (decoder_int8 or qops.site_batch(k[:-4]) != 1)),
             "int8_dense_layers": len(q), "int8_backbone_layers": (len(ch.convs) + sum(len(b) for b in ch.plan)) if ch else 0,
-            "activation_chain": bool(ch), "calibration_frames": n}
+            "activation_chain": bool(ch), "calibration_frames": n, "sca_site": "int8 plugin" if sca_int8 else "fp16 projected sampler"}
     return model, qops, note
 
 
