@@ -23,6 +23,7 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+int g_conv_variant = 0;                          // bevops_conv3x3_c32_set_variant
 constexpr int kTile = 32;                       // pixels per wave; WPB waves (= tiles) per block
 constexpr int kDepth = 4;                       // (tap, chunk) steps in flight per wave
 constexpr unsigned kOob = 0xFFFFFF00u;          // beyond any buffer: reads as zero
@@ -48,20 +49,52 @@ __global__ __launch_bounds__(256) void pack_conv3x3_c32_kernel(const __half *__r
   dst[idx] = m < cout ? w[((size_t)m * Cin + c) * 9 + tap] : __float2half(0.f);
 }
 
-template <int CCP, int WPB>  // 64-channel chunks per phase (1, 2 or 4); waves per block
-__global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__restrict__ x,
+// KS (round 5): K split across waves.  With one wave per 32-pixel tile a CU holds 2 .. 8 waves, each a chain of 9 * CCP
+// dependent steps whose image loads come from the fabric (the activation was written by another XCD a moment ago):
+// too few requests in flight, 29 us per stage-3 call against a ~10 us byte / matrix floor.  KS = 3 gives every tile
+// three waves -- wave (tile, part) takes the taps of kernel ROW part (dy = part - 1; taps 3 part .. 3 part + 2)
+// -- so three times the loads are in flight per CU; the partial tiles meet in LDS (the weight image is dead by then)
+// and part 0 stores.  fp32 partial sums: the summation order differs from KS = 1 in the last bits only.
+// 4 x 4 transpose across the lanes of a quad: in: r[i] of lane c = M[i][c]; out: r[i] of lane c = M[c][i].  Two stages
+// of "send the element my partner needs, take its" (partner c ^ 2, then c ^ 1) through DPP quad permutes.
+__device__ __forceinline__ void quad_transpose4(unsigned &r0, unsigned &r1, unsigned &r2, unsigned &r3, bool c2, bool c1) {
+  auto xchg = [](unsigned &x, unsigned &y, bool upper, auto perm) __attribute__((always_inline)) {
+    const unsigned send = upper ? x : y;         // lanes of the lower half hand over y, the upper ones x
+    const unsigned recv = perm(send);
+    if (upper) x = recv; else y = recv;
+  };
+  auto p2 = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); };   // quad_perm [2,3,0,1]
+  auto p1 = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
+  xchg(r0, r2, c2, p2);
+  xchg(r1, r3, c2, p2);
+  xchg(r0, r1, c1, p1);
+  xchg(r2, r3, c1, p1);
+}
+
+// KS == 3 also changes HOW the image operand is fetched (round 5, after counters: profiles/r05/conv_offset_pmc.txt).
+// With lane = (k-half hi, pixel n) every 16-byte load of a wave instruction falls into another pixel row: 64 separate
+// 64-byte sectors per instruction, 8.7 M L1 accesses per stage-3 call = 40 k cycles of tag look-ups per CU -- the
+// whole 28 us; the matrix cores, the L2 and the fabric idle.  Now the four lanes of a quad (hi, a) read the four
+// 16-byte slabs of ONE 64-byte sector: load i of a step fetches pixel 4 a + i (both hi halves: its whole 128-byte
+// line), 16 sectors per instruction, and a 4 x 4 transpose across the quad's lanes (16 dwords, 48 VALU operations per
+// step on an otherwise idle VALU) hands lane (hi, 4 a + b) the 64 bytes of pixel 4 a + b the MFMA operand layout wants.
+template <int CCP, int WPB, int KS = 1>  // 64-channel chunks per phase (1, 2 or 4); tiles per block; waves per tile
+__global__ __launch_bounds__(WPB * KS * 64) void conv3x3_c32_kernel(const __half *__restrict__ x,
                                                                const __half *__restrict__ wp,
                                                                const __half *__restrict__ bias,
                                                                __half *__restrict__ out, int B, int H, int W, int Cin,
                                                                int phases) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kThreads = WPB * 64, kTilesPerBlock = WPB;
-  constexpr int kSteps = 9 * CCP;
-  constexpr int kGroups = kSteps * 4 * 64;  // 16-byte groups per phase
+  static_assert(KS == 1 || KS == 3, "one wave per tile, or one per kernel row");
+  constexpr int kThreads = WPB * KS * 64, kTilesPerBlock = WPB;
+  constexpr int kTaps = 9 / KS;             // taps this wave walks
+  constexpr int kSteps = kTaps * CCP;       // ... and its (tap, chunk) steps per phase
+  constexpr int kGroups = 9 * CCP * 4 * 64;  // 16-byte groups per phase (the whole weight image)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_w = KS == 1 ? wave : wave % WPB, part = KS == 1 ? 0 : wave / WPB;
   const int n = lane & 31, hi = lane >> 5;
   const long npix = (long)B * H * W;
-  const long pix = ((long)blockIdx.x * kTilesPerBlock + wave) * kTile + n;
+  const long pix = ((long)blockIdx.x * kTilesPerBlock + tile_w) * kTile + n;
   const bool live = pix < npix;
   int pb = 0, ph = 0, pw = 0;
   if (live) {
@@ -73,12 +106,36 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__half *>(x), 0, (unsigned)((size_t)npix * Cin * 2), 0x00020000);
   // byte offset of (tap, channel 0) for this lane's pixel, or kOob
-  unsigned toff[9];
+  // KS == 1: slot i = tap i of this lane's pixel n.  KS == 3: slot [i][k] = tap (row part - 1, column i - 1) of pixel
+  // 4 a + k of the tile (a = (lane & 31) >> 2), this lane's 16-byte slab b = lane & 3 of the k-half hi
+  constexpr int kSub = KS == 1 ? 1 : 4;
+  unsigned toff[kTaps][kSub];
+  if constexpr (KS == 1) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int hh = ph + t / 3 - 1, ww = pw + t % 3 - 1;
-    const bool ok = live && hh >= 0 && hh < H && ww >= 0 && ww < W;
-    toff[t] = ok ? (unsigned)((((size_t)pb * H + hh) * W + ww) * Cin * 2) + (unsigned)(hi * 64) : kOob;
+    for (int i = 0; i < kTaps; ++i) {
+      const int hh = ph + i / 3 - 1, ww = pw + i % 3 - 1;
+      const bool ok = live && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      toff[i][0] = ok ? (unsigned)((((size_t)pb * H + hh) * W + ww) * Cin * 2) + (unsigned)(hi * 64) : kOob;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long pk = ((long)blockIdx.x * kTilesPerBlock + tile_w) * kTile + (n & ~3) + k;
+      const bool lk = pk < npix;
+      int kb = 0, kh = 0, kw = 0;
+      if (lk) {
+        kb = (int)(pk / ((long)H * W));
+        const int r = (int)(pk - (long)kb * H * W);
+        kh = r / W;
+        kw = r - kh * W;
+      }
+#pragma unroll
+      for (int i = 0; i < kTaps; ++i) {
+        const int hh = kh + part - 1, ww = kw + i - 1;
+        const bool ok = lk && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        toff[i][k] = ok ? (unsigned)((((size_t)kb * H + hh) * W + ww) * Cin * 2) + (unsigned)(hi * 64 + (n & 3) * 16) : kOob;
+      }
+    }
   }
   f32x16 acc;
 #pragma unroll
@@ -112,12 +169,15 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
     const unsigned cbase = (unsigned)(phase * CCP * 128);  // byte offset of the phase's first channel
     u32x4 ring[kDepth][4];
     auto issue = [&](int s, int slot) {
-      const int tap = s / CCP, chunk = s % CCP;
-      const unsigned vo = toff[tap];
+      // KS == 1: tap-major (s = tap * CCP + chunk).  KS == 3: this wave owns kernel ROW part; s = chunk * 3 + column,
+      // the three columns of a chunk back to back -- they read the same lines shifted by a pixel, which are then L1 hits
+      const int chunk = KS == 1 ? s % CCP : s / 3;
       const unsigned so = cbase + (unsigned)(chunk * 128);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * j), (int)so, 0);
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vo = KS == 1 ? toff[s / CCP][0] + 16u * j : toff[s % 3][KS == 1 ? 0 : j];
+        ring[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, (int)so, 0);
+      }
     };
 #pragma unroll
     for (int s = 0; s < kDepth && s < kSteps; ++s) issue(s, s);
@@ -126,7 +186,18 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
       const int slot = s % kDepth;
-      const f16x8 *ag = reinterpret_cast<const f16x8 *>(smem) + (size_t)s * 256 + hi * 32 + n;
+      // weight groups of global step (tap, chunk): tap = s / CCP (KS == 1) or 3 part + s % 3, chunk s / 3
+      const int gs = KS == 1 ? s : (3 * part + s % 3) * CCP + s / 3;
+      const f16x8 *ag = reinterpret_cast<const f16x8 *>(smem) + (size_t)gs * 256 + hi * 32 + n;
+      if constexpr (KS != 1) {   // ring[slot][k] = slab b of pixel 4 a + k  ->  slab k of pixel 4 a + b
+        const bool c2 = (lane & 2) != 0, c1 = (lane & 1) != 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          unsigned r0 = ring[slot][0][d], r1 = ring[slot][1][d], r2 = ring[slot][2][d], r3 = ring[slot][3][d];
+          quad_transpose4(r0, r1, r2, r3, c2, c1);
+          ring[slot][0][d] = r0; ring[slot][1][d] = r1; ring[slot][2][d] = r2; ring[slot][3][d] = r3;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f16x8 a = ag[j * 64];
@@ -136,6 +207,26 @@ __global__ __launch_bounds__(WPB * 64) void conv3x3_c32_kernel(const __half *__r
       if (s + kDepth < kSteps) issue(s + kDepth, slot);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if constexpr (KS > 1) {
+    // the row partials of a tile meet in LDS: [tile][part - 1][quad of accumulators 4][lane 64] float4 (a lane's
+    // 16-byte pieces of one quad are consecutive across the wave: conflict-free), parts 1 .. KS - 1 write, part 0 adds
+    __syncthreads();   // every wave is through with the weight image
+    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)tile_w * (KS - 1) * 256;
+    if (part > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        red[((part - 1) * 4 + g) * 64 + lane] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    }
+    __syncthreads();
+    if (part > 0) return;
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = red[(q * 4 + g) * 64 + lane];
+        acc[4 * g] += v.x; acc[4 * g + 1] += v.y; acc[4 * g + 2] += v.z; acc[4 * g + 3] += v.w;
+      }
   }
   if (!live) return;
   // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -268,8 +359,6 @@ __global__ __launch_bounds__(kRowsThreads) void conv3x3_c32_rows_kernel(const __
   }
 }
 
-int g_conv_variant = 0;
-
 int launch_conv_rows(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W,
                      int Cin, int CCP, hipStream_t st) {
   const size_t lds = (size_t)kWGroups * 16 + ((size_t)32 * kRowsWaves + 2 * W + 3) * 128;
@@ -285,13 +374,15 @@ int launch_conv_rows(const __half *x, const __half *wp, const __half *bias, __ha
   return launch_status();
 }
 
-template <int CCP, int WPB>
+template <int CCP, int WPB, int KS = 1>
 int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W, int Cin,
                 int phases, hipStream_t st) {
-  const size_t lds = (size_t)9 * CCP * 4 * 64 * 16;
+  size_t lds = (size_t)9 * CCP * 4 * 64 * 16;
+  const size_t red = (size_t)WPB * (KS - 1) * 4096;   // the row partials reuse the (dead) weight image
+  if (red > lds) lds = red;
   static bool ready = false;  // attribute set once per process (idempotent; benign if raced)
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_kernel<CCP, WPB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c32_kernel<CCP, WPB, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return BEVOPS_FAILURE;
     ready = true;
@@ -299,8 +390,8 @@ int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *o
   const long npix = (long)B * H * W;
   const long blocks = (npix + kTile * WPB - 1) / (kTile * WPB);
   if (blocks > 0x7FFFFFFFL) return BEVOPS_NOT_SUPPORTED;
-  hipLaunchKernelGGL((conv3x3_c32_kernel<CCP, WPB>), dim3((unsigned)blocks), dim3(WPB * 64), lds, st, x, wp, bias,
-                     out, B, H, W, Cin, phases);
+  hipLaunchKernelGGL((conv3x3_c32_kernel<CCP, WPB, KS>), dim3((unsigned)blocks), dim3(WPB * KS * 64), lds, st, x, wp,
+                     bias, out, B, H, W, Cin, phases);
   return launch_status();
 }
 
@@ -316,8 +407,12 @@ int launch_conv_any(const __half *x, const __half *wp, const __half *bias, __hal
     return BEVOPS_FAILURE;
   const long tiles = ((long)B * H * W + kTile - 1) / kTile;
   const long need = (tiles + cus - 1) / cus;
-  if (need <= 2) return launch_conv<CCP, 2>(x, wp, bias, out, B, H, W, Cin, phases, st);
-  if (need <= 5) return launch_conv<CCP, 5>(x, wp, bias, out, B, H, W, Cin, phases, st);
+  // three waves per tile (one per kernel row) wherever the block still fits 16 waves; variant 2 = one wave per tile
+  const bool split = g_conv_variant != 2;
+  if (need <= 2) return split ? launch_conv<CCP, 2, 3>(x, wp, bias, out, B, H, W, Cin, phases, st)
+                              : launch_conv<CCP, 2>(x, wp, bias, out, B, H, W, Cin, phases, st);
+  if (need <= 5) return split ? launch_conv<CCP, 5, 3>(x, wp, bias, out, B, H, W, Cin, phases, st)
+                              : launch_conv<CCP, 5>(x, wp, bias, out, B, H, W, Cin, phases, st);
   return launch_conv<CCP, 8>(x, wp, bias, out, B, H, W, Cin, phases, st);
 }
 

@@ -204,8 +204,9 @@ def test_conv_offset_nhwc_matches_conv2d(bev, shape):
     assert (out2[:, :27].float() - want2).abs().max().item() <= 4e-3 * max(1.0, want2.abs().max().item())
 
 
-@pytest.mark.parametrize("shape", [(6, 256, 58, 100), (6, 512, 29, 50), (2, 64, 13, 17), (1, 128, 9, 9), (3, 256, 7, 5)])
-def test_conv_offset_rows_variant_matches_default(bev, shape):
+@pytest.mark.parametrize("shape", [(6, 256, 58, 100), (6, 512, 29, 50), (2, 64, 13, 17), (1, 128, 9, 9), (3, 256, 7, 5),
+                                   (6, 256, 46, 80), (1, 256, 116, 200), (1, 64, 1, 1), (6, 128, 92, 160)])
+def test_conv_offset_variants_match(bev, shape):
     import torch.nn.functional as F
     from bevformer_tensorrt_amd.utils import load_library
     lib = load_library()
@@ -215,15 +216,20 @@ def test_conv_offset_rows_variant_matches_default(bev, shape):
     w = (torch.randn(27, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().cuda()
     b = torch.randn(27, generator=g).half().cuda()
     try:
-        lib.bevops_conv3x3_c32_set_variant(2)     # tile kernel
+        lib.bevops_conv3x3_c32_set_variant(2)     # tile kernel, one wave per 32-pixel tile (rounds 1-4)
         ref = bev.conv_offset_nhwc(x, w, b)
-        lib.bevops_conv3x3_c32_set_variant(1)     # rows-in-LDS kernel (the default for large maps)
+        lib.bevops_conv3x3_c32_set_variant(1)     # rows-in-LDS kernel
         got = bev.conv_offset_nhwc(x, w, b)
+        lib.bevops_conv3x3_c32_set_variant(0)     # default: tile kernel, three waves per tile (one per kernel column)
+        split = bev.conv_offset_nhwc(x, w, b)
     finally:
         lib.bevops_conv3x3_c32_set_variant(0)
     want = F.conv2d(x.float(), w.float(), b.float(), 1, 1)
-    assert (got[:, :27].float() - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
-    assert (got.float() - ref.float()).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())  # same products, other sum order
+    for o in (got, split):     # same products, other sum order
+        assert (o[:, :27].float() - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
+        assert (o.float() - ref.float()).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+        assert not o[:, 27:].any()
+    assert torch.equal(split, bev.conv_offset_nhwc(x, w, b))      # deterministic
 
 
 def test_packed_weight_cache_survives_dtype_conversion():
