@@ -367,9 +367,32 @@ def geometry_rooflines(bev, wl, dev):
     return out
 
 
-def frame_rooflines(bev, dev, iters=20):
+def graph_us(fn, iters=10, rounds=4):
+    """Mean microseconds per call of `fn` under HIP-graph replay -- how the frame launches its kernels: `iters` calls
+    captured once, `rounds` replays, each between two HIP events on the replay's stream."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    ms = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record()
+        b.synchronize()
+        ms.append(a.elapsed_time(b))
+    return sum(ms) / len(ms) * 1e3 / iters
+
+
+def frame_rooflines(bev, dev, iters=10, rounds=4):
     """roofline_frame + roofline_mfma (see the module docstring): the two kernels the graph-replayed frame spends its
-    sampling time in, each launched as the frame launches it, HIP events around every launch."""
+    sampling time in, each launched as the frame launches it (HIP-graph replay, HIP events around every replay of
+    `iters` launches)."""
     from bevformer_tensorrt_amd import geometry as G
     from bevformer_tensorrt_amd.functions import spatial_cross_attention as S
     from bevformer_tensorrt_amd.functions.multi_scale_deformable_attn import _host_shapes, _shapes_i32
@@ -398,15 +421,15 @@ def frame_rooflines(bev, dev, iters=20):
         geom = (shapes_host, 6, nk, heads, 32, 4, nq, 8, 4)
         planes = S._project_planes(handle, feats, wgt, bias, geom)
         plan = S.spatial_cross_attention_plan(bm)
-        us = time_us(lambda: S._sample_planes(handle, planes, geom, ref, off, w, bm, plan), iters=iters)
+        us = graph_us(lambda: S._sample_planes(handle, planes, geom, ref, off, w, bm, plan), iters, rounds)
         byt = (6 * nk * heads * 32 + nq * heads * 32 * 3 + 6 * nq * 8 + 6 * nq + nq * heads * 32) * 2 + 8 * 4
         out["roofline_frame"] = {
             "kernel": "in-frame SCA sampling call = msda_hm5_kernel<2,1024,0,3> (balanced slices of the visibility plan) "
                       "+ sca_camera_reduce_kernel, on the value projection's planes",
             "what": "reference points of the 6-camera rig (%.1f %% of the (camera, query) pairs visible), N(0,1) px offsets"
                     % (100.0 * float(vis.float().mean())),
-            "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters,
-            "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters * rounds,
+            "timing": "HIP-graph replay", "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None}
         try:   # fabric bytes of the two kernels from the newest committed PMC passes (FETCH doubled: gfx950 correction)
             import glob
@@ -427,11 +450,12 @@ def frame_rooflines(bev, dev, iters=20):
         wt = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().to(dev)
         bs = torch.randn(C, generator=g).half().to(dev)
         fn = lambda: bev.modulated_deformable_conv2d_nhwc(x, None, None, wt, bs, 1, 1, 1, 1, 1, True, om)  # noqa: E731
-        us = time_us(fn, iters=iters)
+        us = graph_us(fn, iters, rounds)
         flop = 2.0 * B * H * W * C * C * 9
         out["roofline_mfma"] = {
             "kernel": "DCNv2 ResNet-101 stage 3, channels-last entry = dcn_glds_f16_kernel<4> (+ dcn_tail_finish_kernel)",
-            "bound": "mfma", "flop_per_launch": flop, "avg_launch_us": round(us, 2), "launches": iters,
+            "bound": "mfma", "flop_per_launch": flop, "avg_launch_us": round(us, 2), "launches": iters * rounds,
+            "timing": "HIP-graph replay",
             "achieved": round(flop / us / 1e6, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)}
     except Exception as exc:
