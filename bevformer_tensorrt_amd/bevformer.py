@@ -95,7 +95,11 @@ def _from_rows(y, n, h, w):
 
 _FUSED_LINEAR = {"enabled": os.environ.get("BEVOPS_FUSED_LINEAR", "1") != "0"}   # A/B switch
 _R3 = {"enabled": os.environ.get("BEVOPS_R3_FUSIONS", "1") != "0"}   # A/B switch of the round-3 launch-count work
-_TSA_LOCAL = {"enabled": os.environ.get("BEVOPS_TSA_LOCAL", "0") == "1"}   # A/B switch: TSA's MSDA on the quad kernel (round 4)
+# TSA's MSDA on the layout-preserving quad kernel (its reference points are the BEV grid: neighbouring queries sample
+# neighbouring pixels, the head-major re-layout the default dispatch makes for random points is not needed).  Round 4
+# measured no gain inside the frame on one run each; round 5 repeated it interleaved under graph replay: -0.06 ..
+# -0.12 ms per base frame in three pairs (profiles/r05/model_bench_tsa_local.jsonl) -> default; BEVOPS_TSA_LOCAL=0: off
+_TSA_LOCAL = {"enabled": os.environ.get("BEVOPS_TSA_LOCAL", "1") == "1"}
 
 
 def _fused_linear(ops, x, weight, bias, residual, relu):
@@ -462,7 +466,11 @@ class TemporalSelfAttention(nn.Module):
         nq, nk = query.shape[1], value.shape[1]
         mine = value if rows is None else value[:, rows[0]:rows[1]]      # the value rows that pair with these queries
         both = self._split_projection(query, mine[0], bev_pos)
-        if both is not None:
+        split = getattr(self.ops, "tsa_split", None)
+        pre = None
+        if both is not None and split is not None and self.points == 4:
+            pre = split(both, HEADS, self.points)      # (off [2, nq, H, 8], w [2, nq, H, 4]) in one pass
+        elif both is not None:
             n_off = 2 * HEADS * self.points * 2
             off = both[:, :n_off].view(1, nq, HEADS, 2, 1, self.points, 2)
             w = both[:, n_off:].view(1, nq, HEADS, 2, 1, self.points)
@@ -471,14 +479,21 @@ class TemporalSelfAttention(nn.Module):
             off = self.sampling_offsets(query).view(1, nq, HEADS, 2, 1, self.points, 2)
             w = self.attention_weights(query).view(1, nq, HEADS, 2, 1, self.points)
         value = _dense(self.ops, self.value_proj, value).view(2, nk, HEADS, EMBED // HEADS)
-        w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
-        off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
+        if pre is not None:
+            off, w = pre
+        else:
+            w = w.permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, HEADS, -1)
+            off = off.permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, HEADS, -1)
         # the BEV grid's reference points have locality (neighbouring queries, neighbouring pixels): the operator set's
         # layout-preserving entry skips the head-major re-layout the default dispatch needs for random points
         msda = (getattr(self.ops, "multi_scale_deformable_attn_local", None) if _TSA_LOCAL["enabled"] else None) \
             or self.ops.multi_scale_deformable_attn
         out = msda(value, spatial_shapes, ref_2d, off, w).flatten(2)
-        out = torch.mean(out, keepdim=True, dim=0)
+        mean2 = getattr(self.ops, "queue_mean2", None)
+        if mean2 is not None and out.is_cuda and out.dtype == torch.float16 and out.numel() % 16 == 0 and _R3["enabled"]:
+            out = mean2(out)                            # (x0 + x1) / 2 in fp32, one rounding: torch.mean's bits
+        else:
+            out = torch.mean(out, keepdim=True, dim=0)
         return _dense(self.ops, self.output_proj, out, identity, False)
 
 
@@ -996,7 +1011,15 @@ class FrameRunner:
         # the frame's small host-side inputs travel as ONE upload: [can_bus (18) | bev shift (2)]
         small = torch.zeros(20, device=device)
         self._host_small = torch.zeros(20)
-        self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
+        # the frame's static image buffer is CHANNELS-LAST underneath ([cams, H, W, 3] memory behind the [1, cams, 3, H, W]
+        # view) where the backbone runs channels-last: its first `.contiguous(channels_last)` is then no copy (53 MB per
+        # base frame), and step_raw's normalise pass writes that layout directly
+        layout = getattr(model, "backbone_layout", "nchw")
+        nhwc_in = device.type == "cuda" and dtype == torch.float16 and \
+            (layout == "nhwc" or (layout == "auto" and getattr(model, "ops", None) is _hip_ops))
+        image0 = (torch.zeros(NUM_CAMS, H, W, 3, device=device, dtype=dtype).permute(0, 3, 1, 2).unsqueeze(0) if nhwc_in
+                  else torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype))
+        self._in = dict(image=image0,
                         small=small, can_bus=small[:18], shift=small[18:].view(1, 2),
                         lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
                         use=torch.zeros((), device=device, dtype=dtype))
@@ -1066,7 +1089,10 @@ class FrameRunner:
         if fn is None:
             raise RuntimeError("the operator set has no image_normalize_pad")
         buf = self._in["image"][0]
-        fn(raw_images, dtype=buf.dtype, out=buf)
+        if buf.is_contiguous():
+            fn(raw_images, dtype=buf.dtype, out=buf)
+        else:       # channels-last static buffer (see __init__)
+            fn(raw_images, dtype=buf.dtype, channels_last=True, out=buf)
         return self.step(buf[None], can_bus, lidar2img, scene_token)
 
     def _calibration_changed(self, lidar2img):

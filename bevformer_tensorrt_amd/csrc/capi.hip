@@ -57,6 +57,8 @@ const Entry kTable[] = {
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
     {"bevops_bias_relu_maxpool_nhwc", (void *)&bevops_bias_relu_maxpool_nhwc},
     {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
+    {"bevops_tsa_split", (void *)&bevops_tsa_split},
+    {"bevops_queue_mean2", (void *)&bevops_queue_mean2},
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
     {"bevops_tsgemm_s8", (void *)&bevops_tsgemm_s8},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},

@@ -422,3 +422,34 @@ def _dense_measure(key, x, weight, bias, residual, relu, rounds=3, iters=8):
     if not times:
         return "blaslt"
     return min(times, key=times.get)
+
+
+def tsa_split(both, heads, points):
+    """The stacked sampling_offsets | attention_weights projection of temporal self-attention, [nq, heads * 2 * points * 3]
+    fp16 with the reference's column order ([heads][queue][points][xy] | [heads][queue][points]), as the queue-major
+    operands of the MSDA call: (offsets [2, nq, heads, points * 2], weights [2, nq, heads, points]) in ONE pass
+    (bevops_tsa_split) instead of two permute-copies."""
+    assert both.is_cuda and both.dtype == torch.float16 and both.dim() == 2 and both.is_contiguous()
+    nq = both.shape[0]
+    assert both.shape[1] == heads * 2 * points * 3
+    off = torch.empty((2, nq, heads, points * 2), dtype=both.dtype, device=both.device)
+    w = torch.empty((2, nq, heads, points), dtype=both.dtype, device=both.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(both.device):
+        st = handle.bevops_tsa_split(_lib.F16, both.data_ptr(), off.data_ptr(), w.data_ptr(), nq, heads, points,
+                                     _lib.current_stream_ptr(both.device))
+    _lib.check(st, "bevops_tsa_split")
+    return off, w
+
+
+def queue_mean2(x):
+    """torch.mean(x, dim=0, keepdim=True) for x [2, ...] fp16 as one streaming pass (bevops_queue_mean2)."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.shape[0] == 2 and x.is_contiguous()
+    out = torch.empty((1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if out.numel() == 0:
+        return out
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_queue_mean2(_lib.F16, x.data_ptr(), out.data_ptr(), out.numel(), _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_queue_mean2")
+    return out

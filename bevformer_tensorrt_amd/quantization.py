@@ -181,7 +181,7 @@ class Int8PluginOps:
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
              "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc",
-             "image_normalize_pad", "upsample_add_nhwc_", "feat_embed_nhwc")
+             "image_normalize_pad", "upsample_add_nhwc_", "feat_embed_nhwc", "tsa_split", "queue_mean2")
     # `engine=True` (the build bench.py times, build_int8_engine below) additionally passes the entries whose fp16
     # form is FASTER than any int8 form on MI355X: the channels-last nearest-neighbour rotate of prev_bev (pure data
     # movement: rotating commutes with quantising, the int8 plugin would only add a quantise and a de-quantise pass

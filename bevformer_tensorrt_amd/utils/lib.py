@@ -70,6 +70,8 @@ SIGNATURES = {
     "bevops_tsgemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tsgemm_s8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_int,
                                  c_void_p, c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    "bevops_tsa_split": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "bevops_queue_mean2": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bevops_upsample_add_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "bevops_feat_embed_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_size_t,
                                        c_void_p]),

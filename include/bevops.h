@@ -348,6 +348,16 @@ int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const voi
  * 8-pixel runs where every plane starts 16-byte aligned, 1 = one store per lane and plane (rounds 1-3).  Same values
  * either way.  Returns the previous setting. */
 int bevops_rotate_set_variant(int variant);
+/* Temporal self-attention glue (round 5; not reference plugins; modules/temporal_self_attention.py:350-457).
+ * bevops_tsa_split: one row of the stacked sampling_offsets | attention_weights projection, laid out as the reference
+ * views it -- [heads][bev_queue 2][points][xy] then [heads][bev_queue 2][points] -- split into the queue-major operands
+ * of the MSDA call: offsets [2, num_query, heads, points * 2], weights [2, num_query, heads, points] (what
+ * .view(...).permute(0, 3, 1, 2, 4, 5[, 6]).contiguous() produces twice, as one pass).  fp16, points == 4.
+ * bevops_queue_mean2: out[i] = (x[i] + x[count + i]) / 2 in fp32 with one rounding (= torch.mean over the two queue
+ * entries), fp16, count % 8 == 0. */
+int bevops_tsa_split(int dtype, const void *both, void *offsets, void *weights, int num_query, int heads, int points,
+                     void *stream);
+int bevops_queue_mean2(int dtype, const void *x, void *out, size_t count, void *stream);
 /* bevops_rotate_forward on channels-last data: img / output are [height, width, channels] (fp32 /
  * fp16, channels a multiple of 4 / 8) -- the layout prev_bev [H*W, 1, C] already has in the model,
  * so the permute-copy to [C, H, W] and back around the plugin (transformer.py:296-303) disappears.

@@ -47,3 +47,22 @@ def test_bias_relu_maxpool_equals_two_pass_form(n, c, h, w):
     want = F.max_pool2d(bev.bias_act_nhwc_(x.clone(memory_format=torch.channels_last), b, None, True), 3, 2, 1)
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("nq", [40000, 22500, 2500, 37, 1])
+def test_tsa_split_and_queue_mean_equal_the_framework_ops(nq):
+    """bevops_tsa_split == the two view / permute / contiguous copies of temporal_self_attention.py:409-424 (pure data
+    movement), bevops_queue_mean2 == torch.mean over the two BEV-queue entries (fp32 sum, one rounding): both bit for bit."""
+    import bevformer_tensorrt_amd as bev
+    heads, points = 8, 4
+    g = torch.Generator().manual_seed(nq)
+    both = torch.randn(nq, heads * 2 * points * 3, generator=g).half().cuda()
+    n_off = 2 * heads * points * 2
+    off = both[:, :n_off].view(1, nq, heads, 2, 1, points, 2).permute(0, 3, 1, 2, 4, 5, 6).contiguous().view(2, nq, heads, -1)
+    w = both[:, n_off:].view(1, nq, heads, 2, 1, points).permute(0, 3, 1, 2, 4, 5).contiguous().view(2, nq, heads, -1)
+    o2, w2 = bev.tsa_split(both, heads, points)
+    assert torch.equal(o2, off) and torch.equal(w2, w)
+    x = (torch.randn(2, nq, 256, generator=g) * 3).half().cuda()
+    x[0, 0, :4] = torch.tensor([65504.0, -65504.0, 6.1e-5, 5.96e-8]).half()      # extremes: the sum is formed in fp32
+    x[1, 0, :4] = torch.tensor([65504.0, 65504.0, 6.1e-5, 5.96e-8]).half()
+    assert torch.equal(bev.queue_mean2(x), torch.mean(x, dim=0, keepdim=True))
