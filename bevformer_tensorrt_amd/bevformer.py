@@ -1011,15 +1011,7 @@ class FrameRunner:
         # the frame's small host-side inputs travel as ONE upload: [can_bus (18) | bev shift (2)]
         small = torch.zeros(20, device=device)
         self._host_small = torch.zeros(20)
-        # the frame's static image buffer is CHANNELS-LAST underneath ([cams, H, W, 3] memory behind the [1, cams, 3, H, W]
-        # view) where the backbone runs channels-last: its first `.contiguous(channels_last)` is then no copy (53 MB per
-        # base frame), and step_raw's normalise pass writes that layout directly
-        layout = getattr(model, "backbone_layout", "nchw")
-        nhwc_in = device.type == "cuda" and dtype == torch.float16 and \
-            (layout == "nhwc" or (layout == "auto" and getattr(model, "ops", None) is _hip_ops))
-        image0 = (torch.zeros(NUM_CAMS, H, W, 3, device=device, dtype=dtype).permute(0, 3, 1, 2).unsqueeze(0) if nhwc_in
-                  else torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype))
-        self._in = dict(image=image0,
+        self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
                         small=small, can_bus=small[:18], shift=small[18:].view(1, 2),
                         lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
                         use=torch.zeros((), device=device, dtype=dtype))
@@ -1089,10 +1081,7 @@ class FrameRunner:
         if fn is None:
             raise RuntimeError("the operator set has no image_normalize_pad")
         buf = self._in["image"][0]
-        if buf.is_contiguous():
-            fn(raw_images, dtype=buf.dtype, out=buf)
-        else:       # channels-last static buffer (see __init__)
-            fn(raw_images, dtype=buf.dtype, channels_last=True, out=buf)
+        fn(raw_images, dtype=buf.dtype, out=buf)
         return self.step(buf[None], can_bus, lidar2img, scene_token)
 
     def _calibration_changed(self, lidar2img):
