@@ -100,6 +100,7 @@ _R3 = {"enabled": os.environ.get("BEVOPS_R3_FUSIONS", "1") != "0"}   # A/B switc
 # measured no gain inside the frame on one run each; round 5 repeated it interleaved under graph replay: -0.06 ..
 # -0.12 ms per base frame in three pairs (profiles/r05/model_bench_tsa_local.jsonl) -> default; BEVOPS_TSA_LOCAL=0: off
 _TSA_LOCAL = {"enabled": os.environ.get("BEVOPS_TSA_LOCAL", "1") == "1"}
+_TSA_GLUE = {"enabled": os.environ.get("BEVOPS_TSA_GLUE", "1") == "1"}   # A/B: bevops_tsa_split / bevops_queue_mean2 vs the framework copies
 
 
 def _fused_linear(ops, x, weight, bias, residual, relu):
@@ -466,7 +467,7 @@ class TemporalSelfAttention(nn.Module):
         nq, nk = query.shape[1], value.shape[1]
         mine = value if rows is None else value[:, rows[0]:rows[1]]      # the value rows that pair with these queries
         both = self._split_projection(query, mine[0], bev_pos)
-        split = getattr(self.ops, "tsa_split", None)
+        split = getattr(self.ops, "tsa_split", None) if _TSA_GLUE["enabled"] else None
         pre = None
         if both is not None and split is not None and self.points == 4:
             pre = split(both, HEADS, self.points)      # (off [2, nq, H, 8], w [2, nq, H, 4]) in one pass
@@ -489,7 +490,7 @@ class TemporalSelfAttention(nn.Module):
         msda = (getattr(self.ops, "multi_scale_deformable_attn_local", None) if _TSA_LOCAL["enabled"] else None) \
             or self.ops.multi_scale_deformable_attn
         out = msda(value, spatial_shapes, ref_2d, off, w).flatten(2)
-        mean2 = getattr(self.ops, "queue_mean2", None)
+        mean2 = getattr(self.ops, "queue_mean2", None) if _TSA_GLUE["enabled"] else None
         if mean2 is not None and out.is_cuda and out.dtype == torch.float16 and out.numel() % 16 == 0 and _R3["enabled"]:
             out = mean2(out)                            # (x0 + x1) / 2 in fp32, one rounding: torch.mean's bits
         else:
