@@ -293,7 +293,24 @@ DENSE_MISSES = []      # problems dense_auto met that dispatch_gfx950.json does 
 # hand-written kernels (fixed summation order, no library heuristic).  The camera-sharded frame loop switches it on:
 # ranks that each measured their own winner would evaluate the REPLICATED layers (TSA, FFN, decoder) in different
 # summation orders and drift apart bitwise.  BEVOPS_DENSE_TUNE=0 is the same switch from the environment.
-DETERMINISTIC = {"enabled": False}
+class _PerThreadFlag:
+    """`flag["enabled"]` with one value per THREAD (two frame runners on two threads -- a sharded and a plain one --
+    must not see each other's setting; advisor, round 4).  Dict-style access, default False."""
+
+    def __init__(self):
+        import threading
+        self._tls = threading.local()
+
+    def __getitem__(self, key):
+        assert key == "enabled"
+        return getattr(self._tls, "enabled", False)
+
+    def __setitem__(self, key, value):
+        assert key == "enabled"
+        self._tls.enabled = bool(value)
+
+
+DETERMINISTIC = _PerThreadFlag()
 
 
 # Shipped choices (bevformer_tensorrt_amd/dispatch_gfx950.json, written by tools/dump_dispatch.py from one MI355X's

@@ -69,3 +69,16 @@ def test_frame_runner_keys_the_calibration_cache_on_content():
     same.mul_(2.0)                                            # in-place edit of the SAME object: version counter moves
     r.step(img, can, same, "other scene")
     assert float(m.seen[0].flatten()[0]) == 10.0 and m.projected == n + (1 if B._R3["enabled"] else 0)
+
+
+def test_deterministic_dispatch_flag_is_per_thread():
+    import threading
+    from bevformer_tensorrt_amd.functions import linear as L
+    L.DETERMINISTIC["enabled"] = True
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.DETERMINISTIC["enabled"]))
+    t.start(); t.join()
+    try:
+        assert seen == [False] and L.DETERMINISTIC["enabled"] is True
+    finally:
+        L.DETERMINISTIC["enabled"] = False
