@@ -16,9 +16,8 @@
 //      the 128-byte pair; the two quads of an octet run the quad algorithm of msda.hip
 //      (points split 4 ways, DPP broadcasts) on their own corner and are summed at the end
 //      with one DPP row_shl:4 per channel;
-//   4. (STAGE) the trailing pyramid levels that fit (<= ~150 KiB per (camera, head), e.g.
-//      29x50 + 15x25 at base) are copied once per block into LDS and their taps served by
-//      ds_read_b128 (~3x the L2-resident tap rate), leaving the L1/TA path to the big levels.
+//   (LDS staging of the trailing levels with 1024- / 512-thread blocks and a two-copy layout were built in round 1,
+//   measured slower, and are no longer in this file: profiles/r01c, design/msda.md.)
 #include "msda_common.h"
 
 namespace bevops {
@@ -45,8 +44,7 @@ __device__ __forceinline__ void build_levels(const int32_t *shapes, int L, int4 
 __global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              __half *__restrict__ vh, int bs,
-                                                             int nk, int heads, int L, int nkp,
-                                                             unsigned copy_b) {
+                                                             int nk, int heads, int L, int nkp) {
   __shared__ int4 tab[kMaxLevels + 1];
   if (threadIdx.x == 0) build_levels(shapes, L, tab);
   __syncthreads();
@@ -69,9 +67,6 @@ __global__ __launch_bounds__(256) void msda_hm_repack_kernel(const __half *__res
     v = *reinterpret_cast<const uint4 *>(value + (((size_t)b * nk + src) * heads + h) * 32 + c * 8);
   const size_t o = (((size_t)b * heads + h) * nkp + p) * 32 + c * 8;
   *reinterpret_cast<uint4 *>(vh + o) = v;
-  // second copy, placed 64 B off 128-byte alignment: pixel pairs that START ON AN ODD pixel
-  // are one aligned line there (copy A serves the even ones)
-  if (copy_b) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(vh) + copy_b + o * 2) = v;
 }
 
 __device__ __forceinline__ void fma8(const u32x4 r, float w, float (&acc)[8]) {
@@ -85,14 +80,15 @@ __device__ __forceinline__ float row_shl4(float v) {  // lane i <- lane i+4 (wit
 }
 
 // ---- 2. main kernel ------------------------------------------------------------------
-// PPL = points per quad lane (L*P/4), CH = own points prepared per pass, STAGE = serve the
-// levels >= stage_level from LDS.  Block = (batch*head, query chunk).
-template <int PPL, int CH, bool STAGE, int THREADS, bool TWO = false>
-__global__ __launch_bounds__(THREADS) void msda_hm_kernel(
+// PPL = points per quad lane (L*P/4), CH = own points prepared per pass.  Block = (batch*head, query chunk).
+constexpr int kHmThreads = 256;
+template <int PPL, int CH>
+__global__ __launch_bounds__(kHmThreads) void msda_hm_kernel(
     const __half *__restrict__ vh, unsigned vh_bytes, const int32_t *__restrict__ shapes,
     const __half *__restrict__ ref, const __half *__restrict__ off,
     const __half *__restrict__ logit, __half *__restrict__ out, MsdaDims d, int nkp, int chunk,
-    int nchunk, int stage_level, unsigned copy_b) {
+    int nchunk) {
+  constexpr int THREADS = kHmThreads;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int4 *lvl = reinterpret_cast<int4 *>(smem);
   if (threadIdx.x == 0) build_levels(shapes, d.L, lvl);
@@ -102,16 +98,6 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
   const unsigned bh = vb / (unsigned)nchunk, ck = vb - bh * (unsigned)nchunk;
   const unsigned b = bh / (unsigned)d.heads, h = bh - b * (unsigned)d.heads;
   const unsigned plane = bh * (unsigned)nkp * kPixBytes;  // byte offset of this (b, h) plane
-  int stage_pix0 = 0x7fffffff;                            // first staged pixel (VH index)
-  const int stage_j0 = stage_level * d.P;                 // first point index served from LDS
-  if constexpr (STAGE) {
-    stage_pix0 = lvl[stage_level].z;
-    const unsigned nbytes = (unsigned)(nkp - stage_pix0) * kPixBytes;
-    const char *src = reinterpret_cast<const char *>(vh) + plane + (unsigned)stage_pix0 * kPixBytes;
-    for (unsigned i = threadIdx.x * 16u; i < nbytes; i += THREADS * 16u)
-      *reinterpret_cast<uint4 *>(smem + kTabBytes + i) = *reinterpret_cast<const uint4 *>(src + i);
-    __syncthreads();
-  }
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(vh), 0, vh_bytes, 0x00020000);
 
@@ -208,11 +194,6 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
         const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
         oo[kk][0] = (unsigned)(t.z + y0c * W + cc);
         oo[kk][1] = (unsigned)(t.z + y1c * W + cc);
-        if constexpr (TWO) {  // pick the copy in which this row's pair (xb, xb+1) is one line
-          const unsigned f0 = (unsigned)(t.z + y0c * W + xb), f1 = (unsigned)(t.z + y1c * W + xb);
-          oo[kk][0] = oo[kk][0] * kPixBytes + ((f0 & 1u) ? copy_b : 0u);
-          oo[kk][1] = oo[kk][1] * kPixBytes + ((f1 & 1u) ? copy_b : 0u);
-        }
         ++p; ++g;
         if (g == d.ppg) g = 0;
         if (p == d.P) { p = 0; g = 0; ++l; }
@@ -223,14 +204,8 @@ __global__ __launch_bounds__(THREADS) void msda_hm_kernel(
       _Pragma("unroll") for (int kk = 0; kk < CH; ++kk) {                                    \
         const float w0 = quad_bcast<S>(ow[kk][0]), w1 = quad_bcast<S>(ow[kk][1]);            \
         const unsigned p0 = quad_bcast<S>(oo[kk][0]), p1 = quad_bcast<S>(oo[kk][1]);         \
-        u32x4 r0, r1;                                                                        \
-        if (STAGE && (S * PPL + pass * CH + kk) >= stage_j0) { /* wave-uniform */            \
-          r0 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p0 - stage_pix0) * kPixBytes + sub * 16u); \
-          r1 = *reinterpret_cast<const u32x4 *>(smem + kTabBytes + (p1 - stage_pix0) * kPixBytes + sub * 16u); \
-        } else {                                                                             \
-          r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + (TWO ? p0 : p0 * kPixBytes) + sub * 16u), 0, 0); \
-          r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + (TWO ? p1 : p1 * kPixBytes) + sub * 16u), 0, 0); \
-        }                                                                                    \
+        const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p0 * kPixBytes + sub * 16u), 0, 0); \
+        const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(plane + p1 * kPixBytes + sub * 16u), 0, 0); \
         fma8(r0, w0, acc);                                                                   \
         fma8(r1, w1, acc);                                                                   \
       }                                                                                      \
@@ -473,22 +448,11 @@ size_t hm2_bytes(int bs, int nk, int heads, int L) {
 
 template <int PPL, int CH>
 int launch_hm(const __half *vh, size_t vh_bytes, const int32_t *shapes, const __half *ref,
-              const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp,
-              int stage_level, size_t stage_bytes, bool threads512, unsigned copy_b,
-              hipStream_t st) {
-  // (LDS staging of the pyramid tail with 1024- / 512-thread blocks and the two-copy layout -- variants 12 / 13 / 14
-  // of round 1, measured slower, profiles/r01c -- were removed from the library in round 5; the kernel template keeps
-  // their parameters)
-  (void)stage_level; (void)stage_bytes; (void)threads512;
-  {
-    constexpr int T = 256;
-    const int chunk = 128;
-    const int nchunk = (d.nq + chunk - 1) / chunk;
-    (void)copy_b;
-    hipLaunchKernelGGL((msda_hm_kernel<PPL, CH, false, T>), dim3((unsigned)(d.bs * d.heads * nchunk)),
-                         dim3(T), kTabBytes, st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d,
-                         nkp, chunk, nchunk, d.L, 0u);
-  }
+              const __half *off, const __half *logit, __half *out, const MsdaDims &d, int nkp, hipStream_t st) {
+  const int chunk = 128;
+  const int nchunk = (d.nq + chunk - 1) / chunk;
+  hipLaunchKernelGGL((msda_hm_kernel<PPL, CH>), dim3((unsigned)(d.bs * d.heads * nchunk)), dim3(kHmThreads), kTabBytes,
+                     st, vh, (unsigned)vh_bytes, shapes, ref, off, logit, out, d, nkp, chunk, nchunk);
   return launch_status();
 }
 
@@ -501,9 +465,8 @@ size_t hm_copy_bytes(int bs, int nk, int heads, int L) {
 size_t msda_hm_workspace_bytes(int bs, int nk, int heads, int C, int L) {
   if (C != 32 || L > kMaxLevels - 1) return 0;
   const size_t one = hm_copy_bytes(bs, nk, heads, L);
-  const size_t two = 2 * one + 128;  // room for the second, 64-byte-shifted copy
-  const size_t v2 = hm2_bytes(bs, nk, heads, L);
-  const size_t want = two > v2 ? two : v2;
+  const size_t v2 = hm2_bytes(bs, nk, heads, L);   // (hm2's two alignment copies: the larger of the two layouts)
+  const size_t want = one > v2 ? one : v2;
   if (want < 0xFFFFFF00ull) return want;
   return one < 0xFFFFFF00ull ? one : 0;
 }
@@ -545,26 +508,19 @@ int msda_hm_forward_f16(const __half *value, const int32_t *shapes, const int32_
     return BEVOPS_NOT_SUPPORTED;
   const int nkp = hm_nkp(nk, L);
   __half *vh = static_cast<__half *>(workspace);
-  // variant 14: two copies (A: even-start pairs, B: odd-start pairs) -> 2 lines per sample
-  const bool two = false;
-  const unsigned copy_b = two ? (unsigned)(one + 64) : 0u;
-  const size_t need = two ? 2 * one + 128 : one;
   {
     const size_t threads = (size_t)bs * nkp * heads * 4;
     hipLaunchKernelGGL(msda_hm_repack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                       value, shapes, vh, bs, nk, heads, L, nkp, copy_b);
+                       value, shapes, vh, bs, nk, heads, L, nkp);
   }
-  // LDS staging needs the shapes on the host: stage the longest tail of levels that fits
-  int stage_level = L;
-  size_t stage_bytes = 0;
+  (void)shapes_host;
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
-  const bool t512 = false;
   switch (LP / 4) {
-    case 1: return launch_hm<1, 1>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
-    case 2: return launch_hm<2, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
-    case 4: return launch_hm<4, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
-    case 8: return launch_hm<8, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
-    case 16: return launch_hm<16, 2>(vh, need, shapes, ref, off, logit, out, d, nkp, stage_level, stage_bytes, t512, copy_b, st);
+    case 1: return launch_hm<1, 1>(vh, one, shapes, ref, off, logit, out, d, nkp, st);
+    case 2: return launch_hm<2, 2>(vh, one, shapes, ref, off, logit, out, d, nkp, st);
+    case 4: return launch_hm<4, 2>(vh, one, shapes, ref, off, logit, out, d, nkp, st);
+    case 8: return launch_hm<8, 2>(vh, one, shapes, ref, off, logit, out, d, nkp, st);
+    case 16: return launch_hm<16, 2>(vh, one, shapes, ref, off, logit, out, d, nkp, st);
     default: return BEVOPS_NOT_SUPPORTED;
   }
 }

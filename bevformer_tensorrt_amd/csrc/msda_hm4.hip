@@ -77,10 +77,9 @@ __device__ __forceinline__ RepackPos repack_pos(const Hm3Tab &t, int slab, int p
 __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *__restrict__ value,
                                                                  char *__restrict__ gset,
                                                                  char *__restrict__ sset, Hm3Tab t,
-                                                                 int nk, int heads, unsigned bias, int pair) {
+                                                                 int nk, int heads, unsigned bias) {
   // `bias` = 0x80808080 for the x255 flavour: its planes hold v + 128 as u8 (pads included: they
-  // stand for the value 0), see i8_sample_u.  `pair`: the big set holds 64-byte pixel-pair entries too (the staged
-  // format) -- half the bytes per plane, two 8-byte loads per sample (H4Plan::pair)
+  // stand for the value 0), see i8_sample_u.
   const int c8 = threadIdx.x & 7;
   const RepackPos p = repack_pos(t, blockIdx.x, 32, (int)(threadIdx.x >> 3));
   if (p.f < 0) return;
@@ -96,9 +95,9 @@ __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *_
     };
     px[0] = at(p.yp, p.x);
     px[1] = at(p.yp, p.x + 1);
-    if (p.big && !pair) { px[2] = at(p.yp + 1, p.x); px[3] = at(p.yp + 1, p.x + 1); }
+    if (p.big) { px[2] = at(p.yp + 1, p.x); px[3] = at(p.yp + 1, p.x + 1); }
   }
-  if (p.big && !pair) {
+  if (p.big) {
     unsigned o[4];
     transpose4x4(px[0], px[1], px[2], px[3], o);
     *reinterpret_cast<uint4 *>(gset + ((size_t)bh * t.g_entries + p.f) * kEntBytes + c8 * 16) =
@@ -107,9 +106,7 @@ __global__ __launch_bounds__(256) void msda_hm4_repack_i8_kernel(const int8_t *_
     uint2 o;
     o.x = __builtin_amdgcn_perm(px[1], px[0], 0x05010400u) ^ bias;  // c0(x0), c0(x1), c1(x0), c1(x1)
     o.y = __builtin_amdgcn_perm(px[1], px[0], 0x07030602u) ^ bias;  // c2(x0), c2(x1), c3(x0), c3(x1)
-    char *dst = p.big ? gset + ((size_t)bh * t.g_entries + p.f) * kLdsPixBytes
-                      : sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes;
-    *reinterpret_cast<uint2 *>(dst + c8 * 8) = o;
+    *reinterpret_cast<uint2 *>(sset + ((size_t)bh * t.s_entries + p.f) * kLdsPixBytes + c8 * 8) = o;
   }
 }
 
@@ -177,31 +174,23 @@ __device__ __forceinline__ int gather_hi(int x0, int x1, int x2, int x3) {
 // <float> flavour with signed x127 weights); RefT: reference point type (fp16 path: __half).
 // NBIG: batches (of BT points) served by the L1/L2 path, the remaining ones come from LDS.
 // RR: the PP reference points of an owner lane are one contiguous run (BEVFormer SCA: 4 anchors).
-// ABL: timing ablations for tools/hm4_probe.py (results are WRONG with bits 0-4): 1 no L1/L2 taps,
-// 2 no LDS taps, 4 no operand requests inside the loop, 8 no front end inside the loop, 16 no store.
-// Schedule variants with correct results: 32 operand request at the END of the loop body, 64 one
-// big batch in flight instead of two, 128 default cache policy for the streamed operands / output,
-// 256 operand request BEHIND the first big batches (buffer loads retire in order: requested first,
-// the HBM round trip of the operands gates every tap of the iteration; requested behind batches
-// 0 .. D-1, only the later batches wait for it, after most of the iteration's own work).
-// 1024: compiled for 4 waves per SIMD (<= 128 VGPRs) so that TWO 512-thread blocks share a CU when the staged
-// planes are small (experiment: only the last level staged, variant 18).
-// 2048 (int8 only, results unchanged): the big set holds 64-byte pixel-pair entries (the staged format) instead of
-// 128-byte 2x2 footprints: a sample is two 8-byte loads per lane (row 0, row 1) + the four v_perm of the LDS path,
-// and a (batch, head) plane is half as large -- the base SCA planes (3.96 MB as footprints: as large as an XCD's L2,
-// 63 % hit rate, 2.2 GB fetched per call) become 1.98 MB.
-template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
-__global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel(const H4Args a) {
+// SCHED: schedule bits of the production builds (results identical whatever they are): 32 operand request at the END
+// of the loop body (fp16), 64 one big batch in flight instead of two, 128 default cache policy for the streamed
+// operands / output (int8), 1024 compiled for 4 waves per SIMD (<= 128 VGPRs) so that TWO 512-thread blocks share a
+// CU when the staged planes are small (the int8 two-blocks plan).  The timing ablations, the "request behind the first
+// batches" schedule and the int8 pixel-pair entry format of rounds 2 / 4 are no longer in this file (history;
+// profiles/r02/hm4_ablation.jsonl, hm4_schedule_variants.jsonl, profiles/r04/msda_i8_pair_ab.jsonl).
+template <int LP, int NBIG, int THREADS, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int SCHED = 0>
+__global__ __launch_bounds__(THREADS, (SCHED & 1024) ? 4 : 1) void msda_hm4_kernel(const H4Args a) {
   constexpr int NOWN = LP >= 8 ? 8 : LP;  // owner lanes per octet
   constexpr int PP = LP / NOWN;           // points per owner
   constexpr int BT = LP >= 4 ? 4 : LP;    // points per tap batch
   constexpr int NB = LP / BT;
   constexpr int NLDS = NB - NBIG;
-  constexpr int D = (NBIG >= 2 && !(ABL & 64)) ? 2 : 1;    // big batches in flight
+  constexpr int D = (NBIG >= 2 && !(SCHED & 64)) ? 2 : 1;    // big batches in flight
   constexpr int kBox = LP * 16 + 16;      // mailbox bytes per octet (+16: bank spread)
   constexpr int ESZ = I8 ? 1 : 2;         // bytes per logit / offset component
-  constexpr bool PAIR = I8 && (ABL & 2048) != 0;
-  constexpr unsigned kBigEnt = PAIR ? (unsigned)kLdsPixBytes : (unsigned)kEntBytes;
+  constexpr unsigned kBigEnt = (unsigned)kEntBytes;
   static_assert(NBIG >= 0 && NBIG <= NB, "NBIG");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const MsdaDims &d = a.d;
@@ -221,7 +210,7 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
   if (threadIdx.x < (unsigned)t.L) {
     const int l = threadIdx.x;
     const bool staged = l >= t.ls;
-    const unsigned sh = (staged || PAIR) ? 6u : 7u;
+    const unsigned sh = staged ? 6u : 7u;
     const unsigned base = staged ? (unsigned)kTab : bh * (unsigned)t.g_entries * kBigEnt;
     float4 f;
     f.x = (float)t.W[l];
@@ -310,7 +299,7 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
   const unsigned rf_base = b * (unsigned)d.nq * (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
   const unsigned rf_q = (unsigned)d.ppg * 2u * (unsigned)sizeof(RefT);
   static_assert(!RR || PP == 4, "RR");
-  constexpr int aux = (LP >= 32 && !(ABL & 128)) ? 2 : 0;   // long read-once rows: non-temporal, the maps keep the L2
+  constexpr int aux = (LP >= 32 && !(SCHED & 128)) ? 2 : 0;   // long read-once rows: non-temporal, the maps keep the L2
   auto request = [&](Pre &r, unsigned q) {
     const unsigned o_lg = lg_base + q * lg_q, o_of = 2u * o_lg, o_rf = rf_base + q * rf_q;
 #pragma unroll
@@ -498,8 +487,7 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
   for (; i < n_items; i += kStride) {
     const unsigned q = query_of(i);
     const unsigned q_pre = i + 2 * kStride < n_items ? query_of(i + 2 * kStride) : q0;
-    if constexpr (ABL & 4) pre2 = pre1;
-    else if constexpr (!(ABL & 32) && !(ABL & 256)) request(pre2, q_pre);
+    if constexpr (!(SCHED & 32)) request(pre2, q_pre);
     float s_nxt;
     bool any_nxt;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -507,20 +495,14 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
     if (__any(any_cur)) {
       uint4 bp[D][BT];
       u32x4 r0[D][BT], r1[D][BT];
-      u32x2 p0[D][BT], p1[D][BT];   // PAIR: rows 0 / 1 of the pixel-pair entries
       auto issue = [&](int tb) {
         const int sl = tb % D;
 #pragma unroll
         for (int j = 0; j < BT; ++j) bp[sl][j] = *reinterpret_cast<const uint4 *>(box + (tb * BT + j) * 16);
 #pragma unroll
         for (int j = 0; j < BT; ++j) {
-          if constexpr (PAIR) {
-            p0[sl][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(bp[sl][j].z + lane8b), 0, 0);
-            p1[sl][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(bp[sl][j].w + lane8b), 0, 0);
-          } else {
-            r0[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].z + lane16), 0, 0);
-            if constexpr (!I8) r1[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].w + lane16), 0, 0);
-          }
+          r0[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].z + lane16), 0, 0);
+          if constexpr (!I8) r1[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(bp[sl][j].w + lane16), 0, 0);
         }
       };
       // int8: 4 samples x 4 channels -> requantised samples, gathered per channel, one dot4 each
@@ -556,17 +538,7 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
       };
       auto consume = [&](int tb) {
         const int sl = tb % D;
-        if constexpr (PAIR) {
-          unsigned v[BT][4];
-#pragma unroll
-          for (int j = 0; j < BT; ++j) {   // channel c: (v00, v01) of row 0, (v10, v11) of row 1 -> one dot4 operand
-            v[j][0] = __builtin_amdgcn_perm(p1[sl][j].x, p0[sl][j].x, 0x05040100u);
-            v[j][1] = __builtin_amdgcn_perm(p1[sl][j].x, p0[sl][j].x, 0x07060302u);
-            v[j][2] = __builtin_amdgcn_perm(p1[sl][j].y, p0[sl][j].y, 0x05040100u);
-            v[j][3] = __builtin_amdgcn_perm(p1[sl][j].y, p0[sl][j].y, 0x07060302u);
-          }
-          i8_batch(v, bp[sl]);
-        } else if constexpr (I8) {
+        if constexpr (I8) {
           unsigned v[BT][4];
 #pragma unroll
           for (int j = 0; j < BT; ++j) { v[j][0] = r0[sl][j].x; v[j][1] = r0[sl][j].y; v[j][2] = r0[sl][j].z; v[j][3] = r0[sl][j].w; }
@@ -633,48 +605,32 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
       // request made just before this block: the front end and the LDS head start cover it.
       constexpr int HEAD = NBIG == 0 ? NLDS : (NLDS > NBIG ? NLDS - NBIG + 1 : (NLDS >= 2 ? 2 : NLDS));
       uint4 npl[PP];
-      constexpr bool kBig = !(ABL & 1), kLds = !(ABL & 2), kFront = !(ABL & 8);
 #pragma unroll
-      for (int tb = 0; tb < D && tb < NBIG; ++tb)
-        if constexpr (kBig) issue(tb);
+      for (int tb = 0; tb < D && tb < NBIG; ++tb) issue(tb);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((ABL & 256) && !(ABL & 4)) {
-        request(pre2, q_pre);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (kFront) {
-        front(pre1, npl, s_nxt, any_nxt);
-      } else {
-#pragma unroll
-        for (int k = 0; k < PP; ++k) npl[k] = pl[k];
-        s_nxt = s_cur; any_nxt = any_cur;
-      }
+      front(pre1, npl, s_nxt, any_nxt);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < HEAD; ++u) {
-        if constexpr (kLds) lds_batch(u);
+        lds_batch(u);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int tb = 0; tb < NBIG; ++tb) {
-        if constexpr (kBig) consume(tb);
+        consume(tb);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kBig) {
-          if (tb + D < NBIG) issue(tb + D);
-        }
+        if (tb + D < NBIG) issue(tb + D);
         __builtin_amdgcn_sched_barrier(0);
         if (HEAD + tb < NLDS) {
-          if constexpr (kLds) lds_batch(HEAD + tb);
+          lds_batch(HEAD + tb);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
-      for (int u = HEAD + NBIG; u < NLDS; ++u)
-        if constexpr (kLds) lds_batch(u);
+      for (int u = HEAD + NBIG; u < NLDS; ++u) lds_batch(u);
 #pragma unroll
       for (int k = 0; k < PP; ++k) pl[k] = npl[k];
     } else {
-      if constexpr ((ABL & 256) && !(ABL & 4)) request(pre2, q_pre);
       front(pre1, pl, s_nxt, any_nxt);
     }
     // ---- normalise, store
@@ -692,25 +648,22 @@ __global__ __launch_bounds__(THREADS, (ABL & 1024) ? 4 : 1) void msda_hm4_kernel
           res |= ((unsigned)rq & 0xffu) << (8 * c);
         }
       }
-      if constexpr (!(ABL & 16)) *reinterpret_cast<unsigned *>(outp) = res;
-      else if (res == 0x12345678u && s_cur == 3.f) *reinterpret_cast<unsigned *>(outp) = res;
+      *reinterpret_cast<unsigned *>(outp) = res;
     } else {
       __half *outp = reinterpret_cast<__half *>(a.out) + (((size_t)b * d.nq + q) * d.heads + h) * 32u + lane8 * 4u;
       const float inv = __builtin_amdgcn_rcpf(s_cur);
       uint2 v;
       v.x = pack_h2(acc[0] * inv, acc[1] * inv);
       v.y = pack_h2(acc[2] * inv, acc[3] * inv);
-      if constexpr (ABL & 16) {
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<uint2 *>(outp) = v;  // keeps the math alive
-      } else if constexpr (LP >= 32 && !(ABL & 128)) {
+      if constexpr (LP >= 32 && !(SCHED & 128)) {
         __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x,
                                     reinterpret_cast<unsigned long long *>(outp));
       } else {
         *reinterpret_cast<uint2 *>(outp) = v;
       }
     }
-    if constexpr ((ABL & 32) && !(ABL & 4)) request(pre2, q_pre);
-    if constexpr (!(ABL & 8)) post(pl);
+    if constexpr (SCHED & 32) request(pre2, q_pre);
+    post(pl);
     s_cur = s_nxt;
     any_cur = any_nxt;
     pre1 = pre2;
@@ -735,14 +688,12 @@ struct H4Plan {
   Hm3Plan p;
   int nbig;   // tap batches served by L1/L2
   bool occ2;  // the two-blocks-per-CU plan
-  bool pair;  // (always false since round 5: the pixel-pair entry format of the int8 big set was removed)
 };
 
 bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq, H4Plan &pl, bool i8) {
   const int LP = L * P;
   const int bt = LP >= 4 ? 4 : LP;
   pl.occ2 = false;
-  pl.pair = false;
   if (i8 && !g_h4_no_occ && LP == 32) {
     // (hm3_plan budgets the staged planes as kLdsLimit - kTab - box bytes: a cap is a larger pretended box)
     if (hm3_plan(shapes_host, bs, heads, L, nq, kLdsLimit - kTab - kOccStageCap, pl.p) && pl.p.t.ls < L &&
@@ -758,14 +709,14 @@ bool h4_plan(const int32_t *shapes_host, int bs, int heads, int L, int P, int nq
   return true;
 }
 
-template <int LP, int NBIG, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int ABL = 0>
+template <int LP, int NBIG, bool I8, bool U8W, typename RefT, bool MASKED, bool RR, int SCHED = 0>
 int h4_go(const H4Args &a, hipStream_t st) {
   const size_t lds = kTab + a.stage_bytes + (size_t)h4_box_bytes(LP) + (a.qmask ? a.chunk * 2 + 64 : 0);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR, ABL>>(lds))
+  if (!ensure_dynamic_lds<msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR, SCHED>>(lds))
     return BEVOPS_FAILURE;
   const dim3 grid((unsigned)(a.d.bs * a.d.heads * a.nchunk));
-  hipLaunchKernelGGL((msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR, ABL>), grid,
+  hipLaunchKernelGGL((msda_hm4_kernel<LP, NBIG, kH4Threads, I8, U8W, RefT, MASKED, RR, SCHED>), grid,
                      dim3(kH4Threads), lds, st, a);
   return launch_status();
 }
@@ -773,11 +724,7 @@ int h4_go(const H4Args &a, hipStream_t st) {
 // instantiated (L*P, big batches) combinations: the model's calls.  Anything else -> NOT_SUPPORTED
 // (the caller keeps its older kernels for those).
 template <bool I8, bool U8W, typename RefT, bool MASKED>
-int h4_dispatch(int LP, int nbig, bool occ2, bool pair, const H4Args &a, int ablate, hipStream_t st) {
-  // (the schedule / ablation timing builds of round 2 -- profiles/r02/hm4_ablation.jsonl, hm4_schedule_variants.jsonl --
-  // and the pixel-pair entry format of round 4 -- profiles/r04/msda_i8_pair_ab.jsonl: 40 % fewer bytes fetched, 4-16 %
-  // slower -- were removed from the library in round 5; the kernel template keeps their flag bits)
-  if (ablate || pair) return BEVOPS_NOT_SUPPORTED;
+int h4_dispatch(int LP, int nbig, bool occ2, const H4Args &a, hipStream_t st) {
   // points of an owner lane (4 of them when L*P = 32) share ONE run of reference points
   const bool rr = LP == 32 && a.d.ppg == 4 && a.d.P % 4 == 0;
   // production schedule (profiles/r02/hm4_variants.jsonl): fp16 requests the next operands at
@@ -857,7 +804,7 @@ int msda_hm4_pack(int dtype, int ref_dtype, const void *value, const int32_t *sh
     if (bs * heads > 65535) return BEVOPS_NOT_SUPPORTED;
     const dim3 grid((unsigned)(((t.g_entries + 31) >> 5) + ((t.s_entries + 31) >> 5)), (unsigned)(bs * heads));
     hipLaunchKernelGGL(msda_hm4_repack_i8_kernel, grid, dim3(256), 0, st, (const int8_t *)value, gset, sset, t, nk,
-                       heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u, pl.pair ? 1 : 0);
+                       heads, ref_dtype == BEVOPS_F16 ? 0x80808080u : 0u);
   } else {
     msda_hm3_repack_launch(value, gset, sset, &t, bs, nk, heads, st);
   }
@@ -890,9 +837,10 @@ int msda_hm4_forward_prepacked(int dtype, int ref_dtype, const void *packed, siz
   a.qmask = nullptr;
   a.s_v = s_v; a.s_o = s_o; a.s_w = s_w; a.s_out = s_out;
   const bool i8 = dtype == BEVOPS_I8;
-  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, pl.occ2, false, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, pl.occ2, pl.pair, a, ablate, st);
-  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, pl.occ2, pl.pair, a, ablate, st);
+  if (ablate) return BEVOPS_NOT_SUPPORTED;   // (the timing builds of round 2 are gone)
+  if (dtype == BEVOPS_F16) return h4_dispatch<false, false, __half, false>(LP, pl.nbig, pl.occ2, a, st);
+  if (i8 && ref_dtype == BEVOPS_F32) return h4_dispatch<true, false, float, false>(LP, pl.nbig, pl.occ2, a, st);
+  if (i8 && ref_dtype == BEVOPS_F16) return h4_dispatch<true, true, __half, false>(LP, pl.nbig, pl.occ2, a, st);
   return BEVOPS_NOT_SUPPORTED;
 }
 

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned shor
   if (threadIdx.x == 0) counts[cam] = (int)base;
 }
 
-// ---- sampling kernel.  ABL: ablation bits for the probes (1: no big-level taps, 2: no staged
-// taps, 4: operands loaded once, 8: no store).  LISTED: 0 every query of the chunk, 1 the items whose
+// ---- sampling kernel.  LISTED: 0 every query of the chunk, 1 the items whose
 // visibility byte is set (pre-pass), 2 the (batch, query) pairs with a non-zero `qmask` weight (fused SCA:
 // `vis` then points at the [bs, nq] fp16 bev_mask and the offsets / logits are shared by all batches), 3 the fused SCA
 // op on a visibility PLAN (`vis` points at it, msda_hm5_plan_kernel): the visible (camera, query) pairs of ALL cameras
@@ -218,38 +217,27 @@ __global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned shor
 // 830 items per block on the 6-camera rig, 39 % of the blocks empty, the average non-empty block 3 rounds of 128
 // octets behind a 130 KB plane copy), stages the plane of each camera its slice touches (at most two at one block per
 // CU) and needs no in-kernel compaction.
-// MBOX: the 8 records of a phase reach the octet's lanes through an LDS mailbox (one ds_write_b128 per
-// lane, one broadcast ds_read_b128 per record: 36 LDS cycles per phase and wave, ~70 us of LDS-pipe
-// time per base SCA call -- measured to ADD to the tap time); otherwise through DPP: two row shifts give
-// every lane the record of slot (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot
-// and dword does the rest (26 more VALU instructions per phase, no LDS traffic).
-// (512-thread blocks are the level-class split probe's: two of them -- one per level class -- share a CU, so each
-// is compiled for 4 waves per SIMD, i.e. <= 128 registers, like the 1024-thread block)
-template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX, bool PERSIST>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kernel(
+// The 8 records of a phase reach the octet's lanes through DPP: two row shifts give every lane the record of slot
+// (lane % 4) and of slot 4 + (lane % 4), a quad_perm broadcast per slot and dword does the rest (26 VALU instructions
+// per phase, no LDS traffic; an LDS mailbox -- one ds_write_b128 per lane, one broadcast ds_read_b128 per record --
+// measured 8 us slower per base SCA call in round 3).  Builds measured in rounds 3-5 and no longer in this file (the
+// history has them: 768-thread blocks, two phases of loads in flight, the mailbox, persistent blocks on strided
+// sub-chunks, specialised waves, the level-class split, ablation / timing builds): design/msda.md.
+constexpr int kH5Threads = 1024;   // one block per CU (the staged planes fill the LDS): 16 waves at <= 128 registers
+template <int LISTED>
+__global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
     __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
-    const unsigned char *__restrict__ vis, unsigned *__restrict__ queue) {
-  constexpr int NB = 2 * NBL;   // big-level samples per phase
+    const unsigned char *__restrict__ vis) {
+  constexpr int THREADS = kH5Threads;
+  constexpr int NB = 4;         // big-level samples per phase (two big levels x two lanes)
   constexpr int NS = 8 - NB;    // staged samples per phase
-  constexpr int kBox = 8 * 16 + 16;
   constexpr unsigned OCT = THREADS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // smem: [staged planes][mailboxes][query list][wave totals]
-  // PERSIST: 32 blocks per (batch, head) plane; block j takes the 256-query sub-chunks j, j + 32, j + 64, ...
-  // of its plane, appending their visible queries to its list until it holds >= 1024 items (or its sub-chunks
-  // are used up), and samples them.  A strided sample of the plane sees the plane's average visibility, so the
-  // 32 blocks carry equal work whatever the visibility pattern (one block per contiguous 1 280-query chunk:
-  // 0 .. 830 visible items per block on the rig geometry), their rounds of 128 octets are full, and the
-  // assignment is the same for all heads -- the 8 XCDs still walk the queries together, which the operand
-  // stream needs (a per-plane atomic queue let the heads drift apart: 601 vs 539 us, the 8 heads' pieces of an
-  // offsets row were no longer fetched together).  Measured equal on uniform points (542 vs 542 us) and slower
-  // on the rig geometry (278 vs 271 us: every block copies the plane, none is empty) -- so the DEFAULT stays
-  // !PERSIST: one block per chunk of `chunk` queries; PERSIST is an A/B build (flag 512).
-  constexpr unsigned kSub = 256, kBatch = 1024, kBpp = 32;
+  // smem: [staged planes][query list][wave totals]
   unsigned bh, ck = 0;
-  const unsigned per_plane = PERSIST ? kBpp : (unsigned)nchunk;
+  const unsigned per_plane = (unsigned)nchunk;
   if (d.heads == 8) {   // XCD x keeps head x; all XCDs walk the same (batch, chunk) sequence
     const unsigned rest = blockIdx.x >> 3;
     bh = (rest / per_plane) * 8u + (blockIdx.x & 7u);
@@ -265,8 +253,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     b = 0;
     bh = h;
   }
-  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes + (THREADS / 8) * kBox);
-  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + (THREADS / 8) * kBox + chunk * 2);
+  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes);
+  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + chunk * 2);
   auto visible = [&](unsigned q) -> bool {
     if constexpr (LISTED == 3) return true;
     else if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
@@ -281,7 +269,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     }
   };
   unsigned q0 = 0, n_items = 0;
-  if constexpr (!PERSIST && LISTED != 3) {
+  if constexpr (LISTED != 3) {
     q0 = ck * (unsigned)chunk;
     const unsigned q_end = min(q0 + (unsigned)chunk, (unsigned)d.nq);
     n_items = q_end - q0;
@@ -328,8 +316,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
   unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
   const unsigned out_q = (unsigned)d.heads * 64u;
   const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
-  const unsigned box = sbase + (unsigned)stage_bytes + (threadIdx.x >> 3) * kBox;
-  const unsigned qlist_a = sbase + (unsigned)stage_bytes + (THREADS / 8) * kBox;
+  const unsigned qlist_a = sbase + (unsigned)stage_bytes;
   H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
 
   const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
@@ -337,7 +324,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
   unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
   auto query_of = [&](unsigned i) -> unsigned {
     const unsigned ii = min(i, n_items - 1u);   // octets past the end repeat the last item, unstored
-    return (LISTED != 0 || PERSIST) ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
+    return LISTED != 0 ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
   };
   auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
     const unsigned q = query_of(i);
@@ -386,38 +373,28 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
   };
 
   float acc[4];
-  // record of slot S for every lane of the octet.  MBOX: read from the mailbox; else DPP broadcast
-  u32x4 rlo, rhi;   // DPP: records of slot (lane & 3) and of slot 4 + (lane & 3)
+  // record of slot S for every lane of the octet, by DPP broadcast
+  u32x4 rlo, rhi;   // records of slot (lane & 3) and of slot 4 + (lane & 3)
   auto spread = [&]() __attribute__((always_inline)) {
-    if constexpr (MBOX) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      *(lds_u4 *)(size_t)(box + lane16) = rec;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    } else {
-      // lanes 4..7 of every octet take lane - 4's record (row_shr:4 into banks 1, 3), the others keep
-      // their own; and the other way round (row_shl:4 into banks 0, 2)
-      rlo.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x114, 0xf, 0xa, false);
-      rlo.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x114, 0xf, 0xa, false);
-      rlo.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x114, 0xf, 0xa, false);
-      rhi.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x104, 0xf, 0x5, false);
-      rhi.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x104, 0xf, 0x5, false);
-      rhi.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x104, 0xf, 0x5, false);
-    }
+    // lanes 4..7 of every octet take lane - 4's record (row_shr:4 into banks 1, 3), the others keep
+    // their own; and the other way round (row_shl:4 into banks 0, 2)
+    rlo.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x114, 0xf, 0xa, false);
+    rlo.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x114, 0xf, 0xa, false);
+    rlo.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x114, 0xf, 0xa, false);
+    rhi.x = (unsigned)__builtin_amdgcn_update_dpp((int)rec.x, (int)rec.x, 0x104, 0xf, 0x5, false);
+    rhi.y = (unsigned)__builtin_amdgcn_update_dpp((int)rec.y, (int)rec.y, 0x104, 0xf, 0x5, false);
+    rhi.z = (unsigned)__builtin_amdgcn_update_dpp((int)rec.z, (int)rec.z, 0x104, 0xf, 0x5, false);
   };
   auto record = [&](auto sc) __attribute__((always_inline)) -> u32x4 {
     constexpr int S = decltype(sc)::v;
-    if constexpr (MBOX) {
-      return *(const lds_u4 *)(size_t)(box + S * 16u);
-    } else {
-      const u32x4 &src = S < 4 ? rlo : rhi;
-      u32x4 r;
-      r.x = quad_bcast<S & 3>(src.x);
-      r.y = quad_bcast<S & 3>(src.y);
-      r.z = quad_bcast<S & 3>(src.z);
-      // second row: the slot's level is lane-independent (slot S serves level S / 2)
-      r.w = r.z + (((unsigned)t.W[S >> 1] + 1u) << ((S >> 1) >= t.ls ? 6 : 7));
-      return r;
-    }
+    const u32x4 &src = S < 4 ? rlo : rhi;
+    u32x4 r;
+    r.x = quad_bcast<S & 3>(src.x);
+    r.y = quad_bcast<S & 3>(src.y);
+    r.z = quad_bcast<S & 3>(src.z);
+    // second row: the slot's level is lane-independent (slot S serves level S / 2)
+    r.w = r.z + (((unsigned)t.W[S >> 1] + 1u) << ((S >> 1) >= t.ls ? 6 : 7));
+    return r;
   };
   // one item per octet: 4 phases; `cur` = this item's operands, `nxt` = the next item's (landed)
   auto body = [&](H5Set &cur, const H5Set &nxt, unsigned i, H5Set &far) __attribute__((always_inline)) {
@@ -426,8 +403,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     auto phase = [&](auto jc) __attribute__((always_inline)) {
       constexpr int J = decltype(jc)::v;
       // the segment that ends with the big-level loads runs at raised priority: a wave that is about to feed
-      // the L2 path goes before waves that are in their multiply-add segments (518 vs 524 us; ABL & 16: off)
-      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(3);
+      // the L2 path goes before waves that are in their multiply-add segments (518 vs 524 us)
+      __builtin_amdgcn_s_setprio(3);
       spread();
       // big levels: records, then all 2 * NB loads
       u32x4 rb[NB > 0 ? NB : 1];
@@ -440,14 +417,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
       if constexpr (NB > 5) rb[5] = record(IC<5>{});
       if constexpr (NB > 6) rb[6] = record(IC<6>{});
       if constexpr (NB > 7) rb[7] = record(IC<7>{});
-      if constexpr (!(ABL & 1)) {
 #pragma unroll
-        for (int s = 0; s < NB; ++s) {
-          r0[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].z + lane16), 0, 0);
-          r1[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].w + lane16), 0, 0);
-        }
+      for (int s = 0; s < NB; ++s) {
+        r0[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].z + lane16), 0, 0);
+        r1[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rb[s].w + lane16), 0, 0);
       }
-      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       // staged levels in two halves: records, LDS taps (two ds_read_b64 per row: the laundered second
       // address keeps the compiler from fusing them into the half-rate ds_read2_b64), packed-fp16 row
@@ -473,40 +448,34 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
       // half `H` (0 / 1) of the staged slots
       auto lds_issue = [&](auto hc) __attribute__((always_inline)) {
         constexpr int H0 = decltype(hc)::v * HS;
-        if constexpr (!(ABL & 2)) {
-          if constexpr (H0 + 0 < NS) lds_one(IC<NB + H0 + 0>{}, IC<0>{});
-          if constexpr (H0 + 1 < NS && HS > 1) lds_one(IC<NB + H0 + 1>{}, IC<1>{});
-          if constexpr (H0 + 2 < NS && HS > 2) lds_one(IC<NB + H0 + 2>{}, IC<2>{});
-          if constexpr (H0 + 3 < NS && HS > 3) lds_one(IC<NB + H0 + 3>{}, IC<3>{});
-        }
+        if constexpr (H0 + 0 < NS) lds_one(IC<NB + H0 + 0>{}, IC<0>{});
+        if constexpr (H0 + 1 < NS && HS > 1) lds_one(IC<NB + H0 + 1>{}, IC<1>{});
+        if constexpr (H0 + 2 < NS && HS > 2) lds_one(IC<NB + H0 + 2>{}, IC<2>{});
+        if constexpr (H0 + 3 < NS && HS > 3) lds_one(IC<NB + H0 + 3>{}, IC<3>{});
       };
       auto lds_math = [&](int n) __attribute__((always_inline)) {
-        if constexpr (!(ABL & 2)) {
 #pragma unroll
-          for (int s = 0; s < HS; ++s) {
-            if (s >= n) break;
-            const h2_t w0 = as_h2(rl[s].x), w1 = as_h2(rl[s].y);
-            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
-            h2_t a = as_h2(l0[s].x) * w00, bb = as_h2(l0[s].y) * w00;
-            a = as_h2(q0r[s].x) * w01 + a; bb = as_h2(q0r[s].y) * w01 + bb;
-            a = as_h2(l1[s].x) * w10 + a; bb = as_h2(l1[s].y) * w10 + bb;
-            a = as_h2(q1r[s].x) * w11 + a; bb = as_h2(q1r[s].y) * w11 + bb;
-            add_h2(acc[0], acc[1], a);
-            add_h2(acc[2], acc[3], bb);
-          }
+        for (int s = 0; s < HS; ++s) {
+          if (s >= n) break;
+          const h2_t w0 = as_h2(rl[s].x), w1 = as_h2(rl[s].y);
+          const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
+          h2_t a = as_h2(l0[s].x) * w00, bb = as_h2(l0[s].y) * w00;
+          a = as_h2(q0r[s].x) * w01 + a; bb = as_h2(q0r[s].y) * w01 + bb;
+          a = as_h2(l1[s].x) * w10 + a; bb = as_h2(l1[s].y) * w10 + bb;
+          a = as_h2(q1r[s].x) * w11 + a; bb = as_h2(q1r[s].y) * w11 + bb;
+          add_h2(acc[0], acc[1], a);
+          add_h2(acc[2], acc[3], bb);
         }
       };
       auto big_math = [&](int s0, int n) __attribute__((always_inline)) {
-        if constexpr (!(ABL & 1)) {
 #pragma unroll
-          for (int k = 0; k < HB; ++k) {
-            if (k >= n) break;
-            const int s = s0 + k;
-            acc[0] = dot2f(r0[s].x, rb[s].x, acc[0]); acc[1] = dot2f(r0[s].y, rb[s].x, acc[1]);
-            acc[2] = dot2f(r0[s].z, rb[s].x, acc[2]); acc[3] = dot2f(r0[s].w, rb[s].x, acc[3]);
-            acc[0] = dot2f(r1[s].x, rb[s].y, acc[0]); acc[1] = dot2f(r1[s].y, rb[s].y, acc[1]);
-            acc[2] = dot2f(r1[s].z, rb[s].y, acc[2]); acc[3] = dot2f(r1[s].w, rb[s].y, acc[3]);
-          }
+        for (int k = 0; k < HB; ++k) {
+          if (k >= n) break;
+          const int s = s0 + k;
+          acc[0] = dot2f(r0[s].x, rb[s].x, acc[0]); acc[1] = dot2f(r0[s].y, rb[s].x, acc[1]);
+          acc[2] = dot2f(r0[s].z, rb[s].x, acc[2]); acc[3] = dot2f(r0[s].w, rb[s].x, acc[3]);
+          acc[0] = dot2f(r1[s].x, rb[s].y, acc[0]); acc[1] = dot2f(r1[s].y, rb[s].y, acc[1]);
+          acc[2] = dot2f(r1[s].z, rb[s].y, acc[2]); acc[3] = dot2f(r1[s].w, rb[s].y, acc[3]);
         }
       };
       lds_issue(IC<0>{});
@@ -537,7 +506,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
     phase(IC<3>{});
     const float s = oct_sum(s_cur);
     const float inv = __builtin_amdgcn_rcpf(s);
-    if constexpr (!(ABL & 8)) {
+    {
       // unconditional: an octet past the end of the list recomputes the last item and stores the
       // same bytes again (a conditional store lets the compiler sink the last phase's loads into
       // the branch, behind the LDS taps they are meant to overlap)
@@ -546,15 +515,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
       v.x = pack_h2(acc[0] * inv, acc[1] * inv);
       v.y = pack_h2(acc[2] * inv, acc[3] * inv);
       __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(out_base + q * out_q), 0, 2);
-    } else {
-      asm volatile("" ::"v"(acc[0] * inv), "v"(acc[1] * inv), "v"(acc[2] * inv), "v"(acc[3] * inv));
     }
     // the operand request is the youngest vector memory instruction of the iteration
     cur = nxt;
-    if constexpr (!(ABL & 4)) {
-      const_cast<H5Set &>(nxt) = far;
-      request(far, i + 3u * OCT);
-    }
+    const_cast<H5Set &>(nxt) = far;
+    request(far, i + 3u * OCT);
   };
 
   // S0 = this item's operands, S1 = the next item's (landed), S2 = the one after (in flight).  One body
@@ -609,60 +574,24 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void msda_hm5_kern
         run_items();
       }
     }
-  } else if constexpr (!PERSIST) {
-    run_items();
   } else {
-    const unsigned nsub = ((unsigned)d.nq + kSub - 1u) / kSub;
-    bool done = false, staged = false;
-    unsigned next_sub = ck;   // this block's index within its plane
-    while (!done) {
-      unsigned count = 0;
-      while (count < kBatch) {
-        __syncthreads();   // the list and the wave totals are free again
-        const unsigned sub = next_sub;
-        if (sub >= nsub) { done = true; break; }
-        next_sub += kBpp;
-        const unsigned q = sub * kSub + threadIdx.x;
-        const bool v = threadIdx.x < kSub && q < (unsigned)d.nq && visible(q);
-        const unsigned long long bal = __ballot(v);
-        const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-        if (lane == 0 && wv < kSub / 64) wtot[wv] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned before = count, all = 0;
-#pragma unroll
-        for (unsigned w2 = 0; w2 < kSub / 64; ++w2) {
-          const unsigned cnt = wtot[w2];
-          if (w2 < wv) before += cnt;
-          all += cnt;
-        }
-        if (v) wl[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)q;
-        count += all;
-      }
-      if (count == 0) break;
-      if (!staged) { stage_plane(); staged = true; }
-      __syncthreads();
-      n_items = count;
-      run_items();
-    }
+    run_items();
   }
 }
 
-inline int h5_lds_extra(int threads, int chunk) { return (threads / 8) * (8 * 16 + 16) + chunk * 2 + 128; }
+inline int h5_lds_extra(int threads, int chunk) { (void)threads; return chunk * 2 + 128; }   // query list + wave totals
 constexpr int kH5Chunk = 1280;
 
-template <int NBL, int THREADS, int ABL, int LISTED, bool MBOX = true, bool PERSIST = false>
+template <int LISTED>
 int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *ref, const __half *off,
-          const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st,
-          unsigned *queue = nullptr) {
+          const __half *logit, __half *out, const MsdaDims &d, const unsigned char *vis, int chunk, hipStream_t st) {
   const int nchunk = (d.nq + chunk - 1) / chunk;
-  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, chunk);
+  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(kH5Threads, chunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  if (PERSIST && (d.nq > 65535 || chunk < 1280)) return BEVOPS_NOT_SUPPORTED;   // list entries are absolute u16 queries
-  if (!ensure_dynamic_lds<msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX, PERSIST>>(lds)) return (int)BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<msda_hm5_kernel<LISTED>>(lds)) return (int)BEVOPS_FAILURE;
   const unsigned planes = (unsigned)(d.bs * d.heads);
-  hipLaunchKernelGGL((msda_hm5_kernel<NBL, THREADS, ABL, LISTED, MBOX, PERSIST>),
-                     dim3(PERSIST ? planes * 32u : planes * (unsigned)nchunk), dim3(THREADS), lds, st, gset,
-                     (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk, pl.stage_bytes, vis, queue);
+  hipLaunchKernelGGL((msda_hm5_kernel<LISTED>), dim3(planes * (unsigned)nchunk), dim3(kH5Threads), lds, st, gset,
+                     (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk, pl.stage_bytes, vis);
   return launch_status();
 }
 
@@ -707,9 +636,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
   if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
-  unsigned *queue = nullptr;
-  return h5_go<2, 1024, 0, 2, false, false>(pl, gset, gset + g_room, ref, off, logit, sampled, d,
-                                            reinterpret_cast<const unsigned char *>(qmask), kH5Chunk, st, queue);
+  return h5_go<2>(pl, gset, gset + g_room, ref, off, logit, sampled, d, reinterpret_cast<const unsigned char *>(qmask),
+                  kH5Chunk, st);
 }
 
 // ---- the same sampling on a visibility plan (msda_hm5_plan_kernel): balanced slices of the visible (camera, query)
@@ -753,18 +681,18 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
-  constexpr int THREADS = 1024;
+  constexpr int THREADS = kH5Threads;
   const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  auto kern = msda_hm5_kernel<2, THREADS, 0, 3, false, false>;
-  if (!ensure_dynamic_lds<msda_hm5_kernel<2, THREADS, 0, 3, false, false>>(lds)) return (int)BEVOPS_FAILURE;
+  auto kern = msda_hm5_kernel<3>;
+  if (!ensure_dynamic_lds<msda_hm5_kernel<3>>(lds)) return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)
   const unsigned per_head = (unsigned)((cus > 0 ? cus : 256) * g_h5_plan_k + heads - 1) / (unsigned)heads;
   hipLaunchKernelGGL(kern, dim3(per_head * (unsigned)heads), dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes,
                      gset + g_room, ref, off, logit, sampled, d, pl.t, kH5PlanChunk, 1, pl.stage_bytes,
-                     static_cast<const unsigned char *>(plan), (unsigned *)nullptr);
+                     static_cast<const unsigned char *>(plan));
   return launch_status();
 }
 
@@ -791,11 +719,11 @@ int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const 
   unsigned char *vis = reinterpret_cast<unsigned char *>(gset + ((g_room + pl.s_bytes + 255) & ~size_t(255)));
   if (!prepacked) msda_hm3_repack_launch(value, gset, sset, &pl.t, bs, nk, heads, st);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, shared};
-  if (flags & 1) return h5_go<2, 1024, 0, 0, false>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
+  if (flags & 1) return h5_go<0>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
   const unsigned n_pair = (unsigned)bs * (unsigned)nq;
   const unsigned waves = (n_pair + 63u) / 64u;
   hipLaunchKernelGGL(msda_hm5_vis_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, ref, off, out, vis, d, pl.t, n_pair);
-  return h5_go<2, 1024, 0, 1, false>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
+  return h5_go<1>(pl, gset, sset, ref, off, logit, out, d, vis, kH5Chunk, st);
 }
 
 }  // namespace bevops

@@ -93,28 +93,23 @@ struct TileArgs {
 // NI: 32-column MFMA blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (layers with N <= 64: no
 // matrix work on columns that do not exist)
 // RES8: the identity rows are int8 [M, N] (real = q * s_res) instead of fp16
-// MJ: 32-row MFMA blocks per wave: 2 -> 128-row tiles (three blocks per CU, the default), 1 -> 64-row tiles (four
-// blocks per CU and twice the tiles; an A/B build, measured slower on every layer -- see launch_tile_gemm).
-// KB: bytes of k per row and step.  64 everywhere; 128 ("wide steps", int8 chain GEMMs without convolution mode): the
-// long-K layers of ResNet stages 3 / 4 are ONE sparse round of tiles whose time is their chain of dependent steps
-// (load -> LDS -> barrier -> multiply, ~1.5 us each whatever the step holds) -- a step that holds twice the bytes
-// halves the chain and doubles the bytes a block keeps in flight (two register sets of 32 KB).  72 KB of LDS: two blocks
-// per CU (these layers pose ~2 tiles per CU anyway), dynamic shared memory.
-template <int KB>
+// Tiles are 128 rows (two 32-row MFMA blocks per wave, three blocks per CU) and a step holds 64 bytes of k per row.
+// Two other builds were measured in round 4 and are no longer in this file (history; profiles/r04/tile_rows_ab.jsonl,
+// tile_wide_ab.jsonl): 64-row tiles (four blocks per CU: 3-10 % slower on every layer) and 128-byte steps for the int8
+// chain's plain GEMMs (bit-identical, slower: a step costs its latency whatever it holds).
 constexpr int tile_lds_bytes(int tm) {
-  return 2 * (tm + 128) * (KB + 16) > 4 * 32 * kEpiStride ? 2 * (tm + 128) * (KB + 16) : 4 * 32 * kEpiStride;
+  return 2 * (tm + 128) * (64 + 16) > 4 * 32 * kEpiStride ? 2 * (tm + 128) * (64 + 16) : 4 * 32 * kEpiStride;
 }
-extern __shared__ __attribute__((aligned(16))) char tile_dyn_smem[];
-template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false, int MJ = 2, int KB = 64>
-__global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_gemm_kernel(TileArgs p) {
-  static_assert(KB == 64 || (KB == 128 && MODE == kS8 && !CONV && MJ == 2), "wide steps: the int8 chain's plain GEMMs");
+template <int MODE, bool OUT8, int NI, bool CONV, bool RES8 = false>
+__global__ __launch_bounds__(256, 3) void tile_gemm_kernel(TileArgs p) {
+  constexpr int MJ = 2;                          // 32-row MFMA blocks per wave
+  constexpr int KB = 64;                         // bytes of k per row and step
   constexpr int kTN = 64 * NI;
   constexpr int TM = 64 * MJ;                    // rows per tile
   constexpr int kTLd = KB + 16;                  // LDS row: the step's bytes + 16 (conflict-free 16-byte fragment reads)
   constexpr int kHalves = KB / 64;               // 64-byte halves of a step: a staging thread takes one 16-byte chunk of each
-  // [image][A rows | W rows][KB + 16]; 40 / 34 KB static, 72 KB dynamic (wide steps)
-  __shared__ __attribute__((aligned(16))) char smem_static[KB == 64 ? tile_lds_bytes<64>(TM) : 16];
-  char *const smem = KB == 64 ? smem_static : tile_dyn_smem;
+  // [image][A rows | W rows][KB + 16]; 40 KB static
+  __shared__ __attribute__((aligned(16))) char smem[tile_lds_bytes(TM)];
   constexpr int kAB = MODE == kS8 ? 1 : 2;     // bytes per activation element in memory
   constexpr int kWB = MODE == kF16 ? 2 : 1;    // bytes per weight element
   constexpr int kAV = MODE == kF16Q ? 2 : 1;   // 16-byte loads per activation row and step
@@ -164,10 +159,10 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
       }
     };
     place(m0 + r0, a_off0, tapmask0);
-    if constexpr (MJ == 2) place(m0 + r1, a_off1, tapmask1);
+    place(m0 + r1, a_off1, tapmask1);
   } else {
     a_off0 = m0 + r0 < M ? (unsigned)(((size_t)(m0 + r0) * K + kce) * kAB) : kOob;
-    if constexpr (MJ == 2) a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
+    a_off1 = m0 + r1 < M ? (unsigned)(((size_t)(m0 + r1) * K + kce) * kAB) : kOob;
   }
   int g_tap = 0, g_c = 0;                      // conv mode: the (tap, channel) position of the NEXT gload
   const unsigned w_off0 = n0 + r0 < N ? (unsigned)(((size_t)(n0 + r0) * K + kce) * kWB) : kOob;
@@ -184,17 +179,6 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
     constexpr int S = decltype(setc)::value;
     const int ks = kt * kStepK;
     const bool kok = ks + kce < K;   // K is a multiple of a thread's chunk (host check)
-    if constexpr (KB == 128) {       // wide steps (int8, no convolution mode): the chunk of each 64-byte half
-#pragma unroll
-      for (int hh = 0; hh < kHalves; ++hh) {
-        const bool ok = ks + 64 * hh + kce < K;
-        ra0[S][hh] = bload(rs_a, ok ? a_off0 + 64u * hh : kOob, ks);
-        ra1[S][hh] = bload(rs_a, ok ? a_off1 + 64u * hh : kOob, ks);
-        rb0[S][hh] = bload(rs_w, ok ? w_off0 + 64u * hh : kOob, ks);
-        if constexpr (NI == 2) rb1[S][hh] = bload(rs_w, ok ? w_off1 + 64u * hh : kOob, ks);
-      }
-      return;
-    }
     if constexpr (CONV) {
       const int delta = ((g_tap / p.conv_ks - pad) * p.conv_win + (g_tap % p.conv_ks - pad)) * cin * kAB;
       const unsigned v0 = (tapmask0 >> g_tap) & 1u ? a_off0 + (unsigned)delta : kOob;
@@ -202,7 +186,7 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
         ra0[S][h] = bload(rs_a, v0 + 16u * h, g_c * kAB);
-        if constexpr (MJ == 2) ra1[S][h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
+        ra1[S][h] = bload(rs_a, v1 + 16u * h, g_c * kAB);
       }
       g_c += kStepK;
       if (g_c >= cin) { g_c = 0; ++g_tap; }
@@ -210,7 +194,7 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
 #pragma unroll
       for (int h = 0; h < kAV; ++h) {
         ra0[S][h] = bload(rs_a, kok ? a_off0 + 16u * h : kOob, ks * kAB);
-        if constexpr (MJ == 2) ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
+        ra1[S][h] = bload(rs_a, kok ? a_off1 + 16u * h : kOob, ks * kAB);
       }
     }
     rb0[S][0] = bload(rs_w, kok ? w_off0 : kOob, ks * kWB);
@@ -222,14 +206,14 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
     char *As = smem + buf * (TM + 128) * kTLd, *Ws = As + TM * kTLd;
     if constexpr (MODE == kF16Q) {
       *reinterpret_cast<uint4 *>(As + r0 * kTLd + lchunk) = quant16(ra0[S][0], ra0[S][1], p.inv_sa);
-      if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
+      *reinterpret_cast<uint4 *>(As + r1 * kTLd + lchunk) = quant16(ra1[S][0], ra1[S][1], p.inv_sa);
       *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + lchunk) = rb0[S][0];
       if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + lchunk) = rb1[S][0];
     } else {
 #pragma unroll
       for (int hh = 0; hh < kHalves; ++hh) {
         *reinterpret_cast<uint4 *>(As + r0 * kTLd + 64 * hh + lchunk) = ra0[S][hh];
-        if constexpr (MJ == 2) *reinterpret_cast<uint4 *>(As + r1 * kTLd + 64 * hh + lchunk) = ra1[S][hh];
+        *reinterpret_cast<uint4 *>(As + r1 * kTLd + 64 * hh + lchunk) = ra1[S][hh];
         *reinterpret_cast<uint4 *>(Ws + r0 * kTLd + 64 * hh + lchunk) = rb0[S][hh];
         if constexpr (NI == 2) *reinterpret_cast<uint4 *>(Ws + r1 * kTLd + 64 * hh + lchunk) = rb1[S][hh];
       }
@@ -318,9 +302,7 @@ __global__ __launch_bounds__(256, KB == 128 ? 2 : (MJ == 1 ? 4 : 3)) void tile_g
   }
   // ---- epilogue.  acc[i][j][4 g + c]: n = n0 + wn*32*NI + i*32 + 8 g + 4 (lane >> 5) + c, m = m0 + wm*32*MJ + j*32 + (lane & 31)
   // (the barrier that ended the last step also freed both LDS images)
-  if constexpr (MJ == 2) {
-    if (res_vec) res_request(1);
-  }
+  if (res_vec) res_request(1);
   char *stage = smem + wave * 32 * kEpiStride;
   float sc[8], bs[8];
 #pragma unroll
@@ -476,8 +458,8 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const bool conv = cg.cin > 0, out8 = out_dtype == BEVOPS_I8;
 #define BEVOPS_TG(OUT8_, CONV_, RES8_)                                                                                 \
   do {                                                                                                                 \
-    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);   \
-    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_, 2>), grid, dim3(256), 0, st, p);          \
+    if (narrow) hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 1, CONV_, RES8_>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((tile_gemm_kernel<MODE, OUT8_, 2, CONV_, RES8_>), grid, dim3(256), 0, st, p);             \
     return launch_status();                                                                                            \
   } while (0)
   if constexpr (MODE == kF16) {
