@@ -601,12 +601,21 @@ int msda_int8(const int8_t *value, const int32_t *shapes, const RefT *ref, const
 
 using namespace bevops;
 
+static thread_local bool g_sca_direct = true;   // bevops_sca_forward_planned: see set_variant 3012 / 3013
 static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19 maps to 17 + a flag below)
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant_raw;   // handing this back to set_variant restores the flags too
   g_variant_raw = variant;
   if (variant >= 3001 && variant <= 3008) {   // A/B: slices per CU of the planned fused SCA sampling (default 2)
     msda_hm5_set_plan_blocks(variant - 3000);
+    return prev;
+  }
+  if (variant == 3010 || variant == 3011) {   // A/B: camera reduce of the fused SCA op unrolled (default) / rolled
+    msda_sca_set_reduce_rolled(variant == 3011);
+    return prev;
+  }
+  if (variant == 3012 || variant == 3013) {   // A/B: planned SCA stores single-camera pairs into the output (default) / not
+    g_sca_direct = variant == 3012;
     return prev;
   }
   // 19 (A/B): int8 hm4 on the one-block-per-CU plan (the partner of the default two-blocks plan); g_variant then
@@ -779,7 +788,7 @@ extern "C" int bevops_sca_forward_prepacked(int dtype, const void *packed, size_
                                          (const __half *)bev_mask, sampled, num_cams, nk, heads, channels, num_levels,
                                          num_query, num_point, points_per_group, st);
   if (rc != BEVOPS_SUCCESS) return rc;
-  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, st);
+  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, false, st);
   return launch_status();
 }
 
@@ -814,10 +823,12 @@ extern "C" int bevops_sca_forward_planned(int dtype, const void *packed, size_t 
   __half *sampled = static_cast<__half *>(workspace);
   const int rc = msda_hm5_sca_sample_planned_f16(packed, packed_bytes, spatial_shapes_host,
                                                  (const __half *)reference_points_cam, (const __half *)sampling_offsets,
-                                                 (const __half *)attention_weights, plan, plan_bytes, sampled, num_cams,
-                                                 nk, heads, channels, num_levels, num_query, num_point, points_per_group, st);
+                                                 (const __half *)attention_weights, plan, plan_bytes, sampled,
+                                                 g_sca_direct ? (__half *)output : nullptr, num_cams, nk, heads, channels,
+                                                 num_levels, num_query, num_point, points_per_group, st);
   if (rc != BEVOPS_SUCCESS) return rc;
-  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels, st);
+  msda_sca_reduce_launch(sampled, (const __half *)bev_mask, (__half *)output, num_cams, num_query, heads * channels,
+                         g_sca_direct, st);
   return launch_status();
 }
 

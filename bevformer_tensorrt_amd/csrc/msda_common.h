@@ -253,11 +253,14 @@ size_t msda_hm5_plan_bytes(int bs, int nq);
 int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t plan_bytes, hipStream_t st);
 int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host,
                                     const __half *ref, const __half *off, const __half *logit, const void *plan,
-                                    size_t plan_bytes, __half *sampled, int bs, int nk, int heads, int C, int L, int nq,
-                                    int P, int ppg, hipStream_t st);
+                                    size_t plan_bytes, __half *sampled, __half *direct, int bs, int nk, int heads, int C,
+                                    int L, int nq, int P, int ppg, hipStream_t st);
 void msda_hm5_set_plan_blocks(int k);
+void msda_sca_set_reduce_rolled(bool on);   // A/B partner of the unrolled camera reduce (set_variant 3010 / 3011)
+// skip_sole: rows of queries that exactly one camera sees with weight 1 are left alone (the planned sampler has
+// stored them already, msda_hm5.hip: kSoleBit)
 void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
-                            hipStream_t st);
+                            bool skip_sole, hipStream_t st);
 bool msda_hm5_layout(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq, int P, void *tab,
                      size_t *g_room, size_t *s_bytes);
 void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const void *tab, int bs, int nk, int heads,

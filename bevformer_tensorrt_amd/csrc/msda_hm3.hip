@@ -422,25 +422,74 @@ int launch_hm3(const Hm3Plan &pl, const char *gset, const char *sset, const __ha
 }
 
 // fused SCA, second step: slots[q, :] = sum over cameras of mask[b, q] * sampled[b, q, :], reading
-// only the visible (camera, query) pairs.  thread = (query, 8-channel vector)
+// only the visible (camera, query) pairs (the scratch rows of the others are never written).  thread = (query,
+// 8-channel vector).  BS > 0: the camera loop is unrolled -- all masks are requested first, then all visible rows, and
+// only then does the ascending-camera fma chain start (same order, same bits as the rolled loop, one memory round trip
+// instead of one per visible camera); BS == 0: any camera count, rolled.  SKIP: a query that exactly one camera sees
+// with weight exactly 1 is left alone -- the planned sampler has stored that row itself (msda_hm5.hip: kSoleBit; the
+// same rule on the same mask).
+template <int BS, bool SKIP>
 __global__ __launch_bounds__(256) void sca_camera_reduce_kernel(const __half *__restrict__ sampled,
                                                                 const __half *__restrict__ qmask,
                                                                 __half *__restrict__ out, int bs, int nq,
                                                                 int width) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int vecs = width / 8;
-  const size_t q = idx / vecs;
-  const int c = (int)(idx - q * vecs);
+  size_t q;
+  int c;
+  if constexpr (BS > 0) {   // the launcher sends only grids below 2^31 threads here: 32-bit index arithmetic
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned q32 = idx / (unsigned)vecs;
+    q = q32;
+    c = (int)(idx - q32 * (unsigned)vecs);
+  } else {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    q = idx / vecs;
+    c = (int)(idx - q * vecs);
+  }
   if (q >= (size_t)nq) return;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < bs; ++b) {
-    const float m = __half2float(qmask[(size_t)b * nq + q]);
-    if (m == 0.f) continue;
-    const uint4 v = *reinterpret_cast<const uint4 *>(sampled + ((size_t)b * nq + q) * width + c * 8);
+  auto add = [&](float m, const uint4 &v) {
     acc[0] = fmaf(m, h2f_lo(v.x), acc[0]); acc[1] = fmaf(m, h2f_hi(v.x), acc[1]);
     acc[2] = fmaf(m, h2f_lo(v.y), acc[2]); acc[3] = fmaf(m, h2f_hi(v.y), acc[3]);
     acc[4] = fmaf(m, h2f_lo(v.z), acc[4]); acc[5] = fmaf(m, h2f_hi(v.z), acc[5]);
     acc[6] = fmaf(m, h2f_lo(v.w), acc[6]); acc[7] = fmaf(m, h2f_hi(v.w), acc[7]);
+  };
+  if constexpr (BS > 0) {
+    float m[BS];
+    uint4 v[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b) m[b] = __half2float(qmask[(size_t)b * nq + q]);
+    if constexpr (SKIP) {
+      int seen = 0;
+      bool unit = false;
+#pragma unroll
+      for (int b = 0; b < BS; ++b)
+        if (m[b] != 0.f) { ++seen; unit = m[b] == 1.f; }
+      if (seen == 1 && unit) return;
+    }
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+      v[b] = make_uint4(0u, 0u, 0u, 0u);
+      if (m[b] != 0.f) v[b] = *reinterpret_cast<const uint4 *>(sampled + ((size_t)b * nq + q) * width + c * 8);
+    }
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+      if (m[b] != 0.f) add(m[b], v[b]);
+  } else {
+    if constexpr (SKIP) {
+      int seen = 0;
+      bool unit = false;
+      for (int b = 0; b < bs; ++b) {
+        const float m = __half2float(qmask[(size_t)b * nq + q]);
+        if (m != 0.f) { ++seen; unit = m == 1.f; }
+      }
+      if (seen == 1 && unit) return;
+    }
+    for (int b = 0; b < bs; ++b) {
+      const float m = __half2float(qmask[(size_t)b * nq + q]);
+      if (m == 0.f) continue;
+      add(m, *reinterpret_cast<const uint4 *>(sampled + ((size_t)b * nq + q) * width + c * 8));
+    }
   }
   uint4 o;
   o.x = pack_h2(acc[0], acc[1]); o.y = pack_h2(acc[2], acc[3]);
@@ -461,11 +510,31 @@ void msda_hm3_repack_launch(const void *value, char *gset, char *sset, const voi
                      static_cast<const __half *>(value), gset, sset, t, bs, nk, heads);
 }
 
+static thread_local bool g_reduce_rolled = false;
+void msda_sca_set_reduce_rolled(bool on) { g_reduce_rolled = on; }
+
 void msda_sca_reduce_launch(const __half *sampled, const __half *qmask, __half *out, int bs, int nq, int width,
-                            hipStream_t st) {
+                            bool skip_sole, hipStream_t st) {
   const size_t threads = (size_t)nq * (width / 8);
-  hipLaunchKernelGGL(sca_camera_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sampled,
-                     qmask, out, bs, nq, width);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  const int unrolled = (threads < (1ull << 31) && !g_reduce_rolled && (bs <= 3 || bs == 6)) ? bs : 0;
+#define BEVOPS_REDUCE_GO(BS)                                                                                         \
+  do {                                                                                                               \
+    if (skip_sole)                                                                                                   \
+      hipLaunchKernelGGL((sca_camera_reduce_kernel<BS, true>), grid, dim3(256), 0, st, sampled, qmask, out, bs, nq,  \
+                         width);                                                                                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((sca_camera_reduce_kernel<BS, false>), grid, dim3(256), 0, st, sampled, qmask, out, bs, nq, \
+                         width);                                                                                     \
+  } while (0)
+  switch (unrolled) {   // 6 = the rig; 1 .. 3 = a rank's cameras of the camera-sharded frame
+    case 1: BEVOPS_REDUCE_GO(1); break;
+    case 2: BEVOPS_REDUCE_GO(2); break;
+    case 3: BEVOPS_REDUCE_GO(3); break;
+    case 6: BEVOPS_REDUCE_GO(6); break;
+    default: BEVOPS_REDUCE_GO(0); break;
+  }
+#undef BEVOPS_REDUCE_GO
 }
 
 size_t msda_hm3_workspace_bytes(const int32_t *shapes_host, int bs, int heads, int C, int L, int nq,
@@ -547,10 +616,7 @@ int msda_hm3_sca_forward_f16(const __half *value, const int32_t *shapes_host, co
     default: rc = launch_hm3<64>(pl, gset, sset, ref, off, logit, sampled, d, qmask, st); break;
   }
   if (rc != BEVOPS_SUCCESS) return rc;
-  const int width = heads * C;
-  const size_t threads = (size_t)nq * (width / 8);
-  hipLaunchKernelGGL(sca_camera_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                     sampled, qmask, out, bs, nq, width);
+  msda_sca_reduce_launch(sampled, qmask, out, bs, nq, heads * C, false, st);
   return launch_status();
 }
 

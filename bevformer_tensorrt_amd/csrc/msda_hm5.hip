@@ -42,6 +42,7 @@ typedef __attribute__((address_space(3))) char lds_c;
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
 typedef __attribute__((address_space(3))) u32x2 lds_u2;
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 struct H5Set {
   unsigned lg[2];  // 4 logits of this lane's points
@@ -162,18 +163,21 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 // ---- visibility plan of the fused SCA op (LISTED == 3 below): per camera the ascending list of the queries whose
 // bev_mask weight is non-zero.  bev_mask depends on the calibration matrices only (encoder.py:255-258), so a frame loop
 // builds the plan once per rig and every layer of every frame samples with it.  Layout: int32 counts[kPlanCams] (64
-// bytes), then per camera a u16 list of `nq_pad` entries.  One block per camera; a thread takes 8 consecutive queries
-// (one 16-byte load of the fp16 mask) per pass.
+// bytes), then per camera a list of `nq_pad` 32-bit entries: the query index in bits 0-15 and, in bit 16, "this camera
+// is the only one that sees the query, with weight exactly 1" -- the sampler stores such a pair's result straight into
+// the op's output row (1 * v + 0 is v) and the camera reduce leaves those rows alone (kSoleBit).  One block per camera;
+// a thread takes 8 consecutive queries per pass.
 constexpr int kPlanCams = 16;
 inline size_t h5_plan_pad(int nq) { return ((size_t)nq + 63) & ~size_t(63); }
 __device__ __forceinline__ unsigned h5_plan_pad_dev(int nq) { return ((unsigned)nq + 63u) & ~63u; }
-__global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned short *__restrict__ qmask, int nq,
+constexpr unsigned kSoleBit = 0x10000u;
+__global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned short *__restrict__ qmask, int bs, int nq,
                                                              unsigned nq_pad, int *__restrict__ counts,
-                                                             unsigned short *__restrict__ lists) {
+                                                             unsigned *__restrict__ lists) {
   __shared__ unsigned wtot[16];
   const unsigned cam = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const unsigned short *mk = qmask + (size_t)cam * nq;
-  unsigned short *dst = lists + (size_t)cam * nq_pad;
+  unsigned *dst = lists + (size_t)cam * nq_pad;
   unsigned base = 0;
   for (unsigned q0 = 0; q0 < (unsigned)nq; q0 += 8192u) {
     const unsigned q = q0 + threadIdx.x * 8u;
@@ -201,7 +205,12 @@ __global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned shor
     unsigned o = before + incl - n;
 #pragma unroll
     for (unsigned k = 0; k < 8; ++k)
-      if (bits & (1u << k)) dst[o++] = (unsigned short)(q + k);
+      if (bits & (1u << k)) {
+        bool sole = mk[q + k] == 0x3c00u;   // binary16 1.0
+        for (int c2 = 0; c2 < bs; ++c2)
+          if (c2 != (int)cam && (qmask[(size_t)c2 * nq + q + k] & 0x7fffu) != 0) sole = false;
+        dst[o++] = (q + k) | (sole ? kSoleBit : 0u);
+      }
     base += all;
     __syncthreads();
   }
@@ -229,13 +238,13 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
     __half *__restrict__ out, MsdaDims d, Hm3Tab t, int chunk, int nchunk, int stage_bytes,
-    const unsigned char *__restrict__ vis) {
+    const unsigned char *__restrict__ vis, __half *__restrict__ direct) {
   constexpr int THREADS = kH5Threads;
   constexpr int NB = 4;         // big-level samples per phase (two big levels x two lanes)
   constexpr int NS = 8 - NB;    // staged samples per phase
   constexpr unsigned OCT = THREADS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // smem: [staged planes][query list][wave totals]
+  // smem: [staged planes][query list (u16; LISTED == 3: the plan's 32-bit entries)][wave totals]
   unsigned bh, ck = 0;
   const unsigned per_plane = (unsigned)nchunk;
   if (d.heads == 8) {   // XCD x keeps head x; all XCDs walk the same (batch, chunk) sequence
@@ -311,6 +320,9 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       const_cast<__half *>(ref), 0, (unsigned)d.bs * (unsigned)d.nq * 16u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
       out, 0, (unsigned)d.bs * (unsigned)d.nq * (unsigned)d.heads * 64u, 0x00020000);
+  // LISTED == 3: the op's own output rows [nq, heads, 32], for the pairs the plan marks kSoleBit (no `direct`: none)
+  const __amdgpu_buffer_rsrc_t rs_dir = __builtin_amdgcn_make_buffer_rsrc(
+      direct, 0, direct ? (unsigned)d.nq * (unsigned)d.heads * 64u : 0u, 0x00020000);
   const unsigned lane8 = threadIdx.x & 7u;
   const unsigned lane16 = lane8 * 16u, lane8b = lane8 * 8u;
   unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
@@ -324,7 +336,8 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
   unsigned rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
   auto query_of = [&](unsigned i) -> unsigned {
     const unsigned ii = min(i, n_items - 1u);   // octets past the end repeat the last item, unstored
-    return LISTED != 0 ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
+    if constexpr (LISTED == 3) return (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 4u);   // low half of the entry
+    else return LISTED != 0 ? q0 + (unsigned)*(const lds_u16 *)(size_t)(qlist_a + ii * 2u) : q0 + ii;
   };
   auto request = [&](H5Set &s, unsigned i) __attribute__((always_inline)) {
     const unsigned q = query_of(i);
@@ -510,11 +523,27 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       // unconditional: an octet past the end of the list recomputes the last item and stores the
       // same bytes again (a conditional store lets the compiler sink the last phase's loads into
       // the branch, behind the LDS taps they are meant to overlap)
-      const unsigned q = query_of(i);
       u32x2 v;
       v.x = pack_h2(acc[0] * inv, acc[1] * inv);
       v.y = pack_h2(acc[2] * inv, acc[3] * inv);
-      __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(out_base + q * out_q), 0, 2);
+      if constexpr (LISTED == 3) {
+        // two unconditional stores, one of them past the end of its buffer (dropped by the range check): the
+        // per-camera scratch row, or -- a pair only this camera sees -- the op's output row itself
+        const unsigned e = *(const lds_u32 *)(size_t)(qlist_a + min(i, n_items - 1u) * 4u);
+        const unsigned q = e & 0xffffu;
+        const bool sole = (e & kSoleBit) != 0u;
+        const unsigned none = 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(sole ? none : out_base + q * out_q), 0, 2);
+        // (the reduce computes fma(1, v, +0): a -0 of the binary16 rounding becomes +0 there, so it does here)
+        const h2_t zero = {(_Float16)0.f, (_Float16)0.f};
+        u32x2 vd;
+        vd.x = __builtin_bit_cast(unsigned, as_h2(v.x) + zero);
+        vd.y = __builtin_bit_cast(unsigned, as_h2(v.y) + zero);
+        __builtin_amdgcn_raw_buffer_store_b64(vd, rs_dir, (int)(sole ? h * 64u + lane8b + q * out_q : none), 0, 2);
+      } else {
+        const unsigned q = query_of(i);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(out_base + q * out_q), 0, 2);
+      }
     }
     // the operand request is the youngest vector memory instruction of the iteration
     cur = nxt;
@@ -543,7 +572,9 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
   if constexpr (LISTED == 3) {
     const int *counts = reinterpret_cast<const int *>(vis);
     const unsigned nq_pad = (unsigned)h5_plan_pad_dev(d.nq);
-    const unsigned short *lists = reinterpret_cast<const unsigned short *>(vis + kPlanCams * 4);
+    const unsigned *lists = reinterpret_cast<const unsigned *>(vis + kPlanCams * 4);
+    unsigned *wl32 = reinterpret_cast<unsigned *>(smem + stage_bytes);
+    const unsigned keep = direct ? ~0u : 0xffffu;   // without an output to store into, no pair is "sole"
     const unsigned nb = gridDim.x / (unsigned)d.heads, j = blockIdx.x / (unsigned)d.heads;
     unsigned total = 0;
     for (int cam = 0; cam < d.bs; ++cam) total += (unsigned)__builtin_amdgcn_readfirstlane(counts[cam]);
@@ -563,12 +594,12 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       c = h5_lane_consts(t, lane8, bh, sbase);
       out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
       rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
-      const unsigned short *src = lists + (size_t)cam * nq_pad + first;
+      const unsigned *src = lists + (size_t)cam * nq_pad + first;
       bool staged = false;
       for (unsigned done = 0; done < hi - lo; done += (unsigned)chunk) {   // pieces of at most `chunk` list entries
         __syncthreads();   // every wave is through with the previous piece's list (and the previous camera's planes)
         n_items = min((unsigned)chunk, hi - lo - done);
-        for (unsigned i = threadIdx.x; i < n_items; i += THREADS) wl[i] = src[done + i];
+        for (unsigned i = threadIdx.x; i < n_items; i += THREADS) wl32[i] = src[done + i] & keep;
         if (!staged) { stage_plane(); staged = true; }
         __syncthreads();
         run_items();
@@ -580,6 +611,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
 }
 
 inline int h5_lds_extra(int threads, int chunk) { (void)threads; return chunk * 2 + 128; }   // query list + wave totals
+inline int h5_plan_lds_extra(int chunk) { return chunk * 4; }                                  // the plan's 32-bit entries
 constexpr int kH5Chunk = 1280;
 
 template <int LISTED>
@@ -591,7 +623,8 @@ int h5_go(const Hm3Plan &pl, const char *gset, const char *sset, const __half *r
   if (!ensure_dynamic_lds<msda_hm5_kernel<LISTED>>(lds)) return (int)BEVOPS_FAILURE;
   const unsigned planes = (unsigned)(d.bs * d.heads);
   hipLaunchKernelGGL((msda_hm5_kernel<LISTED>), dim3(planes * (unsigned)nchunk), dim3(kH5Threads), lds, st, gset,
-                     (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk, pl.stage_bytes, vis);
+                     (unsigned)pl.g_bytes, sset, ref, off, logit, out, d, pl.t, chunk, nchunk, pl.stage_bytes, vis,
+                     (__half *)nullptr);
   return launch_status();
 }
 
@@ -650,7 +683,7 @@ void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k)
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
-  return (size_t)kPlanCams * 4 + (size_t)bs * h5_plan_pad(nq) * 2;
+  return (size_t)kPlanCams * 4 + (size_t)bs * h5_plan_pad(nq) * 4;
 }
 
 int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t plan_bytes, hipStream_t st) {
@@ -658,17 +691,17 @@ int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t 
   if (need == 0) return BEVOPS_NOT_SUPPORTED;
   if (!qmask || !plan || plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
   hipLaunchKernelGGL(msda_hm5_plan_kernel, dim3((unsigned)bs), dim3(1024), 0, st,
-                     reinterpret_cast<const unsigned short *>(qmask), nq, (unsigned)h5_plan_pad(nq),
+                     reinterpret_cast<const unsigned short *>(qmask), bs, nq, (unsigned)h5_plan_pad(nq),
                      static_cast<int *>(plan),
-                     reinterpret_cast<unsigned short *>(static_cast<char *>(plan) + kPlanCams * 4));
+                     reinterpret_cast<unsigned *>(static_cast<char *>(plan) + kPlanCams * 4));
   return launch_status();
 }
 
 constexpr int kH5PlanChunk = 2048;   // list entries of a slice kept in LDS at a time
 int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, const int32_t *shapes_host,
                                     const __half *ref, const __half *off, const __half *logit, const void *plan,
-                                    size_t plan_bytes, __half *sampled, int bs, int nk, int heads, int C, int L, int nq,
-                                    int P, int ppg, hipStream_t st) {
+                                    size_t plan_bytes, __half *sampled, __half *direct, int bs, int nk, int heads, int C,
+                                    int L, int nq, int P, int ppg, hipStream_t st) {
   Hm3Plan pl;
   if (!h5_shape_ok(C, L, P, ppg) || !packed || (reinterpret_cast<uintptr_t>(packed) & 127u) ||
       !hm3_plan(shapes_host, bs, heads, L, nq, h5_lds_extra(1024, kH5Chunk), pl) || pl.t.ls != 2)
@@ -682,7 +715,7 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
   constexpr int THREADS = kH5Threads;
-  const size_t lds = (size_t)pl.stage_bytes + h5_lds_extra(THREADS, kH5PlanChunk);
+  const size_t lds = (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
   auto kern = msda_hm5_kernel<3>;
   if (!ensure_dynamic_lds<msda_hm5_kernel<3>>(lds)) return (int)BEVOPS_FAILURE;
@@ -692,7 +725,7 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   const unsigned per_head = (unsigned)((cus > 0 ? cus : 256) * g_h5_plan_k + heads - 1) / (unsigned)heads;
   hipLaunchKernelGGL(kern, dim3(per_head * (unsigned)heads), dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes,
                      gset + g_room, ref, off, logit, sampled, d, pl.t, kH5PlanChunk, 1, pl.stage_bytes,
-                     static_cast<const unsigned char *>(plan));
+                     static_cast<const unsigned char *>(plan), direct);
   return launch_status();
 }
 

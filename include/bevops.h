@@ -139,6 +139,9 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
  *    19       int8 hm4 on the one-block-per-CU plan (partner of the default two-blocks plan)
  *    1000 / 1001  the fp16 SCA sampler hm5 with / without its visibility pre-pass
  *    3001 .. 3008 slices per CU of the planned fused SCA sampling (default 2; sticky until set again)
+ *    3010 / 3011  camera reduce of the fused SCA op with its camera loop unrolled (default) / rolled (sticky)
+ *    3012 / 3013  planned fused SCA sampling stores the pairs only one camera sees straight into the output and the
+ *                 reduce skips those rows (default) / every pair through the per-camera scratch (sticky)
  * (The measured-and-rejected builds of rounds 1-4 -- LDS-staged hm, two-copy hm, hm4 chunk sizes / schedule ablations,
  * int8 pixel-pair entries, hm5 with 768 threads / mailbox / persistent blocks / level-class split -- are no longer in
  * the library; their measurements are under profiles/.)  A packed value (bevops_msda_pack_value) must be sampled under
@@ -534,7 +537,10 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
  * mask is valid; num_cams <= 16, num_query <= 65 535), and bevops_sca_forward_planned gives every block of the sampling
  * kernel an EQUAL slice of the global (camera, query) sequence -- no empty blocks, no per-block compaction, the same
  * number of rounds on every CU -- with the results of bevops_sca_forward_prepacked (bit-identical: same arithmetic
- * per pair, same reduction).  `plan` must have been built from the `bev_mask` passed here. */
+ * per pair, same reduction).  The plan also marks the pairs whose query no other camera sees and whose weight is
+ * exactly 1 (89 % of the visible pairs of the 6-camera rig): the sampler stores those rows straight into `output`
+ * (1 * v + 0 = v) and the camera reduce touches only the others.  `plan` must have been built from the VALUES of the
+ * `bev_mask` passed here (not only from its zero pattern). */
 size_t bevops_sca_plan_size(int num_cams, int num_query);
 int bevops_sca_plan_build(int dtype, const void *bev_mask, int num_cams, int num_query, void *plan, size_t plan_bytes,
                           void *stream);

@@ -202,18 +202,22 @@ def _plan_case(kind, nq, seed):
         else:                               # "random": uneven per-camera counts
             p = torch.tensor([0.05, 0.9, 0.3, 0.0, 0.5, 0.2]).view(6, 1)
             vis = torch.rand(6, nq, generator=g) < p
-    bm = (vis.float() / vis.sum(0).clamp(min=1)).half().cuda()
+    bm = vis.float() / vis.sum(0).clamp(min=1)
+    if kind == "weights":                   # weights that are not 1 / count: a lone camera with weight 0.5 is NOT "sole"
+        bm = vis.float() * torch.tensor([1.0, 0.5, 0.25])[torch.randint(0, 3, vis.shape, generator=g)]
+    bm = bm.half().cuda()
     sh = torch.tensor(levels, dtype=torch.int32)
     return feats, wgt, bias, sh, ref.half().cuda(), off, w, bm, heads
 
 
 @pytest.mark.parametrize("kind,nq", [("rig", 40000), ("random", 40000), ("all", 9000), ("one_camera", 12345),
-                                     ("few", 3000), ("none", 2500), ("random", 65535)])
+                                     ("few", 3000), ("none", 2500), ("random", 65535), ("weights", 20000)])
 def test_planned_sampling_is_bit_identical_to_the_chunked_sampling(kind, nq):
     """bevops_sca_forward_planned (every block an equal slice of the visible (camera, query) pairs of a plan built
     from bev_mask by bevops_sca_plan_build) against bevops_sca_forward_prepacked (one block per 1 280-query chunk,
     in-kernel compaction): same arithmetic per pair, same camera reduction -> the same bits, whatever the visibility
-    pattern and the number of slices per CU."""
+    pattern and the number of slices per CU; with the pairs only one camera sees (weight exactly 1) stored by the
+    sampler straight into the output rows (the default) and with every pair through the per-camera scratch."""
     import bevformer_tensorrt_amd as bev
     from bevformer_tensorrt_amd.utils import lib as L
     args = _plan_case(kind, nq, seed=nq % 97)
@@ -221,31 +225,43 @@ def test_planned_sampling_is_bit_identical_to_the_chunked_sampling(kind, nq):
     want = bev.spatial_cross_attention_projected(*args)
     plan = bev.spatial_cross_attention_plan(bm)
     assert plan is not None and plan.dtype == torch.uint8
-    # the plan itself: counts and ascending lists
+    # the plan itself: counts, ascending lists (bits 0-15 of an entry) and the "only this camera, weight 1" bit (16)
     ncam = bm.shape[0]
     counts = plan[:64].view(torch.int32)[:ncam].cpu()
     pad = (nq + 63) // 64 * 64
-    lists = plan[64:].view(torch.int16).view(ncam, pad).cpu().to(torch.int32) & 0xffff
+    entries = plan[64:].view(torch.int32).view(ncam, pad).cpu()
+    seen = (bm != 0).cpu()
     for c in range(ncam):
-        vis_q = torch.nonzero(bm[c].cpu() != 0).flatten().to(torch.int32)
-        assert int(counts[c]) == vis_q.numel()
-        assert torch.equal(lists[c, :vis_q.numel()], vis_q)
+        vis_q = torch.nonzero(seen[c]).flatten()
+        n = vis_q.numel()
+        assert int(counts[c]) == n
+        assert torch.equal(entries[c, :n] & 0xffff, vis_q.to(torch.int32))
+        sole = (seen.sum(0) == 1) & (bm[c].cpu() == 1.0)
+        assert torch.equal((entries[c, :n] >> 16) == 1, sole[vis_q]) and int((entries[c, :n] >> 17).abs().sum()) == 0
     handle = L.load_library()
     try:
-        for k in (1, 2, 3):
-            handle.bevops_msda_set_variant(3000 + k)
-            got = bev.spatial_cross_attention_projected(*args, plan=plan)
-            torch.cuda.synchronize()
-            assert torch.equal(got, want), (kind, k, (got.float() - want.float()).abs().max().item())
+        for direct in (3012, 3013):
+            handle.bevops_msda_set_variant(direct)
+            for k in (1, 2, 3):
+                handle.bevops_msda_set_variant(3000 + k)
+                got = bev.spatial_cross_attention_projected(*args, plan=plan)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (kind, direct, k, (got.float() - want.float()).abs().max().item())
+        handle.bevops_msda_set_variant(3011)      # the rolled camera reduce (partner of the unrolled default)
+        got = bev.spatial_cross_attention_projected(*args, plan=plan)
+        assert torch.equal(got, want)
+        assert torch.equal(bev.spatial_cross_attention_projected(*args), want)      # ... and on the chunked path
     finally:
-        handle.bevops_msda_set_variant(3002)      # the default: two slices per CU
+        handle.bevops_msda_set_variant(3002)      # the defaults: two slices per CU, direct stores, unrolled reduce
+        handle.bevops_msda_set_variant(3012)
+        handle.bevops_msda_set_variant(3010)
         handle.bevops_msda_set_variant(0)
 
 
 def test_plan_entry_validates_its_arguments():
     from bevformer_tensorrt_amd.utils import lib as L
     h = L.load_library()
-    assert h.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 2      # 40 000 is a multiple of 64
+    assert h.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 4      # 40 000 is a multiple of 64
     assert h.bevops_sca_plan_size(17, 100) == 0 and h.bevops_sca_plan_size(6, 65536) == 0
     m = torch.zeros(6, 100, dtype=torch.half, device="cuda")
     plan = torch.empty(h.bevops_sca_plan_size(6, 100), dtype=torch.uint8, device="cuda")

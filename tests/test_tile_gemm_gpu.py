@@ -109,16 +109,26 @@ def test_conv3x3_tile_matches_fp32_conv(B, C, H, W, Cout, epi):
         assert bool(((out[-1:].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
 
 
-def test_conv3x3_auto_picks_a_measured_winner():
+def test_conv3x3_auto_picks_a_measured_winner(monkeypatch):
+    """A problem the shipped dispatch table does not list (the table is emptied for the test) is timed once, both
+    candidates, and the faster one is kept for the process."""
     import bevformer_tensorrt_amd as bev
-    from bevformer_tensorrt_amd.functions import conv as Cv
+    from bevformer_tensorrt_amd.functions import conv as Cv, linear as Ln
+    monkeypatch.setattr(Ln, "_TABLE", {"loaded": True, "dense": {}, "conv": {}})
+    monkeypatch.setattr(Cv, "_CHOICE", {})
+    monkeypatch.setattr(Cv, "CONV_LOG", [])
+    monkeypatch.setattr(Cv, "CONV_MISSES", [])
     g = torch.Generator().manual_seed(2)
     x = torch.randn(6, 128, 116, 200, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).half().cuda()
     b = torch.randn(128, generator=g).half().cuda()
     y = bev.conv3x3_auto(x, w, b, True)
+    assert len(Cv.CONV_LOG) == 1 and len(Cv.CONV_MISSES) == 1
     key, times = Cv.CONV_LOG[-1]
+    assert key[1:6] == (6, 116, 200, 128, 128)
     assert set(times) == {"tile", "library"} and Cv._CHOICE[key] == min(times, key=times.get)
+    bev.conv3x3_auto(x, w, b, True)
+    assert len(Cv.CONV_LOG) == 1      # decided once
     want = torch.relu(torch.nn.functional.conv2d(x[:1].float(), w.float(), b.float(), 1, 1))
     assert bool(((y[:1].float() - want).abs() <= 1e-3 * want.abs().clamp_min(1.0) + 2e-3).all())
 

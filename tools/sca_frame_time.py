@@ -2,7 +2,8 @@
 """The SCA sampling call the model frame replays (value-projection planes -> fused sampling -> camera reduce) on the
 reference points of the 6-camera rig, WITHOUT the projection GEMM: one block per 1 280-query chunk
 (bevops_sca_forward_prepacked) against the balanced slices of a visibility plan (bevops_sca_forward_planned; k = slices
-per CU), under HIP-graph replay, interleaved.  One JSON line; --offsets S scales the N(0, 1) sampling offsets (pixels).
+per CU; "_scratch": every pair through the per-camera scratch instead of single-camera pairs stored straight into the
+output; "_rolled": the rolled camera reduce = the round-5 first-half build), under HIP-graph replay, interleaved.  One JSON line; --offsets S scales the N(0, 1) sampling offsets (pixels).
 --once K: K plain launches of every flavour (for rocprofv3 --kernel-trace / --pmc runs).  (The ablation builds whose
 timings are in profiles/r05/sca_plan_ablation.jsonl were removed from the library after that measurement.)"""
 import argparse
@@ -55,14 +56,19 @@ def chunked():
     return S._sample_planes(handle, planes, geom, ref, off, w, bm, None)
 
 
-def planned(k):
+def planned(k, direct=True, unrolled=True):
+    """k slices per CU; direct: single-camera pairs stored by the sampler into the output rows (3012) or every pair
+    through the per-camera scratch (3013); unrolled: the camera reduce with its loop unrolled (3010) or rolled (3011)."""
     def fn():
         handle.bevops_msda_set_variant(3000 + k)
+        handle.bevops_msda_set_variant(3012 if direct else 3013)
+        handle.bevops_msda_set_variant(3010 if unrolled else 3011)
         return S._sample_planes(handle, planes, geom, ref, off, w, bm, plan)
     return fn
 
 
-fns = {"chunked": chunked, **{f"planned_k{k}": planned(k) for k in ks}}
+fns = {"chunked": chunked, **{f"planned_k{k}": planned(k) for k in ks},
+       "planned_k2_scratch": planned(2, direct=False), "planned_k2_scratch_rolled": planned(2, False, False)}
 
 want = chunked()
 for name, fn in fns.items():
@@ -84,5 +90,5 @@ print(json.dumps({"what": "fused SCA sampling call on prepacked planes (sampler 
                   "offsets_sigma_px": args.offsets, "visible_pairs": pairs, "visible_frac": round(pairs / (6 * nq), 4),
                   "us": med, "algorithmic_bytes": fused_bytes,
                   "frac_of_8TBs": {k: round(fused_bytes / v / 8e6, 4) for k, v in med.items()}}), flush=True)
-handle.bevops_msda_set_variant(3002)
-handle.bevops_msda_set_variant(0)
+for v in (3002, 3012, 3010, 0):
+    handle.bevops_msda_set_variant(v)
