@@ -351,7 +351,22 @@ class ResNet(nn.Module):
                 outs.append(x)
         return outs
 
+    def _stem_fused(self, x, ops):
+        """The one-kernel stem (functions/conv.py: stem_conv_pool) when the operator set has it and the input is in
+        its domain: planar fp16 images of even width, the 7x7 / 2 / 3 convolution from 3 to 64 channels."""
+        fused = getattr(ops, "stem_conv_pool", None)
+        if fused is None or not (_R3["enabled"] and _FUSED_LINEAR["enabled"]):
+            return None
+        from .functions.conv import STEM_FUSED
+        st = self.stem
+        ok = (STEM_FUSED["enabled"] and x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+              and tuple(st.weight.shape) == (64, 3, 7, 7) and st.stride == (2, 2) and st.padding == (3, 3))
+        return fused(x, st.weight, st.bias) if ok else None
+
     def forward_nhwc(self, x, ops):
+        y = self._stem_fused(x, ops)
+        if y is not None:
+            return self._stages_nhwc(y, ops)
         x = x.contiguous(memory_format=torch.channels_last)
         pool = getattr(ops, "bias_relu_maxpool_nhwc", None)
         if pool is not None and _R3["enabled"] and _FUSED_LINEAR["enabled"] and x.dtype == torch.float16 and x.is_cuda:
@@ -362,6 +377,9 @@ class ResNet(nn.Module):
             x = pool(y, self.stem.bias)
         else:
             x = F.max_pool2d(_conv_nhwc(ops, x, self.stem, True), 3, 2, 1)
+        return self._stages_nhwc(x, ops)
+
+    def _stages_nhwc(self, x, ops):
         outs = []
         for i, st in enumerate(self.stages):
             for blk in st:

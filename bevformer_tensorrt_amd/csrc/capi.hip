@@ -56,6 +56,10 @@ const Entry kTable[] = {
     {"bevops_conv3x3_c32_forward_nhwc", (void *)&bevops_conv3x3_c32_forward_nhwc},
     {"bevops_bias_act_nhwc", (void *)&bevops_bias_act_nhwc},
     {"bevops_bias_relu_maxpool_nhwc", (void *)&bevops_bias_relu_maxpool_nhwc},
+    {"bevops_stem_packed_size", (void *)&bevops_stem_packed_size},
+    {"bevops_stem_pack", (void *)&bevops_stem_pack},
+    {"bevops_stem_conv_pool", (void *)&bevops_stem_conv_pool},
+    {"bevops_stem_set_variant", (void *)&bevops_stem_set_variant},
     {"bevops_upsample_add_nhwc", (void *)&bevops_upsample_add_nhwc},
     {"bevops_tsa_split", (void *)&bevops_tsa_split},
     {"bevops_queue_mean2", (void *)&bevops_queue_mean2},

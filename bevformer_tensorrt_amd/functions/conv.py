@@ -132,3 +132,45 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
             CONV_LOG.append((key, times))
             name = _CHOICE[key] = min(times, key=times.get)
     return (conv_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual, stride)
+
+
+_STEM_PACKED = _TensorCache()   # stem weight -> (bias stamp, packed matrix-core operand image)
+STEM_FUSED = {"enabled": os.environ.get("BEVOPS_STEM_FUSED", "1") != "0"}   # A/B: library convolution + pooling pass
+
+
+def stem_conv_pool(x, weight, bias=None, scale_out=None):
+    """The ResNet stem as ONE kernel (bevops_stem_conv_pool): max_pool2d(relu(conv2d(x, weight, bias, stride 2,
+    pad 3)), 3, 2, 1) from the PLANAR images x [N, 3, H, W] (fp16, contiguous, W even) and weight [64, 3, 7, 7] to the
+    pooled activation [N, 64, Hp, Wp] channels-last -- fp16, or int8 with `scale_out` (q = min(rne(v / scale_out),
+    127): the first tensor of the INT8 engine's activation chain).  fp32 accumulation, one rounding.  The
+    matrix-core operand image of (weight, bias) is built once per weight tensor (bevops_stem_pack)."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.is_contiguous()
+    n, c, h, w = x.shape
+    if tuple(weight.shape) != (64, 3, 7, 7) or c != 3 or w % 2:
+        raise ValueError("stem_conv_pool: a 7x7 convolution from 3 to 64 channels on images of even width")
+    handle = _lib.load_library()
+    bstamp = None if bias is None else _TensorCache._stamp(bias)
+    hit = _STEM_PACKED.get(weight)
+    if hit is None or hit[0] != bstamp:
+        wt = weight.detach().to(torch.float16).contiguous()
+        bs = None if bias is None else bias.detach().to(torch.float16).contiguous()
+        packed = torch.empty(handle.bevops_stem_packed_size(), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            st = handle.bevops_stem_pack(_lib.F16, wt.data_ptr(), bs.data_ptr() if bs is not None else None,
+                                         packed.data_ptr(), _lib.current_stream_ptr(x.device))
+        _lib.check(st, "bevops_stem_pack")
+        hit = _STEM_PACKED.put(weight, (bstamp, packed))
+    hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
+    out = torch.empty((n, 64, hp, wp), dtype=torch.float16 if scale_out is None else torch.int8, device=x.device,
+                      memory_format=torch.channels_last)
+    if n == 0:
+        return out
+    with torch.cuda.device(x.device):
+        st = handle.bevops_stem_conv_pool(_lib.F16, _lib.F16 if scale_out is None else _lib.I8, x.data_ptr(),
+                                          hit[1].data_ptr(), out.data_ptr(), n, h, w,
+                                          0.0 if scale_out is None else float(scale_out),
+                                          _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_stem_conv_pool")
+    return out
+

@@ -180,7 +180,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc",
+             "linear_bias_act", "dense_auto", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "stem_conv_pool",
              "image_normalize_pad", "upsample_add_nhwc_", "feat_embed_nhwc", "tsa_split", "queue_mean2")
     # `engine=True` (the build bench.py times, build_int8_engine below) additionally passes the entries whose fp16
     # form is FASTER than any int8 form on MI355X: the channels-last nearest-neighbour rotate of prev_bev (pure data
@@ -690,11 +690,16 @@ class Int8ChainBackbone:
         m = self.model
         ops = m.ops
         bb = m.backbone
-        x = img.contiguous(memory_format=torch.channels_last)
-        y = F.conv2d(x, bb.stem.weight, None, bb.stem.stride, bb.stem.padding)       # 7x7 stem: library convolution
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        x = C.bias_relu_maxpool_nhwc_int8(y, bb.stem.bias, self.s_stem)
+        from .functions.conv import STEM_FUSED, stem_conv_pool
+        if (STEM_FUSED["enabled"] and img.is_contiguous() and img.shape[-1] % 2 == 0
+                and tuple(bb.stem.weight.shape) == (64, 3, 7, 7) and bb.stem.stride == (2, 2) and bb.stem.padding == (3, 3)):
+            x = stem_conv_pool(img, bb.stem.weight, bb.stem.bias, self.s_stem)       # 7x7 stem + pool: one kernel, int8 out
+        else:
+            x = img.contiguous(memory_format=torch.channels_last)
+            y = F.conv2d(x, bb.stem.weight, None, bb.stem.stride, bb.stem.padding)   # 7x7 stem: library convolution
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            x = C.bias_relu_maxpool_nhwc_int8(y, bb.stem.bias, self.s_stem)
         i8 = torch.int8
         lats = []
         for si, blocks in enumerate(self.plan):

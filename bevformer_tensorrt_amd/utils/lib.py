@@ -99,6 +99,10 @@ SIGNATURES = {
     "bevops_tile_gemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "bevops_bias_relu_maxpool_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bevops_stem_packed_size": (c_size_t, []),
+    "bevops_stem_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bevops_stem_conv_pool": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "bevops_stem_set_variant": (c_int, [c_int]),
     "bevops_conv_tile_int8_fused": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]
                                     + [c_int] * 8 + [c_void_p]),
     "bevops_linear_int8_chain": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int,

@@ -317,6 +317,22 @@ int bevops_bias_act_nhwc(int dtype, void *x, const void *bias, const void *resid
  * Bit-equal to bevops_bias_act_nhwc followed by the framework's max_pool2d (rounding is monotonic). */
 int bevops_bias_relu_maxpool_nhwc(int dtype, const void *x, const void *bias, void *out, int n, int h, int w,
                                   int channels, void *stream);
+/* The whole ResNet stem of the re-hosted backbone as ONE kernel (round 5; not a reference plugin): conv 7x7 / stride 2 /
+ * pad 3 from 3 to 64 channels (folded-BN shift `bias`) -> ReLU -> max_pool2d 3 / stride 2 / pad 1
+ * (third_party/bev_mmdet3d/models/backbones/resnet.py:619-624: conv1, norm1, relu, maxpool), from the PLANAR camera
+ * images x [n, 3, h, w] (fp16, w even) to the pooled channels-last activation out [n, hp, wp, 64]
+ * (hc = (h - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, likewise w), fp16 or -- out_dtype BEVOPS_I8, scale_out -- int8 with
+ * q = min(rne(v / scale_out), 127): the first tensor of the INT8 engine's activation chain.  fp32 accumulation, one
+ * rounding at the end (the two-pass form rounds the convolution's output to fp16 first: results agree to that
+ * rounding).  bevops_stem_pack turns weight [64, 3, 7, 7] + bias [64] (fp16; bias may be NULL) into the kernel's
+ * matrix-core operand image (bevops_stem_packed_size bytes, 16-byte aligned, device memory): once per model.
+ * bevops_stem_set_variant (thread-local, A/B switch of the tests): 0 = pooling neighbours through wave-wide DPP
+ * shifts, 1 = through ds_bpermute; identical results.  Returns the previous value. */
+size_t bevops_stem_packed_size(void);
+int bevops_stem_pack(int dtype, const void *weight, const void *bias, void *packed, void *stream);
+int bevops_stem_conv_pool(int dtype, int out_dtype, const void *x, const void *packed, void *out, int n, int h, int w,
+                          float scale_out, void *stream);
+int bevops_stem_set_variant(int variant);
 
 /* FPN top-down step of the re-hosted neck on channels-last fp16 activations (not a reference plugin):
  * a[n, y, x, :] += b[n, sy(y), sx(x), :], source indices as aten's nearest up-sampling -- the reference's
