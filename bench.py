@@ -424,8 +424,9 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
         us = graph_us(lambda: S._sample_planes(handle, planes, geom, ref, off, w, bm, plan), iters, rounds)
         byt = (6 * nk * heads * 32 + nq * heads * 32 * 3 + 6 * nq * 8 + 6 * nq + nq * heads * 32) * 2 + 8 * 4
         out["roofline_frame"] = {
-            "kernel": "in-frame SCA sampling call = msda_hm5_kernel<2,1024,0,3> (balanced slices of the visibility plan) "
-                      "+ sca_camera_reduce_kernel, on the value projection's planes",
+            "kernel": "in-frame SCA sampling call = msda_hm5_kernel<3> (balanced slices of the visibility plan, pairs only "
+                      "one camera sees stored straight into the output) + sca_camera_reduce_kernel<6, true> (the other "
+                      "queries), on the value projection's planes",
             "what": "reference points of the 6-camera rig (%.1f %% of the (camera, query) pairs visible), N(0,1) px offsets"
                     % (100.0 * float(vis.float().mean())),
             "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters * rounds,
@@ -436,7 +437,8 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "sca_plan_pmc_fetch_write.json")))[-1]
             pm = json.load(open(f))
             tot = sum((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024 for k, v in pm.items()
-                      if isinstance(v, dict) and ("msda_hm5_kernel<2, 1024, 0, 3" in k or "sca_camera_reduce_kernel" in k))
+                      if isinstance(v, dict) and ("msda_hm5_kernel<3>" in k or "msda_hm5_kernel<2, 1024, 0, 3" in k
+                                                  or "sca_camera_reduce_kernel" in k))
             out["roofline_frame"]["traffic"], out["roofline_frame"]["traffic_src"] = int(tot), os.path.relpath(f, ROOT)
         except Exception:
             pass

@@ -733,7 +733,7 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
 // sampled; the partner of the default).  The other builds of rounds 3 / 4 -- 768-thread blocks, 2 560-query chunks,
 // records through an LDS mailbox, persistent blocks on strided sub-chunks, no raised priority, the level-class split
 // probe and the ablation (timing) builds -- were measured (design/msda.md, profiles/r03, profiles/r04) and removed from
-// the library in round 5; the kernel template keeps their parameters.
+// the library in round 5, their template parameters with them.
 int msda_hm5_forward_f16(const __half *value, const int32_t *shapes_host, const __half *ref, const __half *off,
                          const __half *logit, __half *out, int bs, int nk, int heads, int C, int L, int nq, int P,
                          int ppg, int shared, void *workspace, size_t workspace_bytes, int flags, bool prepacked,

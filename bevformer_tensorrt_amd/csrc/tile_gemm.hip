@@ -446,7 +446,7 @@ int launch_tile_gemm(const void *a, float scale_a, const void *w, const float *w
   const int tn = narrow ? 64 : 128;
   p.tiles_n = (N + tn - 1) / tn;
   // 128-row tiles, 64-byte k-steps.  Two other builds were measured in round 4 and removed from the library in round
-  // 5 (the kernel template keeps their parameters): 64-row tiles (four blocks per CU: 3-10 % SLOWER on every
+  // 5 (their template parameters with them): 64-row tiles (four blocks per CU: 3-10 % SLOWER on every
   // base-model layer and flavour, profiles/r04/tile_rows_ab.jsonl) and 128-byte k-steps for the int8 chain's plain
   // GEMMs (bit-identical, slower: a step costs 0.53 us whatever it holds, profiles/r04/tile_wide_ab.jsonl)
   const int tm = kTM;

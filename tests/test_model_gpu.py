@@ -353,8 +353,13 @@ def test_base_frame_is_the_same_with_and_without_the_visibility_plan(cams):
     """BEVFormer-base, fp16: the frame with the SCA sampling on the per-rig visibility plan (round-5 default; for a
     camera-sharded rank the plan lists ITS cameras) against the same frame with the plan switched off (one block per
     1 280-query chunk, in-kernel compaction): identical BEV features and heads, bit for bit, over three frames with a
-    calibration change in between (the plan is rebuilt with the projection)."""
+    calibration change in between (the plan is rebuilt with the projection).
+    Under the REPRODUCIBLE dispatch (functions/linear.py: DETERMINISTIC -- the dense layers and convolutions on the
+    hand-written kernels): with the measured default dispatch two runs of the SAME six-camera frame differ in the last
+    bits (the library GEMMs the table picks for some encoder layers do not keep one summation order from run to run:
+    tools/probes/frame_determinism.py, op_determinism.py), so a bit comparison of two runs says nothing there."""
     from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    from bevformer_tensorrt_amd.functions import linear as Ln
     from bevformer_tensorrt_amd.functions import spatial_cross_attention as S
 
     class LocalOnly:            # the "reduce" exchange without a wire: this rank's masked camera sum is the result
@@ -373,17 +378,20 @@ def test_base_frame_is_the_same_with_and_without_the_visibility_plan(cams):
     l2i_b = l2i_a.clone()
     l2i_b[:, :, 0, 3] += 3.0            # another rig: other visible sets
     outs = {}
-    for planned in (True, False):
-        S.PLANNED["enabled"] = planned
-        try:
+    was = Ln.DETERMINISTIC["enabled"]
+    Ln.DETERMINISTIC["enabled"] = True
+    try:
+        for planned in (True, False):
+            S.PLANNED["enabled"] = planned
             r = B.FrameRunner(model, dev, dtype, cams=cams, gather=None if cams is None else LocalOnly(cams))
             got = []
             for i, (img, can, scene) in enumerate(frames((H, W), 3, dev, dtype)):
                 cls, crd = r.step(img, can, l2i_a if i < 2 else l2i_b, scene)
                 got.append((r.prev_bev.clone(), cls.clone(), crd.clone()))
             outs[planned] = got
-        finally:
-            S.PLANNED["enabled"] = True
+    finally:
+        S.PLANNED["enabled"] = True
+        Ln.DETERMINISTIC["enabled"] = was
     for (ba, ca, da), (bb, cb, db) in zip(outs[True], outs[False]):
         assert torch.isfinite(ba.float()).all()
         assert torch.equal(ba, bb) and torch.equal(ca, cb) and torch.equal(da, db)

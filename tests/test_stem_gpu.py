@@ -69,7 +69,7 @@ def test_stem_int8_output_is_the_quantised_fp32_result(n, h, w):
     import bevformer_tensorrt_amd as bev
     x, wt, b = _case(n, h, w, seed=11)
     want = _want(x, wt, b)
-    s = float(want.max()) / 100.0          # (the largest values clamp at 127)
+    s = float(want.max()) / 150.0          # (the largest values clamp at 127)
     q = bev.stem_conv_pool(x, wt, b, s)
     assert q.dtype == torch.int8 and q.is_contiguous(memory_format=torch.channels_last)
     ref = torch.clamp(torch.round(want / s), max=127)

@@ -43,7 +43,9 @@ for name, out in (("bench.json", "bench_n1.json"), ("bench_n1.json", "bench_n1.j
                   ("model_frame_int8_kernel_trace.txt", "model_frame_int8_kernel_trace.txt"),
                   ("dense_time.jsonl", "dense_time.jsonl"), ("linear_q_time.jsonl", "linear_q_time.jsonl"),
                   ("conv_time.jsonl", "conv_time.jsonl"), ("int8_model_delta.jsonl", "int8_model_delta.jsonl"),
-                  ("model_bench_small_ab.jsonl", "model_bench_small_ab.jsonl")):
+                  ("model_bench_small_ab.jsonl", "model_bench_small_ab.jsonl"),
+                  ("sca_plan_pmc_fetch_write.json", "sca_plan_pmc_fetch_write.json"),
+                  ("sca_plan_kernel_stats.txt", "sca_plan_kernel_stats.txt"), ("stem_time.jsonl", "stem_time.jsonl")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         lines = [l for l in open(p) if "amdgpu.ids" not in l]

@@ -24,6 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--offsets", type=float, default=1.0)
 ap.add_argument("--once", type=int, default=0)
 ap.add_argument("--ks", default="1,2,3")
+ap.add_argument("--only", default="", help="comma-separated flavour names: run just these (for counter passes)")
 args = ap.parse_args()
 
 g = torch.Generator().manual_seed(0)
@@ -71,6 +72,8 @@ fns = {"chunked": chunked, **{f"planned_k{k}": planned(k) for k in ks},
        "planned_k2_scratch": planned(2, direct=False), "planned_k2_scratch_rolled": planned(2, False, False)}
 
 want = chunked()
+if args.only:
+    fns = {k: v for k, v in fns.items() if k in args.only.split(",")}
 for name, fn in fns.items():
     assert torch.equal(fn(), want), name
 if args.once:
