@@ -78,6 +78,36 @@ def test_msda_rejects_bad_params_without_gpu(lib):
     assert st == 2  # nk != sum(h*w)
 
 
+def test_round5_entries_reject_bad_params_without_gpu(lib):
+    """Argument checks of the round-5 entries (visibility plan, one-kernel stem) that return before any device call:
+    status codes as helper.h:19-25 (2 = BAD_PARAM, 3 = NOT_SUPPORTED), sizes as plain arithmetic."""
+    f = ctypes.c_float
+    lib.bevops_sca_plan_size.restype = ctypes.c_size_t
+    lib.bevops_stem_packed_size.restype = ctypes.c_size_t
+    assert lib.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 4       # counts + 32-bit entries
+    assert lib.bevops_sca_plan_size(6, 100) == 64 + 6 * 128 * 4           # lists padded to 64 entries
+    assert lib.bevops_sca_plan_size(17, 100) == 0 and lib.bevops_sca_plan_size(6, 65536) == 0 and lib.bevops_sca_plan_size(0, 5) == 0
+    assert lib.bevops_stem_packed_size() == 11 * 2 * 64 * 8 * 2
+    buf = (ctypes.c_char * 256)()
+    p = ctypes.addressof(buf)
+    assert lib.bevops_sca_plan_build(1, None, 6, 100, p, ctypes.c_size_t(4096), None) == 2          # no mask
+    assert lib.bevops_sca_plan_build(1, p, 0, 100, p, ctypes.c_size_t(4096), None) == 2             # no cameras
+    assert lib.bevops_sca_plan_build(0, p, 6, 100, p, ctypes.c_size_t(4096), None) == 3             # fp32 mask
+    assert lib.bevops_stem_pack(1, None, None, p, None) == 2
+    assert lib.bevops_stem_pack(0, p, None, p, None) == 3
+    assert lib.bevops_stem_conv_pool(1, 1, None, p, p, 1, 16, 16, f(0), None) == 2
+    assert lib.bevops_stem_conv_pool(1, 1, p, p, p, 1, 16, 15, f(0), None) == 3                     # odd width
+    assert lib.bevops_stem_conv_pool(1, 0, p, p, p, 1, 16, 16, f(0), None) == 3                     # fp32 output
+    assert lib.bevops_stem_conv_pool(0, 1, p, p, p, 1, 16, 16, f(0), None) == 3                     # fp32 input
+    assert lib.bevops_stem_conv_pool(1, 2, p, p, p, 1, 16, 16, f(0), None) == 2                     # int8 out, no scale
+    assert lib.bevops_stem_conv_pool(1, 1, p, p, p, -1, 16, 16, f(0), None) == 2
+    assert lib.bevops_stem_set_variant(1) == 0 and lib.bevops_stem_set_variant(0) == 1              # returns the previous value
+    host_shapes = (ctypes.c_int32 * 8)(116, 200, 58, 100, 29, 50, 15, 25)
+    st = lib.bevops_sca_forward_planned(1, p, ctypes.c_size_t(64), ctypes.addressof(host_shapes), p, p, p, p, None,
+                                        ctypes.c_size_t(0), p, 6, 30825, 8, 32, 4, 40000, 8, 4, p, ctypes.c_size_t(0), None)
+    assert st == 2      # no plan
+
+
 def test_registry_mirrors_reference_names():
     import bevformer_tensorrt_amd as bev
     for name in ("multi_scale_deformable_attn", "multi_scale_deformable_attn2"):
