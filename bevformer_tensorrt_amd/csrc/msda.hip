@@ -605,7 +605,9 @@ static thread_local bool g_sca_direct = true;   // bevops_sca_forward_planned: s
 static thread_local int g_variant_raw = 0;   // the value last REQUESTED (19 maps to 17 + a flag below)
 extern "C" int bevops_msda_set_variant(int variant) {
   const int prev = g_variant_raw;   // handing this back to set_variant restores the flags too
-  g_variant_raw = variant;
+  // The 30xx values are independent knobs of the fused SCA op, NOT kernel-family selectors: they leave the family
+  // selection (g_variant / g_variant_raw) alone, so a save / restore pair around a family switch -- prev =
+  // set_variant(10); ...; set_variant(prev) -- still restores the family after any 30xx call in between.
   if (variant >= 3001 && variant <= 3008) {   // A/B: slices per CU of the planned fused SCA sampling (default 2)
     msda_hm5_set_plan_blocks(variant - 3000);
     return prev;
@@ -618,6 +620,7 @@ extern "C" int bevops_msda_set_variant(int variant) {
     g_sca_direct = variant == 3012;
     return prev;
   }
+  g_variant_raw = variant;
   // 19 (A/B): int8 hm4 on the one-block-per-CU plan (the partner of the default two-blocks plan); g_variant then
   // reads 17 = "hm4 wherever it is instantiated"
   msda_hm4_set_no_occ(variant == 19);

@@ -145,7 +145,9 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
  * (The measured-and-rejected builds of rounds 1-4 -- LDS-staged hm, two-copy hm, hm4 chunk sizes / schedule ablations,
  * int8 pixel-pair entries, hm5 with 768 threads / mailbox / persistent blocks / level-class split -- are no longer in
  * the library; their measurements are under profiles/.)  A packed value (bevops_msda_pack_value) must be sampled under
- * the variant it was packed under.  Returns the previously REQUESTED value. */
+ * the variant it was packed under.  Returns the previously REQUESTED kernel-family value; the 30xx knobs are independent
+ * of the family selection: they are neither recorded as, nor returned as, the requested value, so
+ * `prev = set_variant(10); ...; set_variant(prev)` restores the family whatever 30xx calls came before or in between. */
 int bevops_msda_set_variant(int variant);
 
 

@@ -108,6 +108,25 @@ def test_round5_entries_reject_bad_params_without_gpu(lib):
     assert st == 2      # no plan
 
 
+def test_sca_knobs_do_not_disturb_the_kernel_family_selection(lib):
+    """The 30xx values of bevops_msda_set_variant are knobs of the fused SCA op, not kernel-family selectors: after one of
+    them, a save / restore pair around a family switch (what multi_scale_deformable_attn_local does with variant 10)
+    must leave the default family in force -- the base SCA shape keeps its head-major workspace (round-5 advisor: the
+    knob used to be handed back as "previous" and the restore then left variant 10 behind for the whole thread)."""
+    lib.bevops_msda_workspace_size.restype = ctypes.c_size_t
+    base_sca_i8 = (2, 6, 30825, 8, 32, 4, 40000, 8)           # BEVOPS_I8: its size is 0 under "never head-major"
+    assert lib.bevops_msda_set_variant(0) in (0, 10, 19)       # whatever an earlier test of this process left
+    assert lib.bevops_msda_workspace_size(*base_sca_i8) > 0
+    for knob in (3002, 3010, 3012):
+        assert lib.bevops_msda_set_variant(knob) == 0          # knobs report the family request, and do not become it
+        prev = lib.bevops_msda_set_variant(10)
+        assert prev == 0
+        assert lib.bevops_msda_workspace_size(*base_sca_i8) == 0
+        assert lib.bevops_msda_set_variant(prev) == 10
+        assert lib.bevops_msda_workspace_size(*base_sca_i8) > 0, "variant 10 survived the restore after knob %d" % knob
+    assert lib.bevops_msda_set_variant(19) == 0 and lib.bevops_msda_set_variant(0) == 19   # family values round-trip
+
+
 def test_registry_mirrors_reference_names():
     import bevformer_tensorrt_amd as bev
     for name in ("multi_scale_deformable_attn", "multi_scale_deformable_attn2"):
