@@ -815,21 +815,31 @@ class BEVFormer(nn.Module):
         return self._static
 
     @torch.no_grad()
-    def project(self, lidar2img, image_shape, dtype):
-        """point_sampling_trt (encoder.py:197-259) of the BEV pillars for one rig: (reference_points_cam, bev_mask) in
-        the model's dtype.  It depends on the calibration matrices only -- they change per scene, not per frame -- so
-        the frame loop evaluates it when `lidar2img` changes and hands the result to `forward(proj=...)`."""
+    def project(self, lidar2img, image_shape, dtype, cams=None):
+        """point_sampling_trt (encoder.py:197-259) of the BEV pillars for one rig: (reference_points_cam, bev_mask[,
+        visibility plan]) in the model's dtype.  It depends on the calibration matrices only, and those change on EVERY
+        nuScenes frame (ego motion between the camera and lidar timestamps; the reference evaluates this inside the
+        engine per frame, lidar2img being an engine input: tools/bevformer/evaluate_trt.py:131-132, encoder.py:293):
+        `forward` calls it on every frame, inside the frame's HIP graph -- one launch (ops.point_sampling, bit-identical
+        to the torch op sequence of geometry.project_points) plus the two launches of the plan build.  `cams`: the
+        cameras sampled on this rank (camera sharding); the plan then lists those only."""
         _, _, pillars = self._geometry(lidar2img.device)
-        ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
-        ref_cam, bev_mask = ref_cam.to(dtype), bev_mask.to(dtype)
-        plan = self._sca_plan(bev_mask, None)
+        fused = getattr(self.ops, "point_sampling", None)
+        if fused is not None and _R3["enabled"] and lidar2img.is_cuda and dtype in (torch.float16, torch.float32) \
+                and pillars.shape[0] == 4:
+            ref_cam, bev_mask = fused(pillars, lidar2img, image_shape, dtype)
+        else:
+            ref_cam, bev_mask = G.project_points(pillars, lidar2img.float(), image_shape, projection="fma")
+            ref_cam, bev_mask = ref_cam.to(dtype), bev_mask.to(dtype)
+        plan = self._sca_plan(bev_mask, cams)
         return (ref_cam, bev_mask) if plan is None else (ref_cam, bev_mask, plan)
 
     def _sca_plan(self, bev_mask, cams):
         """Visibility plan of the fused SCA sampling for the cameras sampled on this rank (None: no such operator, or
         outside its domain).  Depends on the calibration only, like bev_mask itself."""
         fn = getattr(self.ops, "spatial_cross_attention_plan", None)
-        if fn is None or not _R3["enabled"] or not bev_mask.is_cuda or bev_mask.dtype != torch.float16:
+        if fn is None or not _R3["enabled"] or not bev_mask.is_cuda or bev_mask.dtype != torch.float16 \
+                or self.cfg["levels"] != 4:      # (the planned sampler's domain: the 4-level x 8-point pyramid of "base")
             return None
         mask_l = bev_mask if cams is None else _take_cams(bev_mask, cams)
         return fn(mask_l) if mask_l.shape[0] > 0 else None
@@ -837,7 +847,8 @@ class BEVFormer(nn.Module):
     def forward(self, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams=None, gather=None, shift=None, proj=None):
         """`shift` [1, 2]: optional precomputed G.bev_shift(can_bus) -- the frame loop evaluates it
         on the host (atan / sin / cos differ in the last ulp between host and device libraries;
-        the host value is the reference's CPU path bit for bit).  `proj`: optional precomputed `project(lidar2img)`."""
+        the host value is the reference's CPU path bit for bit).  `proj`: optional precomputed `project(lidar2img, ..., cams)`
+        (callers that know the calibration to be constant; the frame loop does not: it changes every frame)."""
         dev, dtype = image.device, image.dtype
         image_shape = image.shape[-2:]
         mlvl = self.extract_feat(image, cams)
@@ -895,9 +906,11 @@ class BEVFormer(nn.Module):
 
         # ---- encoder.forward_trt (:261-334)
         ref_3d, ref_2d, pillars = self._geometry(dev)
-        ref_cam, bev_mask, *rest = proj if proj is not None else self.project(lidar2img, image_shape, dtype)
-        # the plan that comes with the projection lists all cameras; a camera-sharded rank samples its own only
-        plan = (rest[0] if rest else None) if cams is None else self._sca_plan(bev_mask, cams)
+        if cams is None and gather is not None and hasattr(gather, "cams"):
+            cams = gather.cams     # the exchange object knows this rank's cameras: the plan must list exactly those
+        # (a precomputed `proj` must have been made for the same `cams`: its plan lists the cameras sampled HERE)
+        ref_cam, bev_mask, *rest = proj if proj is not None else self.project(lidar2img, image_shape, dtype, cams)
+        plan = rest[0] if rest else None
         hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
         q = bev_queries.view(1, nq, EMBED)
         pos = bev_pos.view(1, nq, EMBED)
@@ -1027,15 +1040,17 @@ class FrameRunner:
         self.prev = {"scene": None, "pos": None, "angle": None}
         self.use_graph, self._graphs, self._use = graph, {}, 0.0
         H, W = model.cfg["image"]
-        # the frame's small host-side inputs travel as ONE upload: [can_bus (18) | bev shift (2)]
-        small = torch.zeros(20, device=device)
-        self._host_small = torch.zeros(20)
+        # the frame's small host-side inputs travel as ONE upload: [can_bus (18) | bev shift (2) | lidar2img (6 x 4 x 4)].
+        # The calibration matrices are per-FRAME inputs, as in the reference (an engine input next to can_bus,
+        # tools/bevformer/evaluate_trt.py:99,131-132): the camera projection of the BEV pillars and the SCA visibility
+        # plan are evaluated from this buffer INSIDE the frame (and its graph), on every frame.
+        n_small = 20 + NUM_CAMS * 16
+        small = torch.zeros(n_small, device=device)
+        self._host_small = torch.zeros(n_small)
         self._in = dict(image=torch.zeros(1, NUM_CAMS, 3, H, W, device=device, dtype=dtype),
-                        small=small, can_bus=small[:18], shift=small[18:].view(1, 2),
-                        lidar2img=torch.zeros(1, NUM_CAMS, 4, 4, device=device),
+                        small=small, can_bus=small[:18], shift=small[18:20].view(1, 2),
+                        lidar2img=small[20:].view(1, NUM_CAMS, 4, 4),
                         use=torch.zeros((), device=device, dtype=dtype))
-        self._l2i_seen = None
-        self._proj = None               # (reference_points_cam, bev_mask) of the current rig, static buffers
 
     @property
     def image_buffer(self):
@@ -1065,7 +1080,7 @@ class FrameRunner:
             return self.model(i["image"], self.prev_bev, i["use"], i["can_bus"], i["lidar2img"], self.cams, self.gather,
                               shift=i["shift"])
         return self.model(i["image"], self.prev_bev, self._use, i["can_bus"], i["lidar2img"], self.cams, self.gather,
-                          shift=i["shift"], proj=self._proj)
+                          shift=i["shift"])
 
     def _capture(self):
         s = torch.cuda.Stream()
@@ -1103,21 +1118,6 @@ class FrameRunner:
         fn(raw_images, dtype=buf.dtype, out=buf)
         return self.step(buf[None], can_bus, lidar2img, scene_token)
 
-    def _calibration_changed(self, lidar2img):
-        """True when the 6 x 4 x 4 lidar2img matrices differ IN CONTENT from the ones last uploaded.  nuScenes matrices
-        change every frame (ego motion between the camera and lidar timestamps) and the reference's loop builds a fresh
-        tensor per frame (tools/bevformer/evaluate_pth.py:93), which routinely lands on the address the previous one
-        freed: tensor identity says nothing.  The very tensor OBJECT of the previous frame with an unchanged version
-        counter is the one case decided without looking (a held reference keeps its address from being reused); otherwise
-        the 96 values are compared on the host (a host tensor costs no synchronisation, a device tensor one small D2H)."""
-        seen = self._l2i_seen
-        if seen is not None and seen[0] is lidar2img and seen[1] == lidar2img._version:
-            return False
-        host = lidar2img.detach().to("cpu", torch.float32).reshape(-1).clone()
-        changed = seen is None or seen[2].shape != host.shape or not torch.equal(seen[2], host)
-        self._l2i_seen = (lidar2img, lidar2img._version, host)
-        return changed
-
     def step(self, image, can_bus, lidar2img, scene_token):
         can_bus = can_bus.clone().float()
         use_prev = 0.0 if scene_token != self.prev["scene"] else 1.0          # evaluate_trt.py:86-88
@@ -1132,21 +1132,21 @@ class FrameRunner:
         i = self._in
         if image.data_ptr() != i["image"].data_ptr():      # (the caller may have filled the static buffer itself)
             i["image"].copy_(image, non_blocking=True)
-        if self._calibration_changed(lidar2img):
-            i["lidar2img"].copy_(lidar2img, non_blocking=True)
-            if _R3["enabled"]:      # ... and so does the projection of the BEV pillars into the cameras: evaluated here,
-                proj = self.model.project(i["lidar2img"], i["image"].shape[-2:], self.dtype)   # not once per frame
-                if self._proj is None:
-                    self._proj = tuple(t.clone() for t in proj)
-                else:
-                    for dst, src in zip(self._proj, proj):
-                        dst.copy_(src)
         m = self.model
         grid_length = ((PC_RANGE[4] - PC_RANGE[1]) / m.bev_h, (PC_RANGE[3] - PC_RANGE[0]) / m.bev_w)
         can_host = can_bus.cpu()
         self._host_small[:18] = can_host
-        self._host_small[18:] = G.bev_shift(can_host, m.bev_h, m.bev_w, grid_length)[0]
+        self._host_small[18:20] = G.bev_shift(can_host, m.bev_h, m.bev_w, grid_length)[0]
+        # this frame's calibration: no cache, no comparison -- nuScenes matrices differ on every frame (ego motion
+        # between the camera and lidar timestamps; the reference's loop builds a fresh tensor per frame,
+        # tools/bevformer/evaluate_pth.py:93).  A host tensor rides the one upload below; a device tensor is copied
+        # device-to-device behind it (no host synchronisation either way).
+        on_host = lidar2img.device.type == "cpu"
+        if on_host:
+            self._host_small[20:] = lidar2img.detach().reshape(-1).to(torch.float32)
         i["small"].copy_(self._host_small)                  # one upload (pageable source: staged before the call returns)
+        if not on_host:
+            i["lidar2img"].copy_(lidar2img.detach().reshape(i["lidar2img"].shape), non_blocking=True)
         if not _R3["enabled"]:
             i["use"].fill_(use_prev)
         self._use = use_prev

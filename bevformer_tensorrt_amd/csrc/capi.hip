@@ -73,6 +73,7 @@ const Entry kTable[] = {
     {"bevops_sca_plan_size", (void *)&bevops_sca_plan_size},
     {"bevops_sca_plan_build", (void *)&bevops_sca_plan_build},
     {"bevops_sca_forward_planned", (void *)&bevops_sca_forward_planned},
+    {"bevops_point_sampling", (void *)&bevops_point_sampling},
     {"bevops_feat_embed_nhwc", (void *)&bevops_feat_embed_nhwc},
     {"bevops_linear_bias_act", (void *)&bevops_linear_bias_act},
     {"bevops_linear_tune", (void *)&bevops_linear_tune},

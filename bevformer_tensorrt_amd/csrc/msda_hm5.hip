@@ -161,60 +161,67 @@ __global__ __launch_bounds__(256) void msda_hm5_vis_kernel(const __half *__restr
 }
 
 // ---- visibility plan of the fused SCA op (LISTED == 3 below): per camera the ascending list of the queries whose
-// bev_mask weight is non-zero.  bev_mask depends on the calibration matrices only (encoder.py:255-258), so a frame loop
-// builds the plan once per rig and every layer of every frame samples with it.  Layout: int32 counts[kPlanCams] (64
-// bytes), then per camera a list of `nq_pad` 32-bit entries: the query index in bits 0-15 and, in bit 16, "this camera
-// is the only one that sees the query, with weight exactly 1" -- the sampler stores such a pair's result straight into
-// the op's output row (1 * v + 0 is v) and the camera reduce leaves those rows alone (kSoleBit).  One block per camera;
-// a thread takes 8 consecutive queries per pass.
+// bev_mask weight is non-zero.  bev_mask depends on the calibration matrices only (encoder.py:255-258); nuScenes matrices
+// change every frame, so the frame's graph rebuilds the plan behind bevops_point_sampling on every replay and every layer
+// of the frame samples with it.  Layout: int32 counts[kPlanCams] (64 bytes), then per camera a list of `nq_pad` 32-bit
+// entries: the query index in bits 0-15 and, in bit 16, "this camera is the only one that sees the query, with weight
+// exactly 1" -- the sampler stores such a pair's result straight into the op's output row (1 * v + 0 is v) and the
+// camera reduce leaves those rows alone (kSoleBit); then the builder's scratch: kPlanBlocks block counts per camera.
+// Round 6: two launches of (256-query block, camera) grids -- count, then place behind the sum of the blocks in front
+// -- instead of one 1 024-thread block per camera walking its 40 000 queries (63 us at the base size: it was built
+// once per rig then; now it is on every frame's critical path).
 constexpr int kPlanCams = 16;
+constexpr int kPlanBlocks = 256;   // 256-query blocks per camera: num_query <= 65 535
 inline size_t h5_plan_pad(int nq) { return ((size_t)nq + 63) & ~size_t(63); }
 __device__ __forceinline__ unsigned h5_plan_pad_dev(int nq) { return ((unsigned)nq + 63u) & ~63u; }
 constexpr unsigned kSoleBit = 0x10000u;
-__global__ __launch_bounds__(1024) void msda_hm5_plan_kernel(const unsigned short *__restrict__ qmask, int bs, int nq,
-                                                             unsigned nq_pad, int *__restrict__ counts,
-                                                             unsigned *__restrict__ lists) {
-  __shared__ unsigned wtot[16];
-  const unsigned cam = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const unsigned short *mk = qmask + (size_t)cam * nq;
-  unsigned *dst = lists + (size_t)cam * nq_pad;
-  unsigned base = 0;
-  for (unsigned q0 = 0; q0 < (unsigned)nq; q0 += 8192u) {
-    const unsigned q = q0 + threadIdx.x * 8u;
-    unsigned bits = 0;
+
+__device__ __forceinline__ bool h5_plan_visible(const unsigned short *__restrict__ qmask, unsigned cam, unsigned q, int nq) {
+  return q < (unsigned)nq && (qmask[(size_t)cam * nq + q] & 0x7fffu) != 0;   // not +-0
+}
+
+__global__ __launch_bounds__(256) void msda_hm5_plan_count_kernel(const unsigned short *__restrict__ qmask, int nq,
+                                                                  unsigned *__restrict__ partial) {
+  __shared__ unsigned wcnt[4];
+  const unsigned cam = blockIdx.y, q = blockIdx.x * 256u + threadIdx.x;
+  const unsigned long long bal = __ballot(h5_plan_visible(qmask, cam, q, nq));
+  if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = (unsigned)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) partial[cam * kPlanBlocks + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+__global__ __launch_bounds__(256) void msda_hm5_plan_place_kernel(const unsigned short *__restrict__ qmask, int bs, int nq,
+                                                                  unsigned nq_pad, int *__restrict__ counts,
+                                                                  unsigned *__restrict__ lists,
+                                                                  const unsigned *__restrict__ partial) {
+  __shared__ unsigned wsum[4], wcnt[4];
+  const unsigned cam = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const unsigned q = blk * 256u + threadIdx.x;
+  // entries of this camera in front of this block: the sum of the earlier blocks' counts (gridDim.x <= 256: one each)
+  unsigned before = threadIdx.x < blk ? partial[cam * kPlanBlocks + threadIdx.x] : 0u;
 #pragma unroll
-    for (unsigned k = 0; k < 8; ++k)
-      if (q + k < (unsigned)nq && (mk[q + k] & 0x7fffu) != 0) bits |= 1u << k;   // not +-0
-    const unsigned n = (unsigned)__popc(bits);
-    // inclusive prefix over the wave (DPP-free: 6 shuffle steps), then over the block's 16 waves through LDS
-    unsigned incl = n;
-#pragma unroll
-    for (unsigned d = 1; d < 64; d <<= 1) {
-      const unsigned up = (unsigned)__shfl_up((int)incl, d, 64);
-      if (lane >= d) incl += up;
-    }
-    if (lane == 63u) wtot[wv] = incl;
-    __syncthreads();
-    unsigned before = base, all = 0;
-#pragma unroll
-    for (unsigned w2 = 0; w2 < 16; ++w2) {
-      const unsigned c = wtot[w2];
-      if (w2 < wv) before += c;
-      all += c;
-    }
-    unsigned o = before + incl - n;
-#pragma unroll
-    for (unsigned k = 0; k < 8; ++k)
-      if (bits & (1u << k)) {
-        bool sole = mk[q + k] == 0x3c00u;   // binary16 1.0
-        for (int c2 = 0; c2 < bs; ++c2)
-          if (c2 != (int)cam && (qmask[(size_t)c2 * nq + q + k] & 0x7fffu) != 0) sole = false;
-        dst[o++] = (q + k) | (sole ? kSoleBit : 0u);
-      }
-    base += all;
-    __syncthreads();
+  for (unsigned d = 32; d >= 1; d >>= 1) before += (unsigned)__shfl_xor((int)before, (int)d, 64);
+  const bool v = h5_plan_visible(qmask, cam, q, nq);
+  const unsigned long long bal = __ballot(v);
+  if (lane == 0u) {
+    wsum[wv] = before;
+    wcnt[wv] = (unsigned)__popcll(bal);
   }
-  if (threadIdx.x == 0) counts[cam] = (int)base;
+  __syncthreads();
+  unsigned o = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  unsigned all = 0;
+#pragma unroll
+  for (unsigned w2 = 0; w2 < 4; ++w2) {
+    if (w2 < wv) o += wcnt[w2];
+    all += wcnt[w2];
+  }
+  if (blk == gridDim.x - 1u && threadIdx.x == 0) counts[cam] = (int)(o + all);   // (o = the blocks in front: wv == 0)
+  if (v) {
+    bool sole = qmask[(size_t)cam * nq + q] == 0x3c00u;   // binary16 1.0
+    for (int c2 = 0; c2 < bs; ++c2)
+      if (c2 != (int)cam && (qmask[(size_t)c2 * nq + q] & 0x7fffu) != 0) sole = false;
+    lists[(size_t)cam * nq_pad + o + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = q | (sole ? kSoleBit : 0u);
+  }
 }
 
 // ---- sampling kernel.  LISTED: 0 every query of the chunk, 1 the items whose
@@ -683,17 +690,20 @@ void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k)
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
-  return (size_t)kPlanCams * 4 + (size_t)bs * h5_plan_pad(nq) * 4;
+  return (size_t)kPlanCams * 4 + (size_t)bs * h5_plan_pad(nq) * 4 + (size_t)bs * kPlanBlocks * 4;   // counts, lists, scratch
 }
 
 int msda_hm5_plan_build(const __half *qmask, int bs, int nq, void *plan, size_t plan_bytes, hipStream_t st) {
   const size_t need = msda_hm5_plan_bytes(bs, nq);
   if (need == 0) return BEVOPS_NOT_SUPPORTED;
   if (!qmask || !plan || plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
-  hipLaunchKernelGGL(msda_hm5_plan_kernel, dim3((unsigned)bs), dim3(1024), 0, st,
-                     reinterpret_cast<const unsigned short *>(qmask), bs, nq, (unsigned)h5_plan_pad(nq),
-                     static_cast<int *>(plan),
-                     reinterpret_cast<unsigned *>(static_cast<char *>(plan) + kPlanCams * 4));
+  const unsigned short *mk = reinterpret_cast<const unsigned short *>(qmask);
+  unsigned *lists = reinterpret_cast<unsigned *>(static_cast<char *>(plan) + kPlanCams * 4);
+  unsigned *partial = lists + (size_t)bs * h5_plan_pad(nq);
+  const dim3 grid(((unsigned)nq + 255u) / 256u, (unsigned)bs);
+  hipLaunchKernelGGL(msda_hm5_plan_count_kernel, grid, dim3(256), 0, st, mk, nq, partial);
+  hipLaunchKernelGGL(msda_hm5_plan_place_kernel, grid, dim3(256), 0, st, mk, bs, nq, (unsigned)h5_plan_pad(nq),
+                     static_cast<int *>(plan), lists, partial);
   return launch_status();
 }
 
@@ -709,7 +719,9 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   if ((double)nq * heads * 32 * 4.0 >= 4294967040.0 || (double)bs * nq * heads * 64.0 >= 4294967040.0) return BEVOPS_NOT_SUPPORTED;
   const size_t need = msda_hm5_plan_bytes(bs, nq);
   if (need == 0) return BEVOPS_NOT_SUPPORTED;
-  if (!plan || plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
+  // the plan of ANOTHER camera set or query count (a 6-camera plan handed to a camera-sharded rank's subset) has
+  // another size: rejected here instead of sampling from the wrong lists
+  if (!plan || plan_bytes != need || (reinterpret_cast<uintptr_t>(plan) & 15u)) return BEVOPS_BAD_PARAM;
   const size_t g_room = (pl.g_bytes + 127) & ~size_t(127);
   if (packed_bytes < g_room + pl.s_bytes) return BEVOPS_BAD_PARAM;
   const char *gset = static_cast<const char *>(packed);

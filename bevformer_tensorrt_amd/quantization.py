@@ -186,7 +186,8 @@ class Int8PluginOps:
     # form is FASTER than any int8 form on MI355X: the channels-last nearest-neighbour rotate of prev_bev (pure data
     # movement: rotating commutes with quantising, the int8 plugin would only add a quantise and a de-quantise pass
     # around it) and the value projection that writes the SCA sampler's planes itself.
-    _ENGINE_PASS = ("rotate_hwc", "spatial_cross_attention_projected", "spatial_cross_attention_plan")
+    # ... and the camera projection of the BEV pillars (index generation: fp32 and bit-exact in every build).
+    _ENGINE_PASS = ("rotate_hwc", "spatial_cross_attention_projected", "spatial_cross_attention_plan", "point_sampling")
 
     def __init__(self, calibrator="entropy", fp_ops=None, channels_last=False, fused_sca=False, engine=False):
         from . import functions as _f

@@ -67,6 +67,8 @@ SIGNATURES = {
     "bevops_sca_plan_build": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "bevops_sca_forward_planned": (c_int, [c_int, c_void_p, c_size_t] + [c_void_p] * 6 + [c_size_t, c_void_p] + [c_int] * 8 +
                                    [c_void_p, c_size_t, c_void_p]),
+    "bevops_point_sampling": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                      c_void_p]),
     "bevops_tsgemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tsgemm_s8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_int,
                                  c_void_p, c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),

@@ -551,14 +551,18 @@ int bevops_sca_forward_prepacked(int dtype, const void *packed, size_t packed_by
 /* The same sampling on a VISIBILITY PLAN (round 5).  bev_mask depends on the calibration matrices only
  * (modules/encoder.py:255-258), so which (camera, query) pairs are sampled is known per rig, not per call:
  * bevops_sca_plan_build turns the fp16 bev_mask [num_cams, num_query] into per-camera ascending lists of the visible
- * queries (`plan`: >= bevops_sca_plan_size bytes, 16-byte aligned, device memory the caller keeps for as long as the
- * mask is valid; num_cams <= 16, num_query <= 65 535), and bevops_sca_forward_planned gives every block of the sampling
+ * queries (`plan`: bevops_sca_plan_size bytes -- 64 of counts, the lists, 1 KB of builder scratch per camera --
+ * 16-byte aligned, device memory the caller keeps for as long as the mask is valid; num_cams <= 16, num_query <= 65 535;
+ * two launches, no host synchronisation: a frame loop whose calibration changes per frame captures it in the frame's
+ * graph behind bevops_point_sampling), and bevops_sca_forward_planned gives every block of the sampling
  * kernel an EQUAL slice of the global (camera, query) sequence -- no empty blocks, no per-block compaction, the same
  * number of rounds on every CU -- with the results of bevops_sca_forward_prepacked (bit-identical: same arithmetic
  * per pair, same reduction).  The plan also marks the pairs whose query no other camera sees and whose weight is
  * exactly 1 (89 % of the visible pairs of the 6-camera rig): the sampler stores those rows straight into `output`
  * (1 * v + 0 = v) and the camera reduce touches only the others.  `plan` must have been built from the VALUES of the
- * `bev_mask` passed here (not only from its zero pattern). */
+ * `bev_mask` passed here (not only from its zero pattern); bevops_sca_forward_planned returns BEVOPS_BAD_PARAM unless
+ * plan_bytes == bevops_sca_plan_size(num_cams, num_query) -- a plan built for another camera set or query count is
+ * rejected (what the plan's CONTENT was built from cannot be checked without a host synchronisation and is not). */
 size_t bevops_sca_plan_size(int num_cams, int num_query);
 int bevops_sca_plan_build(int dtype, const void *bev_mask, int num_cams, int num_query, void *plan, size_t plan_bytes,
                           void *stream);
@@ -568,6 +572,19 @@ int bevops_sca_forward_planned(int dtype, const void *packed, size_t packed_byte
                                void *output, int num_cams, int nk, int heads, int channels, int num_levels,
                                int num_query, int num_point, int points_per_group, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+/* point_sampling_trt (det2trt/models/modules/encoder.py:197-259) as one launch (csrc/point_sampling.hip): the BEV
+ * pillar anchors `pillars` [num_points_in_pillar, num_query, 4] (fp32 metric homogeneous points: the frame-independent
+ * first half, encoder.py:199-219) projected with `lidar2img` [num_cams, 4, 4] (fp32, row-major, DEVICE memory: the
+ * reference feeds it as an engine input on every frame, tools/bevformer/evaluate_trt.py:131-132), divided by the depth
+ * and the image size -> reference_points_cam [num_cams, num_query, num_points_in_pillar, 2] and the visibility weights
+ * bev_mask [num_cams, num_query] = (any anchor inside the image and in front of the camera) / max(number of cameras that
+ * see the pillar, 1e-4), both in `out_dtype` (BEVOPS_F16 | BEVOPS_F32).  Index generation is bit-exact (SURVEY 8a row
+ * a6): fp32 arithmetic in the reference's op order -- separately rounded products and sums in ascending k, IEEE
+ * divisions -- rounded once to the output type.  BEVOPS_NOT_SUPPORTED unless num_points_in_pillar == 4. */
+int bevops_point_sampling(int out_dtype, const float *pillars, const float *lidar2img, void *reference_points_cam,
+                          void *bev_mask, int num_cams, int num_query, int num_points_in_pillar, float image_h,
+                          float image_w, void *stream);
 
 /* Hand-written tall-skinny fp16 GEMM on the matrix cores (csrc/tsgemm.hip) for the dense layers that wrap the
  * samplers (the reference runs them as cuBLAS / TensorRT layers: spatial_cross_attention.py:694-768,

@@ -84,8 +84,8 @@ def test_round5_entries_reject_bad_params_without_gpu(lib):
     f = ctypes.c_float
     lib.bevops_sca_plan_size.restype = ctypes.c_size_t
     lib.bevops_stem_packed_size.restype = ctypes.c_size_t
-    assert lib.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 4       # counts + 32-bit entries
-    assert lib.bevops_sca_plan_size(6, 100) == 64 + 6 * 128 * 4           # lists padded to 64 entries
+    assert lib.bevops_sca_plan_size(6, 40000) == 64 + 6 * 40000 * 4 + 6 * 1024    # counts + 32-bit entries + builder scratch
+    assert lib.bevops_sca_plan_size(6, 100) == 64 + 6 * 128 * 4 + 6 * 1024        # lists padded to 64 entries
     assert lib.bevops_sca_plan_size(17, 100) == 0 and lib.bevops_sca_plan_size(6, 65536) == 0 and lib.bevops_sca_plan_size(0, 5) == 0
     assert lib.bevops_stem_packed_size() == 11 * 2 * 64 * 8 * 2
     buf = (ctypes.c_char * 256)()
@@ -106,6 +106,13 @@ def test_round5_entries_reject_bad_params_without_gpu(lib):
     st = lib.bevops_sca_forward_planned(1, p, ctypes.c_size_t(64), ctypes.addressof(host_shapes), p, p, p, p, None,
                                         ctypes.c_size_t(0), p, 6, 30825, 8, 32, 4, 40000, 8, 4, p, ctypes.c_size_t(0), None)
     assert st == 2      # no plan
+    # round 6: the camera projection of the BEV pillars (bevops_point_sampling)
+    assert lib.bevops_point_sampling(1, None, p, p, p, 6, 100, 4, f(928), f(1600), None) == 2      # no pillars
+    assert lib.bevops_point_sampling(1, p, p, p, p, 0, 100, 4, f(928), f(1600), None) == 2         # no cameras
+    assert lib.bevops_point_sampling(1, p, p, p, p, 6, 100, 4, f(0), f(1600), None) == 2           # empty image
+    assert lib.bevops_point_sampling(1, p, p, p, p, 6, 100, 3, f(928), f(1600), None) == 3         # three anchors per pillar
+    assert lib.bevops_point_sampling(2, p, p, p, p, 6, 100, 4, f(928), f(1600), None) == 3         # int8 output
+    assert lib.bevops_point_sampling(1, p + 4, p, p, p, 6, 100, 4, f(928), f(1600), None) == 2     # misaligned pillars
 
 
 def test_sca_knobs_do_not_disturb_the_kernel_family_selection(lib):

@@ -62,3 +62,23 @@ def test_fractional_offset_is_bilinear_blend(oracle_mod):
     a = F.conv2d(xp, w)[:, :, 1:9, 1:11]
     b = F.conv2d(xp, w)[:, :, 1:9, 2:12]
     np.testing.assert_allclose(out, (0.75 * a + 0.25 * b).numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cfg", [dict(B=2, Cin=8, Cout=6, H=9, W=11, stride=1, pad=1, dil=1),
+                                 dict(B=1, Cin=4, Cout=5, H=12, W=10, stride=2, pad=1, dil=1),
+                                 dict(B=1, Cin=4, Cout=4, H=8, W=9, stride=1, pad=2, dil=2)])
+def test_torch_statement_of_dcn_matches_the_c_oracle(oracle_mod, cfg):
+    """oracle/ref_ops.py: mdconv_torch (the DCNv2 formulation the model-level parity tests of the big configs evaluate
+    on the device) against oracle.mdconv (pinned bit-exact against the reference's own kernels compiled for the host,
+    tests/test_ref_kernels_cpu.py): offsets of several pixels, taps that leave the image on every side, masks in [0, 1]."""
+    from oracle.ref_ops import mdconv_torch
+    c = cfg
+    x, w, b = rnd(c["B"], c["Cin"], c["H"], c["W"]), rnd(c["Cout"], c["Cin"], 3, 3, seed=1), rnd(c["Cout"], seed=2)
+    Ho = (c["H"] + 2 * c["pad"] - c["dil"] * 2 - 1) // c["stride"] + 1
+    Wo = (c["W"] + 2 * c["pad"] - c["dil"] * 2 - 1) // c["stride"] + 1
+    off = rnd(c["B"], 18, Ho, Wo, seed=3) * 2.5
+    mask = torch.sigmoid(rnd(c["B"], 9, Ho, Wo, seed=4))
+    want = oracle_mod.mdconv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy(), (c["stride"],) * 2,
+                             (c["pad"],) * 2, (c["dil"],) * 2, 1, 1)
+    got = mdconv_torch(x, off, mask, w, b, c["stride"], c["pad"], c["dil"]).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which station bounds each kernel of the frame?  Reads the rocprofv3 --pmc --kernel-trace csv directories of a few eager
-frames (tools/r5/frame_pmc.sh) and prints, per kernel name: launches, mean duration, and per launch the counters turned
+frames (tools/frame_pmc.sh) and prints, per kernel name: launches, mean duration, and per launch the counters turned
 into cycles per CU -- L1 tag look-ups (TCP_TOTAL_CACHE_ACCESSES / CUs: one 64-byte sector per cycle), VALU issue
 (SQ_INSTS_VALU x 4 / SIMDs), matrix-core busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs... as reported), LDS
 (SQ_LDS_IDX_ACTIVE / CUs, of which bank conflicts), L2 requests (bytes) -- next to the duration in cycles at 2.1 GHz.

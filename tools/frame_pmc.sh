@@ -1,6 +1,6 @@
 #!/bin/bash
 # counters of every kernel of the fp16 (and INT8) base frame: three passes over a few eager frames
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5pmc; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc}/framepmc; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
 for kind in ${KINDS:-fp16 int8}; do
   EXTRA=""; [ $kind = int8 ] && EXTRA="--int8"
