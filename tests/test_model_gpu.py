@@ -481,4 +481,8 @@ def test_graph_replay_follows_the_calibration_of_every_frame():
         assert (be - bg).abs().max().item() <= 4e-2 * scale and (be - bg).abs().mean().item() <= 4e-3 * scale
     d_true = (eager[2][0] - graph[2][0]).abs().mean().item()
     d_stale = (eager[2][0] - stale[2][0]).abs().mean().item()
-    assert d_stale > 20 * max(d_true, 1e-4), (d_true, d_stale)      # the replay really used frame 3's matrices
+    # the replay really used frame 3's matrices (measured: the graph equals the eager frame bit for bit under the
+    # reproducible dispatch, d_true = 0; the frame on the stale calibration is 8e-4 away on average)
+    assert d_true <= 1e-5 and d_stale > 2e-4, (d_true, d_stale)
+    changed = ((eager[2][0] - stale[2][0]).abs().amax(-1) > 1e-2).float().mean().item()
+    assert changed > 0.01, changed             # ... and whole BEV rows differ, not rounding noise
