@@ -620,6 +620,10 @@ extern "C" int bevops_msda_set_variant(int variant) {
     g_sca_direct = variant == 3012;
     return prev;
   }
+  if (variant == 3014 || variant == 3015) {   // A/B: planned SCA sampler with the record broadcasts folded into their consumers (default) / not
+    msda_hm5_set_fold(variant == 3014);
+    return prev;
+  }
   g_variant_raw = variant;
   // 19 (A/B): int8 hm4 on the one-block-per-CU plan (the partner of the default two-blocks plan); g_variant then
   // reads 17 = "hm4 wherever it is instantiated"

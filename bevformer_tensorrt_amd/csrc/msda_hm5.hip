@@ -240,7 +240,13 @@ __global__ __launch_bounds__(256) void msda_hm5_plan_place_kernel(const unsigned
 // history has them: 768-thread blocks, two phases of loads in flight, the mailbox, persistent blocks on strided
 // sub-chunks, specialised waves, the level-class split, ablation / timing builds): design/msda.md.
 constexpr int kH5Threads = 1024;   // one block per CU (the staged planes fill the LDS): 16 waves at <= 128 registers
-template <int LISTED>
+// FOLD (round 6, the planned kernel's default): the DPP broadcast of a record dword is folded INTO the instruction that
+// consumes it -- the two weight pairs of a big-level sample ride as the DPP source of its sixteen v_dot2c_f32_f16
+// (v_dot2c is VOP2: it takes a quad_perm source; hand-placed asm blocks, the compiler does not combine a broadcast
+// with eight uses), a slot's entry address is ONE v_add_u32 with a DPP source (the compiler's own combine: the
+// broadcast has a single use) and its second row one more add -- instead of 3 broadcast moves + 3 address adds per
+// sample and register copies of all eight records: same arithmetic in the same order, the same bits.
+template <int LISTED, bool FOLD = false>
 __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
@@ -426,6 +432,109 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       // the L2 path goes before waves that are in their multiply-add segments (518 vs 524 us)
       __builtin_amdgcn_s_setprio(3);
       spread();
+      if constexpr (FOLD) {
+        static_assert(!FOLD || (NB == 4 && NS == 4), "the folded phase is written for 4 big + 4 staged slots");
+        const unsigned row_b0 = ((unsigned)t.W[0] + 1u) << 7, row_b1 = ((unsigned)t.W[1] + 1u) << 7;
+        const unsigned row_s2 = ((unsigned)t.W[2] + 1u) << 6, row_s3 = ((unsigned)t.W[3] + 1u) << 6;
+        // big levels: slot S = lane S of every quad (rlo); its address is one add with a DPP source
+        u32x4 r0[4], r1[4];
+        {
+          const unsigned a0 = quad_bcast<0>(rlo.z) + lane16, a1 = quad_bcast<1>(rlo.z) + lane16;
+          const unsigned a2 = quad_bcast<2>(rlo.z) + lane16, a3 = quad_bcast<3>(rlo.z) + lane16;
+          r0[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
+          r1[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a0 + row_b0), 0, 0);
+          r0[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a1, 0, 0);
+          r1[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a1 + row_b0), 0, 0);
+          r0[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2, 0, 0);
+          r1[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a2 + row_b1), 0, 0);
+          r0[3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0);
+          r1[3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a3 + row_b1), 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // staged levels, two slots at a time (slots 4, 5 = level 2; 6, 7 = level 3; records in rhi)
+        unsigned wx[2], wy[2];
+        u32x2 l0[2], q0r[2], l1[2], q1r[2];
+        auto lds_pair = [&](auto hc) __attribute__((always_inline)) {
+          constexpr int Hh = decltype(hc)::v;
+          const unsigned row = Hh == 0 ? row_s2 : row_s3;
+          constexpr int SA = 2 * Hh, SB = 2 * Hh + 1;     // lanes of the quad (rhi holds slot 4 + (lane & 3))
+          wx[0] = quad_bcast<SA>(rhi.x); wy[0] = quad_bcast<SA>(rhi.y);
+          wx[1] = quad_bcast<SB>(rhi.x); wy[1] = quad_bcast<SB>(rhi.y);
+          const unsigned aA = quad_bcast<SA>(rhi.z) + lane8b, aB = quad_bcast<SB>(rhi.z) + lane8b;
+          unsigned aAr = aA + (unsigned)kLdsPixBytes, aA1 = aA + row, aA1r = aA + row + (unsigned)kLdsPixBytes;
+          unsigned aBr = aB + (unsigned)kLdsPixBytes, aB1 = aB + row, aB1r = aB + row + (unsigned)kLdsPixBytes;
+          asm("" : "+v"(aAr));    // (laundered: keeps the two ds_read_b64 of a row from fusing into one ds_read2_b64)
+          asm("" : "+v"(aA1r));
+          asm("" : "+v"(aBr));
+          asm("" : "+v"(aB1r));
+          l0[0] = *(const lds_u2 *)(size_t)aA;   q0r[0] = *(const lds_u2 *)(size_t)aAr;
+          l1[0] = *(const lds_u2 *)(size_t)aA1;  q1r[0] = *(const lds_u2 *)(size_t)aA1r;
+          l0[1] = *(const lds_u2 *)(size_t)aB;   q0r[1] = *(const lds_u2 *)(size_t)aBr;
+          l1[1] = *(const lds_u2 *)(size_t)aB1;  q1r[1] = *(const lds_u2 *)(size_t)aB1r;
+        };
+        auto lds_math2 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const h2_t w0 = as_h2(wx[s]), w1 = as_h2(wy[s]);
+            const h2_t w00 = {w0[0], w0[0]}, w01 = {w0[1], w0[1]}, w10 = {w1[0], w1[0]}, w11 = {w1[1], w1[1]};
+            h2_t a = as_h2(l0[s].x) * w00, bb = as_h2(l0[s].y) * w00;
+            a = as_h2(q0r[s].x) * w01 + a; bb = as_h2(q0r[s].y) * w01 + bb;
+            a = as_h2(l1[s].x) * w10 + a; bb = as_h2(l1[s].y) * w10 + bb;
+            a = as_h2(q1r[s].x) * w11 + a; bb = as_h2(q1r[s].y) * w11 + bb;
+            add_h2(acc[0], acc[1], a);
+            add_h2(acc[2], acc[3], bb);
+          }
+        };
+        // sixteen dots of two big slots: weights as the DPP source (lane SA / SB of the quad), hazards padded by hand
+        // (a VALU write needs 2 states before a DPP read of it; a DOT result 3 states before another VALU reads it --
+        // invisible to the compiler inside an asm statement)
+#define H5_DOTS(SA, SB, K0, K1)                                                                                         \
+        asm("s_nop 1\n\t"                                                                                               \
+            "v_dot2c_f32_f16_dpp %0, %4, %6 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_dot2c_f32_f16_dpp %1, %4, %7 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_dot2c_f32_f16_dpp %2, %4, %8 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_dot2c_f32_f16_dpp %3, %4, %9 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_dot2c_f32_f16_dpp %0, %5, %10 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %1, %5, %11 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %2, %5, %12 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %3, %5, %13 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %0, %4, %14 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %1, %4, %15 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %2, %4, %16 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %3, %4, %17 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %0, %5, %18 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %1, %5, %19 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %2, %5, %20 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "v_dot2c_f32_f16_dpp %3, %5, %21 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
+            "s_nop 2"                                                                                                   \
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                    \
+            : "v"(rlo.x), "v"(rlo.y), "v"(r0[K0].x), "v"(r0[K0].y), "v"(r0[K0].z), "v"(r0[K0].w), "v"(r1[K0].x),        \
+              "v"(r1[K0].y), "v"(r1[K0].z), "v"(r1[K0].w), "v"(r0[K1].x), "v"(r0[K1].y), "v"(r0[K1].z), "v"(r0[K1].w),  \
+              "v"(r1[K1].x), "v"(r1[K1].y), "v"(r1[K1].z), "v"(r1[K1].w))
+        lds_pair(IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J < 3) {
+          fe(cur, IC<J + 1>{});
+        } else {
+          s_cur = ssum;
+          fe_begin(nxt);
+          fe(nxt, IC<0>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_math2();
+        __builtin_amdgcn_sched_barrier(0);
+        lds_pair(IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        H5_DOTS(0, 1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_math2();
+        __builtin_amdgcn_sched_barrier(0);
+        H5_DOTS(2, 3, 2, 3);
+        __builtin_amdgcn_sched_barrier(0);
+#undef H5_DOTS
+        return;
+      }
       // big levels: records, then all 2 * NB loads
       u32x4 rb[NB > 0 ? NB : 1];
       u32x4 r0[NB > 0 ? NB : 1], r1[NB > 0 ? NB : 1];
@@ -687,6 +796,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 // so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
 static thread_local int g_h5_plan_k = 2;
 void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
+static thread_local bool g_h5_fold = true;      // the FOLD build of the planned kernel (default) / its A/B partner
+void msda_hm5_set_fold(bool on) { g_h5_fold = on; }
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
@@ -729,8 +840,10 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   constexpr int THREADS = kH5Threads;
   const size_t lds = (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  auto kern = msda_hm5_kernel<3>;
-  if (!ensure_dynamic_lds<msda_hm5_kernel<3>>(lds)) return (int)BEVOPS_FAILURE;
+  const bool fold = g_h5_fold;
+  auto kern = fold ? msda_hm5_kernel<3, true> : msda_hm5_kernel<3, false>;
+  if (!(fold ? ensure_dynamic_lds<msda_hm5_kernel<3, true>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, false>>(lds)))
+    return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)

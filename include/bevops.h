@@ -142,6 +142,8 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
  *    3010 / 3011  camera reduce of the fused SCA op with its camera loop unrolled (default) / rolled (sticky)
  *    3012 / 3013  planned fused SCA sampling stores the pairs only one camera sees straight into the output and the
  *                 reduce skips those rows (default) / every pair through the per-camera scratch (sticky)
+ *    3014 / 3015  planned fused SCA sampling with the DPP broadcasts of the sample records folded into the instructions
+ *                 that consume them (default, round 6) / the round-5 build with broadcast moves (sticky)
  * (The measured-and-rejected builds of rounds 1-4 -- LDS-staged hm, two-copy hm, hm4 chunk sizes / schedule ablations,
  * int8 pixel-pair entries, hm5 with 768 threads / mailbox / persistent blocks / level-class split -- are no longer in
  * the library; their measurements are under profiles/.)  A packed value (bevops_msda_pack_value) must be sampled under
