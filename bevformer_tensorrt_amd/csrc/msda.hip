@@ -620,8 +620,8 @@ extern "C" int bevops_msda_set_variant(int variant) {
     g_sca_direct = variant == 3012;
     return prev;
   }
-  if (variant == 3014 || variant == 3015) {   // A/B: planned SCA sampler with the record broadcasts folded into their consumers (default) / not
-    msda_hm5_set_fold(variant == 3014);
+  if (variant >= 3014 && variant <= 3016) {   // A/B: planned SCA sampler with the record broadcasts folded into their
+    msda_hm5_set_fold(variant == 3014 ? 1 : variant == 3015 ? 0 : 2);   // consumers (3014, default) / not (3015) / folded + ds_read2 (3016)
     return prev;
   }
   g_variant_raw = variant;

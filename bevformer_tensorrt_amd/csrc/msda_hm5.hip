@@ -246,7 +246,7 @@ constexpr int kH5Threads = 1024;   // one block per CU (the staged planes fill t
 // with eight uses), a slot's entry address is ONE v_add_u32 with a DPP source (the compiler's own combine: the
 // broadcast has a single use) and its second row one more add -- instead of 3 broadcast moves + 3 address adds per
 // sample and register copies of all eight records: same arithmetic in the same order, the same bits.
-template <int LISTED, bool FOLD = false>
+template <int LISTED, int FOLD = 0>
 __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
@@ -464,10 +464,12 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
           const unsigned aA = quad_bcast<SA>(rhi.z) + lane8b, aB = quad_bcast<SB>(rhi.z) + lane8b;
           unsigned aAr = aA + (unsigned)kLdsPixBytes, aA1 = aA + row, aA1r = aA + row + (unsigned)kLdsPixBytes;
           unsigned aBr = aB + (unsigned)kLdsPixBytes, aB1 = aB + row, aB1r = aB + row + (unsigned)kLdsPixBytes;
-          asm("" : "+v"(aAr));    // (laundered: keeps the two ds_read_b64 of a row from fusing into one ds_read2_b64)
-          asm("" : "+v"(aA1r));
-          asm("" : "+v"(aBr));
-          asm("" : "+v"(aB1r));
+          if constexpr (FOLD != 2) {   // (FOLD == 2, A/B: let them fuse -- half the LDS rate, two address adds less per slot)
+            asm("" : "+v"(aAr));    // laundered: keeps the two ds_read_b64 of a row from fusing into one ds_read2_b64
+            asm("" : "+v"(aA1r));
+            asm("" : "+v"(aBr));
+            asm("" : "+v"(aB1r));
+          }
           l0[0] = *(const lds_u2 *)(size_t)aA;   q0r[0] = *(const lds_u2 *)(size_t)aAr;
           l1[0] = *(const lds_u2 *)(size_t)aA1;  q1r[0] = *(const lds_u2 *)(size_t)aA1r;
           l0[1] = *(const lds_u2 *)(size_t)aB;   q0r[1] = *(const lds_u2 *)(size_t)aBr;
@@ -796,8 +798,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 // so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
 static thread_local int g_h5_plan_k = 2;
 void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
-static thread_local bool g_h5_fold = true;      // the FOLD build of the planned kernel (default) / its A/B partner
-void msda_hm5_set_fold(bool on) { g_h5_fold = on; }
+static thread_local int g_h5_fold = 1;      // the FOLD build of the planned kernel (default) / its A/B partners (0, 2)
+void msda_hm5_set_fold(int mode) { g_h5_fold = mode; }
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
@@ -840,9 +842,10 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   constexpr int THREADS = kH5Threads;
   const size_t lds = (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  const bool fold = g_h5_fold;
-  auto kern = fold ? msda_hm5_kernel<3, true> : msda_hm5_kernel<3, false>;
-  if (!(fold ? ensure_dynamic_lds<msda_hm5_kernel<3, true>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, false>>(lds)))
+  const int fold = g_h5_fold;
+  auto kern = fold == 1 ? msda_hm5_kernel<3, 1> : fold == 2 ? msda_hm5_kernel<3, 2> : msda_hm5_kernel<3, 0>;
+  if (!(fold == 1 ? ensure_dynamic_lds<msda_hm5_kernel<3, 1>>(lds)
+                  : fold == 2 ? ensure_dynamic_lds<msda_hm5_kernel<3, 2>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, 0>>(lds)))
     return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -250,11 +250,16 @@ def test_planned_sampling_is_bit_identical_to_the_chunked_sampling(kind, nq):
         handle.bevops_msda_set_variant(3011)      # the rolled camera reduce (partner of the unrolled default)
         got = bev.spatial_cross_attention_projected(*args, plan=plan)
         assert torch.equal(got, want)
+        for fold in (3015, 3016, 3014):           # round-5 build with broadcast moves / folded + ds_read2 / folded (default)
+            handle.bevops_msda_set_variant(fold)
+            got = bev.spatial_cross_attention_projected(*args, plan=plan)
+            assert torch.equal(got, want), (kind, fold)
         assert torch.equal(bev.spatial_cross_attention_projected(*args), want)      # ... and on the chunked path
     finally:
         handle.bevops_msda_set_variant(3002)      # the defaults: two slices per CU, direct stores, unrolled reduce
         handle.bevops_msda_set_variant(3012)
         handle.bevops_msda_set_variant(3010)
+        handle.bevops_msda_set_variant(3014)
         handle.bevops_msda_set_variant(0)
 
 

@@ -57,18 +57,20 @@ def chunked():
     return S._sample_planes(handle, planes, geom, ref, off, w, bm, None)
 
 
-def planned(k, direct=True, unrolled=True):
+def planned(k, direct=True, unrolled=True, fold=3014):
     """k slices per CU; direct: single-camera pairs stored by the sampler into the output rows (3012) or every pair
     through the per-camera scratch (3013); unrolled: the camera reduce with its loop unrolled (3010) or rolled (3011)."""
     def fn():
         handle.bevops_msda_set_variant(3000 + k)
         handle.bevops_msda_set_variant(3012 if direct else 3013)
         handle.bevops_msda_set_variant(3010 if unrolled else 3011)
+        handle.bevops_msda_set_variant(fold)     # 3014: record broadcasts folded into their consumers (default); 3015: not; 3016: + ds_read2
         return S._sample_planes(handle, planes, geom, ref, off, w, bm, plan)
     return fn
 
 
 fns = {"chunked": chunked, **{f"planned_k{k}": planned(k) for k in ks},
+       "planned_k2_nofold": planned(2, fold=3015), "planned_k2_read2": planned(2, fold=3016),
        "planned_k2_scratch": planned(2, direct=False), "planned_k2_scratch_rolled": planned(2, False, False)}
 
 want = chunked()
@@ -93,5 +95,5 @@ print(json.dumps({"what": "fused SCA sampling call on prepacked planes (sampler 
                   "offsets_sigma_px": args.offsets, "visible_pairs": pairs, "visible_frac": round(pairs / (6 * nq), 4),
                   "us": med, "algorithmic_bytes": fused_bytes,
                   "frac_of_8TBs": {k: round(fused_bytes / v / 8e6, 4) for k, v in med.items()}}), flush=True)
-for v in (3002, 3012, 3010, 0):
+for v in (3002, 3012, 3010, 3014, 0):
     handle.bevops_msda_set_variant(v)
