@@ -3,6 +3,7 @@
 # Every step writes under gpurun_out/TAG/ (merged back by gpurun); the summaries worth judging are copied to
 # profiles/<round>/ afterwards (tools/collect_profiles.py).  Steps (each bounded by its own timeout):
 #   tests[:EXPR]   GPU suite (pytest -m gpu [-k EXPR]) -> pytest_gpu_tail.log
+#   testsv:EXPR    the same with -s (the tests' printed error figures) -> pytest_gpu_verbose.log
 #   smoke          __graft_entry__.smoke()              -> smoke.log
 #   bench[:ARGS]   python bench.py ARGS (default --steps 20 --warmup 5) -> bench_n1.json (+ bench.err)
 #   trace[:int8]   kernel trace of one base frame (tools/model_profile.sh) -> model_frame[_int8]_kernel_trace.txt
@@ -20,6 +21,7 @@ for step in "$@"; do
   cd $GRAFT_REPO_ROOT
   case $name in
     tests) ( timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider ${arg:+-k "$arg"} 2>&1 | tail -40 ) > $OUT/pytest_gpu_tail.log; tail -8 $OUT/pytest_gpu_tail.log ;;
+    testsv) ( timeout 1700 python -m pytest tests -m gpu -q -s -p no:cacheprovider -k "$arg" 2>&1 | grep -vE "^\s*$" | tail -200 ) > $OUT/pytest_gpu_verbose.log; grep -E "passed|failed|err|agreement|max " $OUT/pytest_gpu_verbose.log | tail -30 ;;
     smoke) ( timeout 200 python __graft_entry__.py smoke 2>&1 | tail -4 ) > $OUT/smoke.log; tail -2 $OUT/smoke.log ;;
     bench) ( timeout 1500 python bench.py ${arg:---steps 20 --warmup 5} 2>$OUT/bench.err | tail -1 ) > $OUT/bench_n1.json; cut -c1-700 $OUT/bench_n1.json; tail -3 $OUT/bench.err ;;
     trace) if [ "$arg" = int8 ]; then bash tools/model_profile.sh $TAG/model_int8 base --int8 > $OUT/model_frame_int8_kernel_trace.txt 2>&1; rm -rf $OUT/model_int8
