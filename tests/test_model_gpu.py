@@ -415,9 +415,10 @@ def test_fp16_product_frames_track_the_fp32_reference_formulation(name):
     evaluated module by module in fp32 with the reference's PyTorch formulations of the samplers (oracle/ref_ops.py:
     multi_scale_deformable_attn_pytorch, grid_sample rotate, DCNv2 in torch pinned to the C oracle; reference layout, no
     fusion, torch projection).  Dataflow: modules/transformer.py:245-398, modules/encoder.py:261-334.
-    Bars (measured values in the test's output; fp16 through ~110 layers with random weights -- the tiny config's
-    fp16-vs-fp32 distance, test_tiny_fp16_runs_and_tracks_fp32, is the yardstick): bev_embed mean |err| <= 4 % of its
-    standard deviation, class logits within 0.05 on average, boxes within 0.05, >= 93 % identical top-1 classes."""
+    Measured (profiles/r06/model_parity.txt): small 0.32 / 0.35 % of the bev_embed standard deviation, class logits
+    0.004, boxes 0.009, 97.7 / 96.7 % identical top-1 classes; base 0.57 / 0.65 %, 0.006, 0.011, 97.6 / 97.8 % (random
+    weights: many near-ties between the ten class logits).  Bars, ~3 x the measured distance: bev_embed mean |err| <= 2 %
+    of its standard deviation, class logits within 0.02 on average, boxes within 0.03, >= 95 % identical top-1 classes."""
     import bevformer_tensorrt_amd.functions as hip_ops
     from bevformer_tensorrt_amd import bevformer as B, geometry as G
     from oracle.ref_ops import TorchRefOps
@@ -445,7 +446,7 @@ def test_fp16_product_frames_track_the_fp32_reference_formulation(name):
         rel, cls_mae, box_mae, top1 = _frame_metrics(g_, w_)
         print(f"{name} frame {k}: bev_embed rel err {rel:.4f}, class-logit MAE {cls_mae:.4f}, box MAE {box_mae:.4f}, "
               f"top-1 agreement {top1:.4f}")
-        assert rel <= 0.04 and cls_mae <= 0.05 and box_mae <= 0.05 and top1 >= 0.93
+        assert rel <= 0.02 and cls_mae <= 0.02 and box_mae <= 0.03 and top1 >= 0.95
 
 
 def test_graph_replay_follows_the_calibration_of_every_frame():
@@ -460,7 +461,7 @@ def test_graph_replay_follows_the_calibration_of_every_frame():
     H, W = B.CONFIGS["base"]["image"]
     a = G.synthetic_lidar2img((H, W))
     a2 = a.clone(); a2[:, :, :3, 3] += 0.05                 # frame-to-frame ego-motion jitter
-    b = a.clone(); b[:, :, 0, 3] += 3.0                     # another rig: other visible sets
+    b = a.clone(); b[:, :, :2, :] *= 0.8                    # another rig (shorter focal lengths): other visible sets
     was = Ln.DETERMINISTIC["enabled"]
     Ln.DETERMINISTIC["enabled"] = True
     try:
@@ -481,8 +482,9 @@ def test_graph_replay_follows_the_calibration_of_every_frame():
         assert (be - bg).abs().max().item() <= 4e-2 * scale and (be - bg).abs().mean().item() <= 4e-3 * scale
     d_true = (eager[2][0] - graph[2][0]).abs().mean().item()
     d_stale = (eager[2][0] - stale[2][0]).abs().mean().item()
-    # the replay really used frame 3's matrices (measured: the graph equals the eager frame bit for bit under the
-    # reproducible dispatch, d_true = 0; the frame on the stale calibration is 8e-4 away on average)
+    # the replay really used frame 3's matrices (measured with a 3-unit principal-point shift as the other rig: the
+    # graph equals the eager frame bit for bit under the reproducible dispatch, d_true = 0, the frame on the stale
+    # calibration 8e-4 away on average with 0.6 % of the BEV rows off by more than 1e-2)
     assert d_true <= 1e-5 and d_stale > 2e-4, (d_true, d_stale)
     changed = ((eager[2][0] - stale[2][0]).abs().amax(-1) > 1e-2).float().mean().item()
     assert changed > 0.01, changed             # ... and whole BEV rows differ, not rounding noise
