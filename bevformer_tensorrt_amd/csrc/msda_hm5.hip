@@ -275,8 +275,15 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     b = 0;
     bh = h;
   }
-  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes);
-  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + chunk * 2);
+  // FOLD == 3: the LAST staged level sits in LDS as 128-byte pixel-PAIR entries (the big levels' format, built while
+  // the plane is staged), so its samples run on v_dot2c like the big levels': l3_off = bytes of the levels in front of
+  // it (64-byte pixels, incl. the set's leading entry), then one pair entry per padded pixel + one in front (the pixel
+  // "before" row 0: the previous level's trailing pad with row 0's first pad)
+  const int l3_off = FOLD == 3 ? t.ent0[3] * kLdsPixBytes : 0;
+  const int l3_pairs = FOLD == 3 ? (t.H[3] + 2) * (t.W[3] + 1) + 1 : 0;
+  const int stage_lds = FOLD == 3 ? l3_off + l3_pairs * kEntBytes : stage_bytes;     // LDS bytes of the staged image
+  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_lds);
+  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_lds + chunk * 2);
   auto visible = [&](unsigned q) -> bool {
     if constexpr (LISTED == 3) return true;
     else if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
@@ -287,7 +294,24 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     if (stage_bytes) {
       const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
       uint4 *dst = reinterpret_cast<uint4 *>(smem);
-      for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
+      if constexpr (FOLD == 3) {
+        for (int i = threadIdx.x; i < l3_off / 16; i += THREADS) dst[i] = src[i];
+        // pair p = (pixel ent0[3] - 1 + p, the pixel after it); a thread makes 16 bytes = 4 channels of one pair
+        const char *sb = reinterpret_cast<const char *>(src) + l3_off - kLdsPixBytes;
+        for (int i = threadIdx.x; i < l3_pairs * 8; i += THREADS) {
+          const int pr = i >> 3, k = i & 7;
+          const uint2 a = *reinterpret_cast<const uint2 *>(sb + pr * kLdsPixBytes + k * 8);
+          const uint2 n = *reinterpret_cast<const uint2 *>(sb + (pr + 1) * kLdsPixBytes + k * 8);
+          uint4 o;
+          o.x = (a.x & 0xffffu) | (n.x << 16);
+          o.y = (a.x >> 16) | (n.x & 0xffff0000u);
+          o.z = (a.y & 0xffffu) | (n.y << 16);
+          o.w = (a.y >> 16) | (n.y & 0xffff0000u);
+          *reinterpret_cast<uint4 *>(smem + l3_off + pr * kEntBytes + k * 16) = o;
+        }
+      } else {
+        for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
+      }
     }
   };
   unsigned q0 = 0, n_items = 0;
@@ -341,8 +365,19 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
   unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
   const unsigned out_q = (unsigned)d.heads * 64u;
   const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
-  const unsigned qlist_a = sbase + (unsigned)stage_bytes;
-  H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
+  const unsigned qlist_a = sbase + (unsigned)stage_lds;
+  auto lane_consts = [&](unsigned bh_) -> H5Lane {
+    H5Lane k = h5_lane_consts(t, lane8, bh_, sbase);
+    if constexpr (FOLD == 3) {
+      if ((lane8 >> 1) == 3u) {   // the lanes of the last staged level: pair entries behind l3_off (entry 0 = padded (0, 0))
+        k.sh = 7;
+        k.base = sbase + (unsigned)l3_off + (unsigned)kEntBytes;
+        k.row = (unsigned)(t.W[3] + 1) << 7;
+      }
+    }
+    return k;
+  };
+  H5Lane c = lane_consts(bh);
 
   const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
   const unsigned lg_q = (unsigned)d.heads * 64u;
@@ -464,7 +499,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
           const unsigned aA = quad_bcast<SA>(rhi.z) + lane8b, aB = quad_bcast<SB>(rhi.z) + lane8b;
           unsigned aAr = aA + (unsigned)kLdsPixBytes, aA1 = aA + row, aA1r = aA + row + (unsigned)kLdsPixBytes;
           unsigned aBr = aB + (unsigned)kLdsPixBytes, aB1 = aB + row, aB1r = aB + row + (unsigned)kLdsPixBytes;
-          if constexpr (FOLD != 2) {   // (FOLD == 2, A/B: let them fuse -- half the LDS rate, two address adds less per slot)
+          if constexpr (FOLD == 1) {   // (FOLD >= 2: let them fuse -- half the LDS rate, two address adds less per slot)
             asm("" : "+v"(aAr));    // laundered: keeps the two ds_read_b64 of a row from fusing into one ds_read2_b64
             asm("" : "+v"(aA1r));
             asm("" : "+v"(aBr));
@@ -491,7 +526,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
         // sixteen dots of two big slots: weights as the DPP source (lane SA / SB of the quad), hazards padded by hand
         // (a VALU write needs 2 states before a DPP read of it; a DOT result 3 states before another VALU reads it --
         // invisible to the compiler inside an asm statement)
-#define H5_DOTS(SA, SB, K0, K1)                                                                                         \
+#define H5_DOTS(WX, WY, SA, SB, A0, A1, B0, B1)                                                                         \
         asm("s_nop 1\n\t"                                                                                               \
             "v_dot2c_f32_f16_dpp %0, %4, %6 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
             "v_dot2c_f32_f16_dpp %1, %4, %7 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
@@ -511,9 +546,8 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
             "v_dot2c_f32_f16_dpp %3, %5, %21 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
             "s_nop 2"                                                                                                   \
             : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                    \
-            : "v"(rlo.x), "v"(rlo.y), "v"(r0[K0].x), "v"(r0[K0].y), "v"(r0[K0].z), "v"(r0[K0].w), "v"(r1[K0].x),        \
-              "v"(r1[K0].y), "v"(r1[K0].z), "v"(r1[K0].w), "v"(r0[K1].x), "v"(r0[K1].y), "v"(r0[K1].z), "v"(r0[K1].w),  \
-              "v"(r1[K1].x), "v"(r1[K1].y), "v"(r1[K1].z), "v"(r1[K1].w))
+            : "v"(WX), "v"(WY), "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), \
+              "v"(B0.x), "v"(B0.y), "v"(B0.z), "v"(B0.w), "v"(B1.x), "v"(B1.y), "v"(B1.z), "v"(B1.w))
         lds_pair(IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (J < 3) {
@@ -526,14 +560,29 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
         __builtin_amdgcn_sched_barrier(0);
         lds_math2();
         __builtin_amdgcn_sched_barrier(0);
-        lds_pair(IC<1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        H5_DOTS(0, 1, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_math2();
-        __builtin_amdgcn_sched_barrier(0);
-        H5_DOTS(2, 3, 2, 3);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FOLD == 3) {
+          // last staged level on pair entries: two 16-byte rows per slot, sixteen dots with DPP-source weights (rhi)
+          const unsigned row_p = ((unsigned)t.W[3] + 1u) << 7;
+          const unsigned aA = quad_bcast<2>(rhi.z) + lane16, aB = quad_bcast<3>(rhi.z) + lane16;
+          const u32x4 pA0 = *(const lds_u4 *)(size_t)aA, pA1 = *(const lds_u4 *)(size_t)(aA + row_p);
+          const u32x4 pB0 = *(const lds_u4 *)(size_t)aB, pB1 = *(const lds_u4 *)(size_t)(aB + row_p);
+          __builtin_amdgcn_sched_barrier(0);
+          H5_DOTS(rlo.x, rlo.y, 0, 1, r0[0], r1[0], r0[1], r1[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          H5_DOTS(rhi.x, rhi.y, 2, 3, pA0, pA1, pB0, pB1);
+          __builtin_amdgcn_sched_barrier(0);
+          H5_DOTS(rlo.x, rlo.y, 2, 3, r0[2], r1[2], r0[3], r1[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          lds_pair(IC<1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          H5_DOTS(rlo.x, rlo.y, 0, 1, r0[0], r1[0], r0[1], r1[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          lds_math2();
+          __builtin_amdgcn_sched_barrier(0);
+          H5_DOTS(rlo.x, rlo.y, 2, 3, r0[2], r1[2], r0[3], r1[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #undef H5_DOTS
         return;
       }
@@ -691,7 +740,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const int *counts = reinterpret_cast<const int *>(vis);
     const unsigned nq_pad = (unsigned)h5_plan_pad_dev(d.nq);
     const unsigned *lists = reinterpret_cast<const unsigned *>(vis + kPlanCams * 4);
-    unsigned *wl32 = reinterpret_cast<unsigned *>(smem + stage_bytes);
+    unsigned *wl32 = reinterpret_cast<unsigned *>(smem + stage_lds);
     const unsigned keep = direct ? ~0u : 0xffffu;   // without an output to store into, no pair is "sole"
     const unsigned nb = gridDim.x / (unsigned)d.heads, j = blockIdx.x / (unsigned)d.heads;
     unsigned total = 0;
@@ -709,7 +758,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       if (lo >= hi) continue;
       b = (unsigned)cam;
       bh = b * (unsigned)d.heads + h;
-      c = h5_lane_consts(t, lane8, bh, sbase);
+      c = lane_consts(bh);
       out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
       rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
       const unsigned *src = lists + (size_t)cam * nq_pad + first;
@@ -840,19 +889,26 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
   constexpr int THREADS = kH5Threads;
-  const size_t lds = (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
+  int fold = g_h5_fold;
+  // fold 3: the last level's LDS image doubles (pair entries); the slice's list is then held 1 024 entries at a time
+  const size_t lds3 = (size_t)pl.t.ent0[3] * kLdsPixBytes + ((size_t)(pl.t.H[3] + 2) * (pl.t.W[3] + 1) + 1) * kEntBytes +
+                      h5_plan_lds_extra(kH5PlanChunk / 2);
+  if (fold == 3 && lds3 > (size_t)kLdsLimit) fold = 2;
+  const int chunk = fold == 3 ? kH5PlanChunk / 2 : kH5PlanChunk;
+  const size_t lds = fold == 3 ? lds3 : (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  const int fold = g_h5_fold;
-  auto kern = fold == 1 ? msda_hm5_kernel<3, 1> : fold == 2 ? msda_hm5_kernel<3, 2> : msda_hm5_kernel<3, 0>;
+  auto kern = fold == 1 ? msda_hm5_kernel<3, 1> : fold == 2 ? msda_hm5_kernel<3, 2> : fold == 3 ? msda_hm5_kernel<3, 3>
+                                                                                                 : msda_hm5_kernel<3, 0>;
   if (!(fold == 1 ? ensure_dynamic_lds<msda_hm5_kernel<3, 1>>(lds)
-                  : fold == 2 ? ensure_dynamic_lds<msda_hm5_kernel<3, 2>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, 0>>(lds)))
+        : fold == 2 ? ensure_dynamic_lds<msda_hm5_kernel<3, 2>>(lds)
+        : fold == 3 ? ensure_dynamic_lds<msda_hm5_kernel<3, 3>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, 0>>(lds)))
     return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)
   const unsigned per_head = (unsigned)((cus > 0 ? cus : 256) * g_h5_plan_k + heads - 1) / (unsigned)heads;
   hipLaunchKernelGGL(kern, dim3(per_head * (unsigned)heads), dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes,
-                     gset + g_room, ref, off, logit, sampled, d, pl.t, kH5PlanChunk, 1, pl.stage_bytes,
+                     gset + g_room, ref, off, logit, sampled, d, pl.t, chunk, 1, pl.stage_bytes,
                      static_cast<const unsigned char *>(plan), direct);
   return launch_status();
 }
