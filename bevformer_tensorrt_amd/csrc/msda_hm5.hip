@@ -847,7 +847,7 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 // so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
 static thread_local int g_h5_plan_k = 2;
 void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
-static thread_local int g_h5_fold = 1;      // the FOLD build of the planned kernel (default) / its A/B partners (0, 2)
+static thread_local int g_h5_fold = 3;      // the build of the planned kernel: 3 = default (FOLD 3), A/B partners 0, 1, 2
 void msda_hm5_set_fold(int mode) { g_h5_fold = mode; }
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
