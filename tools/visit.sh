@@ -10,6 +10,7 @@
 #   prof           rocprofv3 --kernel-trace --stats of the hot-path bench command -> prof/
 #   pmc            FETCH_SIZE / WRITE_SIZE passes of the same command (separate runs) -> pmc_fetch/, pmc_write/
 #   sca            the in-frame SCA sampling call: kernel stats + FETCH / WRITE passes -> sca_plan_*.{txt,json}
+#   scapmc[:NAMES] SQ / LDS / TCP counters + kernel stats of flavours of tools/sca_frame_time.py -> sca_pmc.txt
 #   framepmc       SQ / TCP / TCC counters of every kernel of the frame (tools/frame_pmc.sh)
 #   py:SCRIPT ARGS python tools/SCRIPT ARGS (quote the step) -> SCRIPT.jsonl
 TAG=${1:?tag}; shift
@@ -37,6 +38,13 @@ for step in "$@"; do
          cd $GRAFT_REPO_ROOT
          python tools/pmc_fetch_write.py "gpurun_out/$TAG (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tools/sca_frame_time.py --once 6 --ks 2 --only planned_k2; per-kernel means; KiB as the counters report them, FETCH not yet doubled)" $OUT/sca_fetch $OUT/sca_write msda_hm5 sca_camera_reduce_kernel > $OUT/sca_plan_pmc_fetch_write.json
          ( grep -hE "msda_hm5|sca_camera_reduce|tsgemm" $(find $OUT/sca_prof -name "*kernel_stats.csv") | cut -c1-260 ) > $OUT/sca_plan_kernel_stats.txt; cat $OUT/sca_plan_kernel_stats.txt ;;
+    scapmc) cd /tmp; P="python $GRAFT_REPO_ROOT/tools/sca_frame_time.py --once 6 --ks 2 --only ${arg:-planned_k2}"
+         ( timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/scapmc1 -o p -- $P 2>&1 | tail -2 ) > $OUT/scapmc1.log
+         ( timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $OUT/scapmc2 -o p -- $P 2>&1 | tail -2 ) > $OUT/scapmc2.log
+         ( timeout 200 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/scapmc3 -o p -- $P 2>&1 | tail -2 ) > $OUT/scapmc3.log
+         ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scapmc0 -o p -- $P 2>&1 | tail -2 ) > $OUT/scapmc0.log
+         cd $GRAFT_REPO_ROOT; python tools/pmc_table.py msda_hm5_kernel $OUT/scapmc1 $OUT/scapmc2 $OUT/scapmc3 > $OUT/sca_pmc.txt 2>&1
+         ( grep -hE "msda_hm5|sca_camera_reduce" $(find $OUT/scapmc0 -name "*kernel_stats.csv") | cut -c1-200 ) >> $OUT/sca_pmc.txt; cat $OUT/sca_pmc.txt ;;
     framepmc) KINDS=${arg:-fp16} bash tools/frame_pmc.sh $TAG ;;
     py) set -- $arg; s=$1; shift; ( timeout 900 python tools/$s "$@" 2>>$OUT/py.err ) > $OUT/$(basename $s .py).jsonl; tail -20 $OUT/$(basename $s .py).jsonl | cut -c1-400; tail -3 $OUT/py.err ;;
     *) echo "unknown step $step" ;;
