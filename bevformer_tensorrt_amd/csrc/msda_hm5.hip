@@ -526,28 +526,24 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
         // sixteen dots of two big slots: weights as the DPP source (lane SA / SB of the quad), hazards padded by hand
         // (a VALU write needs 2 states before a DPP read of it; a DOT result 3 states before another VALU reads it --
         // invisible to the compiler inside an asm statement)
-#define H5_DOTS(WX, WY, SA, SB, A0, A1, B0, B1)                                                                         \
-        asm("s_nop 1\n\t"                                                                                               \
-            "v_dot2c_f32_f16_dpp %0, %4, %6 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
-            "v_dot2c_f32_f16_dpp %1, %4, %7 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
-            "v_dot2c_f32_f16_dpp %2, %4, %8 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
-            "v_dot2c_f32_f16_dpp %3, %4, %9 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"   \
-            "v_dot2c_f32_f16_dpp %0, %5, %10 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %1, %5, %11 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %2, %5, %12 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %3, %5, %13 quad_perm:[" #SA "," #SA "," #SA "," #SA "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %0, %4, %14 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %1, %4, %15 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %2, %4, %16 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %3, %4, %17 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %0, %5, %18 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %1, %5, %19 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %2, %5, %20 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "v_dot2c_f32_f16_dpp %3, %5, %21 quad_perm:[" #SB "," #SB "," #SB "," #SB "] row_mask:0xf bank_mask:0xf\n\t"  \
-            "s_nop 2"                                                                                                   \
-            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                    \
-            : "v"(WX), "v"(WY), "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), \
-              "v"(B0.x), "v"(B0.y), "v"(B0.z), "v"(B0.w), "v"(B1.x), "v"(B1.y), "v"(B1.z), "v"(B1.w))
+// one slot = 8 dots (one asm statement per slot: the compiler then waits for THAT slot's two loads only).  The DPP
+// source registers (rlo / rhi) are written by spread() at the head of the phase, far more than the 2 wait states a DPP
+// read needs; TAIL = "\n\ts_nop 2" on the last slot of a run (the next VALU that reads an accumulator may follow within
+// the 3 states a DOT result needs; between dots of one opcode chained through the accumulator there is no hazard)
+#define H5_DOT8(WX, WY, S, A0, A1, TAIL)                                                                              \
+        asm("v_dot2c_f32_f16_dpp %0, %4, %6 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"     \
+            "v_dot2c_f32_f16_dpp %1, %4, %7 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"     \
+            "v_dot2c_f32_f16_dpp %2, %4, %8 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"     \
+            "v_dot2c_f32_f16_dpp %3, %4, %9 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"     \
+            "v_dot2c_f32_f16_dpp %0, %5, %10 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"    \
+            "v_dot2c_f32_f16_dpp %1, %5, %11 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"    \
+            "v_dot2c_f32_f16_dpp %2, %5, %12 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf\n\t"    \
+            "v_dot2c_f32_f16_dpp %3, %5, %13 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf" TAIL   \
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                  \
+            : "v"(WX), "v"(WY), "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w))
+#define H5_DOTS(WX, WY, SA, SB, A0, A1, B0, B1) \
+        H5_DOT8(WX, WY, SA, A0, A1, "");         \
+        H5_DOT8(WX, WY, SB, B0, B1, "\n\ts_nop 2")
         lds_pair(IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (J < 3) {
@@ -584,6 +580,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
           __builtin_amdgcn_sched_barrier(0);
         }
 #undef H5_DOTS
+#undef H5_DOT8
         return;
       }
       // big levels: records, then all 2 * NB loads
