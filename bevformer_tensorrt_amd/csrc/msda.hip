@@ -620,9 +620,8 @@ extern "C" int bevops_msda_set_variant(int variant) {
     g_sca_direct = variant == 3012;
     return prev;
   }
-  if (variant >= 3014 && variant <= 3017) {   // A/B: planned SCA sampler with the record broadcasts folded into their
-    // consumers (3014) / not: the round-5 build (3015) / folded + ds_read2 (3016) / + last level as pair entries (3017)
-    msda_hm5_set_fold(variant == 3014 ? 1 : variant == 3015 ? 0 : variant == 3016 ? 2 : 3);
+  if (variant == 3014 || variant == 3015) {   // A/B: planned SCA sampler with the record broadcasts folded into their
+    msda_hm5_set_fold(variant == 3014);       // consumers + fused LDS row taps (3014, default) / the round-5 build (3015)
     return prev;
   }
   g_variant_raw = variant;

@@ -256,7 +256,7 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
                                     size_t plan_bytes, __half *sampled, __half *direct, int bs, int nk, int heads, int C,
                                     int L, int nq, int P, int ppg, hipStream_t st);
 void msda_hm5_set_plan_blocks(int k);
-void msda_hm5_set_fold(int mode);
+void msda_hm5_set_fold(bool on);
 void msda_sca_set_reduce_rolled(bool on);   // A/B partner of the unrolled camera reduce (set_variant 3010 / 3011)
 // skip_sole: rows of queries that exactly one camera sees with weight 1 are left alone (the planned sampler has
 // stored them already, msda_hm5.hip: kSoleBit)

@@ -245,8 +245,12 @@ constexpr int kH5Threads = 1024;   // one block per CU (the staged planes fill t
 // (v_dot2c is VOP2: it takes a quad_perm source; hand-placed asm blocks, the compiler does not combine a broadcast
 // with eight uses), a slot's entry address is ONE v_add_u32 with a DPP source (the compiler's own combine: the
 // broadcast has a single use) and its second row one more add -- instead of 3 broadcast moves + 3 address adds per
-// sample and register copies of all eight records: same arithmetic in the same order, the same bits.
-template <int LISTED, int FOLD = 0>
+// sample and register copies of all eight records: same arithmetic in the same order, the same bits.  The two 8-byte
+// LDS taps of a staged row are also left to fuse into one ds_read2_b64 (two address adds less per slot; the LDS pipe has
+// the room on the rig geometry).  724 -> 660 VALU instructions per wave and item, 96-97 -> 92 us per call
+// (profiles/r06/sca_fold_ab*.jsonl, sca_fold_pmc.txt).  Built, measured and removed in the same round: the last staged
+// level as pair entries in LDS so that its samples run on v_dot2c too (612 instructions, 93.5-94 us: slower).
+template <int LISTED, bool FOLD = false>
 __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const char *__restrict__ gset, unsigned g_bytes, const char *__restrict__ sset,
     const __half *__restrict__ ref, const __half *__restrict__ off, const __half *__restrict__ logit,
@@ -275,15 +279,8 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     b = 0;
     bh = h;
   }
-  // FOLD == 3: the LAST staged level sits in LDS as 128-byte pixel-PAIR entries (the big levels' format, built while
-  // the plane is staged), so its samples run on v_dot2c like the big levels': l3_off = bytes of the levels in front of
-  // it (64-byte pixels, incl. the set's leading entry), then one pair entry per padded pixel + one in front (the pixel
-  // "before" row 0: the previous level's trailing pad with row 0's first pad)
-  const int l3_off = FOLD == 3 ? t.ent0[3] * kLdsPixBytes : 0;
-  const int l3_pairs = FOLD == 3 ? (t.H[3] + 2) * (t.W[3] + 1) + 1 : 0;
-  const int stage_lds = FOLD == 3 ? l3_off + l3_pairs * kEntBytes : stage_bytes;     // LDS bytes of the staged image
-  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_lds);
-  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_lds + chunk * 2);
+  unsigned short *wl = reinterpret_cast<unsigned short *>(smem + stage_bytes);
+  unsigned *wtot = reinterpret_cast<unsigned *>(smem + stage_bytes + chunk * 2);
   auto visible = [&](unsigned q) -> bool {
     if constexpr (LISTED == 3) return true;
     else if constexpr (LISTED == 2) return (reinterpret_cast<const unsigned short *>(vis)[(size_t)b * d.nq + q] & 0x7fffu) != 0;   // not +-0
@@ -294,24 +291,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     if (stage_bytes) {
       const uint4 *src = reinterpret_cast<const uint4 *>(sset + (size_t)bh * stage_bytes);
       uint4 *dst = reinterpret_cast<uint4 *>(smem);
-      if constexpr (FOLD == 3) {
-        for (int i = threadIdx.x; i < l3_off / 16; i += THREADS) dst[i] = src[i];
-        // pair p = (pixel ent0[3] - 1 + p, the pixel after it); a thread makes 16 bytes = 4 channels of one pair
-        const char *sb = reinterpret_cast<const char *>(src) + l3_off - kLdsPixBytes;
-        for (int i = threadIdx.x; i < l3_pairs * 8; i += THREADS) {
-          const int pr = i >> 3, k = i & 7;
-          const uint2 a = *reinterpret_cast<const uint2 *>(sb + pr * kLdsPixBytes + k * 8);
-          const uint2 n = *reinterpret_cast<const uint2 *>(sb + (pr + 1) * kLdsPixBytes + k * 8);
-          uint4 o;
-          o.x = (a.x & 0xffffu) | (n.x << 16);
-          o.y = (a.x >> 16) | (n.x & 0xffff0000u);
-          o.z = (a.y & 0xffffu) | (n.y << 16);
-          o.w = (a.y >> 16) | (n.y & 0xffff0000u);
-          *reinterpret_cast<uint4 *>(smem + l3_off + pr * kEntBytes + k * 16) = o;
-        }
-      } else {
-        for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
-      }
+      for (int i = threadIdx.x; i < stage_bytes / 16; i += THREADS) dst[i] = src[i];
     }
   };
   unsigned q0 = 0, n_items = 0;
@@ -365,19 +345,8 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
   unsigned out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
   const unsigned out_q = (unsigned)d.heads * 64u;
   const unsigned sbase = (unsigned)(uintptr_t)(lds_c *)smem;
-  const unsigned qlist_a = sbase + (unsigned)stage_lds;
-  auto lane_consts = [&](unsigned bh_) -> H5Lane {
-    H5Lane k = h5_lane_consts(t, lane8, bh_, sbase);
-    if constexpr (FOLD == 3) {
-      if ((lane8 >> 1) == 3u) {   // the lanes of the last staged level: pair entries behind l3_off (entry 0 = padded (0, 0))
-        k.sh = 7;
-        k.base = sbase + (unsigned)l3_off + (unsigned)kEntBytes;
-        k.row = (unsigned)(t.W[3] + 1) << 7;
-      }
-    }
-    return k;
-  };
-  H5Lane c = lane_consts(bh);
+  const unsigned qlist_a = sbase + (unsigned)stage_bytes;
+  H5Lane c = h5_lane_consts(t, lane8, bh, sbase);
 
   const unsigned lg_base = (((d.shared ? 0u : b) * (unsigned)d.nq * (unsigned)d.heads + h) * 32u + lane8 * 4u) * 2u;
   const unsigned lg_q = (unsigned)d.heads * 64u;
@@ -499,12 +468,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
           const unsigned aA = quad_bcast<SA>(rhi.z) + lane8b, aB = quad_bcast<SB>(rhi.z) + lane8b;
           unsigned aAr = aA + (unsigned)kLdsPixBytes, aA1 = aA + row, aA1r = aA + row + (unsigned)kLdsPixBytes;
           unsigned aBr = aB + (unsigned)kLdsPixBytes, aB1 = aB + row, aB1r = aB + row + (unsigned)kLdsPixBytes;
-          if constexpr (FOLD == 1) {   // (FOLD >= 2: let them fuse -- half the LDS rate, two address adds less per slot)
-            asm("" : "+v"(aAr));    // laundered: keeps the two ds_read_b64 of a row from fusing into one ds_read2_b64
-            asm("" : "+v"(aA1r));
-            asm("" : "+v"(aBr));
-            asm("" : "+v"(aB1r));
-          }
+          // (not laundered: the two ds_read_b64 of a row fuse into one ds_read2_b64 -- see the kernel's header)
           l0[0] = *(const lds_u2 *)(size_t)aA;   q0r[0] = *(const lds_u2 *)(size_t)aAr;
           l1[0] = *(const lds_u2 *)(size_t)aA1;  q1r[0] = *(const lds_u2 *)(size_t)aA1r;
           l0[1] = *(const lds_u2 *)(size_t)aB;   q0r[1] = *(const lds_u2 *)(size_t)aBr;
@@ -556,29 +520,14 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
         __builtin_amdgcn_sched_barrier(0);
         lds_math2();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FOLD == 3) {
-          // last staged level on pair entries: two 16-byte rows per slot, sixteen dots with DPP-source weights (rhi)
-          const unsigned row_p = ((unsigned)t.W[3] + 1u) << 7;
-          const unsigned aA = quad_bcast<2>(rhi.z) + lane16, aB = quad_bcast<3>(rhi.z) + lane16;
-          const u32x4 pA0 = *(const lds_u4 *)(size_t)aA, pA1 = *(const lds_u4 *)(size_t)(aA + row_p);
-          const u32x4 pB0 = *(const lds_u4 *)(size_t)aB, pB1 = *(const lds_u4 *)(size_t)(aB + row_p);
-          __builtin_amdgcn_sched_barrier(0);
-          H5_DOTS(rlo.x, rlo.y, 0, 1, r0[0], r1[0], r0[1], r1[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          H5_DOTS(rhi.x, rhi.y, 2, 3, pA0, pA1, pB0, pB1);
-          __builtin_amdgcn_sched_barrier(0);
-          H5_DOTS(rlo.x, rlo.y, 2, 3, r0[2], r1[2], r0[3], r1[3]);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          lds_pair(IC<1>{});
-          __builtin_amdgcn_sched_barrier(0);
-          H5_DOTS(rlo.x, rlo.y, 0, 1, r0[0], r1[0], r0[1], r1[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          lds_math2();
-          __builtin_amdgcn_sched_barrier(0);
-          H5_DOTS(rlo.x, rlo.y, 2, 3, r0[2], r1[2], r0[3], r1[3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        lds_pair(IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        H5_DOTS(rlo.x, rlo.y, 0, 1, r0[0], r1[0], r0[1], r1[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_math2();
+        __builtin_amdgcn_sched_barrier(0);
+        H5_DOTS(rlo.x, rlo.y, 2, 3, r0[2], r1[2], r0[3], r1[3]);
+        __builtin_amdgcn_sched_barrier(0);
 #undef H5_DOTS
 #undef H5_DOT8
         return;
@@ -737,7 +686,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
     const int *counts = reinterpret_cast<const int *>(vis);
     const unsigned nq_pad = (unsigned)h5_plan_pad_dev(d.nq);
     const unsigned *lists = reinterpret_cast<const unsigned *>(vis + kPlanCams * 4);
-    unsigned *wl32 = reinterpret_cast<unsigned *>(smem + stage_lds);
+    unsigned *wl32 = reinterpret_cast<unsigned *>(smem + stage_bytes);
     const unsigned keep = direct ? ~0u : 0xffffu;   // without an output to store into, no pair is "sole"
     const unsigned nb = gridDim.x / (unsigned)d.heads, j = blockIdx.x / (unsigned)d.heads;
     unsigned total = 0;
@@ -755,7 +704,7 @@ __global__ __launch_bounds__(kH5Threads, 1) void msda_hm5_kernel(
       if (lo >= hi) continue;
       b = (unsigned)cam;
       bh = b * (unsigned)d.heads + h;
-      c = lane_consts(bh);
+      c = h5_lane_consts(t, lane8, bh, sbase);
       out_base = (b * (unsigned)d.nq * (unsigned)d.heads + h) * 64u + lane8b;
       rf_base = b * (unsigned)d.nq * 16u + (lane8 & 3u) * 4u;
       const unsigned *src = lists + (size_t)cam * nq_pad + first;
@@ -844,8 +793,8 @@ int msda_hm5_sca_sample_f16(const void *packed, size_t packed_bytes, const int32
 // so that the per-item requests hit the L2 was built and measured SLOWER, 117 us, and removed)
 static thread_local int g_h5_plan_k = 2;
 void msda_hm5_set_plan_blocks(int k) { g_h5_plan_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
-static thread_local int g_h5_fold = 3;      // the build of the planned kernel: 3 = default (FOLD 3), A/B partners 0, 1, 2
-void msda_hm5_set_fold(int mode) { g_h5_fold = mode; }
+static thread_local bool g_h5_fold = true;      // the FOLD build of the planned kernel (default) / the round-5 build
+void msda_hm5_set_fold(bool on) { g_h5_fold = on; }
 
 size_t msda_hm5_plan_bytes(int bs, int nq) {
   if (bs <= 0 || bs > kPlanCams || nq <= 0 || nq > 65535) return 0;
@@ -886,26 +835,18 @@ int msda_hm5_sca_sample_planned_f16(const void *packed, size_t packed_bytes, con
   const char *gset = static_cast<const char *>(packed);
   const MsdaDims d{bs, nk, heads, C, L, nq, P, ppg, 1};
   constexpr int THREADS = kH5Threads;
-  int fold = g_h5_fold;
-  // fold 3: the last level's LDS image doubles (pair entries); the slice's list is then held 1 024 entries at a time
-  const size_t lds3 = (size_t)pl.t.ent0[3] * kLdsPixBytes + ((size_t)(pl.t.H[3] + 2) * (pl.t.W[3] + 1) + 1) * kEntBytes +
-                      h5_plan_lds_extra(kH5PlanChunk / 2);
-  if (fold == 3 && lds3 > (size_t)kLdsLimit) fold = 2;
-  const int chunk = fold == 3 ? kH5PlanChunk / 2 : kH5PlanChunk;
-  const size_t lds = fold == 3 ? lds3 : (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
+  const size_t lds = (size_t)pl.stage_bytes + h5_plan_lds_extra(kH5PlanChunk);
   if (lds > (size_t)kLdsLimit) return BEVOPS_NOT_SUPPORTED;
-  auto kern = fold == 1 ? msda_hm5_kernel<3, 1> : fold == 2 ? msda_hm5_kernel<3, 2> : fold == 3 ? msda_hm5_kernel<3, 3>
-                                                                                                 : msda_hm5_kernel<3, 0>;
-  if (!(fold == 1 ? ensure_dynamic_lds<msda_hm5_kernel<3, 1>>(lds)
-        : fold == 2 ? ensure_dynamic_lds<msda_hm5_kernel<3, 2>>(lds)
-        : fold == 3 ? ensure_dynamic_lds<msda_hm5_kernel<3, 3>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, 0>>(lds)))
+  const bool fold = g_h5_fold;
+  auto kern = fold ? msda_hm5_kernel<3, true> : msda_hm5_kernel<3, false>;
+  if (!(fold ? ensure_dynamic_lds<msda_hm5_kernel<3, true>>(lds) : ensure_dynamic_lds<msda_hm5_kernel<3, false>>(lds)))
     return (int)BEVOPS_FAILURE;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // slices per head: the CUs an XCD's share of the grid lands on (block i runs on XCD i % 8, head = i % heads)
   const unsigned per_head = (unsigned)((cus > 0 ? cus : 256) * g_h5_plan_k + heads - 1) / (unsigned)heads;
   hipLaunchKernelGGL(kern, dim3(per_head * (unsigned)heads), dim3(THREADS), lds, st, gset, (unsigned)pl.g_bytes,
-                     gset + g_room, ref, off, logit, sampled, d, pl.t, chunk, 1, pl.stage_bytes,
+                     gset + g_room, ref, off, logit, sampled, d, pl.t, kH5PlanChunk, 1, pl.stage_bytes,
                      static_cast<const unsigned char *>(plan), direct);
   return launch_status();
 }

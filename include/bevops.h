@@ -143,7 +143,7 @@ int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_
  *    3012 / 3013  planned fused SCA sampling stores the pairs only one camera sees straight into the output and the
  *                 reduce skips those rows (default) / every pair through the per-camera scratch (sticky)
  *    3014 / 3015  planned fused SCA sampling with the DPP broadcasts of the sample records folded into the instructions
- *                 that consume them (default, round 6) / the round-5 build with broadcast moves (sticky)
+ *                 that consume them and the LDS row taps fused (default, round 6) / the round-5 build (sticky); same bits
  * (The measured-and-rejected builds of rounds 1-4 -- LDS-staged hm, two-copy hm, hm4 chunk sizes / schedule ablations,
  * int8 pixel-pair entries, hm5 with 768 threads / mailbox / persistent blocks / level-class split -- are no longer in
  * the library; their measurements are under profiles/.)  A packed value (bevops_msda_pack_value) must be sampled under

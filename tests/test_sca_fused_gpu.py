@@ -6,7 +6,6 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-DEFAULT_FOLD = 3017      # bevops_msda_set_variant value of the planned sampler's default build (csrc/msda_hm5.hip: g_h5_fold)
 
 SHAPES = {
     # (num_cams, levels, nq, P, ppg)
@@ -251,22 +250,16 @@ def test_planned_sampling_is_bit_identical_to_the_chunked_sampling(kind, nq):
         handle.bevops_msda_set_variant(3011)      # the rolled camera reduce (partner of the unrolled default)
         got = bev.spatial_cross_attention_projected(*args, plan=plan)
         assert torch.equal(got, want)
-        for fold in (3015, 3016, 3014):           # round-5 build with broadcast moves / folded + ds_read2 / folded
+        for fold in (3015, 3014):                 # the round-5 build with broadcast moves / the folded default
             handle.bevops_msda_set_variant(fold)
             got = bev.spatial_cross_attention_projected(*args, plan=plan)
             assert torch.equal(got, want), (kind, fold)
-        # ... and with the last staged level on pair entries (its products accumulate in fp32 on v_dot2c instead of a
-        # packed-binary16 blend: not the same bits, closer to the oracle -- the direct-oracle test below runs on it)
-        handle.bevops_msda_set_variant(3017)
-        got = bev.spatial_cross_attention_projected(*args, plan=plan)
-        assert (got.float() - want.float()).abs().max().item() <= 4e-3 * max(1.0, want.float().abs().max().item()), kind
-        assert torch.equal(got == 0, want == 0) or kind == "weights"      # untouched rows stay exact zeros
         assert torch.equal(bev.spatial_cross_attention_projected(*args), want)      # ... and on the chunked path
     finally:
         handle.bevops_msda_set_variant(3002)      # the defaults: two slices per CU, direct stores, unrolled reduce
         handle.bevops_msda_set_variant(3012)
         handle.bevops_msda_set_variant(3010)
-        handle.bevops_msda_set_variant(DEFAULT_FOLD)
+        handle.bevops_msda_set_variant(3014)
         handle.bevops_msda_set_variant(0)
 
 
