@@ -867,15 +867,26 @@ class BEVFormer(nn.Module):
             shift = G.bev_shift(can_bus.float(), bev_h, bev_w, grid_length)
         shift = shift.to(dtype)
         rot_hwc = getattr(self.ops, "rotate_hwc", None)
-        if rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0:
-            # prev_bev [nq, 1, C] already is [H, W, C]: rotate in place of the permute / copy / permute
+        stack = None     # TSA's keys [prev_bev | query] (encoder.py:586-588), assembled without a concatenation
+        if rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0 and _R3["enabled"] \
+                and prev_bev.dtype == dtype and prev_bev.shape[-1] == EMBED:
+            # prev_bev [nq, 1, C] already is [H, W, C]: rotated straight into row 0 of the stack; the can_bus-shifted
+            # queries are added straight into row 1 (round 6: the torch.cat of the two moved 41 MB per frame)
+            stack = torch.empty((2, nq, EMBED), dtype=dtype, device=dev)
+            rot_hwc(prev_bev.view(bev_h, bev_w, -1), can_bus[-1].float().reshape(1), self.rotate_center.float(),
+                    out=stack[0].view(bev_h, bev_w, EMBED))
+            prev_bev = stack[0].view(nq, 1, EMBED)
+            bev_queries = torch.add(bev_queries, self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1),
+                                    out=stack[1].view(nq, 1, EMBED))
+        elif rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0:
             prev_bev = rot_hwc(prev_bev.view(bev_h, bev_w, -1), can_bus[-1].float().reshape(1),
                                self.rotate_center.float()).view(nq, 1, -1)
         else:
             prev_bev = self.ops.rotate(prev_bev.view(bev_h, bev_w, -1).permute(2, 0, 1),
                                        can_bus[-1].float().reshape(1), self.rotate_center.float())
             prev_bev = prev_bev.permute(1, 2, 0).reshape(nq, 1, -1)
-        bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
+        if stack is None:
+            bev_queries = bev_queries + self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1)
         feats, level_hw = [], []
         cam_embed = self.cams_embeds if cams is None else _take_cams(self.cams_embeds, cams)
         embed_fn = getattr(self.ops, "feat_embed_nhwc", None)
@@ -914,7 +925,7 @@ class BEVFormer(nn.Module):
         hybrid = G.hybrid_ref_2d(ref_2d, shift.float(), use_prev_bev).to(dtype)
         q = bev_queries.view(1, nq, EMBED)
         pos = bev_pos.view(1, nq, EMBED)
-        prev = torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
+        prev = stack if stack is not None else torch.cat([prev_bev.view(1, nq, EMBED), q], dim=0)
         rows = None
         if getattr(gather, "mode", None) == "scatter":       # the encoder beyond the cameras sharded by query range
             lo, hi, _ = gather.query_range(nq)

@@ -814,7 +814,31 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // tp.rotate: the upper half of the waves runs the same loop rotated by half an iteration (its barrier sits
   // between the blend and the MFMAs, MFMA(0) is peeled): between two barriers one half issues its loads while
   // the other half reads fragments and feeds the matrix cores (see dcn_glds_s8_kernel)
-  const bool late = tp.rotate && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  const bool late = tp.rotate == 1 && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  // tp.rotate == 2 (round 6): OPPOSED halves.  Every wave of the block issues 6 vector-memory instructions per step
+  // (2 weight DMA pieces, 4 corner gathers): 96 wave-instructions of 1 KB through a 64 B/clk L1 path = 1 536 cycles in
+  // which, with all 16 waves in the same order, nobody is in its matrix segment (and the round-2 rotation above keeps
+  // "loads, then MFMAs" in both halves).  Here the upper half runs  DMA -> MFMA(step) -> blend(step + 1) -> gathers
+  // while the lower half runs  blend -> DMA -> gathers -> MFMA(step): between two barriers one half occupies the L1
+  // path while the other occupies the matrix cores and the LDS read path, then they swap.  Same barrier per step, same
+  // buffers (a step consumes buffer step & 1 and produces the other), same arithmetic and summation order.
+  const bool opp = tp.rotate == 2 && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  if (opp) {
+    for (int step = 0; step < n_my_steps; ++step) {
+      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+      if (more1) weights_next((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(step & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) blend_store((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) gather_next();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   if (late) {
     if (n_my_steps > 1) weights_next(1);
     mfma_step(0);
@@ -837,6 +861,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       __builtin_amdgcn_s_barrier();
     }
   }
+  }   // (!opp)
   if (is_tail) {  // fp32 partials, thread-private order (the finish kernel uses the same mapping)
     float4 *pp = reinterpret_cast<float4 *>(tp.partial) +
                  ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * kTh + tid;
@@ -891,7 +916,7 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half 
 
 
 thread_local bool g_mdconv_old_copy = false;   // variant 12: the r01 NCHW -> NHWC copy kernel (A/B)
-thread_local bool g_mdconv_rotate = false;   // variant 7: fp16 LDS-DMA kernel with the wave halves in opposite phase order
+thread_local int g_mdconv_rotate = 0;   // variant 7: fp16 LDS-DMA kernel with the wave halves rotated by half an iteration; 8: opposed halves
 
 template <int WN>
 int glds_resident_blocks() {
@@ -922,7 +947,7 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
   const int slots = glds_resident_blocks<WN>();
   if (slots <= 0) return BEVOPS_FAILURE;
   // tail plan: leftover tiles of a sparsely filled last round are split along K
-  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0, om_channels, g_mdconv_rotate ? 1 : 0};
+  TailPlan tp{0, 1, (int)grid.x, nullptr, nhwc_io ? 1 : 0, relu ? 1 : 0, om_channels, g_mdconv_rotate};
   const int blocks = (int)(grid.x * grid.y);
   if (allow_tail && blocks > slots && grid.y == 1) {
     const int left = blocks % slots;
@@ -1062,9 +1087,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7;
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : 0);
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 12) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12) ? 0 : variant;
   return prev;
 }
 

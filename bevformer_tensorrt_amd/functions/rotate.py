@@ -64,10 +64,11 @@ def rotate_int8(img, angle, center, scale_in, scale_out, interpolation="nearest"
     return _rotate(img, angle, center, interpolation, (scale_in, scale_out))
 
 
-def rotate_hwc(img, angle, center, interpolation="nearest"):
+def rotate_hwc(img, angle, center, interpolation="nearest", out=None):
     """`rotate` on channels-last data: img [H, W, C] -> [H, W, C] (fp32 / fp16).  Element for element
     the same result as rotate(img.permute(2, 0, 1), ...).permute(1, 2, 0), without the two layout
-    copies (not a reference plugin: the layout prev_bev already has between frames)."""
+    copies (not a reference plugin: the layout prev_bev already has between frames).  `out`: optional contiguous
+    destination of the same shape and dtype (the model rotates prev_bev straight into its [prev_bev | query] stack)."""
     assert img.is_cuda and img.ndim == 3
     if interpolation not in _MODE:
         raise KeyError(interpolation)
@@ -79,7 +80,11 @@ def rotate_hwc(img, angle, center, interpolation="nearest"):
         center = center.to(angle.dtype)
     if img.dtype == torch.float32 and angle.dtype != torch.float32:
         angle, center = angle.float(), center.float()
-    out = torch.empty_like(img)
+    if out is None:
+        out = torch.empty_like(img)
+    elif out.shape != img.shape or out.dtype != img.dtype or not out.is_contiguous() or out.device != img.device \
+            or out.data_ptr() == img.data_ptr():
+        raise ValueError("rotate_hwc: `out` must be another contiguous tensor of the input's shape, dtype and device")
     H, W, C = img.shape
     with torch.cuda.device(img.device):
         st = handle.bevops_rotate_forward_hwc(
