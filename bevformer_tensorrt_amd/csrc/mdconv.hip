@@ -631,7 +631,9 @@ __device__ __forceinline__ void dcn_store4(__half *__restrict__ out, const __hal
   }
 }
 
-template <int WN>
+// SCHED: the order of a step's segments per wave half (0: one order, optionally rotated by tp.rotate == 1; 2: opposed
+// halves; 3: 2 + raised priority in the matrix segment)
+template <int WN, int SCHED = 0>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
     const __half *__restrict__ mask, const __half *__restrict__ wt,
@@ -814,7 +816,8 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // tp.rotate: the upper half of the waves runs the same loop rotated by half an iteration (its barrier sits
   // between the blend and the MFMAs, MFMA(0) is peeled): between two barriers one half issues its loads while
   // the other half reads fragments and feeds the matrix cores (see dcn_glds_s8_kernel)
-  const bool late = tp.rotate == 1 && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  const bool upper = __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  const bool late = SCHED < 2 && tp.rotate == 1 && upper;
   // tp.rotate == 2 (round 6): OPPOSED halves.  Every wave of the block issues 6 vector-memory instructions per step
   // (2 weight DMA pieces, 4 corner gathers): 96 wave-instructions of 1 KB through a 64 B/clk L1 path = 1 536 cycles in
   // which, with all 16 waves in the same order, nobody is in its matrix segment (and the round-2 rotation above keeps
@@ -822,17 +825,25 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // while the lower half runs  blend -> DMA -> gathers -> MFMA(step): between two barriers one half occupies the L1
   // path while the other occupies the matrix cores and the LDS read path, then they swap.  Same barrier per step, same
   // buffers (a step consumes buffer step & 1 and produces the other), same arithmetic and summation order.
-  const bool opp = tp.rotate == 2 && __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
-  if (opp) {
+  if constexpr (SCHED >= 2) {
+    // ONE loop body, the segments a half does not run at a position skipped by a wave-uniform branch (two copies of the
+    // loop, one per half, cost the 1 024-thread build ten spilled registers):
+    //   lower half: blend -> DMA -> gathers -> MFMA            upper half: DMA -> MFMA -> blend -> gathers
+    // SCHED 3 (A/B): the matrix segment at raised priority.
     for (int step = 0; step < n_my_steps; ++step) {
       const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+      if (!upper && more1) blend_store((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
       if (more1) weights_next((step + 1) & 1);
+      if (!upper && more2) gather_next();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(2);
       mfma_step(step & 1);
+      if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more1) blend_store((step + 1) & 1);
+      if (upper && more1) blend_store((step + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (more2) gather_next();
+      if (upper && more2) gather_next();
       __builtin_amdgcn_sched_barrier(0);
       if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -861,7 +872,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       __builtin_amdgcn_s_barrier();
     }
   }
-  }   // (!opp)
+  }   // (SCHED < 2)
   if (is_tail) {  // fp32 partials, thread-private order (the finish kernel uses the same mapping)
     float4 *pp = reinterpret_cast<float4 *>(tp.partial) +
                  ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * kTh + tid;
@@ -963,7 +974,24 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
     }
   }
   const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
-  hipLaunchKernelGGL(dcn_glds_f16_kernel<WN>, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
+  auto kern = dcn_glds_f16_kernel<WN, 0>;
+  switch (tp.rotate) {
+    case 2: kern = dcn_glds_f16_kernel<WN, 2>; break;
+    case 3: kern = dcn_glds_f16_kernel<WN, 3>; break;
+    default: break;
+  }
+  if (tp.rotate >= 2) {
+    static thread_local int lds_set[8][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds_set[tp.rotate & 7][WN == 4] != dev + 1) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              Glds<WN>::kLds) != hipSuccess)
+        return BEVOPS_FAILURE;
+      lds_set[tp.rotate & 7][WN == 4] = dev + 1;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
                      (const __half *)offset, (const __half *)mask, wt, (const __half *)bias, (__half *)output, d,
                      g, tp);
   if (tp.tail_tiles)
@@ -1087,9 +1115,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : 0);
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : 0));
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80) ? 0 : variant;
   return prev;
 }
 
