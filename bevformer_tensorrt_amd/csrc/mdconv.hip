@@ -639,6 +639,9 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     const __half *__restrict__ mask, const __half *__restrict__ wt,
     const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g, TailPlan tp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
+  // SCHED >= 16: TIMING builds (wrong results) of the one-order loop with segments removed, bit mask SCHED - 16:
+  // 1 no corner gathers, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no blend + pixel-row store
+  constexpr int ABL = SCHED >= 16 ? SCHED - 16 : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
@@ -760,7 +763,8 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     const int c0 = g_chunk * kFK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+      if constexpr (!(ABL & 1)) rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+      else asm volatile("" : "+v"(rb[q].x) : "v"(fidx[q] + c0));
       c_fw[q] = fw[q];
     }
     if (++g_chunk == chunks) { g_chunk = 0; g_tap = g_tap + 1 < KK ? g_tap + 1 : 0; }
@@ -770,12 +774,18 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     char *adst = smem + buf * kGA + wave * (kPc * 1024);
 #pragma unroll
     for (int j = 0; j < kPc; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
+      if constexpr (!(ABL & 2))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
     if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
   };
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned b_lds = (unsigned)(size_t)((lds_char *)smem) + (unsigned)(2 * kGA) + b_dst;
   auto blend_store = [&](int buf) {
+    if constexpr (ABL & 8) {
+      asm volatile("" ::"v"(rb[0].x), "v"(rb[0].w), "v"(rb[1].x), "v"(rb[1].w), "v"(rb[2].x), "v"(rb[2].w), "v"(rb[3].x),
+                   "v"(rb[3].w), "v"(c_fw[0]), "v"(c_fw[3]));
+      return;
+    }
     u32x4_t bl;
     bl.x = pk_mul(rb[0].x, c_fw[0]); bl.y = pk_mul(rb[0].y, c_fw[0]);
     bl.z = pk_mul(rb[0].z, c_fw[0]); bl.w = pk_mul(rb[0].w, c_fw[0]);
@@ -799,6 +809,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   __builtin_amdgcn_s_barrier();
 
   auto mfma_step = [&](int buf) {
+    if constexpr (ABL & 4) return;
     const char *Ab = smem + buf * kGA;
     const char *Bb = smem + 2 * kGA + buf * kGB;
 #pragma unroll
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // between the blend and the MFMAs, MFMA(0) is peeled): between two barriers one half issues its loads while
   // the other half reads fragments and feeds the matrix cores (see dcn_glds_s8_kernel)
   const bool upper = __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
-  const bool late = SCHED < 2 && tp.rotate == 1 && upper;
+  const bool late = SCHED == 0 && tp.rotate == 1 && upper;
   // tp.rotate == 2 (round 6): OPPOSED halves.  Every wave of the block issues 6 vector-memory instructions per step
   // (2 weight DMA pieces, 4 corner gathers): 96 wave-instructions of 1 KB through a 64 B/clk L1 path = 1 536 cycles in
   // which, with all 16 waves in the same order, nobody is in its matrix segment (and the round-2 rotation above keeps
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // while the lower half runs  blend -> DMA -> gathers -> MFMA(step): between two barriers one half occupies the L1
   // path while the other occupies the matrix cores and the LDS read path, then they swap.  Same barrier per step, same
   // buffers (a step consumes buffer step & 1 and produces the other), same arithmetic and summation order.
-  if constexpr (SCHED >= 2) {
+  if constexpr (SCHED == 2 || SCHED == 3) {
     // ONE loop body, the segments a half does not run at a position skipped by a wave-uniform branch (two copies of the
     // loop, one per half, cost the 1 024-thread build ten spilled registers):
     //   lower half: blend -> DMA -> gathers -> MFMA            upper half: DMA -> MFMA -> blend -> gathers
@@ -867,7 +878,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     __builtin_amdgcn_sched_barrier(0);
     if (late ? more1 : true) mfma_step(late ? ((step + 1) & 1) : (step & 1));
     if (!late) {
-      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (more2 && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -978,17 +989,24 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
   switch (tp.rotate) {
     case 2: kern = dcn_glds_f16_kernel<WN, 2>; break;
     case 3: kern = dcn_glds_f16_kernel<WN, 3>; break;
+    case 17: kern = dcn_glds_f16_kernel<WN, 17>; break;   // timing builds (see the kernel)
+    case 18: kern = dcn_glds_f16_kernel<WN, 18>; break;
+    case 19: kern = dcn_glds_f16_kernel<WN, 19>; break;
+    case 20: kern = dcn_glds_f16_kernel<WN, 20>; break;
+    case 24: kern = dcn_glds_f16_kernel<WN, 24>; break;
+    case 27: kern = dcn_glds_f16_kernel<WN, 27>; break;
+    case 31: kern = dcn_glds_f16_kernel<WN, 31>; break;
     default: break;
   }
   if (tp.rotate >= 2) {
-    static thread_local int lds_set[8][2] = {};
+    static thread_local int lds_set[32][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds_set[tp.rotate & 7][WN == 4] != dev + 1) {
+    if (lds_set[tp.rotate & 31][WN == 4] != dev + 1) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               Glds<WN>::kLds) != hipSuccess)
         return BEVOPS_FAILURE;
-      lds_set[tp.rotate & 7][WN == 4] = dev + 1;
+      lds_set[tp.rotate & 31][WN == 4] = dev + 1;
     }
   }
   hipLaunchKernelGGL(kern, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
@@ -1115,9 +1133,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : 0));
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant < 116 ? variant - 100 + 16 : 0)));
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant < 116)) ? 0 : variant;
   return prev;
 }
 

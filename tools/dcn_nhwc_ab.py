@@ -33,7 +33,7 @@ for (B, C, H, W) in ((6, 256, 58, 100), (6, 512, 29, 50), (1, 256, 58, 100)):
     same = {}
     for v in variants:
         lib.bevops_mdconv_set_variant(v)
-        same[v] = bool(torch.equal(call(), want))
+        same[v] = bool(torch.equal(call(), want)) if v < 100 else None      # (101 .. 115: timing builds)
     for _ in range(3):
         for v in variants:
             lib.bevops_mdconv_set_variant(v)
