@@ -16,6 +16,11 @@ from bevformer_tensorrt_amd.functions.linear import graph_time_us  # noqa: E402
 from bevformer_tensorrt_amd.utils import load_library  # noqa: E402
 
 lib = load_library()
+once = 0
+if "--once" in sys.argv:          # --once K: K plain launches per variant of the first shape (rocprofv3 runs)
+    i = sys.argv.index("--once")
+    once = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 variants = [int(a) for a in sys.argv[1:]] or [0, 7, 8]
 g = torch.Generator().manual_seed(0)
 for (B, C, H, W) in ((6, 256, 58, 100), (6, 512, 29, 50), (1, 256, 58, 100)):
@@ -27,6 +32,14 @@ for (B, C, H, W) in ((6, 256, 58, 100), (6, 512, 29, 50), (1, 256, 58, 100)):
     def call():
         return bev.modulated_deformable_conv2d_nhwc(x, None, None, wt, bs, 1, 1, 1, 1, 1, True, om)
 
+    if once:
+        for v in variants:
+            lib.bevops_mdconv_set_variant(v)
+            for _ in range(once):
+                call()
+        torch.cuda.synchronize()
+        lib.bevops_mdconv_set_variant(0)
+        break
     lib.bevops_mdconv_set_variant(0)
     want = call()
     res = {v: [] for v in variants}

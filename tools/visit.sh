@@ -11,6 +11,7 @@
 #   pmc            FETCH_SIZE / WRITE_SIZE passes of the same command (separate runs) -> pmc_fetch/, pmc_write/
 #   sca            the in-frame SCA sampling call: kernel stats + FETCH / WRITE passes -> sca_plan_*.{txt,json}
 #   scapmc[:NAMES] SQ / LDS / TCP counters + kernel stats of flavours of tools/sca_frame_time.py -> sca_pmc.txt
+#   kpmc:SUBSTR:SCRIPT ARGS   SQ / LDS / TCP counters + kernel stats of the kernels named *SUBSTR* in python tools/SCRIPT ARGS -> kernel_pmc.txt
 #   framepmc       SQ / TCP / TCC counters of every kernel of the frame (tools/frame_pmc.sh)
 #   py:SCRIPT ARGS python tools/SCRIPT ARGS (quote the step) -> SCRIPT.jsonl
 TAG=${1:?tag}; shift
@@ -45,6 +46,13 @@ for step in "$@"; do
          ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scapmc0 -o p -- $P 2>&1 | tail -2 ) > $OUT/scapmc0.log
          cd $GRAFT_REPO_ROOT; python tools/pmc_table.py msda_hm5_kernel $OUT/scapmc1 $OUT/scapmc2 $OUT/scapmc3 > $OUT/sca_pmc.txt 2>&1
          ( grep -hE "msda_hm5|sca_camera_reduce" $(find $OUT/scapmc0 -name "*kernel_stats.csv") | cut -c1-200 ) >> $OUT/sca_pmc.txt; cat $OUT/sca_pmc.txt ;;
+    kpmc) sub=${arg%%:*}; cmd=${arg#*:}; cd /tmp; P="python $GRAFT_REPO_ROOT/tools/$cmd"
+         ( timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/kpmc1 -o p -- $P 2>&1 | tail -2 ) > $OUT/kpmc1.log
+         ( timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA --output-format csv -d $OUT/kpmc2 -o p -- $P 2>&1 | tail -2 ) > $OUT/kpmc2.log
+         ( timeout 200 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d $OUT/kpmc3 -o p -- $P 2>&1 | tail -2 ) > $OUT/kpmc3.log
+         ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kpmc0 -o p -- $P 2>&1 | tail -2 ) > $OUT/kpmc0.log
+         cd $GRAFT_REPO_ROOT; python tools/pmc_table.py "$sub" $OUT/kpmc1 $OUT/kpmc2 $OUT/kpmc3 > $OUT/kernel_pmc.txt 2>&1
+         ( grep -hE "$sub" $(find $OUT/kpmc0 -name "*kernel_stats.csv") | cut -c1-60,300-420 ) >> $OUT/kernel_pmc.txt; cat $OUT/kernel_pmc.txt ;;
     framepmc) KINDS=${arg:-fp16} bash tools/frame_pmc.sh $TAG ;;
     py) set -- $arg; s=$1; shift; ( timeout 900 python tools/$s "$@" 2>>$OUT/py.err ) > $OUT/$(basename $s .py).jsonl; tail -20 $OUT/$(basename $s .py).jsonl | cut -c1-400; tail -3 $OUT/py.err ;;
     *) echo "unknown step $step" ;;
