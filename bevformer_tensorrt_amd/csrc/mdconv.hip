@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
   // SCHED >= 16: TIMING builds (wrong results) of the one-order loop with segments removed, bit mask SCHED - 16:
   // 1 no corner gathers, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no blend + pixel-row store
-  constexpr int ABL = SCHED >= 16 ? SCHED - 16 : 0;
+  constexpr int ABL = SCHED >= 16 && SCHED < 32 ? SCHED - 16 : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
@@ -860,6 +860,48 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+  } else if constexpr (SCHED == 32) {
+    // PHASE PROBE (timing build; the first 48 bytes of output pixel n0 + wave are overwritten with the wave's cycle
+    // totals): the one-order loop with an s_memtime stamp between its segments -- blend (incl. the wait for the
+    // gathers), load issue, fragment reads + MFMAs, the trailing s_waitcnt, the barrier
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t0;
+    for (int step = 0; step < n_my_steps; ++step) {
+      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+      if (more1) blend_store((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      ph[0] += t1 - t0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) weights_next((step + 1) & 1);
+      if (more2) gather_next();
+      __builtin_amdgcn_sched_barrier(0);
+      t0 = __builtin_amdgcn_s_memtime();
+      ph[1] += t0 - t1;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(step & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      t1 = __builtin_amdgcn_s_memtime();
+      ph[2] += t1 - t0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      t0 = __builtin_amdgcn_s_memtime();
+      ph[3] += t0 - t1;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      t1 = __builtin_amdgcn_s_memtime();
+      ph[4] += t1 - t0;
+      t0 = t1;
+    }
+    if (!is_tail && lane == 0 && n0 + wave < N) {
+      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + (size_t)(n0 + wave) * d.Cout);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int i = 0; i < 5; ++i) __builtin_nontemporal_store(ph[i], dbg + 8 + i);
+      __builtin_nontemporal_store(t0 - t_begin, dbg + 13);
+    }
+    return;
   } else {
   if (late) {
     if (n_my_steps > 1) weights_next(1);
@@ -996,17 +1038,18 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
     case 24: kern = dcn_glds_f16_kernel<WN, 24>; break;
     case 27: kern = dcn_glds_f16_kernel<WN, 27>; break;
     case 31: kern = dcn_glds_f16_kernel<WN, 31>; break;
+    case 32: kern = dcn_glds_f16_kernel<WN, 32>; break;   // phase probe
     default: break;
   }
   if (tp.rotate >= 2) {
-    static thread_local int lds_set[32][2] = {};
+    static thread_local int lds_set[64][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds_set[tp.rotate & 31][WN == 4] != dev + 1) {
+    if (lds_set[tp.rotate & 63][WN == 4] != dev + 1) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               Glds<WN>::kLds) != hipSuccess)
         return BEVOPS_FAILURE;
-      lds_set[tp.rotate & 31][WN == 4] = dev + 1;
+      lds_set[tp.rotate & 63][WN == 4] = dev + 1;
     }
   }
   hipLaunchKernelGGL(kern, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
@@ -1133,9 +1176,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant < 116 ? variant - 100 + 16 : 0)));
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant <= 116 ? variant - 100 + 16 : 0)));
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant < 116)) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant <= 116)) ? 0 : variant;
   return prev;
 }
 
