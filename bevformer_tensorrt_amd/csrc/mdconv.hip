@@ -860,6 +860,44 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+  } else if constexpr (SCHED == 33) {
+    // PHASE PROBE of the opposed-halves order (SCHED 2), seven segments
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t0;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      ph[i] += t1 - t0;
+      t0 = t1;
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int step = 0; step < n_my_steps; ++step) {
+      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+      if (!upper && more1) blend_store((step + 1) & 1);
+      stamp(0);
+      if (more1) weights_next((step + 1) & 1);
+      if (!upper && more2) gather_next();
+      stamp(1);
+      mfma_step(step & 1);
+      stamp(2);
+      if (upper && more1) blend_store((step + 1) & 1);
+      stamp(3);
+      if (upper && more2) gather_next();
+      stamp(4);
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      stamp(5);
+      __builtin_amdgcn_s_barrier();
+      stamp(6);
+    }
+    if (!is_tail && lane == 0 && n0 + wave < N) {
+      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + (size_t)(n0 + wave) * d.Cout);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int i = 0; i < 7; ++i) __builtin_nontemporal_store(ph[i], dbg + 8 + i);
+      __builtin_nontemporal_store(t0 - t_begin, dbg + 15);
+    }
+    return;
   } else if constexpr (SCHED == 32) {
     // PHASE PROBE (timing build; the first 48 bytes of output pixel n0 + wave are overwritten with the wave's cycle
     // totals): the one-order loop with an s_memtime stamp between its segments -- blend (incl. the wait for the
@@ -1038,7 +1076,8 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
     case 24: kern = dcn_glds_f16_kernel<WN, 24>; break;
     case 27: kern = dcn_glds_f16_kernel<WN, 27>; break;
     case 31: kern = dcn_glds_f16_kernel<WN, 31>; break;
-    case 32: kern = dcn_glds_f16_kernel<WN, 32>; break;   // phase probe
+    case 32: kern = dcn_glds_f16_kernel<WN, 32>; break;   // phase probes
+    case 33: kern = dcn_glds_f16_kernel<WN, 33>; break;
     default: break;
   }
   if (tp.rotate >= 2) {
@@ -1176,9 +1215,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant <= 116 ? variant - 100 + 16 : 0)));
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant <= 117 ? variant - 100 + 16 : 0)));
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant <= 116)) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant <= 117)) ? 0 : variant;
   return prev;
 }
 

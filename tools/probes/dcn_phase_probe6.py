@@ -19,21 +19,25 @@ x = torch.randn(B, C, H, W, generator=g).half().cuda().contiguous(memory_format=
 om = torch.randn(B, 32, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
 wt = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().cuda()
 bs = torch.randn(C, generator=g).half().cuda()
-lib.bevops_mdconv_set_variant(116)
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 116      # 116: one order for all waves; 117: opposed halves
+lib.bevops_mdconv_set_variant(variant)
 for _ in range(3):
     out = bev.modulated_deformable_conv2d_nhwc(x, None, None, wt, bs, 1, 1, 1, 1, 1, True, om)
 torch.cuda.synchronize()
 lib.bevops_mdconv_set_variant(0)
 rows = out.permute(0, 2, 3, 1).reshape(-1, C).contiguous().view(torch.int64).view(-1, C // 4)     # 64 int64 per pixel
 tiles = 256                      # main tiles of 128 pixels
-acc = torch.zeros(16, 6, dtype=torch.float64)
+ncol = 6 if variant == 116 else 8
+acc = torch.zeros(16, ncol, dtype=torch.float64)
 n = 0
 for t in range(0, tiles, 7):
-    blk = rows[t * 128:t * 128 + 16, 8:14].double().cpu()
-    if (blk[:, 5] > 0).all() and (blk[:, 5] < 1e7).all():
+    blk = rows[t * 128:t * 128 + 16, 8:8 + ncol].double().cpu()
+    if (blk[:, ncol - 1] > 0).all() and (blk[:, ncol - 1] < 1e7).all():
         acc += blk
         n += 1
 acc /= max(n, 1)
 names = ["blend (+ wait for gathers)", "load issue (DMA + footprint + gathers)", "fragment reads + MFMAs", "s_waitcnt", "barrier", "loop total"]
+if variant != 116:
+    names = ["lower: blend", "DMA issue (+ lower: gathers)", "fragment reads + MFMAs", "upper: blend", "upper: gathers", "s_waitcnt", "barrier", "loop total"]
 print(json.dumps({"tiles_sampled": n, "cycles_per_wave_mean_over_tiles": {nm: [round(float(v)) for v in acc[:, i]] for i, nm in enumerate(names)},
                   "mean_over_waves": {nm: round(float(acc[:, i].mean())) for i, nm in enumerate(names)}}), flush=True)
