@@ -677,10 +677,15 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   const unsigned ximg_off = (unsigned)(((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 8) * 2);
   const unsigned b_dst = (unsigned)(pp * 128 + ((cq ^ swz8(pp)) << 4));
   // weight DMA role: piece j of this wave = rows (wave*4 + j)*8 .. +8, lane -> (row, chunk)
-  unsigned a_off[kPc];
+  // SCHED 4: the LOWER half of the waves issues ALL the weight pieces (two waves' worth each), the upper half none --
+  // an upper wave then has no vector-memory instruction in front of its matrix segment (phase probe, round 6: with the
+  // 16 waves' loads arbitrated oldest first, even the two DMA pieces of an upper wave sat ~1 000 cycles behind the lower
+  // waves' gathers before its MFMAs could start)
+  constexpr int kPcS = SCHED == 4 ? 2 * kPc : kPc;
+  unsigned a_off[kPcS];
 #pragma unroll
-  for (int j = 0; j < kPc; ++j) {
-    const unsigned row = (unsigned)((wave * kPc + j) * 8 + (lane >> 3));
+  for (int j = 0; j < kPcS; ++j) {
+    const unsigned row = (unsigned)((wave * kPcS + j) * 8 + (lane >> 3));
     const unsigned chunk = (lane & 7u) ^ swz8(row);
     a_off[j] = (m0 + (int)row) < cout_g ? (unsigned)(((size_t)(m0 + row) * Kg) * 2 + chunk * 16) : 0xFFFFFFF0u;
   }
@@ -771,9 +776,9 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   };
   auto weights_next = [&](int buf) {
     const int a_s = (w_tap * cin_g + w_chunk * kFK) * 2;
-    char *adst = smem + buf * kGA + wave * (kPc * 1024);
+    char *adst = smem + buf * kGA + wave * (kPcS * 1024);
 #pragma unroll
-    for (int j = 0; j < kPc; ++j)
+    for (int j = 0; j < kPcS; ++j)
       if constexpr (!(ABL & 2))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
     if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   gather_next();
   blend_store(0);
   __builtin_amdgcn_sched_barrier(0);
-  weights_next(0);
+  if (SCHED != 4 || __builtin_amdgcn_readfirstlane(wave) < kTh / 128) weights_next(0);
   if (n_my_steps > 1) gather_next();
   if (n_my_steps > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // while the lower half runs  blend -> DMA -> gathers -> MFMA(step): between two barriers one half occupies the L1
   // path while the other occupies the matrix cores and the LDS read path, then they swap.  Same barrier per step, same
   // buffers (a step consumes buffer step & 1 and produces the other), same arithmetic and summation order.
-  if constexpr (SCHED == 2 || SCHED == 3) {
+  if constexpr (SCHED == 2 || SCHED == 3 || SCHED == 4) {
     // ONE loop body, the segments a half does not run at a position skipped by a wave-uniform branch (two copies of the
     // loop, one per half, cost the 1 024-thread build ten spilled registers):
     //   lower half: blend -> DMA -> gathers -> MFMA            upper half: DMA -> MFMA -> blend -> gathers
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
       if (!upper && more1) blend_store((step + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (more1) weights_next((step + 1) & 1);
+      if ((SCHED != 4 || !upper) && more1) weights_next((step + 1) & 1);
       if (!upper && more2) gather_next();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(2);
@@ -1069,6 +1074,7 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
   switch (tp.rotate) {
     case 2: kern = dcn_glds_f16_kernel<WN, 2>; break;
     case 3: kern = dcn_glds_f16_kernel<WN, 3>; break;
+    case 4: kern = dcn_glds_f16_kernel<WN, 4>; break;
     case 17: kern = dcn_glds_f16_kernel<WN, 17>; break;   // timing builds (see the kernel)
     case 18: kern = dcn_glds_f16_kernel<WN, 18>; break;
     case 19: kern = dcn_glds_f16_kernel<WN, 19>; break;
@@ -1215,9 +1221,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : (variant > 100 && variant <= 117 ? variant - 100 + 16 : 0)));
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : variant == 81 ? 4 : (variant > 100 && variant <= 117 ? variant - 100 + 16 : 0)));
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || (variant > 100 && variant <= 117)) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || variant == 80 || variant == 81 || (variant > 100 && variant <= 117)) ? 0 : variant;
   return prev;
 }
 
