@@ -631,17 +631,14 @@ __device__ __forceinline__ void dcn_store4(__half *__restrict__ out, const __hal
   }
 }
 
-// SCHED: the order of a step's segments per wave half (0: one order, optionally rotated by tp.rotate == 1; 2: opposed
-// halves; 3: 2 + raised priority in the matrix segment)
+// SCHED: 0 = every wave runs a step's segments in one order (rounds 2-5; tp.rotate == 1: upper half rotated by half an
+// iteration); 4 = round 6's default, see the loop
 template <int WN, int SCHED = 0>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel(
     const __half *__restrict__ xt, const __half *__restrict__ offset,
     const __half *__restrict__ mask, const __half *__restrict__ wt,
     const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g, TailPlan tp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
-  // SCHED >= 16: TIMING builds (wrong results) of the one-order loop with segments removed, bit mask SCHED - 16:
-  // 1 no corner gathers, 2 no weight DMA, 4 no fragment reads / MFMAs, 8 no blend + pixel-row store
-  constexpr int ABL = SCHED >= 16 && SCHED < 32 ? SCHED - 16 : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
@@ -681,7 +678,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // an upper wave then has no vector-memory instruction in front of its matrix segment (phase probe, round 6: with the
   // 16 waves' loads arbitrated oldest first, even the two DMA pieces of an upper wave sat ~1 000 cycles behind the lower
   // waves' gathers before its MFMAs could start)
-  constexpr int kPcS = (SCHED == 4 || SCHED == 6) ? 2 * kPc : kPc;
+  constexpr int kPcS = SCHED == 4 ? 2 * kPc : kPc;
   unsigned a_off[kPcS];
 #pragma unroll
   for (int j = 0; j < kPcS; ++j) {
@@ -762,43 +759,28 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   //   across the barrier (r01: gathers issued and consumed inside one step, their round trip exposed).
   int g_tap = tap_begin, g_chunk = 0, w_tap = tap_begin, w_chunk = 0;
   unsigned c_fw[4] = {0u, 0u, 0u, 0u};   // blend weights of the corners held in rb
-  // SCHED 5 / 6: a SECOND set of corner registers.  Phase probe (round 6): with one set a wave's gathers are issued
-  // right after the blend that frees the registers and are needed by the next step's blend, one iteration later --
-  // the last wave's gathers leave the 96-instruction load queue ~1 us after the step began, their L2 round trip then
-  // sits in front of its next blend, and its next loads cannot be issued before that blend: queue time + round trip
-  // per step, on every step.  With two sets a gather has two iterations to land.
-  uint4 rb2[4];
-  unsigned c_fw2[4] = {0u, 0u, 0u, 0u};
-  auto gather_into = [&](uint4 (&R)[4], unsigned (&CW)[4]) __attribute__((always_inline)) {
+  auto gather_next = [&]() {
     if (g_chunk == 0) footprint(g_tap);   // (also requests the offsets / mask of the tap after it: younger than the
                                           // step's weight DMA, older than the gathers -- retired by the same vmcnt(4))
     const int c0 = g_chunk * kFK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if constexpr (!(ABL & 1)) R[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
-      else asm volatile("" : "+v"(R[q].x) : "v"(fidx[q] + c0));
-      CW[q] = fw[q];
+      rb[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[q], c0 * 2, 0));
+      c_fw[q] = fw[q];
     }
     if (++g_chunk == chunks) { g_chunk = 0; g_tap = g_tap + 1 < KK ? g_tap + 1 : 0; }
   };
-  auto gather_next = [&]() __attribute__((always_inline)) { gather_into(rb, c_fw); };
   auto weights_next = [&](int buf) {
     const int a_s = (w_tap * cin_g + w_chunk * kFK) * 2;
     char *adst = smem + buf * kGA + wave * (kPcS * 1024);
 #pragma unroll
     for (int j = 0; j < kPcS; ++j)
-      if constexpr (!(ABL & 2))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
     if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
   };
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned b_lds = (unsigned)(size_t)((lds_char *)smem) + (unsigned)(2 * kGA) + b_dst;
-  auto blend_from = [&](const uint4 (&rb)[4], const unsigned (&c_fw)[4], int buf) __attribute__((always_inline)) {
-    if constexpr (ABL & 8) {
-      asm volatile("" ::"v"(rb[0].x), "v"(rb[0].w), "v"(rb[1].x), "v"(rb[1].w), "v"(rb[2].x), "v"(rb[2].w), "v"(rb[3].x),
-                   "v"(rb[3].w), "v"(c_fw[0]), "v"(c_fw[3]));
-      return;
-    }
+  auto blend_store = [&](int buf) {
     u32x4_t bl;
     bl.x = pk_mul(rb[0].x, c_fw[0]); bl.y = pk_mul(rb[0].y, c_fw[0]);
     bl.z = pk_mul(rb[0].z, c_fw[0]); bl.w = pk_mul(rb[0].w, c_fw[0]);
@@ -810,25 +792,19 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     // hand-written store (see dcn_glds_s8_kernel): a compiler-visible LDS store would drain vmcnt to 0
     asm volatile("ds_write_b128 %0, %1" ::"v"(b_lds + (unsigned)(buf * kGB)), "v"(bl) : "memory");
   };
-  auto blend_store = [&](int buf) __attribute__((always_inline)) { blend_from(rb, c_fw, buf); };
-  constexpr bool kTwoSets = SCHED == 5 || SCHED == 6;
-  constexpr bool kLowerDma = SCHED == 4 || SCHED == 6;
+  constexpr bool kLowerDma = SCHED == 4;
 
-  // prologue: step 0 -> buffer 0, corners of step 1 (two sets: and of step 2) in flight
+  // prologue: step 0 -> buffer 0, corners of step 1 in flight
   gather_next();
   blend_store(0);
   __builtin_amdgcn_sched_barrier(0);
   if (!kLowerDma || __builtin_amdgcn_readfirstlane(wave) < kTh / 128) weights_next(0);
   if (n_my_steps > 1) gather_next();
-  if (kTwoSets && n_my_steps > 2) {
-    gather_into(rb2, c_fw2);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  } else if (n_my_steps > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  if (n_my_steps > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   auto mfma_step = [&](int buf) {
-    if constexpr (ABL & 4) return;
     const char *Ab = smem + buf * kGA;
     const char *Bb = smem + 2 * kGA + buf * kGB;
 #pragma unroll
@@ -855,47 +831,29 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
   // while the lower half runs  blend -> DMA -> gathers -> MFMA(step): between two barriers one half occupies the L1
   // path while the other occupies the matrix cores and the LDS read path, then they swap.  Same barrier per step, same
   // buffers (a step consumes buffer step & 1 and produces the other), same arithmetic and summation order.
-  if constexpr (kTwoSets) {
-    // corners of step g live in rb (g odd) / rb2 (g even, g >= 2); iteration s blends step s + 1 out of one set and
-    // refills that set with the gathers of step s + 3.  SCHED 6: with the roles of SCHED 4 on top (the lower half issues
-    // all the weight pieces, the upper half runs its matrix segment first).
-    auto body = [&](int step, uint4 (&R)[4], unsigned (&CW)[4]) __attribute__((always_inline)) {
-      const bool more1 = step + 1 < n_my_steps, more3 = step + 3 < n_my_steps;
-      const bool first = !kLowerDma || !upper;       // this wave's blend / loads come before its matrix segment
-      if (first && more1) blend_from(R, CW, (step + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if ((!kLowerDma || !upper) && more1) weights_next((step + 1) & 1);
-      if (first && more3) gather_into(R, CW);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(step & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!first && more1) blend_from(R, CW, (step + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!first && more3) gather_into(R, CW);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    for (int step = 0; step < n_my_steps; step += 2) {
-      body(step, rb, c_fw);
-      if (step + 1 < n_my_steps) body(step + 1, rb2, c_fw2);
-    }
-  } else if constexpr (SCHED == 2 || SCHED == 3 || SCHED == 4) {
-    // ONE loop body, the segments a half does not run at a position skipped by a wave-uniform branch (two copies of the
-    // loop, one per half, cost the 1 024-thread build ten spilled registers):
-    //   lower half: blend -> DMA -> gathers -> MFMA            upper half: DMA -> MFMA -> blend -> gathers
-    // SCHED 3 (A/B): the matrix segment at raised priority.
+  if constexpr (SCHED == 4) {
+    // Round 6 (default).  The phase probe of the one-order loop (s_memtime stamps between the segments,
+    // profiles/r06/dcn_phase_probe.jsonl) showed where a step goes: its 96 vector-memory wave-instructions (32 weight
+    // DMA pieces, 64 corner gathers: 768 cache lines) leave the CU's L1 path at ~0.4 lines per clock, arbitrated oldest
+    // wave first -- waves 12-15 sit in their load-issue segment for 58 % of the loop (waves 0-3: 27 %, the rest of
+    // their time at the barrier), and nobody is in a matrix segment meanwhile.  Even the two DMA pieces of an upper
+    // wave queue ~1 000 cycles behind the lower waves' gathers.  Here the LOWER half of the waves issues all the
+    // weight pieces (kPcS = two waves' worth each) and the upper half none:
+    //   lower half: blend -> DMA (all pieces) -> gathers -> MFMA       upper half: MFMA -> blend -> gathers
+    // so an upper wave has no vector-memory instruction in front of its matrix segment.  One loop body, the segments a
+    // half does not run at a position skipped by a wave-uniform branch (two copies of the loop, one per half, cost the
+    // 1 024-thread build ten spilled registers).  Same barrier per step, same buffers, same arithmetic and summation
+    // order: bit-identical.  Measured with it (and removed): both halves issuing their own pieces in opposed order
+    // (+- 1 %), raised priority in the matrix segment (+- 1 %), a second set of corner registers so that a gather has
+    // two iterations to land (no gain): design/dcn.md.
     for (int step = 0; step < n_my_steps; ++step) {
       const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
       if (!upper && more1) blend_store((step + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if ((SCHED != 4 || !upper) && more1) weights_next((step + 1) & 1);
+      if (!upper && more1) weights_next((step + 1) & 1);
       if (!upper && more2) gather_next();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(2);
       mfma_step(step & 1);
-      if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (upper && more1) blend_store((step + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -905,86 +863,6 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-  } else if constexpr (SCHED == 33) {
-    // PHASE PROBE of the opposed-halves order (SCHED 2), seven segments
-    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_begin = t0;
-    auto stamp = [&](int i) __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      ph[i] += t1 - t0;
-      t0 = t1;
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int step = 0; step < n_my_steps; ++step) {
-      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
-      if (!upper && more1) blend_store((step + 1) & 1);
-      stamp(0);
-      if (more1) weights_next((step + 1) & 1);
-      if (!upper && more2) gather_next();
-      stamp(1);
-      mfma_step(step & 1);
-      stamp(2);
-      if (upper && more1) blend_store((step + 1) & 1);
-      stamp(3);
-      if (upper && more2) gather_next();
-      stamp(4);
-      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      stamp(5);
-      __builtin_amdgcn_s_barrier();
-      stamp(6);
-    }
-    if (!is_tail && lane == 0 && n0 + wave < N) {
-      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + (size_t)(n0 + wave) * d.Cout);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int i = 0; i < 7; ++i) __builtin_nontemporal_store(ph[i], dbg + 8 + i);
-      __builtin_nontemporal_store(t0 - t_begin, dbg + 15);
-    }
-    return;
-  } else if constexpr (SCHED == 32) {
-    // PHASE PROBE (timing build; the first 48 bytes of output pixel n0 + wave are overwritten with the wave's cycle
-    // totals): the one-order loop with an s_memtime stamp between its segments -- blend (incl. the wait for the
-    // gathers), load issue, fragment reads + MFMAs, the trailing s_waitcnt, the barrier
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-    unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_begin = t0;
-    for (int step = 0; step < n_my_steps; ++step) {
-      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
-      if (more1) blend_store((step + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      ph[0] += t1 - t0;
-      __builtin_amdgcn_sched_barrier(0);
-      if (more1) weights_next((step + 1) & 1);
-      if (more2) gather_next();
-      __builtin_amdgcn_sched_barrier(0);
-      t0 = __builtin_amdgcn_s_memtime();
-      ph[1] += t0 - t1;
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(step & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      t1 = __builtin_amdgcn_s_memtime();
-      ph[2] += t1 - t0;
-      __builtin_amdgcn_sched_barrier(0);
-      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      t0 = __builtin_amdgcn_s_memtime();
-      ph[3] += t0 - t1;
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      t1 = __builtin_amdgcn_s_memtime();
-      ph[4] += t1 - t0;
-      t0 = t1;
-    }
-    if (!is_tail && lane == 0 && n0 + wave < N) {
-      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out + (size_t)(n0 + wave) * d.Cout);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int i = 0; i < 5; ++i) __builtin_nontemporal_store(ph[i], dbg + 8 + i);
-      __builtin_nontemporal_store(t0 - t_begin, dbg + 13);
-    }
-    return;
   } else {
   if (late) {
     if (n_my_steps > 1) weights_next(1);
@@ -1003,7 +881,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
     __builtin_amdgcn_sched_barrier(0);
     if (late ? more1 : true) mfma_step(late ? ((step + 1) & 1) : (step & 1));
     if (!late) {
-      if (more2 && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -1063,7 +941,8 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half 
 
 
 thread_local bool g_mdconv_old_copy = false;   // variant 12: the r01 NCHW -> NHWC copy kernel (A/B)
-thread_local int g_mdconv_rotate = 0;   // variant 7: fp16 LDS-DMA kernel with the wave halves rotated by half an iteration; 8: opposed halves
+thread_local int g_mdconv_rotate = 0;   // fp16 LDS-DMA kernel: 0 = round 6's wave order; variant 7 -> 1: halves rotated by half an iteration
+                                        // (round 2); variant 13 -> 2: one order for all waves (rounds 2-5, the A/B partner)
 
 template <int WN>
 int glds_resident_blocks() {
@@ -1110,33 +989,17 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
     }
   }
   const dim3 grid2((unsigned)(tp.tail_tiles * tp.split + tp.main_tiles), grid.y);
-  auto kern = dcn_glds_f16_kernel<WN, 0>;
-  switch (tp.rotate) {
-    case 2: kern = dcn_glds_f16_kernel<WN, 2>; break;
-    case 3: kern = dcn_glds_f16_kernel<WN, 3>; break;
-    case 4: kern = dcn_glds_f16_kernel<WN, 4>; break;
-    case 5: kern = dcn_glds_f16_kernel<WN, 5>; break;
-    case 6: kern = dcn_glds_f16_kernel<WN, 6>; break;
-    case 17: kern = dcn_glds_f16_kernel<WN, 17>; break;   // timing builds (see the kernel)
-    case 18: kern = dcn_glds_f16_kernel<WN, 18>; break;
-    case 19: kern = dcn_glds_f16_kernel<WN, 19>; break;
-    case 20: kern = dcn_glds_f16_kernel<WN, 20>; break;
-    case 24: kern = dcn_glds_f16_kernel<WN, 24>; break;
-    case 27: kern = dcn_glds_f16_kernel<WN, 27>; break;
-    case 31: kern = dcn_glds_f16_kernel<WN, 31>; break;
-    case 32: kern = dcn_glds_f16_kernel<WN, 32>; break;   // phase probes
-    case 33: kern = dcn_glds_f16_kernel<WN, 33>; break;
-    default: break;
-  }
-  if (tp.rotate >= 2) {
-    static thread_local int lds_set[64][2] = {};
+  // tp.rotate: 0 = round 6's order (SCHED 4), 1 = the round-2 rotation, 2 = one order for all waves (rounds 2-5)
+  auto kern = tp.rotate == 0 ? dcn_glds_f16_kernel<WN, 4> : dcn_glds_f16_kernel<WN, 0>;
+  if (tp.rotate == 0) {
+    static thread_local int lds_set[2] = {0, 0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds_set[tp.rotate & 63][WN == 4] != dev + 1) {
+    if (lds_set[WN == 4] != dev + 1) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               Glds<WN>::kLds) != hipSuccess)
         return BEVOPS_FAILURE;
-      lds_set[tp.rotate & 63][WN == 4] = dev + 1;
+      lds_set[WN == 4] = dev + 1;
     }
   }
   hipLaunchKernelGGL(kern, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
@@ -1263,9 +1126,9 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   const int prev = g_mdconv_no_tail ? 4 : (g_mdconv_wide ? 5 : g_mdconv_variant);
   g_mdconv_no_tail = variant == 4;
   g_mdconv_wide = variant == 5;
-  g_mdconv_rotate = variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 80 ? 3 : variant == 81 ? 4 : variant == 82 ? 5 : variant == 83 ? 6 : (variant > 100 && variant <= 117 ? variant - 100 + 16 : 0)));
+  g_mdconv_rotate = variant == 7 ? 1 : (variant == 13 ? 2 : 0);
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 12 || (variant >= 80 && variant <= 83) || (variant > 100 && variant <= 117)) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 12 || variant == 13) ? 0 : variant;
   return prev;
 }
 

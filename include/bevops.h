@@ -263,7 +263,9 @@ int bevops_sca_forward(int dtype, const void *value, const int32_t *spatial_shap
 /* Tuning hook like bevops_msda_set_variant: 0 = automatic (fused implicit GEMM when the
  * channel counts allow), 1 = force the im2col + GEMM pipeline, 2 / 3 = the register-staged
  * fused kernels (256 / 512 threads), 4 = LDS-DMA kernel with 64-pixel tiles and no split-K
- * tail, 5 = LDS-DMA kernel with 128-pixel tiles; INT8: 6 = im2col + GEMM pair, 8 = register-staged
+ * tail, 5 = LDS-DMA kernel with 128-pixel tiles, 7 / 13 = LDS-DMA kernel with the round-2 wave rotation / with one
+ * segment order for all waves (rounds 2-5; the default since round 6 lets the lower half of a block's waves issue all
+ * the weight DMA and the upper half run its matrix segment first: same bits); INT8: 6 = im2col + GEMM pair, 8 = register-staged
  * fused kernel, 9 = LDS-DMA kernel whatever the tile count, 20 + mask = timing experiments (wrong
  * results).  Returns the previous value. */
 int bevops_mdconv_set_variant(int variant);

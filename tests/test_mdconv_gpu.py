@@ -133,6 +133,15 @@ def test_lds_dma_kernel_and_split_k_tail_match_register_staged_kernel(bev, shape
     assert (outs[5].float() - outs[2].float()).abs().max().item() <= 4e-3 * scale   # 1024-thread / 128-pixel tiles
     for _ in range(3):
         assert torch.equal(bev.modulated_deformable_conv2d(*args), outs[0])
+    # the wave orders of the LDS-DMA kernel (default since round 6: the lower half of a block's waves issues all the
+    # weight DMA, the upper half runs its matrix segment first; 13: one order for all waves; 7: the round-2 rotation)
+    # differ in WHEN a wave does what, never in what is summed in which order: the same bits
+    for v in (13, 7):
+        try:
+            lib.bevops_mdconv_set_variant(v)
+            assert torch.equal(bev.modulated_deformable_conv2d(*args), outs[0]), v
+        finally:
+            lib.bevops_mdconv_set_variant(0)
 
 
 def _q(x, s=None):
