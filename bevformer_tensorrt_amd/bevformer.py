@@ -876,7 +876,9 @@ class BEVFormer(nn.Module):
             rot_hwc(prev_bev.view(bev_h, bev_w, -1), can_bus[-1].float().reshape(1), self.rotate_center.float(),
                     out=stack[0].view(bev_h, bev_w, EMBED))
             prev_bev = stack[0].view(nq, 1, EMBED)
-            bev_queries = torch.add(bev_queries, self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1),
+            # (inference only: `out=` does not record a graph, the operands are detached to say so)
+            bev_queries = torch.add(bev_queries.detach(),
+                                    self.can_bus_mlp(can_bus.view(1, -1).to(dtype)).view(1, 1, -1).detach(),
                                     out=stack[1].view(nq, 1, EMBED))
         elif rot_hwc is not None and prev_bev.is_cuda and prev_bev.shape[-1] % 8 == 0:
             prev_bev = rot_hwc(prev_bev.view(bev_h, bev_w, -1), can_bus[-1].float().reshape(1),
