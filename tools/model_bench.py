@@ -64,6 +64,7 @@ if __name__ == "__main__":
     ap.add_argument("--int8", action="store_true", help="the INT8 (PTQ) build of the base model, as bench.py makes it")
     ap.add_argument("--conv-variant", type=int, default=0, help="bevops_conv3x3_c32_set_variant (A/B)")
     ap.add_argument("--mdconv-variant", type=int, default=0, help="bevops_mdconv_set_variant (A/B)")
+    ap.add_argument("--msda-variant", type=int, default=0, help="bevops_msda_set_variant before the frames are captured (A/B), e.g. 3015")
     ap.add_argument("--no-clone", action="store_true", help="hand out the graph's output buffers instead of copies")
     ap.add_argument("--static-image", action="store_true", help="images already in the frame's static input buffer")
     a = ap.parse_args()
@@ -71,6 +72,10 @@ if __name__ == "__main__":
         from bevformer_tensorrt_amd.utils import load_library
         load_library().bevops_conv3x3_c32_set_variant(a.conv_variant)
         load_library().bevops_mdconv_set_variant(a.mdconv_variant)
+    if a.msda_variant:
+        from bevformer_tensorrt_amd.utils import load_library
+        load_library().bevops_msda_set_variant(a.msda_variant)
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
     for m in a.models:
-        print(json.dumps(run(m, a.frames, dt, a.graph, a.int8, not a.no_clone, a.static_image)), flush=True)
+        print(json.dumps(dict(run(m, a.frames, dt, a.graph, a.int8, not a.no_clone, a.static_image),
+                              mdconv_variant=a.mdconv_variant, msda_variant=a.msda_variant)), flush=True)
