@@ -10,6 +10,7 @@ namespace bevops {
 extern thread_local int g_mdconv_variant;
 extern thread_local bool g_mdconv_no_tail;
 extern thread_local bool g_mdconv_wide;
+extern thread_local int g_mdconv_rotate;   // LDS-DMA kernels' wave order: 0 default (round 6), 1 round-2 rotation (fp16), 2 one order
 
 namespace {
 

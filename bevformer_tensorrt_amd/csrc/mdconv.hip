@@ -29,6 +29,8 @@ namespace bevops {
 thread_local int g_mdconv_variant = 0;
 thread_local bool g_mdconv_no_tail = false;
 thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles whatever the tile count
+thread_local int g_mdconv_rotate = 0;   // fp16 LDS-DMA kernel: 0 = round 6's wave order; variant 7 -> 1: halves rotated by half an iteration
+                                        // (round 2); variant 13 -> 2: one order for all waves (rounds 2-5, the A/B partner)
 namespace {
 
 // fp16, HW % 8 == 0 and C % 8 == 0: 64 channels x 64 pixels per block, 16-byte global accesses on
@@ -941,8 +943,6 @@ __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half 
 
 
 thread_local bool g_mdconv_old_copy = false;   // variant 12: the r01 NCHW -> NHWC copy kernel (A/B)
-thread_local int g_mdconv_rotate = 0;   // fp16 LDS-DMA kernel: 0 = round 6's wave order; variant 7 -> 1: halves rotated by half an iteration
-                                        // (round 2); variant 13 -> 2: one order for all waves (rounds 2-5, the A/B partner)
 
 template <int WN>
 int glds_resident_blocks() {

@@ -611,10 +611,13 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned b_lds = (unsigned)(size_t)((lds_char *)smem) + (unsigned)(2 * kGA) +
                          (unsigned)(pp * 128 + ((cq ^ swz8(pp)) << 4));   // LDS byte address of the thread's B chunk
-  unsigned a_off[kPc];
+  // ABL & 32 (round 6, the default order: see the loop): the lower half of the waves issues all the weight pieces
+  constexpr bool kLowerDma = (ABL & 32) != 0;
+  constexpr int kPcS = kLowerDma ? 2 * kPc : kPc;
+  unsigned a_off[kPcS];
 #pragma unroll
-  for (int j = 0; j < kPc; ++j) {
-    const unsigned row = (unsigned)((wave * kPc + j) * 8 + (lane >> 3));
+  for (int j = 0; j < kPcS; ++j) {
+    const unsigned row = (unsigned)((wave * kPcS + j) * 8 + (lane >> 3));
     const unsigned chunk = (lane & 7u) ^ swz8(row);
     a_off[j] = (m0 + (int)row) < cout_g ? (unsigned)((size_t)(m0 + row) * Kp + chunk * 16) : 0xFFFFFFF0u;
   }
@@ -726,10 +729,10 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   typedef __attribute__((address_space(3))) void lds_void;
   auto weights_next = [&](int buf) {
     const int a_s = w_tap * cin_g + w_chunk * kStepK;
-    char *adst = smem + buf * kGA + wave * (kPc * 1024);
+    char *adst = smem + buf * kGA + wave * (kPcS * 1024);
     if constexpr (!(ABL & 4)) {
 #pragma unroll
-      for (int j = 0; j < kPc; ++j)
+      for (int j = 0; j < kPcS; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
     }
     if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
@@ -776,7 +779,8 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   next_gathers();
   produce(0);
   __builtin_amdgcn_sched_barrier(0);
-  weights_next(0);
+  const bool upper = __builtin_amdgcn_readfirstlane(wave) >= kTh / 128;
+  if (!kLowerDma || !upper) weights_next(0);
   if (n_my_steps > 1) next_gathers();
   if (n_my_steps > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -810,6 +814,30 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
   // sits between the producer work and the MFMAs, and it runs MFMA(step + 1) where the early half runs
   // MFMA(step); MFMA(0) is peeled.  Between two barriers the early half does producer(s + 1), DMA, gathers,
   // MFMA(s); the late half DMA, gathers, MFMA(s), producer(s + 1).
+  if constexpr (kLowerDma) {
+    // Round 6 (the fp16 kernel's finding, mdconv.hip / design/dcn.md): a step's vector-memory instructions leave the
+    // CU's load path oldest wave first at ~0.4 lines per clock, and a wave cannot start its matrix segment before its
+    // own loads are accepted.  The lower half of the waves issues ALL the weight pieces and runs
+    //   producer -> DMA -> gathers -> MFMA,    the upper half    MFMA -> producer -> gathers:
+    // an upper wave has no load in front of its matrix segment.  One loop body; same buffers, same sums (int32: exact).
+    for (int step = 0; step < n_my_steps; ++step) {
+      const bool more1 = step + 1 < n_my_steps, more2 = step + 2 < n_my_steps;
+      if (!upper && more1) produce((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!upper && more1) weights_next((step + 1) & 1);
+      if (!upper && more2) next_gathers();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(step & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (upper && more1) produce((step + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (upper && more2) next_gathers();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   if (late) {
     if (n_my_steps > 1) weights_next(1);
     mfma_step(0);
@@ -832,6 +860,7 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_s8_kernel(
       __builtin_amdgcn_s_barrier();
     }
   }
+  }   // (!kLowerDma)
   if (is_tail) {  // int32 partials (exact in any order), thread-private layout shared with the finish kernel
     int4 *pq = reinterpret_cast<int4 *>(tp.partial) +
                ((((size_t)part * tp.tail_tiles + (ntile - tp.main_tiles)) * gridDim.y + blockIdx.y) * 8) * kTh + tid;
@@ -1026,10 +1055,11 @@ int run_s8(const void *input, const void *offset, const void *mask, const void *
 #define BEVOPS_S8_GO(WN_, ABL_) \
   rc = launch_glds_s8<WN_, ABL_>(xt, offset, mask, wt, bias, output, d, g, Kp, pw, room, !g_mdconv_no_tail, s_off, s_mask, s_iw, s_out, st)
       const bool w4 = wide_blocks * 2 >= (size_t)cus || g_mdconv_wide;
-      if (!w4) BEVOPS_S8_GO(2, 0);
+      const bool one_order = g_mdconv_rotate == 2;     // variant 13: the rounds 2-5 order (A/B partner of the default)
+      if (!w4) { if (one_order) BEVOPS_S8_GO(2, 0); else BEVOPS_S8_GO(2, 32); }
       else
         switch (abl) {
-          case 0: BEVOPS_S8_GO(4, 0); break;
+          case 0: if (one_order) BEVOPS_S8_GO(4, 0); else BEVOPS_S8_GO(4, 32); break;
           case 1: BEVOPS_S8_GO(4, 1); break;
           case 2: BEVOPS_S8_GO(4, 2); break;
           case 4: BEVOPS_S8_GO(4, 4); break;
@@ -1171,12 +1201,14 @@ extern "C" int bevops_mdconv_forward_int8_nhwc(const void *input_nhwc, float sca
   const S8Eng eng{offset_mask_channels, relu ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int g = 0; g < groups; ++g) {
-#define BEVOPS_S8E(WN_, FAST_)                                                                                       \
-  launch_glds_s8<WN_, 0, true, FAST_>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr, (const int8_t *)packed_weight, \
+#define BEVOPS_S8E(WN_, FAST_) (g_mdconv_rotate == 2 ? BEVOPS_S8E_(WN_, FAST_, 0) : BEVOPS_S8E_(WN_, FAST_, 32))
+#define BEVOPS_S8E_(WN_, FAST_, ABL_)                                                                                \
+  launch_glds_s8<WN_, ABL_, true, FAST_>((const int8_t *)input_nhwc, offset_mask_nhwc, nullptr, (const int8_t *)packed_weight, \
                                       bias, output_nhwc, d, g, Kp, pw, room, !g_mdconv_no_tail, scale_offset, scale_mask,   \
                                       scale_in * scale_weight, scale_out, st, eng)
     const int rc = exact ? (w4 ? BEVOPS_S8E(4, false) : BEVOPS_S8E(2, false)) : (w4 ? BEVOPS_S8E(4, true) : BEVOPS_S8E(2, true));
 #undef BEVOPS_S8E
+#undef BEVOPS_S8E_
     if (rc != BEVOPS_SUCCESS) return rc;
   }
   return launch_status();
