@@ -175,6 +175,27 @@ def _layer_norm(ops, norm, x):
     return fn(x, norm.weight, norm.bias, norm.eps)
 
 
+_LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
+
+
+def _dense_norm(ops, lin, x, residual, norm):
+    """norm(lin(x) + residual): the dense layer that ends an attention / FFN block and the block's LayerNorm
+    (modules/encoder.py:586-636) as ONE launch when the operator set has it (ops.tsgemm_ln: the persistent MFMA GEMM
+    with the normalisation in its epilogue; 256 output columns, fp16 on the GPU, a plain Linear -- a LinearQ of the INT8
+    build keeps its own path), else the GEMM followed by the one-pass norm."""
+    fn = getattr(ops, "tsgemm_ln", None)
+    if fn is not None and _LN_FUSED["enabled"] and _R3["enabled"] and _FUSED_LINEAR["enabled"] and type(lin) is nn.Linear \
+            and x.dtype == torch.float16 and x.is_cuda and lin.out_features == EMBED and lin.in_features % 64 == 0 \
+            and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.normalized_shape == (EMBED,) \
+            and x.numel() // x.shape[-1] >= 32:
+        try:
+            return fn(x, lin.weight, lin.bias, residual, norm.weight, norm.bias, norm.eps)
+        except _lib.BevopsError as exc:
+            if exc.status != _lib.NOT_SUPPORTED:
+                raise
+    return _layer_norm(ops, norm, _dense(ops, lin, x, residual, False))
+
+
 def _conv1x1_nhwc(ops, x, conv, relu, residual=None):
     s = conv.stride[0]
     if s > 1:
@@ -432,8 +453,10 @@ class FFN(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
 
-    def forward(self, x, ops=None):
-        return _dense(ops, self.fc2, _dense(ops, self.fc1, x, None, True), x, False)
+    def forward(self, x, ops=None, norm=None):
+        """`norm`: the block's LayerNorm behind the FFN (then evaluated here, in fc2's epilogue when the operator set can)."""
+        h = _dense(ops, self.fc1, x, None, True)
+        return _dense(ops, self.fc2, h, x, False) if norm is None else _dense_norm(ops, self.fc2, h, x, norm)
 
 
 class TemporalSelfAttention(nn.Module):
@@ -478,8 +501,9 @@ class TemporalSelfAttention(nn.Module):
                 raise
             return None
 
-    def forward(self, query, value, bev_pos, ref_2d, spatial_shapes, rows=None):
-        """`rows` = (lo, hi): query-range sharding (camera_shard.py, mode "scatter") -- `query`, `bev_pos` and `ref_2d`
+    def forward(self, query, value, bev_pos, ref_2d, spatial_shapes, rows=None, norm=None):
+        """`norm`: the block's LayerNorm behind this attention (evaluated in output_proj's epilogue when possible).
+        `rows` = (lo, hi): query-range sharding (camera_shard.py, mode "scatter") -- `query`, `bev_pos` and `ref_2d`
         hold rows lo .. hi - 1 of the BEV queries only, `value` (the keys: prev_bev | query stack) is whole."""
         identity = query
         nq, nk = query.shape[1], value.shape[1]
@@ -513,6 +537,8 @@ class TemporalSelfAttention(nn.Module):
             out = mean2(out)                            # (x0 + x1) / 2 in fp32, one rounding: torch.mean's bits
         else:
             out = torch.mean(out, keepdim=True, dim=0)
+        if norm is not None:
+            return _dense_norm(self.ops, self.output_proj, out, identity, norm)
         return _dense(self.ops, self.output_proj, out, identity, False)
 
 
@@ -528,7 +554,7 @@ class SpatialCrossAttention(nn.Module):
         self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
 
     def forward(self, query, value, reference_points_cam, bev_mask, spatial_shapes, cams=None, gather=None, plan=None,
-                residual=None):
+                residual=None, norm=None):
         """`plan`: the visibility plan (functions.spatial_cross_attention_plan) of the bev_mask rows of the cameras
         sampled here -- all of them, or this rank's -- or None.  `residual`: query-range sharding (exchange mode
         "scatter") -- `query` is the whole gathered tensor (every camera's sampler needs every query's offsets), the
@@ -590,6 +616,8 @@ class SpatialCrossAttention(nn.Module):
             slots = gather.reduce(slots)      # this rank's masked camera sum -> everyone's
         elif mode == "scatter":
             slots = gather.reduce_scatter_queries(slots, nq)      # ... -> the sum of MY rows only
+        if norm is not None:    # the block's LayerNorm behind this attention, in output_proj's epilogue when possible
+            return _dense_norm(self.ops, self.output_proj, slots, inp_residual, norm)
         return _dense(self.ops, self.output_proj, slots, inp_residual, False)
 
 
@@ -614,21 +642,22 @@ class BEVFormerLayer(nn.Module):
                     if torch.is_tensor(use_prev_bev) else full.repeat(2, 1, 1)
             else:
                 prev = prev_bev
-            query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos[:, lo:hi], ref_2d[:, lo:hi].contiguous(),
-                                                             bev_shapes, rows=rows))
+            query = self.tsa(query, prev, bev_pos[:, lo:hi], ref_2d[:, lo:hi].contiguous(), bev_shapes, rows=rows,
+                             norm=self.norms[0])
             full = gather.all_gather_queries(query, nq)       # every camera's sampler needs every query's offsets
-            query = _layer_norm(ops, self.norms[1], self.sca(full, value, ref_cam, bev_mask, spatial_shapes, cams, gather,
-                                                             plan, residual=query))
-            return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
+            query = self.sca(full, value, ref_cam, bev_mask, spatial_shapes, cams, gather, plan, residual=query,
+                             norm=self.norms[1])
+            return self.ffn(query, ops, norm=self.norms[2])
         # encoder.py:586-588: use_prev_bev * prev_bev + (1 - use_prev_bev) * query.repeat(2, 1, 1) with
         # use_prev_bev in {0, 1} -- a select (one pass, exact) instead of two scalings, a copy and an add
         if torch.is_tensor(use_prev_bev):
             prev = torch.where(use_prev_bev.to(torch.bool), prev_bev, query.expand(2, -1, -1))
         else:
             prev = prev_bev if use_prev_bev else query.repeat(2, 1, 1)
-        query = _layer_norm(ops, self.norms[0], self.tsa(query, prev, bev_pos, ref_2d, bev_shapes))
-        query = _layer_norm(ops, self.norms[1], self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather, plan))
-        return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
+        # (each block's LayerNorm rides in the epilogue of the block's last GEMM: _dense_norm)
+        query = self.tsa(query, prev, bev_pos, ref_2d, bev_shapes, norm=self.norms[0])
+        query = self.sca(query, value, ref_cam, bev_mask, spatial_shapes, cams, gather, plan, norm=self.norms[1])
+        return self.ffn(query, ops, norm=self.norms[2])
 
 
 def _static_term(cache, owner, key, pos, fn, weight, bias):
@@ -664,7 +693,7 @@ class CustomMSDeformableAttention(nn.Module):
         self.value_proj, self.output_proj = nn.Linear(EMBED, EMBED), nn.Linear(EMBED, EMBED)
         self._pos_so = self._pos_aw = None
 
-    def forward(self, query, value, query_pos, reference_points, spatial_shapes):
+    def forward(self, query, value, query_pos, reference_points, spatial_shapes, norm=None):
         identity = query                               # [900, 1, 256]
         ops, so, aw = self.ops, self.sampling_offsets, self.attention_weights
         n = query.shape[0]
@@ -688,6 +717,8 @@ class CustomMSDeformableAttention(nn.Module):
             w = aw(q).view(1, n, HEADS, -1)
         out = ops.multi_scale_deformable_attn(value, spatial_shapes, reference_points, off, w).flatten(2)
         # [1, 900, 256] -> [900, 1, 256] is the same memory: the identity goes into the GEMM epilogue
+        if norm is not None:
+            return _dense_norm(ops, self.output_proj, out.view(n, 1, EMBED), identity, norm)
         return _dense(ops, self.output_proj, out.view(n, 1, EMBED), identity, False)
 
 
@@ -699,7 +730,7 @@ class DecoderLayer(nn.Module):
         self.norms = nn.ModuleList(nn.LayerNorm(EMBED) for _ in range(3))
         self._pos_qkv = None
 
-    def _self_attention(self, ops, query, query_pos):
+    def _self_attention(self, ops, query, query_pos, norm=None):
         """query + MultiheadAttention(q = k = query + query_pos, v = query) (mmcv MultiheadAttention
         with its identity, decoder layer operation order) as: ONE [900, 768] in-projection whose
         query_pos part is a cached identity term, the fused attention kernel on head-strided views,
@@ -726,17 +757,16 @@ class DecoderLayer(nn.Module):
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))           # [1, heads, 900, 32] views
         o = F.scaled_dot_product_attention(q, k, v)                          # [1, heads, 900, 32]
         o = o.transpose(1, 2).reshape(n, 1, EMBED)
-        return _dense(ops, mha.out_proj, o, query, False)
+        return _dense(ops, mha.out_proj, o, query, False) if norm is None else _dense_norm(ops, mha.out_proj, o, query, norm)
 
     def forward(self, query, value, query_pos, reference_points, spatial_shapes):
         ops = self.cross_attn.ops
-        attn = self._self_attention(ops, query, query_pos)
-        if attn is None:
+        query_n = self._self_attention(ops, query, query_pos, norm=self.norms[0])
+        if query_n is None:
             qk = query + query_pos
-            attn = query + self.self_attn(qk, qk, query, need_weights=False)[0]
-        query = _layer_norm(ops, self.norms[0], attn)
-        query = _layer_norm(ops, self.norms[1], self.cross_attn(query, value, query_pos, reference_points, spatial_shapes))
-        return _layer_norm(ops, self.norms[2], self.ffn(query, ops))
+            query_n = _layer_norm(ops, self.norms[0], query + self.self_attn(qk, qk, query, need_weights=False)[0])
+        query = self.cross_attn(query_n, value, query_pos, reference_points, spatial_shapes, norm=self.norms[1])
+        return self.ffn(query, ops, norm=self.norms[2])
 
 
 class BEVFormer(nn.Module):

@@ -65,6 +65,7 @@ const Entry kTable[] = {
     {"bevops_queue_mean2", (void *)&bevops_queue_mean2},
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
     {"bevops_tsgemm_s8", (void *)&bevops_tsgemm_s8},
+    {"bevops_tsgemm_f16_ln", (void *)&bevops_tsgemm_f16_ln},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},
     {"bevops_value_proj_packed", (void *)&bevops_value_proj_packed},
     {"bevops_value_pack_planes", (void *)&bevops_value_pack_planes},

@@ -42,14 +42,28 @@ constexpr int kTsStages = 3;               // two k-steps of DMA in flight behin
 constexpr int kTsLds = kTsStages * kTsStage;   // 156 KB; the epilogue staging (160 x 528 = 82.5 KB) reuses it
 
 struct TsPacked {   // EPI == 1: destination of the encoder's value projection
-  char *gset, *sset;
+  char *gset, *sset;   // (EPI == 2: the LayerNorm's weight and bias, fp16 [N])
   Hm3Tab t;
   int nk, heads;    // rows per camera, heads (N == heads * 32)
+  float eps;        // EPI == 2
 };
+
+// sum over the 16 lanes of a DPP row (= the 16 threads that share an output row in the epilogue), in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+  v = quad_sum(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+}
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // EPI 0: out = act(acc + bias (+ residual)) -> [M, N] fp16.  EPI 1: acc + bias -> packed planes.
+// EPI 2 (round 6, N == 256): out = LayerNorm(fp16(acc + bias + residual)) -- the layer the encoder / decoder blocks put
+// behind output_proj and the FFN's second linear (modules/encoder.py:586-636: attention or FFN, then norm).  A thread
+// owns the same 8 columns of the same rows in both 128-column halves of the epilogue, so the rounded sums of a row stay
+// in registers (5 rows x 2 halves x 16 bytes) and its mean / variance are two 16-lane DPP reductions: the row is
+// normalised from exactly the binary16 values the unfused pair (GEMM, then bevops_layer_norm) would have read back,
+// two passes (mean, then centred squares), one rounding; no second launch, no 20 MB written and re-read.
 template <int EPI>
 __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__restrict__ x,
                                                                 const __half *__restrict__ w,
@@ -180,6 +194,12 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
     __builtin_amdgcn_s_barrier();   // every wave is done with the stages: the epilogue reuses them
     // ---- epilogue through LDS (fp32), two halves of 128 columns: waves 0..3, then waves 4..7
     const int rows = min(G * 32, M - r0);
+    uint4 keep[2][kTsG];          // EPI == 2: the rounded sums of this thread's (row, 8 columns), per half and row pass
+    float rsum[kTsG];
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int i = 0; i < kTsG; ++i) rsum[i] = 0.f;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if ((wave >> 2) == half) {
@@ -199,14 +219,27 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
       }
       __builtin_amdgcn_s_barrier();
       // thread -> (row, 8 columns): 16 chunks per row of 128 columns, 32 rows per pass
-      for (int r = tid >> 4; r < rows; r += kTsThreads / 16) {
+      auto row_pass = [&](int r, auto itc) __attribute__((always_inline)) {
+        constexpr int it = decltype(itc)::value;
+        (void)it;
         const int c8 = tid & 15;
         const float4 lo = *reinterpret_cast<const float4 *>(smem + r * kTsEpiStride + c8 * 32);
         const float4 hi4 = *reinterpret_cast<const float4 *>(smem + r * kTsEpiStride + c8 * 32 + 16);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
         const int col = n0 + half * 128 + c8 * 8;
         const size_t m = (size_t)(r0 + r);
-        if constexpr (EPI == 0) {
+        if constexpr (EPI == 2) {
+          if (res) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(res + m * N + col);
+            v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
+            v[4] += h2f_lo(q.z); v[5] += h2f_hi(q.z); v[6] += h2f_lo(q.w); v[7] += h2f_hi(q.w);
+          }
+          uint4 o;
+          o.x = pack_h2(v[0], v[1]); o.y = pack_h2(v[2], v[3]); o.z = pack_h2(v[4], v[5]); o.w = pack_h2(v[6], v[7]);
+          keep[half][it] = o;
+          rsum[it] += (h2f_lo(o.x) + h2f_hi(o.x)) + (h2f_lo(o.y) + h2f_hi(o.y)) + (h2f_lo(o.z) + h2f_hi(o.z)) +
+                      (h2f_lo(o.w) + h2f_hi(o.w));
+        } else if constexpr (EPI == 0) {
           if (res) {
             const uint4 q = *reinterpret_cast<const uint4 *>(res + m * N + col);
             v[0] += h2f_lo(q.x); v[1] += h2f_hi(q.x); v[2] += h2f_lo(q.y); v[3] += h2f_hi(q.y);
@@ -279,8 +312,57 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
             }
           }
         }
+      };
+      if constexpr (EPI == 2) {   // compile-time pass index: the kept values live in registers
+        const int rb = tid >> 4;
+        if (rb < rows) row_pass(rb, std::integral_constant<int, 0>{});
+        if (rb + 32 < rows) row_pass(rb + 32, std::integral_constant<int, 1>{});
+        if (rb + 64 < rows) row_pass(rb + 64, std::integral_constant<int, 2>{});
+        if (rb + 96 < rows) row_pass(rb + 96, std::integral_constant<int, 3>{});
+        if (rb + 128 < rows) row_pass(rb + 128, std::integral_constant<int, 4>{});
+      } else {
+        for (int r = tid >> 4; r < rows; r += kTsThreads / 16) row_pass(r, std::integral_constant<int, 0>{});
       }
       __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (EPI == 2) {
+      const int c8 = tid & 15;
+      const __half *gam = reinterpret_cast<const __half *>(pk.gset), *bet = reinterpret_cast<const __half *>(pk.sset);
+      int it = 0;
+#pragma unroll
+      for (int r = tid >> 4; r < kTsG * 32; r += kTsThreads / 16, ++it) {
+        if (r >= rows) break;
+        const float mean = row16_sum(rsum[it]) * (1.f / 256.f);
+        float f[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint4 o = keep[h][it];
+          f[8 * h + 0] = h2f_lo(o.x) - mean; f[8 * h + 1] = h2f_hi(o.x) - mean;
+          f[8 * h + 2] = h2f_lo(o.y) - mean; f[8 * h + 3] = h2f_hi(o.y) - mean;
+          f[8 * h + 4] = h2f_lo(o.z) - mean; f[8 * h + 5] = h2f_hi(o.z) - mean;
+          f[8 * h + 6] = h2f_lo(o.w) - mean; f[8 * h + 7] = h2f_hi(o.w) - mean;
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sq = fmaf(f[k], f[k], sq);
+        const float rstd = rsqrtf(row16_sum(sq) * (1.f / 256.f) + pk.eps);
+        const size_t m = (size_t)(r0 + r);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int col = h * 128 + c8 * 8;
+          const uint4 g4 = *reinterpret_cast<const uint4 *>(gam + col), b4 = *reinterpret_cast<const uint4 *>(bet + col);
+          const float gg[8] = {h2f_lo(g4.x), h2f_hi(g4.x), h2f_lo(g4.y), h2f_hi(g4.y),
+                               h2f_lo(g4.z), h2f_hi(g4.z), h2f_lo(g4.w), h2f_hi(g4.w)};
+          const float bb[8] = {h2f_lo(b4.x), h2f_hi(b4.x), h2f_lo(b4.y), h2f_hi(b4.y),
+                               h2f_lo(b4.z), h2f_hi(b4.z), h2f_lo(b4.w), h2f_hi(b4.w)};
+          float y[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) y[k] = fmaf(f[8 * h + k] * rstd, gg[k], bb[k]);
+          uint4 o;
+          o.x = pack_h2(y[0], y[1]); o.y = pack_h2(y[2], y[3]); o.z = pack_h2(y[4], y[5]); o.w = pack_h2(y[6], y[7]);
+          *reinterpret_cast<uint4 *>(out + m * N + col) = o;
+        }
+      }
     }
   }
 }
@@ -553,6 +635,30 @@ extern "C" int bevops_tsgemm_f16(const void *x, const void *weight, const void *
   hipLaunchKernelGGL(tsgemm_f16_kernel<0>, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
                      (const __half *)x, (const __half *)weight, (const __half *)bias, (const __half *)residual,
                      (__half *)out, (int)m, n, k, relu, units, none);
+  return launch_status();
+}
+
+// out = LayerNorm_256(fp16(x @ weight.T + bias + residual)) * ln_weight + ln_bias in ONE launch (EPI 2 above).
+// N must be 256 (the embedding width of the encoder / decoder blocks), K % 64 == 0; fp16 operands, fp32 statistics.
+extern "C" int bevops_tsgemm_f16_ln(const void *x, const void *weight, const void *bias, const void *residual,
+                                    const void *ln_weight, const void *ln_bias, float eps, void *out, long long m, int n,
+                                    int k, void *stream) {
+  if (!x || !weight || !out || !ln_weight || !ln_bias || m <= 0 || n <= 0 || k <= 0 || !(eps >= 0.f)) return BEVOPS_BAD_PARAM;
+  if (k % 64 != 0 || n != kTsBN) return BEVOPS_NOT_SUPPORTED;
+  if ((double)m * k * 2 >= 4294967040.0 || m > 0x7fffffff) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || (bias && !aligned16(bias)) ||
+      (residual && !aligned16(residual)) || !aligned16(ln_weight) || !aligned16(ln_bias))
+    return BEVOPS_BAD_PARAM;
+  if (!ensure_dynamic_lds<tsgemm_f16_kernel<2>>(kTsLds)) return BEVOPS_FAILURE;
+  const int units = (int)((m + 31) / 32);
+  const dim3 grid((unsigned)ts_grid_x(units, 1), 1u);
+  TsPacked pk{};
+  pk.gset = const_cast<char *>(static_cast<const char *>(ln_weight));
+  pk.sset = const_cast<char *>(static_cast<const char *>(ln_bias));
+  pk.eps = eps;
+  hipLaunchKernelGGL(tsgemm_f16_kernel<2>, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
+                     (const __half *)x, (const __half *)weight, (const __half *)bias, (const __half *)residual,
+                     (__half *)out, (int)m, n, k, 0, units, pk);
   return launch_status();
 }
 

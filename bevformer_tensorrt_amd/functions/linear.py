@@ -199,6 +199,40 @@ def tsgemm(x, weight, bias=None, residual=None, relu=False, out=None):
     return out.view(*x.shape[:-1], N)
 
 
+def tsgemm_ln(x, weight, bias, residual, ln_weight, ln_bias, eps=1e-5):
+    """layer_norm(x @ weight.T + bias + residual) * ln_weight + ln_bias in ONE launch (bevops_tsgemm_f16_ln): the dense
+    layer that ends an attention / FFN block of the encoder or decoder together with the block's norm
+    (modules/encoder.py:586-636).  x [..., K] fp16, weight [256, K], residual [..., 256] or None.  Equal to
+    layer_norm(tsgemm(...)) up to the last bit of the normalisation (same binary16 sums, fp32 statistics).  Raises
+    BevopsError (NOT_SUPPORTED) unless N == 256 and K % 64 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16
+    K, N = x.shape[-1], weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {K}]")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    weight = weight.contiguous()
+    M = x2.shape[0]
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(M, N)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    bias = None if bias is None else bias.to(torch.float16).contiguous()
+    g, b = ln_weight.to(torch.float16).contiguous(), ln_bias.to(torch.float16).contiguous()
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return out.view(*x.shape[:-1], N)
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_tsgemm_f16_ln(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         r2.data_ptr() if r2 is not None else None, g.data_ptr(), b.data_ptr(), float(eps),
+                                         out.data_ptr(), M, N, K, _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_tsgemm_f16_ln")
+    return out.view(*x.shape[:-1], N)
+
+
 def tile_gemm(x, weight, bias=None, residual=None, relu=False, out=None):
     """act(x @ weight.T + bias + residual) on the tiled MFMA GEMM (bevops_tile_gemm_f16, csrc/tile_gemm.hip:
     128 x 128 tiles, three blocks per CU): x [..., K] fp16 contiguous rows, weight [N, K], bias [N] fp16,

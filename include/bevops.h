@@ -598,6 +598,14 @@ int bevops_point_sampling(int out_dtype, const float *pillars, const float *lida
  * (the caller keeps its library GEMM). */
 int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual, void *out,
                       long long m, int n, int k, int relu, void *stream);
+/* The same GEMM with the LayerNorm that follows it in every encoder / decoder block (modules/encoder.py:586-636,
+ * modules/decoder.py:52-112: attention or FFN with its identity, then `norm`) evaluated in the epilogue:
+ *     out = LayerNorm_N(fp16(x w^T + bias (+ residual))) * ln_weight + ln_bias,     N == 256, K % 64 == 0.
+ * The row is normalised from exactly the binary16 sums the unfused pair (this GEMM, then bevops_layer_norm) would have
+ * read back -- fp32 mean, centred squares, one rounding -- without the second launch and the [M, 256] round trip.
+ * ln_weight / ln_bias fp16 [256], 16-byte aligned.  BEVOPS_NOT_SUPPORTED when n != 256 or k % 64 != 0. */
+int bevops_tsgemm_f16_ln(const void *x, const void *weight, const void *bias, const void *residual, const void *ln_weight,
+                         const void *ln_bias, float eps, void *out, long long m, int n, int k, void *stream);
 /* The int8 activation chain's flavour of the same persistent kernel (the int8 1x1 convolutions of ResNet stages
  * 3 / 4; arguments as bevops_linear_int8_chain with an int8 activation): a_q [M, K] / w_q [N, K] int8, int32 sums,
  * fp32 bias, identity rows int8 (res_dtype BEVOPS_I8, real = q * scale_res) or fp16, output int8 (requantised with

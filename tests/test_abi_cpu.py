@@ -113,6 +113,12 @@ def test_round5_entries_reject_bad_params_without_gpu(lib):
     assert lib.bevops_point_sampling(1, p, p, p, p, 6, 100, 3, f(928), f(1600), None) == 3         # three anchors per pillar
     assert lib.bevops_point_sampling(2, p, p, p, p, 6, 100, 4, f(928), f(1600), None) == 3         # int8 output
     assert lib.bevops_point_sampling(1, p + 4, p, p, p, 6, 100, 4, f(928), f(1600), None) == 2     # misaligned pillars
+    # round 6: the GEMM with the LayerNorm in its epilogue
+    ll = ctypes.c_longlong
+    assert lib.bevops_tsgemm_f16_ln(p, p, None, None, None, p, f(1e-5), p, ll(64), 256, 64, None) == 2    # no norm weight
+    assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(1e-5), p, ll(64), 512, 64, None) == 3       # N != 256
+    assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(1e-5), p, ll(64), 256, 48, None) == 3       # K % 64
+    assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(-1.0), p, ll(64), 256, 64, None) == 2       # negative eps
 
 
 def test_sca_knobs_do_not_disturb_the_kernel_family_selection(lib):
