@@ -22,8 +22,6 @@
 //     pixels of the staged ones), which removes the separate re-layout pass (70 us per SCA call).
 // N > 256: grid.y walks the 256-column chunks.  Domain: K % 64 == 0, N % 256 == 0 (other layers stay on
 // hipBLASLt).
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -66,10 +64,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // in registers (5 rows x 2 halves x 16 bytes) and its mean / variance are two 16-lane DPP reductions: the row is
 // normalised from exactly the binary16 values the unfused pair (GEMM, then bevops_layer_norm) would have read back,
 // two passes (mean, then centred squares), one rounding; no second launch, no 20 MB written and re-read.
-// LOWER: waves 0-3 issue ALL the DMA pieces of a step (8 weight + up to 5 activation pieces each), waves 4-7 none, so a
-// wave of the upper half has no vector-memory instruction between the barrier and its matrix instructions (the DCNv2
-// kernel's round-6 finding: a step's loads leave the CU's load path oldest wave first, design/dcn.md)
-template <int EPI, bool LOWER = false>
+template <int EPI>
 __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__restrict__ x,
                                                                 const __half *__restrict__ w,
                                                                 const __half *__restrict__ bias,
@@ -93,14 +88,12 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
   // DMA roles.  Weight tile: 32 pieces of 8 rows, 4 per wave; activation tile: up to 20 pieces, piece
   // wave + 8 j.  lane -> (row in piece, 16-byte chunk); the swizzle sits on the source chunk
   const unsigned prow = (unsigned)(lane >> 3), pchunk = (unsigned)(lane & 7);
-  constexpr int kWp = LOWER ? 8 : 4, kXp = LOWER ? 5 : 3, kXs = LOWER ? 4 : 8;   // pieces per issuing wave, x-piece stride
-  unsigned w_off[kWp];
+  unsigned w_off[4];
 #pragma unroll
-  for (int j = 0; j < kWp; ++j) {
-    const unsigned row = (unsigned)((wave * kWp + j) * 8) + prow;
+  for (int j = 0; j < 4; ++j) {
+    const unsigned row = (unsigned)((wave * 4 + j) * 8) + prow;
     w_off[j] = (unsigned)(((size_t)(n0 + row) * K) * 2) + ((pchunk ^ swz8(row)) << 4);
   }
-  const bool issuer = !LOWER || wave < 4;
   const unsigned hi = (unsigned)(lane >> 5);
   const unsigned fa = (unsigned)(wave * 32 + (lane & 31));   // weight fragment row
   const int nk = K / 64;
@@ -117,10 +110,10 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
     const int G = min(kTsG, u_end - u0);
     const int r0 = u0 * 32;
     const int pieces_x = G * 4;
-    unsigned x_off[kXp];
+    unsigned x_off[3];
 #pragma unroll
-    for (int j = 0; j < kXp; ++j) {
-      const unsigned row = (unsigned)((wave + kXs * j) * 8) + prow;
+    for (int j = 0; j < 3; ++j) {
+      const unsigned row = (unsigned)((wave + 8 * j) * 8) + prow;
       x_off[j] = (unsigned)(((size_t)(r0 + row) * K) * 2) + ((pchunk ^ swz8(row)) << 4);
     }
     // every resident block walks the same weight matrix: start each one at a different k-slice (and wrap), so
@@ -128,19 +121,18 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
     // summation order then depends on the block index only)
     const int k_rot = bi % nk;
     auto dma = [&](int step, int buf) {
-      if (!issuer) return;
-      char *wd = smem + buf * kTsStage + wave * (kWp * 1024);
+      char *wd = smem + buf * kTsStage + wave * 4096;
       int kstep = step + k_rot;
       if (kstep >= nk) kstep -= nk;
       const int soff = kstep * 128;
 #pragma unroll
-      for (int j = 0; j < kWp; ++j)
+      for (int j = 0; j < 4; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wd + j * 1024), 16, (int)w_off[j], soff, 0, 0);
       char *xd = smem + buf * kTsStage + kTsW;
 #pragma unroll
-      for (int j = 0; j < kXp; ++j)
-        if (wave + kXs * j < pieces_x)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(xd + (wave + kXs * j) * 1024), 16,
+      for (int j = 0; j < 3; ++j)
+        if (wave + 8 * j < pieces_x)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(xd + (wave + 8 * j) * 1024), 16,
                                                    (int)x_off[j], soff, 0, 0);
     };
     f32x16 acc[kTsG];
@@ -154,25 +146,13 @@ __global__ __launch_bounds__(kTsThreads) void tsgemm_f16_kernel(const __half *__
     // of step s (vmcnt counts its own DMA instructions: 4 weight pieces + 0..3 activation pieces per
     // step), the barrier then makes everybody's pieces visible -- and also says that stage (s + 2) % 3,
     // last read in step s - 1, is free again.
-    int my_dma = 0;
-    if (issuer) {
-      my_dma = kWp;
-#pragma unroll
-      for (int j = 0; j < kXp; ++j) my_dma += (wave + kXs * j < pieces_x) ? 1 : 0;
-    }
+    const int my_dma = 4 + (wave < pieces_x ? 1 : 0) + (wave + 8 < pieces_x ? 1 : 0) + (wave + 16 < pieces_x ? 1 : 0);
     auto wait_keep_one_step = [&]() {
       switch (my_dma) {
-        case 0: break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
       }
     };
     // the k loop for a compile-time unit count (a run-time `g < G` inside the unrolled multiply loop is a
@@ -640,11 +620,6 @@ inline int ts_grid_x(int units, int chunks_n) {
 
 using namespace bevops;
 
-static bool ts_lower_order() {      // EXPERIMENT switch (round 6): BEVOPS_TSGEMM_ORDER=1 -> waves 0-3 issue all the DMA
-  static const bool on = [] { const char *e = getenv("BEVOPS_TSGEMM_ORDER"); return e && e[0] == '1'; }();
-  return on;
-}
-
 extern "C" int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const void *residual,
                                  void *out, long long m, int n, int k, int relu, void *stream) {
   if (!x || !weight || !out || m <= 0 || n <= 0 || k <= 0) return BEVOPS_BAD_PARAM;
@@ -653,13 +628,11 @@ extern "C" int bevops_tsgemm_f16(const void *x, const void *weight, const void *
   if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || (bias && !aligned16(bias)) ||
       (residual && !aligned16(residual)))
     return BEVOPS_BAD_PARAM;
-  const bool lower = ts_lower_order();
-  if (!(lower ? ensure_dynamic_lds<tsgemm_f16_kernel<0, true>>(kTsLds) : ensure_dynamic_lds<tsgemm_f16_kernel<0>>(kTsLds)))
-    return BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<tsgemm_f16_kernel<0>>(kTsLds)) return BEVOPS_FAILURE;
   const int units = (int)((m + 31) / 32);
   const dim3 grid((unsigned)ts_grid_x(units, n / kTsBN), (unsigned)(n / kTsBN));
   TsPacked none{};
-  hipLaunchKernelGGL((lower ? tsgemm_f16_kernel<0, true> : tsgemm_f16_kernel<0, false>), grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(tsgemm_f16_kernel<0>, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
                      (const __half *)x, (const __half *)weight, (const __half *)bias, (const __half *)residual,
                      (__half *)out, (int)m, n, k, relu, units, none);
   return launch_status();
@@ -676,16 +649,14 @@ extern "C" int bevops_tsgemm_f16_ln(const void *x, const void *weight, const voi
   if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || (bias && !aligned16(bias)) ||
       (residual && !aligned16(residual)) || !aligned16(ln_weight) || !aligned16(ln_bias))
     return BEVOPS_BAD_PARAM;
-  const bool lower = ts_lower_order();
-  if (!(lower ? ensure_dynamic_lds<tsgemm_f16_kernel<2, true>>(kTsLds) : ensure_dynamic_lds<tsgemm_f16_kernel<2>>(kTsLds)))
-    return BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<tsgemm_f16_kernel<2>>(kTsLds)) return BEVOPS_FAILURE;
   const int units = (int)((m + 31) / 32);
   const dim3 grid((unsigned)ts_grid_x(units, 1), 1u);
   TsPacked pk{};
   pk.gset = const_cast<char *>(static_cast<const char *>(ln_weight));
   pk.sset = const_cast<char *>(static_cast<const char *>(ln_bias));
   pk.eps = eps;
-  hipLaunchKernelGGL((lower ? tsgemm_f16_kernel<2, true> : tsgemm_f16_kernel<2, false>), grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(tsgemm_f16_kernel<2>, grid, dim3(kTsThreads), kTsLds, static_cast<hipStream_t>(stream),
                      (const __half *)x, (const __half *)weight, (const __half *)bias, (const __half *)residual,
                      (__half *)out, (int)m, n, k, 0, units, pk);
   return launch_status();
@@ -760,12 +731,10 @@ extern "C" int bevops_value_proj_packed(const void *x, const void *weight, const
   pk.heads = heads;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(tsgemm_pad_zero_kernel, dim3(4, (unsigned)(num_cams * heads)), dim3(256), 0, st, pk, num_cams * heads);
-  const bool lower = ts_lower_order();
-  if (!(lower ? ensure_dynamic_lds<tsgemm_f16_kernel<1, true>>(kTsLds) : ensure_dynamic_lds<tsgemm_f16_kernel<1>>(kTsLds)))
-    return BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<tsgemm_f16_kernel<1>>(kTsLds)) return BEVOPS_FAILURE;
   const int units = (int)((m + 31) / 32);
   const dim3 grid((unsigned)ts_grid_x(units, n / kTsBN), (unsigned)(n / kTsBN));
-  hipLaunchKernelGGL((lower ? tsgemm_f16_kernel<1, true> : tsgemm_f16_kernel<1, false>), grid, dim3(kTsThreads), kTsLds, st, (const __half *)x, (const __half *)weight,
+  hipLaunchKernelGGL(tsgemm_f16_kernel<1>, grid, dim3(kTsThreads), kTsLds, st, (const __half *)x, (const __half *)weight,
                      (const __half *)bias, (const __half *)nullptr, (__half *)nullptr, (int)m, n, k, 0, units, pk);
   return launch_status();
 }
