@@ -175,6 +175,7 @@ def _layer_norm(ops, norm, x):
     return fn(x, norm.weight, norm.bias, norm.eps)
 
 
+_OWN_ATTN = {"enabled": os.environ.get("BEVOPS_OWN_ATTN", "1") == "1"}   # A/B: decoder self-attention on csrc/attention.hip
 _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
 
 
@@ -754,9 +755,18 @@ class DecoderLayer(nn.Module):
             if exc.status != _lib.NOT_SUPPORTED:
                 raise
             return None
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))           # [1, heads, 900, 32] views
-        o = F.scaled_dot_product_attention(q, k, v)                          # [1, heads, 900, 32]
-        o = o.transpose(1, 2).reshape(n, 1, EMBED)
+        own = getattr(ops, "self_attention_qkv", None) if _OWN_ATTN["enabled"] else None
+        o = None
+        if own is not None:
+            try:     # one launch on the matrix cores (K / V of a head staged in LDS): 900 queries x 8 heads x 32
+                o = own(qkv.view(n, 3, HEADS, EMBED // HEADS)).view(n, 1, EMBED)
+            except _lib.BevopsError as exc:
+                if exc.status != _lib.NOT_SUPPORTED:
+                    raise
+        if o is None:
+            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))           # [1, heads, 900, 32] views
+            o = F.scaled_dot_product_attention(q, k, v)                          # [1, heads, 900, 32]
+            o = o.transpose(1, 2).reshape(n, 1, EMBED)
         return _dense(ops, mha.out_proj, o, query, False) if norm is None else _dense_norm(ops, mha.out_proj, o, query, norm)
 
     def forward(self, query, value, query_pos, reference_points, spatial_shapes):

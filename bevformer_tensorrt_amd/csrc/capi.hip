@@ -66,6 +66,8 @@ const Entry kTable[] = {
     {"bevops_tsgemm_f16", (void *)&bevops_tsgemm_f16},
     {"bevops_tsgemm_s8", (void *)&bevops_tsgemm_s8},
     {"bevops_tsgemm_f16_ln", (void *)&bevops_tsgemm_f16_ln},
+    {"bevops_mha_selfattn_f16", (void *)&bevops_mha_selfattn_f16},
+    {"bevops_mha_selfattn_max_queries", (void *)&bevops_mha_selfattn_max_queries},
     {"bevops_value_proj_packed_size", (void *)&bevops_value_proj_packed_size},
     {"bevops_value_proj_packed", (void *)&bevops_value_proj_packed},
     {"bevops_value_pack_planes", (void *)&bevops_value_pack_planes},

@@ -71,6 +71,8 @@ SIGNATURES = {
                                       c_void_p]),
     "bevops_tsgemm_f16": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tsgemm_f16_ln": (c_int, [c_void_p] * 6 + [c_float, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
+    "bevops_mha_selfattn_max_queries": (c_size_t, []),
+    "bevops_mha_selfattn_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "bevops_tsgemm_s8": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_int,
                                  c_void_p, c_float, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
     "bevops_tsa_split": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -606,6 +606,14 @@ int bevops_tsgemm_f16(const void *x, const void *weight, const void *bias, const
  * ln_weight / ln_bias fp16 [256], 16-byte aligned.  BEVOPS_NOT_SUPPORTED when n != 256 or k % 64 != 0. */
 int bevops_tsgemm_f16_ln(const void *x, const void *weight, const void *bias, const void *residual, const void *ln_weight,
                          const void *ln_bias, float eps, void *out, long long m, int n, int k, void *stream);
+/* Self-attention of a few hundred queries on the matrix cores (csrc/attention.hip; the decoder's object queries:
+ * mmcv MultiheadAttention in det2trt/models/modules/decoder.py:52-112 -- 900 queries, 8 heads x 32): qkv
+ * [num_query, 3, heads, 32] fp16 (the in-projection's output: q, k, v of every head side by side, 16-byte aligned) ->
+ * out [num_query, heads, 32] fp16 = softmax(scale q k^T) v per head; fp32 scores / statistics / accumulators.
+ * BEVOPS_NOT_SUPPORTED unless head_dim == 32 and num_query <= bevops_mha_selfattn_max_queries() (the head's keys and
+ * values live in LDS). */
+size_t bevops_mha_selfattn_max_queries(void);
+int bevops_mha_selfattn_f16(const void *qkv, void *out, int num_query, int heads, int head_dim, float scale, void *stream);
 /* The int8 activation chain's flavour of the same persistent kernel (the int8 1x1 convolutions of ResNet stages
  * 3 / 4; arguments as bevops_linear_int8_chain with an int8 activation): a_q [M, K] / w_q [N, K] int8, int32 sums,
  * fp32 bias, identity rows int8 (res_dtype BEVOPS_I8, real = q * scale_res) or fp16, output int8 (requantised with

@@ -119,6 +119,13 @@ def test_round5_entries_reject_bad_params_without_gpu(lib):
     assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(1e-5), p, ll(64), 512, 64, None) == 3       # N != 256
     assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(1e-5), p, ll(64), 256, 48, None) == 3       # K % 64
     assert lib.bevops_tsgemm_f16_ln(p, p, None, None, p, p, f(-1.0), p, ll(64), 256, 64, None) == 2       # negative eps
+    # round 6: the decoder's self-attention
+    lib.bevops_mha_selfattn_max_queries.restype = ctypes.c_size_t
+    assert lib.bevops_mha_selfattn_max_queries() == 1024
+    assert lib.bevops_mha_selfattn_f16(None, p, 900, 8, 32, f(0.17), None) == 2
+    assert lib.bevops_mha_selfattn_f16(p, p, 900, 8, 64, f(0.17), None) == 3          # head width
+    assert lib.bevops_mha_selfattn_f16(p, p, 2000, 8, 32, f(0.17), None) == 3         # more keys than LDS holds
+    assert lib.bevops_mha_selfattn_f16(p, p, 900, 8, 32, f(0.0), None) == 2           # no scale
 
 
 def test_sca_knobs_do_not_disturb_the_kernel_family_selection(lib):
