@@ -5,18 +5,22 @@
 //
 //   out[i, h, :] = sum_j softmax_j( scale * <q[i, h, :], k[j, h, :]> ) v[j, h, :]        qkv [n, 3, heads, 32] fp16
 //
-// MI355X mapping.  A block = one head x 128 queries, four waves of 32 queries; the head's K (80-byte rows: conflict-free
-// 16-byte fragment reads) and V (64-byte rows) are staged in LDS once (n <= 1 024 keys: 144 KB), then a wave walks the
-// keys 32 at a time with v_mfma_f32_32x32x16_f16:
-//   S^T[key, query] = K Q^T                  (A = K rows from LDS, B = the wave's Q fragment, resident in registers)
+// MI355X mapping.  A block = one head x 32 queries, four waves that share the queries and split the KEYS (a wave walks
+// a quarter of the key blocks: with one wave per SIMD nothing hides the chain fragment read -> MFMA -> softmax -> MFMA of a
+// key block, so the chain is made four times shorter and 232 blocks fill the chip; the first build -- four waves x 32
+// queries each over all keys, 64 blocks -- took 21.4 us against the framework's 29.2).  The head's K (80-byte rows:
+// conflict-free 16-byte fragment reads) and V (64-byte rows) are staged in LDS (n <= 1 024 keys: 144 KB), then per 32
+// keys, with v_mfma_f32_32x32x16_f16:
+//   S^T[key, query] = K Q^T                  (A = K rows from LDS, B = the Q fragment, resident in registers)
 //   online softmax down the KEY axis: in the C layout a lane holds 16 keys of ONE query (its partner lane + 32 the
 //     other 16), so the running maximum / sum are lane-local plus one exchange with the partner, and the rescaling
 //     of the output accumulator is a per-lane factor
 //   O^T[d, query] += V^T P^T                 (B = the probabilities straight out of the lane's OWN registers: the key
 //     order of the k index is permuted to the C layout's -- (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- and the A operand
 //     V^T picks its eight keys per lane from LDS in the same order, 2 bytes at a time)
-// fp32 scores, maxima, sums and output accumulators; probabilities rounded to binary16 for the second product (as
-// every fused attention does); exp2 with the scale folded into Q's side (scale * log2 e).
+// and at the end the four waves' (maximum, sum, accumulator) meet in LDS: wave w rescales and adds the four partial
+// results of channels 8 w .. 8 w + 7 and stores them.  fp32 scores, maxima, sums and output accumulators; probabilities
+// rounded to binary16 for the second product (as every fused attention does); exp2 with the scale folded in.
 #include "common.h"
 
 namespace bevops {
@@ -28,7 +32,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int kAtD = 32;            // channels per head
 constexpr int kAtKRow = 80;         // LDS bytes per K row (64 + 16: the 16-byte fragment reads of 16 lanes hit 64 banks)
 constexpr int kAtVRow = 64;
-constexpr int kAtThreads = 256;     // four waves x 32 queries
+constexpr int kAtThreads = 256;     // four waves: the same 32 queries, a quarter of the keys each
 constexpr int kAtMaxN = 1024;
 
 __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __half *__restrict__ qkv,
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
   }
   // ---- the wave's Q fragment (B operand: column = query lane & 31, k = channels 16 t + 8 (lane >> 5) ..)
   const int hi = lane >> 5;
-  const int q_idx = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int q_idx = blockIdx.x * 32 + (lane & 31);
   f16x8_t qf[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -63,14 +67,16 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
     qf[t] = __builtin_bit_cast(f16x8_t, v);
   }
   __syncthreads();
-  if (blockIdx.x * 128 + wave * 32 >= n) return;     // a wave without queries (the staging above needed its threads)
+  // this wave's key blocks
+  const int nblk = n_pad >> 5, per = (nblk + 3) >> 2;
+  const int kb_begin = min(wave * per, nblk) * 32, kb_end = min((wave + 1) * per, nblk) * 32;
 
   f32x16_t acc;                       // O^T: row = channel (r & 3) + 8 (r >> 2) + 4 hi, column = this lane's query
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const int d_lane = lane & 31;       // A-operand row of the second product: channel
-  for (int kb = 0; kb < n_pad; kb += 32) {
+  for (int kb = kb_begin; kb < kb_end; kb += 32) {
     // S^T block: 32 keys x 32 queries
     f32x16_t s;
 #pragma unroll
@@ -123,17 +129,36 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc, 0, 0, 0);
     }
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (q_idx < n) {
-    __half *o = out + ((size_t)q_idx * heads + head) * kAtD;
+  // ---- the four waves' partial results meet in LDS (the K / V images are dead): [wave][18][64 lanes] floats
+  __syncthreads();
+  float *xs = reinterpret_cast<float *>(smem);
+  {
+    float *mine = xs + wave * 18 * 64 + lane;
+    mine[0] = m_run;
+    mine[64] = l_run;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {     // channels 8 g + 4 hi .. + 3: 8 bytes
-      uint2 w;
-      w.x = pack_h2(acc[4 * g] * inv, acc[4 * g + 1] * inv);
-      w.y = pack_h2(acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
-      *reinterpret_cast<uint2 *>(o + 8 * g + 4 * hi) = w;
-    }
+    for (int r = 0; r < 16; ++r) mine[(2 + r) * 64] = acc[r];
+  }
+  __syncthreads();
+  float m_all = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, xs[w * 18 * 64 + lane]);      // (equal in a lane and its partner)
+  float l_tot = 0.f, o4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float *src = xs + w * 18 * 64;
+    const float f = __builtin_amdgcn_exp2f(src[lane] - m_all);                   // a wave without keys: 2^-inf = 0
+    l_tot += (src[64 + lane] + src[64 + (lane ^ 32)]) * f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] += src[(2 + 4 * wave + e) * 64 + lane] * f;
+  }
+  const float inv = 1.f / l_tot;
+  if (q_idx < n) {    // this wave stores channels 8 wave + 4 hi .. + 3 of its lanes' queries: 8 bytes
+    __half *o = out + ((size_t)q_idx * heads + head) * kAtD + 8 * wave + 4 * hi;
+    uint2 w2;
+    w2.x = pack_h2(o4[0] * inv, o4[1] * inv);
+    w2.y = pack_h2(o4[2] * inv, o4[3] * inv);
+    *reinterpret_cast<uint2 *>(o) = w2;
   }
 }
 
@@ -150,9 +175,9 @@ extern "C" int bevops_mha_selfattn_f16(const void *qkv, void *out, int num_query
   if (head_dim != kAtD || num_query > kAtMaxN || heads > 65535) return BEVOPS_NOT_SUPPORTED;
   if (!aligned16(qkv) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEVOPS_BAD_PARAM;
   const int n_pad = (num_query + 31) & ~31;
-  const size_t lds = (size_t)n_pad * (kAtKRow + kAtVRow);
+  const size_t lds = max((size_t)n_pad * (kAtKRow + kAtVRow), (size_t)4 * 18 * 64 * sizeof(float));
   if (!ensure_dynamic_lds<mha_selfattn_f16_kernel>(lds)) return BEVOPS_FAILURE;
-  const dim3 grid((unsigned)((num_query + 127) / 128), (unsigned)heads);
+  const dim3 grid((unsigned)((num_query + 31) / 32), (unsigned)heads);
   hipLaunchKernelGGL(mha_selfattn_f16_kernel, grid, dim3(kAtThreads), lds, static_cast<hipStream_t>(stream),
                      static_cast<const __half *>(qkv), static_cast<__half *>(out), num_query, heads,
                      scale * 1.4426950408889634f);
