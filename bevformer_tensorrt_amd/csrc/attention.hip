@@ -32,7 +32,8 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int kAtD = 32;            // channels per head
 constexpr int kAtKRow = 80;         // LDS bytes per K row (64 + 16: the 16-byte fragment reads of 16 lanes hit 64 banks)
 constexpr int kAtVRow = 64;
-constexpr int kAtThreads = 256;     // four waves: the same 32 queries, a quarter of the keys each
+constexpr int kAtWaves = 8;          // waves per block: the same 32 queries, an eighth of the keys each
+constexpr int kAtThreads = 64 * kAtWaves;
 constexpr int kAtMaxN = 1024;
 
 __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __half *__restrict__ qkv,
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
   }
   __syncthreads();
   // this wave's key blocks
-  const int nblk = n_pad >> 5, per = (nblk + 3) >> 2;
+  const int nblk = n_pad >> 5, per = (nblk + kAtWaves - 1) / kAtWaves;
   const int kb_begin = min(wave * per, nblk) * 32, kb_end = min((wave + 1) * per, nblk) * 32;
 
   f32x16_t acc;                       // O^T: row = channel (r & 3) + 8 (r >> 2) + 4 hi, column = this lane's query
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc, 0, 0, 0);
     }
   }
-  // ---- the four waves' partial results meet in LDS (the K / V images are dead): [wave][18][64 lanes] floats
+  // ---- the waves' partial results meet in LDS (the K / V images are dead): [wave][18][64 lanes] floats
   __syncthreads();
   float *xs = reinterpret_cast<float *>(smem);
   {
@@ -140,12 +141,13 @@ __global__ __launch_bounds__(kAtThreads) void mha_selfattn_f16_kernel(const __ha
     for (int r = 0; r < 16; ++r) mine[(2 + r) * 64] = acc[r];
   }
   __syncthreads();
+  if (wave >= 4) return;               // waves 0-3 finish: four accumulator registers (= 4 channels per lane) each
   float m_all = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, xs[w * 18 * 64 + lane]);      // (equal in a lane and its partner)
+  for (int w = 0; w < kAtWaves; ++w) m_all = fmaxf(m_all, xs[w * 18 * 64 + lane]);      // (equal in a lane and its partner)
   float l_tot = 0.f, o4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < kAtWaves; ++w) {
     const float *src = xs + w * 18 * 64;
     const float f = __builtin_amdgcn_exp2f(src[lane] - m_all);                   // a wave without keys: 2^-inf = 0
     l_tot += (src[64 + lane] + src[64 + (lane ^ 32)]) * f;
@@ -175,7 +177,7 @@ extern "C" int bevops_mha_selfattn_f16(const void *qkv, void *out, int num_query
   if (head_dim != kAtD || num_query > kAtMaxN || heads > 65535) return BEVOPS_NOT_SUPPORTED;
   if (!aligned16(qkv) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEVOPS_BAD_PARAM;
   const int n_pad = (num_query + 31) & ~31;
-  const size_t lds = max((size_t)n_pad * (kAtKRow + kAtVRow), (size_t)4 * 18 * 64 * sizeof(float));
+  const size_t lds = max((size_t)n_pad * (kAtKRow + kAtVRow), (size_t)kAtWaves * 18 * 64 * sizeof(float));
   if (!ensure_dynamic_lds<mha_selfattn_f16_kernel>(lds)) return BEVOPS_FAILURE;
   const dim3 grid((unsigned)((num_query + 31) / 32), (unsigned)heads);
   hipLaunchKernelGGL(mha_selfattn_f16_kernel, grid, dim3(kAtThreads), lds, static_cast<hipStream_t>(stream),
