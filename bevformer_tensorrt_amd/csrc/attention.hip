@@ -5,12 +5,13 @@
 //
 //   out[i, h, :] = sum_j softmax_j( scale * <q[i, h, :], k[j, h, :]> ) v[j, h, :]        qkv [n, 3, heads, 32] fp16
 //
-// MI355X mapping.  A block = one head x 32 queries, four waves that share the queries and split the KEYS (a wave walks
-// a quarter of the key blocks: with one wave per SIMD nothing hides the chain fragment read -> MFMA -> softmax -> MFMA of a
-// key block, so the chain is made four times shorter and 232 blocks fill the chip; the first build -- four waves x 32
-// queries each over all keys, 64 blocks -- took 21.4 us against the framework's 29.2).  The head's K (80-byte rows:
-// conflict-free 16-byte fragment reads) and V (64-byte rows) are staged in LDS (n <= 1 024 keys: 144 KB), then per 32
-// keys, with v_mfma_f32_32x32x16_f16:
+// MI355X mapping.  A block = one head x 32 queries, EIGHT waves that share the queries and split the KEYS (a wave walks
+// an eighth of the 32-key blocks).  With the head's K / V image filling the LDS there is one block per CU, and nothing hides
+// a wave's chain fragment read -> MFMA -> softmax -> MFMA of a key block: so the chain is made short and 232 blocks fill the
+// chip.  Measured under graph replay (profiles/r06/attn_time.jsonl): four waves x 32 queries each over all keys, 64 blocks:
+// 21.4 us; keys split over 4 / 8 / 16 waves: 10.9 / 8.8 / 9.1 us; the framework's fused kernel: 29.2 us.  The head's K
+// (80-byte rows: conflict-free 16-byte fragment reads) and V (64-byte rows) are staged in LDS (n <= 1 024 keys: 144 KB),
+// then per 32 keys, with v_mfma_f32_32x32x16_f16:
 //   S^T[key, query] = K Q^T                  (A = K rows from LDS, B = the Q fragment, resident in registers)
 //   online softmax down the KEY axis: in the C layout a lane holds 16 keys of ONE query (its partner lane + 32 the
 //     other 16), so the running maximum / sum are lane-local plus one exchange with the partner, and the rescaling
@@ -18,7 +19,7 @@
 //   O^T[d, query] += V^T P^T                 (B = the probabilities straight out of the lane's OWN registers: the key
 //     order of the k index is permuted to the C layout's -- (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- and the A operand
 //     V^T picks its eight keys per lane from LDS in the same order, 2 bytes at a time)
-// and at the end the four waves' (maximum, sum, accumulator) meet in LDS: wave w rescales and adds the four partial
+// and at the end the waves' (maximum, sum, accumulator) meet in LDS: wave w < 4 rescales and adds the eight partial
 // results of channels 8 w .. 8 w + 7 and stores them.  fp32 scores, maxima, sums and output accumulators; probabilities
 // rounded to binary16 for the second product (as every fused attention does); exp2 with the scale folded in.
 #include "common.h"
