@@ -305,11 +305,24 @@ def pmc_traffic(int8):
             else:
                 # (msda_hm5_kernel<1>: the drop-in call's sampler behind its visibility pre-pass; <3> is the planned
                 # kernel of roofline_frame, <2, 1024, 0, 1 ...> the same kernel's name in the profiles of rounds 3-4)
-                hit = ("msda_hm5_kernel<1>" in k or "msda_hm5_kernel<2, 1024, 0, 1" in k or "msda_hm5_vis_kernel" in k
-                       or "msda_hm3_repack_kernel" in k)
+                hit = ("msda_hm5_kernel<1>" in k or "msda_hm5_kernel<1, false>" in k or "msda_hm5_kernel<2, 1024, 0, 1" in k
+                       or "msda_hm5_vis_kernel" in k or "msda_hm3_repack_kernel" in k)
             if hit and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
                 total += (2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024
         return (int(total) if total else None), os.path.relpath(f, ROOT)
+    except Exception:
+        return None, None
+
+
+def pmc_kernels(pattern, *needles):
+    """(bytes, source) of the kernels whose names hold one of `needles` in the newest committed per-kernel PMC file
+    matching `pattern` under profiles/r*/ (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction), or (None, None)."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)))[-1]
+        tot = sum((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024 for k, v in json.load(open(f)).items()
+                  if isinstance(v, dict) and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v and any(n in k for n in needles))
+        return (int(tot), os.path.relpath(f, ROOT)) if tot else (None, None)
     except Exception:
         return None, None
 
@@ -432,7 +445,7 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
         us = graph_us(lambda: S._sample_planes(handle, planes, geom, ref, off, w, bm, plan), iters, rounds)
         byt = (6 * nk * heads * 32 + nq * heads * 32 * 3 + 6 * nq * 8 + 6 * nq + nq * heads * 32) * 2 + 8 * 4
         out["roofline_frame"] = {
-            "kernel": "in-frame SCA sampling call = msda_hm5_kernel<3> (balanced slices of the visibility plan, pairs only "
+            "kernel": "in-frame SCA sampling call = msda_hm5_kernel<3, true> (balanced slices of the visibility plan, pairs only "
                       "one camera sees stored straight into the output) + sca_camera_reduce_kernel<6, true> (the other "
                       "queries), on the value projection's planes",
             "what": "reference points of the 6-camera rig (%.1f %% of the (camera, query) pairs visible), N(0,1) px offsets"
@@ -440,16 +453,10 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
             "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters * rounds,
             "timing": "HIP-graph replay", "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None, "traffic_src": None}
-        try:   # fabric bytes of the two kernels from the newest committed PMC passes (FETCH doubled: gfx950 correction)
-            import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "sca_plan_pmc_fetch_write.json")))[-1]
-            pm = json.load(open(f))
-            tot = sum((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024 for k, v in pm.items()
-                      if isinstance(v, dict) and ("msda_hm5_kernel<3>" in k or "msda_hm5_kernel<2, 1024, 0, 3" in k
-                                                  or "sca_camera_reduce_kernel<6, true>" in k))   # (not its A/B partner <6, false>)
-            out["roofline_frame"]["traffic"], out["roofline_frame"]["traffic_src"] = int(tot), os.path.relpath(f, ROOT)
-        except Exception:
-            pass
+        # fabric bytes of the two kernels from the newest committed PMC passes (not the A/B partners <2, false> / <6, false>)
+        out["roofline_frame"]["traffic"], out["roofline_frame"]["traffic_src"] = pmc_kernels(
+            "sca_plan_pmc_fetch_write.json", "msda_hm5_kernel<3, true>", "msda_hm5_kernel<3>", "msda_hm5_kernel<2, 1024, 0, 3",
+            "sca_camera_reduce_kernel<6, true>")
         del feats, planes
     except Exception as exc:
         out["roofline_frame"] = {"error": repr(exc)[:200]}
@@ -469,6 +476,9 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
             "bound": "hbm", "bytes_per_launch": byt, "avg_launch_us": round(us, 2), "launches": iters * rounds,
             "timing": "HIP-graph replay", "achieved": round(byt / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}
+        # (the hot-path command's TSA launches: same kernel and shapes on the op-test generator's uniform points)
+        out["roofline_frame_tsa"]["traffic"], out["roofline_frame_tsa"]["traffic_src"] = pmc_kernels(
+            "rocprofv3_pmc_fetch_write_per_kernel.json", "msda_quad_kernel<__half, 1, 1> grid=2560000")
         del value, off_t, w_t
     except Exception as exc:
         out["roofline_frame_tsa"] = {"error": repr(exc)[:200]}
@@ -496,7 +506,7 @@ def frame_rooflines(bev, dev, iters=10, rounds=4):
         us = graph_us(fn, iters, rounds)
         flop = 2.0 * B * H * W * C * C * 9
         out["roofline_mfma"] = {
-            "kernel": "DCNv2 ResNet-101 stage 3, channels-last entry = dcn_glds_f16_kernel<4> (+ dcn_tail_finish_kernel)",
+            "kernel": "DCNv2 ResNet-101 stage 3, channels-last entry = dcn_glds_f16_kernel<4, 4> (+ dcn_tail_finish_kernel)",
             "bound": "mfma", "flop_per_launch": flop, "avg_launch_us": round(us, 2), "launches": iters * rounds,
             "timing": "HIP-graph replay",
             "achieved": round(flop / us / 1e6, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
