@@ -177,6 +177,9 @@ def _layer_norm(ops, norm, x):
 
 _OWN_ATTN = {"enabled": os.environ.get("BEVOPS_OWN_ATTN", "1") == "1"}   # A/B: decoder self-attention on csrc/attention.hip
 _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
+# The dense layers behind the backbone (the GEMMs that wrap the samplers, SURVEY.md 8a-5, the decoder, the heads) on the
+# hand-written kernels whatever the dispatch table measured: one kernel per layer with a block-index-only summation order.
+_OWN_ENCODER = {"enabled": os.environ.get("BEVOPS_OWN_ENCODER", "0") == "1"}
 
 
 def _dense_norm(ops, lin, x, residual, norm):
@@ -889,9 +892,21 @@ class BEVFormer(nn.Module):
         on the host (atan / sin / cos differ in the last ulp between host and device libraries;
         the host value is the reference's CPU path bit for bit).  `proj`: optional precomputed `project(lidar2img, ..., cams)`
         (callers that know the calibration to be constant; the frame loop does not: it changes every frame)."""
+        mlvl = self.extract_feat(image, cams)
+        if _OWN_ENCODER["enabled"] and image.is_cuda and image.dtype == torch.float16:
+            # everything behind the backbone on the hand-written GEMMs (fixed summation order): see _OWN_ENCODER
+            from .functions.linear import OWN_KERNELS
+            was, OWN_KERNELS["enabled"] = OWN_KERNELS["enabled"], True
+            try:
+                return self._transformer(mlvl, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams, gather, shift, proj)
+            finally:
+                OWN_KERNELS["enabled"] = was
+        return self._transformer(mlvl, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams, gather, shift, proj)
+
+    def _transformer(self, mlvl, image, prev_bev, use_prev_bev, can_bus, lidar2img, cams, gather, shift, proj):
+        """Everything behind the backbone + FPN: embeddings, encoder, decoder, heads."""
         dev, dtype = image.device, image.dtype
         image_shape = image.shape[-2:]
-        mlvl = self.extract_feat(image, cams)
         bev_h, bev_w, nq = self.bev_h, self.bev_w, self.bev_h * self.bev_w
         bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(1)           # [nq, 1, 256]
         pkey = (self.col_embed.weight._version, self.row_embed.weight._version, dtype, dev)

@@ -60,6 +60,19 @@ hipblasLtMatmulDesc_t make_desc(bool relu, const void *bias, bool has_bias) {
   return d;
 }
 
+// Algorithms that need a workspace are the library's split-K / stream-K builds: partial tiles meet in the workspace
+// in arrival order, and one of them (stage-1 conv3 of BEVFormer-small, 353 280 x 256 x 64 with identity rows) was
+// caught giving different last bits in 2 % of otherwise identical calls (tools/probes/backbone_determinism.py).  The
+// selection therefore keeps to workspace-free algorithms (BEVOPS_LINEAR_REPRO=0 lifts that); the lent workspace still
+// holds the numeric screen's flag.
+bool workspace_free_only() {
+  static const bool v = [] {
+    const char *e = getenv("BEVOPS_LINEAR_REPRO");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool relu, bool has_bias,
                size_t ws_bytes) {
   hipblasLtMatmulDesc_t desc = make_desc(relu, nullptr, has_bias);
@@ -74,7 +87,7 @@ bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool rel
     return false;
   hipblasLtMatmulPreference_t pref = nullptr;
   if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
-  const uint64_t wsb = ws_bytes;
+  const uint64_t wsb = workspace_free_only() ? 0 : ws_bytes;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb));
   hipblasLtMatmulHeuristicResult_t res[4];
   int n = 0;
@@ -82,7 +95,7 @@ bool make_plan(hipblasLtHandle_t h, Plan &p, long long M, int N, int K, bool rel
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS) return false;
   for (int i = 0; i < n; ++i)
-    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= ws_bytes) {
+    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= wsb) {
       p.algo = res[i].algo;
       p.ws = res[i].workspaceSize;
       p.ok = true;
@@ -136,7 +149,7 @@ void tune_plan(hipblasLtHandle_t h, Plan &p, hipblasLtMatmulDesc_t desc, const v
     size_t need = 0;
     if (hipblaslt_ext::matmulIsAlgoSupported(h, desc, &alpha, p.a, p.b, &beta, p.c, p.c, r.algo, need) ==
             HIPBLAS_STATUS_SUCCESS &&
-        need <= ws_bytes)
+        need <= ws_bytes && (need == 0 || !workspace_free_only()))
       cands.push_back(Cand{r.algo, need, 1e30f});
   }
   if (cands.empty()) return;

@@ -61,12 +61,13 @@ def linear_bias_act(x, weight, bias=None, residual=None, relu=False, out=None):
     if M == 0:
         return out.view(*x.shape[:-1], N)
     handle = _lib.load_library()
-    nbytes = handle.bevops_linear_workspace_size()
+    import os
+    nbytes = handle.bevops_linear_workspace_size() if os.environ.get("BEVOPS_LINEAR_WS", "1") != "0" else 0
     stream = _lib.current_stream_ptr(x.device)
-    ws = _workspace(x.device, nbytes, stream)
+    ws = _workspace(x.device, nbytes, stream) if nbytes else None
     args = (_lib.F16, x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-            r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K, int(bool(relu)), ws.data_ptr(),
-            nbytes, stream)
+            r2.data_ptr() if r2 is not None else None, out.data_ptr(), M, N, K, int(bool(relu)),
+            ws.data_ptr() if ws is not None else None, nbytes, stream)
     with torch.cuda.device(x.device):
         key = (str(x.device), M, N, K, bool(relu), bias is not None, r2 is not None)
         if key not in _TUNED and not torch.cuda.is_current_stream_capturing():
@@ -345,13 +346,17 @@ class _PerThreadFlag:
 
 
 DETERMINISTIC = _PerThreadFlag()
+# The hand-written kernels only, the FASTEST of them per problem by the shipped table's own measurements (the rule of
+# DETERMINISTIC for a problem the table has not seen): what the model runs behind its backbone (bevformer.py:
+# _OWN_ENCODER) -- one kernel per layer, summation order a function of the block index, same choice in every process.
+OWN_KERNELS = _PerThreadFlag()
 
 
 # Shipped choices (bevformer_tensorrt_amd/dispatch_gfx950.json, written by tools/dump_dispatch.py from one MI355X's
 # measurements): a problem found there takes its recorded winner WITHOUT a measurement, so the kernel that runs is the
 # same on every box and in every process; only problems the table has never seen are timed (BEVOPS_DENSE_TUNE=1: time
 # everything, i.e. regenerate; =0: no table, no timing -- the reproducible defaults).
-_TABLE = {"loaded": False, "dense": {}, "conv": {}}
+_TABLE = {"loaded": False, "dense": {}, "conv": {}, "measured_dense": {}}
 
 
 def _table():
@@ -364,6 +369,7 @@ def _table():
             try:
                 t = json.load(open(path))
                 _TABLE["dense"], _TABLE["conv"] = t.get("dense", {}), t.get("conv", {})
+                _TABLE["measured_dense"] = t.get("measured_us", {}).get("dense", {})
             except (OSError, ValueError):
                 pass
     return _TABLE
@@ -386,6 +392,12 @@ def _dense_deterministic(N, K, M=1 << 30):
     return "tsgemm" if (N % 256 == 0 and K % 64 == 0 and K >= 256) else "tile"
 
 
+def _dense_own(key, N, K, M):
+    times = _table()["measured_dense"].get(_problem(key), {})
+    own = {k: v for k, v in times.items() if k in ("tile", "tsgemm", "small") and k in _DENSE}
+    return min(own, key=own.get) if own else _dense_deterministic(N, K, M)
+
+
 def _dense_default(N, K, has_res):
     """Choice without a measurement (inside stream capture before the problem was seen, or BEVOPS_DENSE_TUNE=0)."""
     if N == 256 and K % 64 == 0 and K >= 256:
@@ -406,7 +418,12 @@ def dense_auto(x, weight, bias=None, residual=None, relu=False):
     if M == 0:          # a rank of the camera-sharded path that owns no camera
         return x.new_empty((*x.shape[:-1], N))
     key = (str(x.device), M, N, K, bool(relu), bias is not None, residual is not None)
-    name = _dense_deterministic(N, K, M) if (DETERMINISTIC["enabled"] and K % 8 == 0) else _DENSE_CHOICE.get(key)
+    if DETERMINISTIC["enabled"] and K % 8 == 0:
+        name = _dense_deterministic(N, K, M)
+    elif OWN_KERNELS["enabled"] and K % 8 == 0:
+        name = _dense_own(key, N, K, M)
+    else:
+        name = _DENSE_CHOICE.get(key)
     if name is None:
         name = _table()["dense"].get(_problem(key))
         if name is not None and name in _DENSE:

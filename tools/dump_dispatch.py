@@ -55,6 +55,11 @@ table = {"dense": {L._problem(k): v for k, v in L._DENSE_CHOICE.items()},
          "conv": {L._problem(k): v for k, v in CV._CHOICE.items()},
          "measured_us": {"dense": {L._problem(k): t for k, t in L.DENSE_LOG}, "conv": {L._problem(k): t for k, t in CV.CONV_LOG}},
          "device": torch.cuda.get_device_name(0)}
+# The library convolution (MIOpen's implicit GEMM with a split reduction) does not keep one summation order from run to
+# run; the hand-written implicit GEMM does.  Where the two are within 5 % the table takes the reproducible one.
+for k, t in table["measured_us"]["conv"].items():
+    if table["conv"].get(k) == "library" and "tile" in t and t["tile"] <= 1.05 * t["library"]:
+        table["conv"][k] = "tile"
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "bevformer_tensorrt_amd", "dispatch_gfx950.json")
 json.dump(table, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps({"dense_problems": len(table["dense"]), "conv_problems": len(table["conv"]), "out": out}))
