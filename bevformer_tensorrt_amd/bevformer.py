@@ -179,7 +179,7 @@ _OWN_ATTN = {"enabled": os.environ.get("BEVOPS_OWN_ATTN", "1") == "1"}   # A/B: 
 _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
 # The dense layers behind the backbone (the GEMMs that wrap the samplers, SURVEY.md 8a-5, the decoder, the heads) on the
 # hand-written kernels whatever the dispatch table measured: one kernel per layer with a block-index-only summation order.
-_OWN_ENCODER = {"enabled": os.environ.get("BEVOPS_OWN_ENCODER", "0") == "1"}
+_OWN_ENCODER = {"enabled": os.environ.get("BEVOPS_OWN_ENCODER", "1") == "1"}
 
 
 def _dense_norm(ops, lin, x, residual, norm):

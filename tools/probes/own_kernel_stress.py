@@ -19,9 +19,13 @@ ap.add_argument("--model", default="small")
 a = ap.parse_args()
 g = torch.Generator().manual_seed(0)
 dev = torch.device("cuda")
-for M in (22500, 40000):
-    for N, K, res, relu in ((512, 256, False, True), (256, 256, False, False), (192, 256, False, False), (256, 256, True, False),
-                            (256, 512, True, False)):
+SHAPES = [(M, N, K, res, relu) for M in (22500, 40000)
+          for N, K, res, relu in ((512, 256, False, True), (256, 256, False, False), (192, 256, False, False),
+                                  (256, 256, True, False), (256, 512, True, False))]
+SHAPES += [(5520, 256, 256, False, False), (22500, 128, 256, False, False), (22500, 64, 256, False, False),   # small's SCA
+           (45000, 256, 256, False, False), (900, 256, 256, True, False), (900, 768, 256, True, False)]
+for M, N, K, res, relu in SHAPES:
+    if True:
         x = torch.randn(M, K, generator=g).half().to(dev)
         w = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
         b = torch.randn(N, generator=g).half().to(dev)
@@ -55,6 +59,45 @@ log = []
 for mod_name, mod in model.named_modules():
     if mod_name and type(mod).__module__.startswith("bevformer_tensorrt_amd"):
         mod.register_forward_hook(lambda m, i, o, n=mod_name: log.append((n, o.detach().clone())) if torch.is_tensor(o) else None)
+# (the backbone's blocks run through forward_nhwc, which hooks do not see: record what encoder.0.sca is handed)
+def _pre(m, args):
+    for i, t in enumerate(args[:4]):
+        if torch.is_tensor(t):
+            log.append(("encoder.0.sca.input%d" % i, t.detach().clone()))
+
+
+model.encoder[0].sca.register_forward_pre_hook(_pre)
+def _stages(x, ops, _bb=model.backbone):
+    outs = []
+    for i, st in enumerate(_bb.stages):
+        for j, blk in enumerate(st):
+            DETAIL["on"] = STAGE_DETAIL == i
+            DETAIL["tag"] = "stage%d.block%d" % (i, j)
+            x = blk.forward_nhwc(x, ops)
+            DETAIL["on"] = False
+        log.append(("stage%d" % i, x.detach().clone()))
+        if i in _bb.out_indices:
+            outs.append(x)
+    return outs
+
+
+STAGE_DETAIL = int(os.environ.get("STAGE_DETAIL", "-1"))
+DETAIL = {"on": False, "tag": "", "n": 0}
+
+
+def _wrap(fn, kind):
+    def inner(*x, **k):
+        y = fn(*x, **k)
+        if DETAIL["on"]:
+            log.append(("%s.%s%s" % (DETAIL["tag"], kind, tuple(y.shape[1:])), y.detach().clone()))
+        return y
+    return inner
+
+
+B._conv1x1_nhwc, B._conv_nhwc = _wrap(B._conv1x1_nhwc, "conv1x1"), _wrap(B._conv_nhwc, "conv")
+model.backbone._stages_nhwc = _stages
+_feat = model.extract_feat
+model.extract_feat = lambda *x, **k: [log.append(("extract_feat.level%d" % i, t.detach().clone())) or t for i, t in enumerate(_feat(*x, **k))]
 with torch.no_grad():
     ref = None
     for f in range(a.frames):
