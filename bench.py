@@ -922,6 +922,10 @@ def main():
                                  "every frame (the metric excludes H2D, det2trt/utils/tensorrt.py:69-80); can_bus and "
                                  "lidar2img: fresh values every frame (one 464-byte upload), the camera projection and the "
                                  "SCA visibility plan evaluated from them inside the frame's graph" if headline else None,
+                       "dense_dispatch": ("backbone: shipped table (library GEMMs where they measured faster, workspace-free "
+                                          "algorithms only); behind the backbone: hand-written kernels only; frames are "
+                                          "bit-reproducible run to run") if headline and not sharded else
+                                         ("hand-written kernels only (every rank the same choice)" if headline else None),
                        "hip_graph": headline["hip_graph"] if headline else None,
                        "int8_build": headline["note"] if headline else None,
                        # (the stand-alone hot path has no query-sharded encoder: "scatter" runs its all-reduce form there)

@@ -180,6 +180,8 @@ _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: 
 # The dense layers behind the backbone (the GEMMs that wrap the samplers, SURVEY.md 8a-5, the decoder, the heads) on the
 # hand-written kernels whatever the dispatch table measured: one kernel per layer with a block-index-only summation order.
 _OWN_ENCODER = {"enabled": os.environ.get("BEVOPS_OWN_ENCODER", "1") == "1"}
+# camera-sharded runners: backbone on the measured dispatch (needs _OWN_ENCODER for the replicated layers)
+_SHARDED_TABLE_BACKBONE = {"enabled": _OWN_ENCODER["enabled"] and os.environ.get("BEVOPS_SHARDED_RULE_DISPATCH", "0") != "1"}
 
 
 def _dense_norm(ops, lin, x, residual, norm):
@@ -1131,9 +1133,13 @@ class FrameRunner:
         return self._graphs.get(self._use, (None, None))[0]
 
     def _forward(self):
-        if self.gather is not None and self.device.type == "cuda":
-            # camera-sharded: every rank must evaluate the replicated layers with the same kernels, so the measured
-            # per-process dispatch (functions/linear.py) is off for the duration of this runner's forwards
+        if self.gather is not None and self.device.type == "cuda" and not _SHARDED_TABLE_BACKBONE["enabled"]:
+            # camera-sharded: every rank must evaluate the REPLICATED layers (TSA, FFN, decoder, heads) with the same
+            # kernels.  With _OWN_ENCODER those layers -- everything behind the backbone -- already run on the
+            # hand-written kernels, chosen by the shipped table (the same file on every rank) or, for a row count
+            # the table has not seen, by a rule of the shape alone; the backbone is per-camera work no other rank
+            # repeats and keeps the measured dispatch.  Without _OWN_ENCODER (or BEVOPS_SHARDED_RULE_DISPATCH=1, the
+            # behaviour of rounds 3-5, 6-9 % slower) the rule-based dispatch is on for the whole forward.
             from .functions.linear import DETERMINISTIC
             prev, DETERMINISTIC["enabled"] = DETERMINISTIC["enabled"], True
             try:
