@@ -57,6 +57,32 @@ def conv_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
     return out
 
 
+def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1):
+    """The 3x3 / stride 1 / pad 1 convolution of a 64 -> 64-channel layer with both operands in LDS
+    (bevops_conv3x3_c64_f16, csrc/conv_halo.hip): x [B, 64, H, W] channels-last fp16, weight [64, 64, 3, 3] ->
+    act(conv2d(x, weight, 1, 1) + bias), bit-identical to conv_nhwc.  Raises BevopsError(NOT_SUPPORTED) for any other
+    layer (channel counts, a stride, identity rows)."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if residual is not None or stride != 1 or tuple(weight.shape[1:]) != (Cin, 3, 3):
+        raise _lib.BevopsError("bevops_conv3x3_c64_f16: 3x3 / stride 1 layers without identity rows only", _lib.NOT_SUPPORTED)
+    wt = pack_taps(weight)
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    if B == 0:
+        return out
+    handle = _lib.load_library()
+    with torch.cuda.device(x.device):
+        st = handle.bevops_conv3x3_c64_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           out.data_ptr(), B, H, W, Cin, Cout, int(bool(relu)),
+                                           _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_conv3x3_c64_f16")
+    return out
+
+
 def conv_int8_nhwc(x, scale_a, w_q_taps, scale_w, bias=None, relu=False, residual=None, stride=1):
     """The INT8 flavour (bevops_conv_tile_int8_fused): x [B, Cin, H, W] channels-last fp16, quantised with scale_a
     inside the kernel; w_q_taps [Cout, k, k, Cin] int8 (taps-major), scale_w a float or an fp32 [Cout] tensor; bias

@@ -435,6 +435,13 @@ int bevops_tile_gemm_f16(const void *x, const void *weight, const void *bias, co
 int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bias, const void *residual,
                          void *out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                          void *stream);
+/* The 3x3 / stride 1 / pad 1 convolution of a 64-channel layer (conv2 of the ResNet stage-1 bottlenecks,
+ * det2trt/models/backbones/resnet.py:106-260) with BOTH operands in LDS: the 64 x 576 weight matrix resident per
+ * persistent block, 16 x 16-pixel output tiles whose 18 x 18 input pixels are staged once (a tap is an LDS address
+ * offset).  Same operands and layouts as bevops_conv_tile_f16 (no identity rows); results bit-identical to it.
+ * NOT_SUPPORTED unless Cin == Cout == 64. */
+int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H, int W,
+                           int Cin, int Cout, int relu, void *stream);
 /* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
  * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
  * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */
