@@ -16,9 +16,12 @@
 //   * k runs [tap][channel] with the same 16-value MFMA steps as tile_gemm's implicit GEMM and the epilogue is the
 //     same arithmetic (fp32 sum + bias, ReLU, one rounding): the results are BIT-IDENTICAL to bevops_conv_tile_f16
 //     (tests/test_conv_halo_gpu.py), so the dispatch may switch between the two freely;
-//   * the tile's outputs go through LDS once more so that a pixel's 128 bytes leave as eight 16-byte stores of
-//     neighbouring lanes.
+//   * the tile's outputs go through an LDS staging region of their own so that a pixel's 128 bytes leave as eight
+//     16-byte stores of neighbouring lanes -- fire and forget: the wait for the next tile's loads comes a whole tile
+//     later (loads and stores share one counter here; sharing the staging region with the input pixels made every
+//     tile wait out a store round trip: 66 against 36 us per launch).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -32,34 +35,41 @@ constexpr int kHC = 64;                          // channels in = channels out
 constexpr int kHT = 16;                          // output tile: 16 x 16 pixels
 constexpr int kHH = kHT + 2;                     // staged input rows / columns
 constexpr int kHPix = kHC * 2 + 16;              // LDS bytes per staged pixel (128 + 16)
+constexpr int kHRow = kHH * kHPix + 224;         // LDS bytes per staged pixel ROW: 2 816 = 0 mod 256, so that the 16 lanes of
+                                                 // a fragment read that sit on the next tile row continue the bank sequence
 constexpr int kHWRow = 9 * kHC * 2 + 16;         // LDS bytes per weight row (1 152 + 16)
 constexpr int kHWBytes = kHC * kHWRow;           // 74 752
-constexpr int kHXBytes = kHH * kHH * kHPix;      // 46 656
-constexpr int kHLds = kHWBytes + kHXBytes;       // 121 408
-constexpr int kHThreads = 256;
+constexpr int kHXBytes = kHH * kHRow;            // 50 688
+constexpr int kHYBytes = kHT * kHT * kHPix;      // output staging: 36 864
+constexpr int kHLds = kHWBytes + kHXBytes + kHYBytes;   // 162 304 of the CU's 163 840
+constexpr int kHThreads = 512;                   // waves 0-3 multiply, waves 4-7 move data
+constexpr int kHRole = 256;
 constexpr int kHChunks = kHH * kHH * 8;          // 16-byte chunks of a staged tile: 2 592
-constexpr int kHRounds = (kHChunks + kHThreads - 1) / kHThreads;   // 11
+constexpr int kHRounds = (kHChunks + kHRole - 1) / kHRole;   // 11
 
-__global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(const __half *__restrict__ x,
+template <bool PROBE>
+__global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned long long *__restrict__ stamps,
+                                                                     const __half *__restrict__ x,
                                                                      const __half *__restrict__ w,
                                                                      const __half *__restrict__ bias,
                                                                      __half *__restrict__ out, int H, int W, int relu,
-                                                                     int tiles_x, int tiles_img, int tiles_total) {
+                                                                     int tiles_x, int tiles_img, int tiles_total,
+                                                                     unsigned x_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Ws = smem, *Xs = smem + kHWBytes;
+  char *Ws = smem, *Xs = smem + kHWBytes, *Ys = Xs + kHXBytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  // ---- weights [64][576] -> LDS, once
-  for (int i = tid; i < kHC * 72; i += kHThreads) {
-    const int row = i / 72, c = i - row * 72;
-    *reinterpret_cast<uint4 *>(Ws + row * kHWRow + c * 16) = reinterpret_cast<const uint4 *>(w)[i];
-  }
-  // ---- this thread's chunks of a staged tile: chunk q = tid + 256 r -> (staged pixel q >> 3, 16-byte piece q & 7)
-  int hyx[kHRounds];
+  const bool mover = wave >= 4;
+  const int rt = tid & (kHRole - 1), cw = wave & 3;      // thread index inside its role, multiply-wave index
+  // ---- weights [64][576] -> LDS, once (all eight waves)
+  {
+    uint4 wr[kHC * 72 / kHThreads];      // 9 loads in flight, then 9 LDS writes (a rolled loop pays one round trip each)
 #pragma unroll
-  for (int r = 0; r < kHRounds; ++r) {
-    const int q = tid + kHThreads * r, pix = q >> 3;
-    const int hy = pix / kHH;
-    hyx[r] = q < kHChunks ? ((hy << 8) | (pix - hy * kHH)) : -1;
+    for (int r = 0; r < kHC * 72 / kHThreads; ++r) wr[r] = reinterpret_cast<const uint4 *>(w)[tid + kHThreads * r];
+#pragma unroll
+    for (int r = 0; r < kHC * 72 / kHThreads; ++r) {
+      const int i = tid + kHThreads * r, row = i / 72, c = i - row * 72;
+      *reinterpret_cast<uint4 *>(Ws + row * kHWRow + c * 16) = wr[r];
+    }
   }
   auto tile_origin = [&](int t, int &b, int &ty0, int &tx0) {
     b = t / tiles_img;
@@ -68,108 +78,189 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(const __hal
     ty0 = ty * kHT;
     tx0 = (rem - ty * tiles_x) * kHT;
   };
-  uint4 pre[kHRounds];
-  auto load_tile = [&](int t) {
-    int b, ty0, tx0;
-    tile_origin(t, b, ty0, tx0);
-#pragma unroll
-    for (int r = 0; r < kHRounds; ++r) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (hyx[r] >= 0) {
-        const int y = ty0 + (hyx[r] >> 8) - 1, xx = tx0 + (hyx[r] & 255) - 1;
-        if (y >= 0 && y < H && xx >= 0 && xx < W)
-          v = *reinterpret_cast<const uint4 *>(x + (((size_t)b * H + y) * W + xx) * kHC + (tid & 7) * 8);
-      }
-      pre[r] = v;
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = PROBE ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long tstart = t0;
+  auto stamp = [&](int k) {
+    if constexpr (PROBE) {
+      const unsigned long long n = __builtin_amdgcn_s_memtime();
+      ph[k] += n - t0;
+      t0 = n;
     }
   };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int r = 0; r < kHRounds; ++r)
-      if (hyx[r] >= 0) {
-        const int q = tid + kHThreads * r;
-        *reinterpret_cast<uint4 *>(Xs + (q >> 3) * kHPix + (q & 7) * 16) = pre[r];
-      }
-  };
-  // fragment bases: operand A = weight rows (output channel 32 i + l31), operand B = pixels (j: rows 4 w + 2 j + (l31 >> 4))
-  const char *wa[2], *xb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) wa[i] = Ws + (32 * i + l31) * kHWRow + 16 * hi;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) xb[j] = Xs + ((4 * wave + 2 * j + (l31 >> 4)) * kHH + (l31 & 15)) * kHPix + 16 * hi;
-  // acc[i][j][4 g + e]: channel 32 i + 8 g + 4 hi + e of pixel (row 4 w + 2 j + (l31 >> 4), column l31 & 15)
-  float bcol[2][16];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bcol[i][4 * g + e] = bias ? __half2float(bias[32 * i + 8 * g + 4 * hi + e]) : 0.f;
-
   int t = blockIdx.x;
   if (t >= tiles_total) return;
-  load_tile(t);
-  store_tile();
-  __syncthreads();
-  for (; t < tiles_total; t += gridDim.x) {
-    const int tn = t + gridDim.x;
-    if (tn < tiles_total) load_tile(tn);      // in flight while this tile is multiplied
-    f32x16_t acc[2][2];
+
+  if (mover) {
+    // ================= waves 4-7: the tile's pixels in, the tile's outputs out
+    // chunk q = rt + 256 r of a staged tile -> (staged pixel q >> 3, 16-byte piece q & 7)
+    int hyx[kHRounds];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int xoff = ((tap / 3) * kHH + (tap % 3)) * kHPix;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        f16x8_t a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f16x8_t *>(wa[i] + tap * (kHC * 2) + kk * 32);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8_t *>(xb[j] + xoff + kk * 32);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+    for (int r = 0; r < kHRounds; ++r) {
+      const int q = rt + kHRole * r, pix = q >> 3;
+      const int hy = pix / kHH;
+      hyx[r] = q < kHChunks ? ((hy << 8) | (pix - hy * kHH)) : -1;
     }
-    __syncthreads();      // everybody is done with the staged pixels: their LDS now stages the outputs
+    // two register sets: the pixels of tile t + 1 wait in one for the multiply to let go of the staged tile while
+    // the loads of tile t + 2 are already in flight in the other -- the memory pipe never idles across the barriers
+    uint4 pre[2][kHRounds];
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(x), 0, x_bytes, 0x00020000);
+    auto load_tile = [&](int tt, auto setc) __attribute__((always_inline)) {
+      constexpr int S = decltype(setc)::value;
+      int b, ty0, tx0;
+      tile_origin(tt, b, ty0, tx0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      char *row = Xs + ((4 * wave + 2 * j + (l31 >> 4)) * kHT + (l31 & 15)) * kHPix;
+      for (int r = 0; r < kHRounds; ++r) {
+        // (a buffer load: a pixel outside the image -- the zero padding -- gets the beyond-the-buffer offset and reads
+        // as zero; no branch, so the wait in front of land_tile counts exactly THIS set's loads)
+        const int y = ty0 + (hyx[r] >> 8) - 1, xx = tx0 + (hyx[r] & 255) - 1;
+        const bool in = hyx[r] >= 0 && y >= 0 && y < H && xx >= 0 && xx < W;
+        const unsigned off = in ? (unsigned)(((((size_t)b * H + y) * W + xx) * kHC + (rt & 7) * 8) * 2) : 0xFFFFFF00u;
+        pre[S][r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+      }
+    };
+    auto land_tile = [&](auto setc) __attribute__((always_inline)) {
+      constexpr int S = decltype(setc)::value;
+#pragma unroll
+      for (int r = 0; r < kHRounds; ++r)
+        if (hyx[r] >= 0)
+          *reinterpret_cast<uint4 *>(Xs + (hyx[r] >> 8) * kHRow + (hyx[r] & 255) * kHPix + (rt & 7) * 16) = pre[S][r];
+    };
+    auto store_outputs = [&](int tt) {
+      int b, ty0, tx0;
+      tile_origin(tt, b, ty0, tx0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int q = rt + kHRole * r, p = q >> 3;
+        const int y = ty0 + (p >> 4), xx = tx0 + (p & 15);
+        if (y < H && xx < W)
+          *reinterpret_cast<uint4 *>(out + (((size_t)b * H + y) * W + xx) * kHC + (q & 7) * 8) =
+              *reinterpret_cast<const uint4 *>(Ys + p * kHPix + (q & 7) * 16);
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int g = (int)gridDim.x;
+    load_tile(t, S0{});
+    land_tile(S0{});
+    if (t + g < tiles_total) load_tile(t + g, S1{});
+    __syncthreads();
+    int prev = -1;
+    // one iteration: tile t is being multiplied, tile t + g waits in set N1, tile t + 2 g is requested into set N2
+    auto iteration = [&](auto n1, auto n2) __attribute__((always_inline)) {
+      if (prev >= 0) store_outputs(prev);        // (staged behind barrier B of the previous iteration)
+      stamp(0);
+      if (t + 2 * g < tiles_total) load_tile(t + 2 * g, n2);   // the memory pipe's back-pressure stalls THESE waves
+      stamp(1);
+      __syncthreads();      // A: the multiply is done with the staged pixels
+      stamp(2);
+      if (t + g < tiles_total) land_tile(n1);
+      stamp(3);
+      __syncthreads();      // B: next pixels and this tile's staged outputs are visible
+      stamp(4);
+      prev = t;
+      t += g;
+    };
+    while (t < tiles_total) {
+      iteration(S1{}, S0{});
+      if (t >= tiles_total) break;
+      iteration(S0{}, S1{});
+    }
+    store_outputs(prev);
+  } else {
+    // ================= waves 0-3: the multiply.  Wave cw owns tile rows 4 cw .. 4 cw + 3, all 64 output channels
+    // fragment bases: operand A = weight rows (output channel 32 i + l31), operand B = pixels (j: row 4 cw + 2 j + (l31 >> 4))
+    const char *wa[2], *xb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wa[i] = Ws + (32 * i + l31) * kHWRow + 16 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xb[j] = Xs + (4 * cw + 2 * j + (l31 >> 4)) * kHRow + (l31 & 15) * kHPix + 16 * hi;
+    // acc[i][j][4 g + e]: channel 32 i + 8 g + 4 hi + e of pixel (row 4 cw + 2 j + (l31 >> 4), column l31 & 15)
+    float bcol[2][16];
+    {
+      uint2 braw[2][4];      // (eight independent 8-byte loads: scalar element loads are serialised by the compiler)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          braw[i][g] = bias ? *reinterpret_cast<const uint2 *>(bias + 32 * i + 8 * g + 4 * hi) : make_uint2(0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[i][j][4 * g + e] + bcol[i][4 * g + e];
-            if (relu) v[e] = fmaxf(v[e], 0.f);
-          }
-          *reinterpret_cast<uint2 *>(row + (32 * i + 8 * g + 4 * hi) * 2) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
+          bcol[i][4 * g] = h2f_lo(braw[i][g].x);
+          bcol[i][4 * g + 1] = h2f_hi(braw[i][g].x);
+          bcol[i][4 * g + 2] = h2f_lo(braw[i][g].y);
+          bcol[i][4 * g + 3] = h2f_hi(braw[i][g].y);
         }
     }
     __syncthreads();
-    {
-      int b, ty0, tx0;
-      tile_origin(t, b, ty0, tx0);
+    __builtin_amdgcn_s_setprio(3);      // the matrix instructions go first; the movers' issue slots are what is left
+    for (; t < tiles_total; t += gridDim.x) {
+      f32x16_t acc[2][2];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int q = tid + kHThreads * r, p = q >> 3;
-        const int y = ty0 + (p >> 4), xx = tx0 + (p & 15);
-        if (y < H && xx < W)
-          *reinterpret_cast<uint4 *>(out + (((size_t)b * H + y) * W + xx) * kHC + (q & 7) * 8) =
-              *reinterpret_cast<const uint4 *>(Xs + p * kHPix + (q & 7) * 16);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      stamp(0);
+      // 36 k-substeps (tap = s / 4, 16 channels each), operand fragments requested TWO substeps ahead of their
+      // matrix instructions: one substep of cover (4 instructions = 128 cycles) leaves the LDS latency exposed
+      f16x8_t fa[3][2], fb[3][2];
+      auto fetch = [&](int sidx, int slot) __attribute__((always_inline)) {
+        const int tap = sidx >> 2, kk = sidx & 3;
+        const int xoff = (tap / 3) * kHRow + (tap % 3) * kHPix;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const f16x8_t *>(wa[i] + tap * (kHC * 2) + kk * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[slot][j] = *reinterpret_cast<const f16x8_t *>(xb[j] + xoff + kk * 32);
+      };
+      fetch(0, 0);
+      fetch(1, 1);
+#pragma unroll
+      for (int sidx = 0; sidx < 36; ++sidx) {
+        if (sidx + 2 < 36) fetch(sidx + 2, (sidx + 2) % 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sidx % 3][i], fb[sidx % 3][j], acc[i][j], 0, 0, 0);
+        // (keep that order in the schedule: the four fragment reads of substep s + 2, then the four matrix instructions of s)
+        if (sidx + 2 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
+      stamp(1);
+      __syncthreads();      // A
+      stamp(2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        char *row = Ys + ((4 * cw + 2 * j + (l31 >> 4)) * kHT + (l31 & 15)) * kHPix;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[i][j][4 * g + e] + bcol[i][4 * g + e];
+              if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<uint2 *>(row + (32 * i + 8 * g + 4 * hi) * 2) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
+          }
+      }
+      stamp(3);
+      __syncthreads();      // B
+      stamp(4);
     }
-    __syncthreads();      // the staged outputs are read: the next tile's pixels may land
-    if (tn < tiles_total) store_tile();
-    __syncthreads();
+  }
+  if constexpr (PROBE) {
+    if (lane == 0) {
+      unsigned long long *o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 6; ++k) o[k] = ph[k];
+      o[6] = tstart;
+      o[7] = __builtin_amdgcn_s_memtime();
+    }
   }
 }
 
@@ -196,16 +287,30 @@ extern "C" int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, co
                                       int W, int Cin, int Cout, int relu, void *stream) {
   if (!x || !weight_taps || !out || B <= 0 || H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
   if (Cin != kHC || Cout != kHC) return BEVOPS_NOT_SUPPORTED;
-  if (!aligned16(x) || !aligned16(weight_taps) || !aligned16(out)) return BEVOPS_BAD_PARAM;
-  if ((long long)B * H * W * kHC * 2 >= (1ll << 40)) return BEVOPS_NOT_SUPPORTED;
+  if (!aligned16(x) || !aligned16(weight_taps) || !aligned16(out) || (reinterpret_cast<uintptr_t>(bias) & 7u))
+    return BEVOPS_BAD_PARAM;
+  if ((long long)B * H * W * kHC * 2 >= 0xFFFFFF00ll) return BEVOPS_NOT_SUPPORTED;     // (32-bit buffer offsets)
   const int tiles_x = (W + kHT - 1) / kHT, tiles_y = (H + kHT - 1) / kHT;
   const long long total = (long long)B * tiles_x * tiles_y;
   if (total > (1ll << 30)) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel>(kHLds)) return BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel<false>>(kHLds)) return BEVOPS_FAILURE;
   const int blocks = (int)std::min<long long>(total, (long long)halo_cu_count());
-  hipLaunchKernelGGL(conv3x3_c64_halo_kernel, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
-                     static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
+  hipLaunchKernelGGL(conv3x3_c64_halo_kernel<false>, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
+                     (unsigned long long *)nullptr, static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
                      static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
-                     (int)total);
+                     (int)total, (unsigned)((size_t)B * H * W * kHC * 2));
+  return launch_status();
+}
+
+extern "C" int bevops_conv3x3_c64_probe(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H,
+                                        int W, int relu, void *stamps, void *stream) {
+  const int tiles_x = (W + kHT - 1) / kHT, tiles_y = (H + kHT - 1) / kHT;
+  const long long total = (long long)B * tiles_x * tiles_y;
+  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel<true>>(kHLds)) return BEVOPS_FAILURE;
+  const int blocks = (int)std::min<long long>(total, (long long)halo_cu_count());
+  hipLaunchKernelGGL(conv3x3_c64_halo_kernel<true>, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
+                     static_cast<unsigned long long *>(stamps), static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
+                     static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
+                     (int)total, (unsigned)((size_t)B * H * W * kHC * 2));
   return launch_status();
 }
