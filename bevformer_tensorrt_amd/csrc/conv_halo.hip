@@ -2,24 +2,29 @@
 // 232 x 400 maps of six cameras; det2trt/models/backbones/resnet.py:106-260) as an implicit GEMM whose operands BOTH
 // live in LDS.  Not a reference plugin (TensorRT owns the layer there).
 //
-// Why a kernel of its own.  As a row of tile_gemm.hip's implicit GEMM the layer takes 87 us for 41 GFLOP and 142 MB:
+// Why a kernel of its own.  As a row of tile_gemm.hip's implicit GEMM the layer takes 88 us for 41 GFLOP and 142 MB:
 // with 64 channels a pixel is ONE 128-byte line, every one of the nine taps fetches it again from L1 / L2 (1.06 GB
 // through the L2 -> L1 path per launch, profiles/r05/frame_pmc_fp16.txt), and K = 576 is nine short k-steps whose
-// latency nothing covers.  Here
+// latency nothing covers.  Here (47 us at the same shape, profiles/r06/conv_halo_time.jsonl)
 //   * the whole weight matrix (64 x 576 fp16 = 72 KB) is loaded into LDS ONCE per (persistent) block;
 //   * a block walks 16 x 16-pixel output tiles; the tile's 18 x 18 input pixels (with the zero padding of the image
-//     border) are staged in LDS once -- 1.27 x the unique bytes instead of 9 x -- and the next tile's pixels are
-//     already in flight (registers) while this one is multiplied;
-//   * a tap is then an LDS address offset: wave w owns pixel rows 4 w .. 4 w + 3 of the tile and all 64 output
-//     channels -- 2 x 2 v_mfma_f32_32x32x16_f16 blocks, four operand fragments (16-byte LDS reads, rows padded to
-//     144 / 1 168 bytes: conflict-free) per four matrix instructions, 36 k-substeps fully unrolled;
+//     border) are staged in LDS once -- 1.27 x the unique bytes instead of 9 x; a tap is then an LDS address offset;
+//   * EIGHT waves in two roles.  Waves 0-3 multiply: wave w owns tile rows 4 w .. 4 w + 3 and all 64 output channels
+//     -- 2 x 2 v_mfma_f32_32x32x16_f16 blocks, four operand fragments (16-byte LDS reads; pixel rows padded to 144,
+//     tile rows to 2 816, weight rows to 1 168 bytes: conflict-free for the instruction's lane groups) per four
+//     matrix instructions, 36 k-substeps unrolled with the fragments requested two substeps ahead.  Waves 4-7 move
+//     data: the pixels of tile t + 1 wait in one register set for the multiply to let go of the staged tile while the
+//     loads of tile t + 2 are already in flight in a second set, and the outputs of tile t - 1 leave from an LDS
+//     staging region of their own.  The first build had every wave do both: a wave that issues 11 loads + 8 stores
+//     per tile into a memory pipe that accepts ~11 bytes per clock and CU stalls AT ISSUE for about as long as the
+//     multiply takes, and nothing overlapped (66 us; s_memtime phase stamps: profiles/r06/conv_halo_phase_probe.json
+//     is the last probe build -- multiply 5.1 k cycles per tile, movers 6.5 k at the pipe's rate, output staging 2.2 k);
 //   * k runs [tap][channel] with the same 16-value MFMA steps as tile_gemm's implicit GEMM and the epilogue is the
 //     same arithmetic (fp32 sum + bias, ReLU, one rounding): the results are BIT-IDENTICAL to bevops_conv_tile_f16
-//     (tests/test_conv_halo_gpu.py), so the dispatch may switch between the two freely;
-//   * the tile's outputs go through an LDS staging region of their own so that a pixel's 128 bytes leave as eight
-//     16-byte stores of neighbouring lanes -- fire and forget: the wait for the next tile's loads comes a whole tile
-//     later (loads and stores share one counter here; sharing the staging region with the input pixels made every
-//     tile wait out a store round trip: 66 against 36 us per launch).
+//     (tests/test_conv_halo_gpu.py), so the dispatch may switch between the two freely.
+// What bounds it now: 73.5 KB of loads + stores per tile at the per-CU memory rate is 6.5 k cycles, the multiply +
+// output staging 7.3 k, and the two barriers per tile keep the roles from overlapping perfectly (LDS is full: 162 KB;
+// no room for a second pixel or output buffer).
 #include <algorithm>
 #include <type_traits>
 
@@ -47,9 +52,7 @@ constexpr int kHRole = 256;
 constexpr int kHChunks = kHH * kHH * 8;          // 16-byte chunks of a staged tile: 2 592
 constexpr int kHRounds = (kHChunks + kHRole - 1) / kHRole;   // 11
 
-template <bool PROBE>
-__global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned long long *__restrict__ stamps,
-                                                                     const __half *__restrict__ x,
+__global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(const __half *__restrict__ x,
                                                                      const __half *__restrict__ w,
                                                                      const __half *__restrict__ bias,
                                                                      __half *__restrict__ out, int H, int W, int relu,
@@ -77,16 +80,6 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned lo
     const int ty = rem / tiles_x;
     ty0 = ty * kHT;
     tx0 = (rem - ty * tiles_x) * kHT;
-  };
-  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long t0 = PROBE ? __builtin_amdgcn_s_memtime() : 0;
-  const unsigned long long tstart = t0;
-  auto stamp = [&](int k) {
-    if constexpr (PROBE) {
-      const unsigned long long n = __builtin_amdgcn_s_memtime();
-      ph[k] += n - t0;
-      t0 = n;
-    }
   };
   int t = blockIdx.x;
   if (t >= tiles_total) return;
@@ -149,15 +142,10 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned lo
     // one iteration: tile t is being multiplied, tile t + g waits in set N1, tile t + 2 g is requested into set N2
     auto iteration = [&](auto n1, auto n2) __attribute__((always_inline)) {
       if (prev >= 0) store_outputs(prev);        // (staged behind barrier B of the previous iteration)
-      stamp(0);
       if (t + 2 * g < tiles_total) load_tile(t + 2 * g, n2);   // the memory pipe's back-pressure stalls THESE waves
-      stamp(1);
       __syncthreads();      // A: the multiply is done with the staged pixels
-      stamp(2);
       if (t + g < tiles_total) land_tile(n1);
-      stamp(3);
       __syncthreads();      // B: next pixels and this tile's staged outputs are visible
-      stamp(4);
       prev = t;
       t += g;
     };
@@ -204,7 +192,6 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned lo
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      stamp(0);
       // 36 k-substeps (tap = s / 4, 16 channels each), operand fragments requested TWO substeps ahead of their
       // matrix instructions: one substep of cover (4 instructions = 128 cycles) leaves the LDS latency exposed
       f16x8_t fa[3][2], fb[3][2];
@@ -230,9 +217,7 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned lo
         if (sidx + 2 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
-      stamp(1);
       __syncthreads();      // A
-      stamp(2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         char *row = Ys + ((4 * cw + 2 * j + (l31 >> 4)) * kHT + (l31 & 15)) * kHPix;
@@ -249,17 +234,7 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(unsigned lo
             *reinterpret_cast<uint2 *>(row + (32 * i + 8 * g + 4 * hi) * 2) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
           }
       }
-      stamp(3);
       __syncthreads();      // B
-      stamp(4);
-    }
-  }
-  if constexpr (PROBE) {
-    if (lane == 0) {
-      unsigned long long *o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-      for (int k = 0; k < 6; ++k) o[k] = ph[k];
-      o[6] = tstart;
-      o[7] = __builtin_amdgcn_s_memtime();
     }
   }
 }
@@ -293,23 +268,10 @@ extern "C" int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, co
   const int tiles_x = (W + kHT - 1) / kHT, tiles_y = (H + kHT - 1) / kHT;
   const long long total = (long long)B * tiles_x * tiles_y;
   if (total > (1ll << 30)) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel<false>>(kHLds)) return BEVOPS_FAILURE;
+  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel>(kHLds)) return BEVOPS_FAILURE;
   const int blocks = (int)std::min<long long>(total, (long long)halo_cu_count());
-  hipLaunchKernelGGL(conv3x3_c64_halo_kernel<false>, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
-                     (unsigned long long *)nullptr, static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
-                     static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
-                     (int)total, (unsigned)((size_t)B * H * W * kHC * 2));
-  return launch_status();
-}
-
-extern "C" int bevops_conv3x3_c64_probe(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H,
-                                        int W, int relu, void *stamps, void *stream) {
-  const int tiles_x = (W + kHT - 1) / kHT, tiles_y = (H + kHT - 1) / kHT;
-  const long long total = (long long)B * tiles_x * tiles_y;
-  if (!ensure_dynamic_lds<conv3x3_c64_halo_kernel<true>>(kHLds)) return BEVOPS_FAILURE;
-  const int blocks = (int)std::min<long long>(total, (long long)halo_cu_count());
-  hipLaunchKernelGGL(conv3x3_c64_halo_kernel<true>, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
-                     static_cast<unsigned long long *>(stamps), static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
+  hipLaunchKernelGGL(conv3x3_c64_halo_kernel, dim3((unsigned)blocks), dim3(kHThreads), kHLds, static_cast<hipStream_t>(stream),
+                     static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
                      static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
                      (int)total, (unsigned)((size_t)B * H * W * kHC * 2));
   return launch_status();
