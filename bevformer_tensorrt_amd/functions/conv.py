@@ -18,6 +18,7 @@ _PACKED = _TensorCache()   # weight tensor -> taps-major copy (weakly keyed: die
 _CHOICE = {}          # problem -> "tile" | "library"
 CONV_LOG = []         # (problem, {name: us})
 CONV_MISSES = []   # problems conv3x3_auto met that dispatch_gfx950.json does not list
+HALO = {"enabled": os.environ.get("BEVOPS_CONV_HALO", "1") == "1"}   # A/B: the LDS-resident 64-channel convolution
 
 
 def pack_taps(weight):
@@ -132,10 +133,18 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
         return conv_nhwc(x, weight, bias, relu, residual, stride)      # (empty result, nothing to measure)
     key = (str(x.device), B, H, W, Cin, weight.shape[0], weight.shape[2], stride, bool(relu), residual is not None)
     from .linear import DETERMINISTIC, _problem, _table
-    name = "tile" if (DETERMINISTIC["enabled"] and Cin % 32 == 0) else _CHOICE.get(key)
+    # 64 -> 64 channels, stride 1, no identity rows (conv2 of the ResNet stage-1 bottlenecks): the LDS-resident kernel
+    # (csrc/conv_halo.hip) -- bit-identical to the tiled implicit GEMM, so also the rule-based dispatch may take it
+    halo_ok = HALO["enabled"] and Cin == 64 and weight.shape[0] == 64 and stride == 1 and residual is None \
+        and weight.shape[2] == 3
+    name = ("halo" if halo_ok else "tile") if (DETERMINISTIC["enabled"] and Cin % 32 == 0) else _CHOICE.get(key)
     if name is None:      # shipped choice (dispatch_gfx950.json): no measurement, the same kernel on every box
         name = _table()["conv"].get(_problem(key))
-        if name in ("tile", "library") and (name == "library" or Cin % 32 == 0):
+        if name == "tile" and halo_ok:
+            # (the table was measured before this kernel existed: 47 against 88 us at the base shape, faster at every
+            # shape of the four models, profiles/r06/conv_halo_time.jsonl)
+            name = "halo"
+        if name in ("tile", "library", "halo") and (name == "library" or Cin % 32 == 0) and (name != "halo" or halo_ok):
             _CHOICE[key] = name
         else:
             name = None
@@ -149,7 +158,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
         else:
             from .linear import graph_time_us
             times = {}
-            for cand, fn in (("tile", conv_nhwc), ("library", _library)):
+            for cand, fn in (("tile", conv_nhwc), ("library", _library)) + ((("halo", conv3x3_c64),) if halo_ok else ()):
                 for _ in range(2):
                     fn(x, weight, bias, relu, residual, stride)
                 torch.cuda.synchronize()
@@ -157,7 +166,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
                 times[cand] = round(graph_time_us(lambda: fn(x, weight, bias, relu, residual, stride), 4, 3), 1)
             CONV_LOG.append((key, times))
             name = _CHOICE[key] = min(times, key=times.get)
-    return (conv_nhwc if name == "tile" else _library)(x, weight, bias, relu, residual, stride)
+    return {"tile": conv_nhwc, "halo": conv3x3_c64, "library": _library}[name](x, weight, bias, relu, residual, stride)
 
 
 _STEM_PACKED = _TensorCache()   # stem weight -> (bias stamp, packed matrix-core operand image)

@@ -393,7 +393,7 @@ def _dense_deterministic(N, K, M=1 << 30):
 
 
 def _dense_own(key, N, K, M):
-    times = _table()["measured_dense"].get(_problem(key), {})
+    times = _table().get("measured_dense", {}).get(_problem(key), {})
     own = {k: v for k, v in times.items() if k in ("tile", "tsgemm", "small") and k in _DENSE}
     return min(own, key=own.get) if own else _dense_deterministic(N, K, M)
 
