@@ -395,6 +395,187 @@ int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *o
   return launch_status();
 }
 
+// ---- "resident" build (round 6; Cin == 256: the 23 + 3 offset convolutions of ResNet-101 stage 3 at base / small) -----
+// The tile kernel above reads every pixel's 512-byte channel row nine times through L1 (once per tap); at ~11 bytes
+// per clock and CU that is what its 18 us are.  Here the roles of the two operands are swapped:
+//   * the WEIGHTS live in registers: wave `part` (0 .. 2) owns kernel row `part`; its 3 taps x 256 channels x 32 outputs are
+//     48 MFMA A-operand fragments = 192 registers per lane, loaded once per (persistent) block from the same packed
+//     image the tile kernel uses;
+//   * the IMAGE goes through LDS: an 8 x 8-pixel output tile needs 10 x 10 input pixels (51 KB, 1.56 x the unique
+//     bytes instead of 9 x), brought in by the block's fourth wave with LDS-DMA (54 one-KiB pieces per tile, no
+//     registers) into one of TWO buffers -- the pixels of tile t + 1 land while tile t is multiplied.  Pixel rows are
+//     padded to 528 bytes and tile rows to 5 504 (= 32 banks mod 64), which makes the 16-byte fragment reads of the
+//     instruction's lane groups conflict-free;
+//   * k order per wave (chunk, column, 16-channel step) and the combination of the three row partials ((p0 + p1) + p2,
+//     then the bias, one rounding) are the tile kernel's: the results are bit-identical to it.
+constexpr int kRT = 8, kRH = kRT + 2;
+constexpr int kRPix = 256 * 2 + 16;                 // LDS bytes per staged pixel
+constexpr int kRRow = kRH * kRPix + 224;            // ... per staged tile row: 5 504
+constexpr int kRPieces = (kRH * kRRow + 1023) / 1024;   // 54 DMA pieces of 1 KiB
+constexpr int kRBuf = kRPieces * 1024;              // 55 296
+constexpr int kRRed = 3 * 2 * 4 * 64 * 16;          // row partials: [part][pixel block][quad][lane] x 16 B = 24 576
+constexpr int kRLds = 2 * kRBuf + kRRed;            // 135 168
+
+typedef __attribute__((address_space(3))) void lds_void_r;
+
+__global__ __launch_bounds__(256) void conv3x3_c32_resident_kernel(const __half *__restrict__ x,
+                                                                   const __half *__restrict__ wp,
+                                                                   const __half *__restrict__ bias,
+                                                                   __half *__restrict__ out, int H, int W, int tiles_x,
+                                                                   int tiles_img, int tiles_total, unsigned x_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *Rs = smem + 2 * kRBuf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+  const int g = (int)gridDim.x;
+  int t = blockIdx.x;
+  if (t >= tiles_total) return;
+  auto tile_origin = [&](int tt, int &b, int &ty0, int &tx0) {
+    b = tt / tiles_img;
+    const int rem = tt - b * tiles_img;
+    const int ty = rem / tiles_x;
+    ty0 = ty * kRT;
+    tx0 = (rem - ty * tiles_x) * kRT;
+  };
+  if (wave == 3) {
+    // ================= the mover: LDS-DMA of the next tile's 10 x 10 pixels
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(x), 0, x_bytes, 0x00020000);
+    auto dma_tile = [&](int tt, int buf) {
+      int b, ty0, tx0;
+      tile_origin(tt, b, ty0, tx0);
+      char *dst = smem + buf * kRBuf;
+#pragma unroll 6
+      for (int p = 0; p < kRPieces; ++p) {
+        // this lane's 16 bytes of piece p sit at byte d of the padded tile image: (row, pixel, channel byte) or padding
+        const int d = p * 1024 + lane * 16;
+        const int row = d / kRRow, rem = d - row * kRRow;
+        const int px = rem / kRPix, c = rem - px * kRPix;
+        const int y = ty0 + row - 1, xx = tx0 + px - 1;
+        const bool ok = row < kRH && px < kRH && c < 512 && y >= 0 && y < H && xx >= 0 && xx < W;
+        const unsigned off = ok ? (unsigned)((((size_t)b * H + y) * W + xx) * 512 + c) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_r *)(dst + p * 1024), 16, (int)off, 0, 0, 0);
+      }
+    };
+    dma_tile(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // P
+    for (int it = 0; t < tiles_total; t += g, ++it) {
+      if (t + g < tiles_total) dma_tile(t + g, (it + 1) & 1);     // (that buffer was last read a tile ago: barrier Y)
+      __syncthreads();    // Y
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();    // X
+    }
+    return;
+  }
+  // ================= waves 0 .. 2: kernel row `part`, weights in registers
+  const int part = wave;
+  f16x8 wr[4][3][4];      // [chunk][column][16-channel step]
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wr[chunk][dx][j] = reinterpret_cast<const f16x8 *>(wp)[((((3 * part + dx) * 4 + chunk) * 4 + j) * 64) + hi * 32 + n];
+  float bcol[16];
+  {
+    u32x2 braw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) braw[q] = bias ? *reinterpret_cast<const u32x2 *>(bias + 8 * q + 4 * hi) : u32x2{0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bcol[4 * q] = h2f_lo(braw[q].x); bcol[4 * q + 1] = h2f_hi(braw[q].x);
+      bcol[4 * q + 2] = h2f_lo(braw[q].y); bcol[4 * q + 3] = h2f_hi(braw[q].y);
+    }
+  }
+  // fragment base of pixel block pb (tile rows 4 pb .. 4 pb + 3): lane n -> pixel (4 pb + (n >> 3), n & 7); the tap of
+  // kernel row `part`, column dx reads staged pixel (row + part, column + dx)
+  unsigned xb[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) xb[pb] = (unsigned)((4 * pb + (n >> 3) + part) * kRRow + (n & 7) * kRPix + hi * 64);
+  float4 *red = reinterpret_cast<float4 *>(Rs);
+  __syncthreads();        // P
+  for (int it = 0; t < tiles_total; t += g, ++it) {
+    const char *Xs = smem + (it & 1) * kRBuf;
+    f32x16 acc[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
+    // 48 substeps (chunk, column, step), the two pixel blocks' fragments requested two substeps ahead
+    f16x8 fb[3][2];
+    auto fetch = [&](int sidx, int slot) __attribute__((always_inline)) {
+      const int chunk = sidx / 12, dx = (sidx / 4) % 3, j = sidx & 3;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+        fb[slot][pb] = *reinterpret_cast<const f16x8 *>(Xs + xb[pb] + dx * kRPix + chunk * 128 + j * 16);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+#pragma unroll
+    for (int sidx = 0; sidx < 48; ++sidx) {
+      if (sidx + 2 < 48) fetch(sidx + 2, (sidx + 2) % 3);
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sidx / 12][(sidx / 4) % 3][sidx & 3], fb[sidx % 3][pb], acc[pb], 0, 0, 0);
+      if (sidx + 2 < 48) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    __syncthreads();      // Y: the staged pixels are free; the previous tile's partials have been read
+    // wave 0 finishes pixel block 0, wave 1 pixel block 1: everybody hands over the blocks it does not finish
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+      if (part != pb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          red[((part * 2 + pb) * 4 + q) * 64 + lane] = make_float4(acc[pb][4 * q], acc[pb][4 * q + 1], acc[pb][4 * q + 2], acc[pb][4 * q + 3]);
+      }
+    __syncthreads();      // X
+    if (part < 2) {
+      const int pb = part;
+      int b, ty0, tx0;
+      tile_origin(t, b, ty0, tx0);
+      const int y = ty0 + 4 * pb + (n >> 3), xx = tx0 + (n & 7);
+      f32x16 a = acc[0];
+      if (pb == 1) a = acc[1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4] = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        if (pb == 0) {          // (p0 + p1) + p2
+          const float4 p1 = red[((1 * 2 + 0) * 4 + q) * 64 + lane], p2 = red[((2 * 2 + 0) * 4 + q) * 64 + lane];
+          v[0] = (v[0] + p1.x) + p2.x; v[1] = (v[1] + p1.y) + p2.y; v[2] = (v[2] + p1.z) + p2.z; v[3] = (v[3] + p1.w) + p2.w;
+        } else {
+          const float4 p0 = red[((0 * 2 + 1) * 4 + q) * 64 + lane], p2 = red[((2 * 2 + 1) * 4 + q) * 64 + lane];
+          v[0] = (p0.x + v[0]) + p2.x; v[1] = (p0.y + v[1]) + p2.y; v[2] = (p0.z + v[2]) + p2.z; v[3] = (p0.w + v[3]) + p2.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bcol[4 * q + e];
+        if (y < H && xx < W) {
+          u32x2 o;
+          o.x = pack_h2(v[0], v[1]);
+          o.y = pack_h2(v[2], v[3]);
+          *reinterpret_cast<u32x2 *>(out + (((size_t)b * H + y) * W + xx) * 32 + 8 * q + 4 * hi) = o;
+        }
+      }
+    }
+  }
+}
+
+int launch_conv_resident(const __half *x, const __half *wp, const __half *bias, __half *out, int B, int H, int W,
+                         hipStream_t st) {
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return BEVOPS_FAILURE;
+  const int tiles_x = (W + kRT - 1) / kRT, tiles_y = (H + kRT - 1) / kRT;
+  const long total = (long)B * tiles_x * tiles_y;
+  if (total > (1l << 30)) return BEVOPS_NOT_SUPPORTED;
+  if (!ensure_dynamic_lds<conv3x3_c32_resident_kernel>(kRLds)) return BEVOPS_FAILURE;
+  const int blocks = (int)(total < cus ? total : cus);
+  hipLaunchKernelGGL(conv3x3_c32_resident_kernel, dim3((unsigned)blocks), dim3(256), kRLds, st, x, wp, bias, out, H, W,
+                     tiles_x, tiles_x * tiles_y, (int)total, (unsigned)((size_t)B * H * W * 512));
+  return launch_status();
+}
+
 // The image operand comes from the fabric (it was written by another XCD a moment ago) at ~11 B/clk
 // per CU whatever the block does, so the launch is as fast as its busiest CU: the LDS image allows
 // one block per CU, hence tiles per block = ceil(tiles / CUs), from {2, 5, 8} waves.
@@ -408,7 +589,7 @@ int launch_conv_any(const __half *x, const __half *wp, const __half *bias, __hal
   const long tiles = ((long)B * H * W + kTile - 1) / kTile;
   const long need = (tiles + cus - 1) / cus;
   // three waves per tile (one per kernel row) wherever the block still fits 16 waves; variant 2 = one wave per tile
-  const bool split = g_conv_variant != 2;
+  const bool split = g_conv_variant != 2;     // (variant 3: this kernel with three waves per tile, as rounds 5's default)
   if (need <= 2) return split ? launch_conv<CCP, 2, 3>(x, wp, bias, out, B, H, W, Cin, phases, st)
                               : launch_conv<CCP, 2>(x, wp, bias, out, B, H, W, Cin, phases, st);
   if (need <= 5) return split ? launch_conv<CCP, 5, 3>(x, wp, bias, out, B, H, W, Cin, phases, st)
@@ -457,6 +638,10 @@ extern "C" int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc
     const int rc = launch_conv_rows(x, wp, b, o, B, H, W, Cin, CP / 64, st);
     if (rc != BEVOPS_NOT_SUPPORTED) return rc;
   }
+  // round 6: weights in registers, image tile in LDS (Cin == 256; bit-identical to the tile kernel); variants 2 / 3 = the
+  // tile kernel (one wave / three waves per tile)
+  if (g_conv_variant == 0 && Cin == 256 && (reinterpret_cast<uintptr_t>(b) & 7u) == 0)
+    return launch_conv_resident(x, wp, b, o, B, H, W, st);
   switch (CP / 64) {
     case 1: return launch_conv_any<1>(x, wp, b, o, B, H, W, Cin, phases, st);
     case 2: return launch_conv_any<2>(x, wp, b, o, B, H, W, Cin, phases, st);

@@ -229,7 +229,7 @@ def test_conv_offset_variants_match(bev, shape):
         ref = bev.conv_offset_nhwc(x, w, b)
         lib.bevops_conv3x3_c32_set_variant(1)     # rows-in-LDS kernel
         got = bev.conv_offset_nhwc(x, w, b)
-        lib.bevops_conv3x3_c32_set_variant(0)     # default: tile kernel, three waves per tile (one per kernel column)
+        lib.bevops_conv3x3_c32_set_variant(3)     # tile kernel, three waves per tile (one per kernel row; round 5's default)
         split = bev.conv_offset_nhwc(x, w, b)
     finally:
         lib.bevops_conv3x3_c32_set_variant(0)
@@ -239,6 +239,35 @@ def test_conv_offset_variants_match(bev, shape):
         assert (o.float() - ref.float()).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
         assert not o[:, 27:].any()
     assert torch.equal(split, bev.conv_offset_nhwc(x, w, b))      # deterministic
+
+
+@pytest.mark.parametrize("shape", [(6, 256, 58, 100), (6, 256, 46, 80), (1, 256, 58, 100), (3, 256, 7, 5), (1, 256, 1, 1),
+                                   (2, 256, 8, 8), (1, 256, 116, 200), (2, 256, 17, 9), (5, 256, 24, 40)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_conv_offset_resident_build_is_bit_identical_to_the_tile_kernel(bev, shape, with_bias):
+    """Round 6: at Cin = 256 the default is the build with the weights in registers and 8 x 8-pixel image tiles in LDS
+    (double-buffered LDS-DMA by a fourth wave).  Same k order per kernel row and the same (p0 + p1) + p2 + bias as the
+    tile kernel with three waves per tile (variant 3): equal bit for bit -- whole tiles, ragged edges, images smaller
+    than a tile, more tiles than blocks (the persistent loop and both buffers), one tile (no second buffer)."""
+    import torch.nn.functional as F
+    from bevformer_tensorrt_amd.utils import load_library
+    lib = load_library()
+    B, Cin, H, W = shape
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(27, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().cuda()
+    b = torch.randn(27, generator=g).half().cuda() if with_bias else None
+    try:
+        lib.bevops_conv3x3_c32_set_variant(3)
+        ref = bev.conv_offset_nhwc(x, w, b).clone()
+    finally:
+        lib.bevops_conv3x3_c32_set_variant(0)
+    got = bev.conv_offset_nhwc(x, w, b)
+    assert torch.equal(got, ref)
+    assert torch.equal(got, bev.conv_offset_nhwc(x, w, b))
+    want = F.conv2d(x.float(), w.float(), None if b is None else b.float(), 1, 1)
+    assert (got[:, :27].float() - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
+    assert not got[:, 27:].any()
 
 
 def test_packed_weight_cache_survives_dtype_conversion():
