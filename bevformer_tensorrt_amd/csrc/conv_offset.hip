@@ -402,8 +402,9 @@ int launch_conv(const __half *x, const __half *wp, const __half *bias, __half *o
 //     48 MFMA A-operand fragments = 192 registers per lane, loaded once per (persistent) block from the same packed
 //     image the tile kernel uses;
 //   * the IMAGE goes through LDS: an 8 x 8-pixel output tile needs 10 x 10 input pixels (51 KB, 1.56 x the unique
-//     bytes instead of 9 x), brought in by the block's fourth wave with LDS-DMA (54 one-KiB pieces per tile, no
-//     registers) into one of TWO buffers -- the pixels of tile t + 1 land while tile t is multiplied.  Pixel rows are
+//     bytes instead of 9 x), brought in with LDS-DMA (54 one-KiB pieces per tile, no registers; every wave issues a
+//     share, the block's fourth wave does nothing else) into one of TWO buffers -- the pixels of tile t + 1 land
+//     while tile t is multiplied.  Pixel rows are
 //     padded to 528 bytes and tile rows to 5 504 (= 32 banks mod 64), which makes the 16-byte fragment reads of the
 //     instruction's lane groups conflict-free;
 //   * k order per wave (chunk, column, 16-channel step) and the combination of the three row partials ((p0 + p1) + p2,
@@ -436,30 +437,43 @@ __global__ __launch_bounds__(256) void conv3x3_c32_resident_kernel(const __half 
     ty0 = ty * kRT;
     tx0 = (rem - ty * tiles_x) * kRT;
   };
+  // LDS-DMA of a tile's 10 x 10 pixels: 54 one-KiB pieces.  ONE wave issuing all of them takes longer than the multiply
+  // (an LDS-DMA instruction costs its wave 60-185 cycles at issue: 26.7 us per launch that way), so every wave issues a
+  // share: the three multiplying waves 12 pieces each, spread between their matrix instructions, the fourth wave 18.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(x), 0, x_bytes, 0x00020000);
+  auto dma_piece = [&](int b, int ty0, int tx0, int buf, int p) __attribute__((always_inline)) {
+    // this lane's 16 bytes of piece p sit at byte d of the padded tile image: (row, pixel, channel byte) or padding
+    const int d = p * 1024 + lane * 16;
+    const int row = d / kRRow, rem = d - row * kRRow;
+    const int px = rem / kRPix, c = rem - px * kRPix;
+    const int y = ty0 + row - 1, xx = tx0 + px - 1;
+    const bool ok = row < kRH && px < kRH && c < 512 && y >= 0 && y < H && xx >= 0 && xx < W;
+    const unsigned off = ok ? (unsigned)((((size_t)b * H + y) * W + xx) * 512 + c) : kOob;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_r *)(smem + buf * kRBuf + p * 1024), 16, (int)off, 0, 0, 0);
+  };
+  constexpr int kMine = 12;      // pieces per multiplying wave (6 / 12 / 16 measured: 15.4 / 15.9 / 17.2 us at base, 12.1 / 11.8 / 12.9 at small); the fourth wave takes 36 .. 53
+  {
+    int b, ty0, tx0;
+    tile_origin(t, b, ty0, tx0);
+    if (wave == 3) {
+#pragma unroll
+      for (int p = 3 * kMine; p < kRPieces; ++p) dma_piece(b, ty0, tx0, 0, p);
+    } else {
+#pragma unroll
+      for (int p = 0; p < kMine; ++p) dma_piece(b, ty0, tx0, 0, wave * kMine + p);
+    }
+  }
   if (wave == 3) {
-    // ================= the mover: LDS-DMA of the next tile's 10 x 10 pixels
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(x), 0, x_bytes, 0x00020000);
-    auto dma_tile = [&](int tt, int buf) {
-      int b, ty0, tx0;
-      tile_origin(tt, b, ty0, tx0);
-      char *dst = smem + buf * kRBuf;
-#pragma unroll 6
-      for (int p = 0; p < kRPieces; ++p) {
-        // this lane's 16 bytes of piece p sit at byte d of the padded tile image: (row, pixel, channel byte) or padding
-        const int d = p * 1024 + lane * 16;
-        const int row = d / kRRow, rem = d - row * kRRow;
-        const int px = rem / kRPix, c = rem - px * kRPix;
-        const int y = ty0 + row - 1, xx = tx0 + px - 1;
-        const bool ok = row < kRH && px < kRH && c < 512 && y >= 0 && y < H && xx >= 0 && xx < W;
-        const unsigned off = ok ? (unsigned)((((size_t)b * H + y) * W + xx) * 512 + c) : kOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_r *)(dst + p * 1024), 16, (int)off, 0, 0, 0);
-      }
-    };
-    dma_tile(t, 0);
+    // ================= the fourth wave: its share of the next tile's pieces, nothing else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // P
     for (int it = 0; t < tiles_total; t += g, ++it) {
-      if (t + g < tiles_total) dma_tile(t + g, (it + 1) & 1);     // (that buffer was last read a tile ago: barrier Y)
+      if (t + g < tiles_total) {        // (that buffer was last read a tile ago: barrier Y)
+        int b, ty0, tx0;
+        tile_origin(t + g, b, ty0, tx0);
+#pragma unroll
+        for (int p = 3 * kMine; p < kRPieces; ++p) dma_piece(b, ty0, tx0, (it + 1) & 1, p);
+      }
       __syncthreads();    // Y
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();    // X
@@ -493,9 +507,13 @@ __global__ __launch_bounds__(256) void conv3x3_c32_resident_kernel(const __half 
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) xb[pb] = (unsigned)((4 * pb + (n >> 3) + part) * kRRow + (n & 7) * kRPix + hi * 64);
   float4 *red = reinterpret_cast<float4 *>(Rs);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();        // P
   for (int it = 0; t < tiles_total; t += g, ++it) {
     const char *Xs = smem + (it & 1) * kRBuf;
+    const bool more = t + g < tiles_total;
+    int nb = 0, ny0 = 0, nx0 = 0;
+    if (more) tile_origin(t + g, nb, ny0, nx0);
     f32x16 acc[2];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
@@ -514,6 +532,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_resident_kernel(const __half 
 #pragma unroll
     for (int sidx = 0; sidx < 48; ++sidx) {
       if (sidx + 2 < 48) fetch(sidx + 2, (sidx + 2) % 3);
+      if (sidx % (48 / kMine) == 1 && sidx / (48 / kMine) < kMine && more) dma_piece(nb, ny0, nx0, (it + 1) & 1, part * kMine + sidx / (48 / kMine));
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
         acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sidx / 12][(sidx / 4) % 3][sidx & 3], fb[sidx % 3][pb], acc[pb], 0, 0, 0);
@@ -529,6 +548,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_resident_kernel(const __half 
         for (int q = 0; q < 4; ++q)
           red[((part * 2 + pb) * 4 + q) * 64 + lane] = make_float4(acc[pb][4 * q], acc[pb][4 * q + 1], acc[pb][4 * q + 2], acc[pb][4 * q + 3]);
       }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next tile have landed
     __syncthreads();      // X
     if (part < 2) {
       const int pb = part;

@@ -363,8 +363,10 @@ int bevops_feat_embed_nhwc(int dtype, const void *src, const void *cam_embed, co
  * offset_mask_channels = 32. */
 size_t bevops_conv3x3_c32_packed_weight_size(int dtype, int Cin);
 int bevops_conv3x3_c32_pack_weight(int dtype, const void *weight, void *packed, int Cout, int Cin, void *stream);
-/* 0 (and 2) = tile kernel; 1 = the variant that stages the image rows in LDS (faster in isolation at the base
- * stage-3 shape, slower inside the model: A/B, tests). Returns the previous value. */
+/* 0 = default: at Cin == 256 the build with the weights in registers and 8 x 8-pixel image tiles in LDS (round 6),
+ * the tile kernel with three waves per 32-pixel tile otherwise; 3 = that tile kernel everywhere (round 5's default;
+ * bit-identical to 0); 2 = the tile kernel with one wave per tile (rounds 1-4); 1 = the variant that stages the
+ * image rows in LDS (A/B, tests).  Returns the previous value. */
 int bevops_conv3x3_c32_set_variant(int variant);
 int bevops_conv3x3_c32_forward_nhwc(int dtype, const void *input_nhwc, const void *packed_weight,
                                     const void *bias32, void *output_nhwc, int B, int H, int W, int Cin,
