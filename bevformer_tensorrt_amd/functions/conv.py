@@ -18,7 +18,9 @@ _PACKED = _TensorCache()   # weight tensor -> taps-major copy (weakly keyed: die
 _CHOICE = {}          # problem -> "tile" | "library"
 CONV_LOG = []         # (problem, {name: us})
 CONV_MISSES = []   # problems conv3x3_auto met that dispatch_gfx950.json does not list
-HALO = {"enabled": os.environ.get("BEVOPS_CONV_HALO", "1") == "1"}   # A/B: the LDS-resident 64-channel convolution
+# A/B: the LDS-tile convolutions of csrc/conv_halo.hip -- "1": 64- and 128-channel layers, "64": the 64-channel one only, "0": none
+HALO = {"enabled": os.environ.get("BEVOPS_CONV_HALO", "1") != "0",
+        "channels": (64,) if os.environ.get("BEVOPS_CONV_HALO", "1") == "64" else (64, 128)}
 
 
 def pack_taps(weight):
@@ -140,7 +142,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
     from .linear import DETERMINISTIC, _problem, _table
     # 64 -> 64 channels, stride 1, no identity rows (conv2 of the ResNet stage-1 bottlenecks): the LDS-resident kernel
     # (csrc/conv_halo.hip) -- bit-identical to the tiled implicit GEMM, so also the rule-based dispatch may take it
-    halo_ok = HALO["enabled"] and Cin == weight.shape[0] and Cin in (64, 128) and stride == 1 and residual is None \
+    halo_ok = HALO["enabled"] and Cin == weight.shape[0] and Cin in HALO["channels"] and stride == 1 and residual is None \
         and weight.shape[2] == 3
     name = ("halo" if halo_ok else "tile") if (DETERMINISTIC["enabled"] and Cin % 32 == 0) else _CHOICE.get(key)
     if name is None:      # shipped choice (dispatch_gfx950.json): no measurement, the same kernel on every box
