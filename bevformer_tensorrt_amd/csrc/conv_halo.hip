@@ -239,142 +239,6 @@ __global__ __launch_bounds__(kHThreads) void conv3x3_c64_halo_kernel(const __hal
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 128 -> 128 channels (conv2 of the ResNet stage-2 bottlenecks, 116 x 200 maps): the weight matrix (128 x 1 152 fp16 =
-// 288 KB) does not fit LDS, so the roles are the offset convolution's (conv_offset.hip, resident build): TWELVE waves,
-// wave (kernel row `part` of 3, output block `ob` of 4 x 32 channels) keeps its 3 taps x 128 channels x 32 outputs in
-// REGISTERS (24 MFMA A fragments = 96 per lane), the image goes through LDS -- 8 x 8-pixel output tiles, their 10 x 10
-// input pixels (272-byte pixel rows, 2 944-byte tile rows: conflict-free fragment reads) by LDS-DMA into one of two
-// buffers, every wave issuing 2-3 of the 29 one-KiB pieces.  The three kernel-row partials of an output meet in LDS
-// (fp32) and the `part == 0` wave of the output block adds them ((p0 + p1) + p2), the bias, applies the ReLU and rounds
-// once.  Not bit-identical to the tiled implicit GEMM (whose k runs through all nine taps in ONE accumulator): same
-// products, fp32 sums in another order.
-constexpr int kQC = 128;
-constexpr int kQT = 8, kQH = kQT + 2;
-constexpr int kQPix = kQC * 2 + 16;                 // 272
-constexpr int kQRow = kQH * kQPix + 224;            // 2 944 (= 32 banks mod 64)
-constexpr int kQPieces = (kQH * kQRow + 1023) / 1024;   // 29
-constexpr int kQBuf = kQPieces * 1024;              // 29 696
-constexpr int kQRed = 2 * 4 * 2 * 4 * 64 * 16;      // partials of parts 1, 2: [part - 1][ob][pixel block][quad][lane] x 16 B = 65 536
-constexpr int kQLds = 2 * kQBuf + kQRed;            // 124 928
-constexpr int kQThreads = 768;
-constexpr unsigned kQOob = 0xFFFFFF00u;
-
-typedef __attribute__((address_space(3))) void lds_void_q;
-
-__global__ __launch_bounds__(kQThreads) void conv3x3_c128_rowsplit_kernel(const __half *__restrict__ x,
-                                                                          const __half *__restrict__ w,
-                                                                          const __half *__restrict__ bias,
-                                                                          __half *__restrict__ out, int H, int W, int relu,
-                                                                          int tiles_x, int tiles_img, int tiles_total,
-                                                                          unsigned x_bytes) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
-  const int part = wave % 3, ob = wave / 3;
-  const int g = (int)gridDim.x;
-  int t = blockIdx.x;
-  if (t >= tiles_total) return;
-  auto tile_origin = [&](int tt, int &b, int &ty0, int &tx0) {
-    b = tt / tiles_img;
-    const int rem = tt - b * tiles_img;
-    const int ty = rem / tiles_x;
-    ty0 = ty * kQT;
-    tx0 = (rem - ty * tiles_x) * kQT;
-  };
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(x), 0, x_bytes, 0x00020000);
-  auto dma_mine = [&](int tt, int buf) __attribute__((always_inline)) {
-    int b, ty0, tx0;
-    tile_origin(tt, b, ty0, tx0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int p = wave + 12 * k;      // (wave-uniform)
-      if (p < kQPieces) {
-        const int d = p * 1024 + lane * 16;
-        const int row = d / kQRow, rem = d - row * kQRow;
-        const int px = rem / kQPix, c = rem - px * kQPix;
-        const int y = ty0 + row - 1, xx = tx0 + px - 1;
-        const bool ok = row < kQH && px < kQH && c < kQC * 2 && y >= 0 && y < H && xx >= 0 && xx < W;
-        const unsigned off = ok ? (unsigned)((((size_t)b * H + y) * W + xx) * (kQC * 2) + c) : kQOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_q *)(smem + buf * kQBuf + p * 1024), 16, (int)off, 0, 0, 0);
-      }
-    }
-  };
-  dma_mine(t, 0);
-  // this wave's weights: kernel row `part`, outputs 32 ob .. 32 ob + 31; fragment (dx, jj): channels 16 jj + 8 hi .. + 7
-  f16x8_t wr[3][8];
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-      wr[dx][jj] = *reinterpret_cast<const f16x8_t *>(w + ((size_t)(ob * 32 + n) * 9 + (3 * part + dx)) * kQC + 16 * jj + 8 * hi);
-  unsigned xb[2];
-#pragma unroll
-  for (int pb = 0; pb < 2; ++pb) xb[pb] = (unsigned)((4 * pb + (n >> 3) + part) * kQRow + (n & 7) * kQPix + hi * 16);
-  float4 *red = reinterpret_cast<float4 *>(smem + 2 * kQBuf);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();        // P
-  for (int it = 0; t < tiles_total; t += g, ++it) {
-    const char *Xs = smem + (it & 1) * kQBuf;
-    if (t + g < tiles_total) dma_mine(t + g, (it + 1) & 1);       // (that buffer was last read a tile ago: barrier Y)
-    f32x16_t acc[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
-    f16x8_t fb[2][2];
-    auto fetch = [&](int sidx, int slot) __attribute__((always_inline)) {
-      const int dx = sidx >> 3, jj = sidx & 7;
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) fb[slot][pb] = *reinterpret_cast<const f16x8_t *>(Xs + xb[pb] + dx * kQPix + jj * 32);
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int sidx = 0; sidx < 24; ++sidx) {
-      if (sidx + 1 < 24) fetch(sidx + 1, (sidx + 1) & 1);
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
-        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sidx >> 3][sidx & 7], fb[sidx & 1][pb], acc[pb], 0, 0, 0);
-      if (sidx + 1 < 24) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    }
-    __syncthreads();      // Y: the staged pixels are free; the previous tile's partials have been read
-    if (part > 0) {
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          red[((((part - 1) * 4 + ob) * 2 + pb) * 4 + q) * 64 + lane] =
-              make_float4(acc[pb][4 * q], acc[pb][4 * q + 1], acc[pb][4 * q + 2], acc[pb][4 * q + 3]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next tile have landed
-    __syncthreads();      // X
-    if (part == 0) {
-      int b, ty0, tx0;
-      tile_origin(t, b, ty0, tx0);
-      // (the bias comes from L2 per quad of outputs: registers held across the multiply would spill at 168 per lane)
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        const int y = ty0 + 4 * pb + (n >> 3), xx = tx0 + (n & 7);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 p1 = red[(((0 * 4 + ob) * 2 + pb) * 4 + q) * 64 + lane], p2 = red[(((1 * 4 + ob) * 2 + pb) * 4 + q) * 64 + lane];
-          float v[4] = {(acc[pb][4 * q] + p1.x) + p2.x, (acc[pb][4 * q + 1] + p1.y) + p2.y, (acc[pb][4 * q + 2] + p1.z) + p2.z,
-                        (acc[pb][4 * q + 3] + p1.w) + p2.w};
-          const uint2 braw = bias ? *reinterpret_cast<const uint2 *>(bias + ob * 32 + 8 * q + 4 * hi) : make_uint2(0, 0);
-          v[0] += h2f_lo(braw.x); v[1] += h2f_hi(braw.x); v[2] += h2f_lo(braw.y); v[3] += h2f_hi(braw.y);
-          if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (y < H && xx < W)
-            *reinterpret_cast<uint2 *>(out + (((size_t)b * H + y) * W + xx) * kQC + ob * 32 + 8 * q + 4 * hi) =
-                make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
-        }
-      }
-    }
-  }
-}
-
 int halo_cu_count() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -410,26 +274,5 @@ extern "C" int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, co
                      static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
                      static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
                      (int)total, (unsigned)((size_t)B * H * W * kHC * 2));
-  return launch_status();
-}
-
-// The same layer shape for 128 -> 128 channels (conv2 of the stage-2 bottlenecks): weights in registers by (kernel row,
-// output block), image tiles in LDS.  Same operands as bevops_conv3x3_c64_f16; NOT_SUPPORTED unless Cin == Cout == 128.
-extern "C" int bevops_conv3x3_c128_f16(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H,
-                                       int W, int Cin, int Cout, int relu, void *stream) {
-  if (!x || !weight_taps || !out || B <= 0 || H <= 0 || W <= 0) return BEVOPS_BAD_PARAM;
-  if (Cin != kQC || Cout != kQC) return BEVOPS_NOT_SUPPORTED;
-  if (!aligned16(x) || !aligned16(weight_taps) || !aligned16(out) || (reinterpret_cast<uintptr_t>(bias) & 7u))
-    return BEVOPS_BAD_PARAM;
-  if ((long long)B * H * W * kQC * 2 >= 0xFFFFFF00ll) return BEVOPS_NOT_SUPPORTED;     // (32-bit buffer offsets)
-  const int tiles_x = (W + kQT - 1) / kQT, tiles_y = (H + kQT - 1) / kQT;
-  const long long total = (long long)B * tiles_x * tiles_y;
-  if (total > (1ll << 30)) return BEVOPS_NOT_SUPPORTED;
-  if (!ensure_dynamic_lds<conv3x3_c128_rowsplit_kernel>(kQLds)) return BEVOPS_FAILURE;
-  const int blocks = (int)std::min<long long>(total, (long long)halo_cu_count());
-  hipLaunchKernelGGL(conv3x3_c128_rowsplit_kernel, dim3((unsigned)blocks), dim3(kQThreads), kQLds, static_cast<hipStream_t>(stream),
-                     static_cast<const __half *>(x), static_cast<const __half *>(weight_taps),
-                     static_cast<const __half *>(bias), static_cast<__half *>(out), H, W, relu, tiles_x, tiles_x * tiles_y,
-                     (int)total, (unsigned)((size_t)B * H * W * kQC * 2));
   return launch_status();
 }

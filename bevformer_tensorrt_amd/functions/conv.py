@@ -18,9 +18,7 @@ _PACKED = _TensorCache()   # weight tensor -> taps-major copy (weakly keyed: die
 _CHOICE = {}          # problem -> "tile" | "library"
 CONV_LOG = []         # (problem, {name: us})
 CONV_MISSES = []   # problems conv3x3_auto met that dispatch_gfx950.json does not list
-# A/B: the LDS-tile convolutions of csrc/conv_halo.hip -- "1": 64- and 128-channel layers, "64": the 64-channel one only, "0": none
-HALO = {"enabled": os.environ.get("BEVOPS_CONV_HALO", "1") != "0",
-        "channels": (64,) if os.environ.get("BEVOPS_CONV_HALO", "1") == "64" else (64, 128)}
+HALO = {"enabled": os.environ.get("BEVOPS_CONV_HALO", "1") == "1"}   # A/B: the LDS-resident 64-channel convolution
 
 
 def pack_taps(weight):
@@ -60,7 +58,7 @@ def conv_nhwc(x, weight, bias=None, relu=False, residual=None, stride=1):
     return out
 
 
-def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1, _entry="bevops_conv3x3_c64_f16"):
+def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1):
     """The 3x3 / stride 1 / pad 1 convolution of a 64 -> 64-channel layer with both operands in LDS
     (bevops_conv3x3_c64_f16, csrc/conv_halo.hip): x [B, 64, H, W] channels-last fp16, weight [64, 64, 3, 3] ->
     act(conv2d(x, weight, 1, 1) + bias), bit-identical to conv_nhwc.  Raises BevopsError(NOT_SUPPORTED) for any other
@@ -70,7 +68,7 @@ def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1, _entr
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     if residual is not None or stride != 1 or tuple(weight.shape[1:]) != (Cin, 3, 3):
-        raise _lib.BevopsError(_entry + ": 3x3 / stride 1 layers without identity rows only", _lib.NOT_SUPPORTED)
+        raise _lib.BevopsError("bevops_conv3x3_c64_f16: 3x3 / stride 1 layers without identity rows only", _lib.NOT_SUPPORTED)
     wt = pack_taps(weight)
     out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if bias is not None:
@@ -79,16 +77,11 @@ def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1, _entr
         return out
     handle = _lib.load_library()
     with torch.cuda.device(x.device):
-        st = getattr(handle, _entry)(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                     out.data_ptr(), B, H, W, Cin, Cout, int(bool(relu)), _lib.current_stream_ptr(x.device))
-    _lib.check(st, _entry)
+        st = handle.bevops_conv3x3_c64_f16(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           out.data_ptr(), B, H, W, Cin, Cout, int(bool(relu)),
+                                           _lib.current_stream_ptr(x.device))
+    _lib.check(st, "bevops_conv3x3_c64_f16")
     return out
-
-
-def conv3x3_c128(x, weight, bias=None, relu=False, residual=None, stride=1):
-    """The same layer shape for 128 -> 128 channels (bevops_conv3x3_c128_f16: weights in registers by kernel row and
-    output block, image tiles in LDS).  Same products as conv_nhwc, fp32 sums in another order (not bit-identical)."""
-    return conv3x3_c64(x, weight, bias, relu, residual, stride, _entry="bevops_conv3x3_c128_f16")
 
 
 def conv_int8_nhwc(x, scale_a, w_q_taps, scale_w, bias=None, relu=False, residual=None, stride=1):
@@ -142,7 +135,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
     from .linear import DETERMINISTIC, _problem, _table
     # 64 -> 64 channels, stride 1, no identity rows (conv2 of the ResNet stage-1 bottlenecks): the LDS-resident kernel
     # (csrc/conv_halo.hip) -- bit-identical to the tiled implicit GEMM, so also the rule-based dispatch may take it
-    halo_ok = HALO["enabled"] and Cin == weight.shape[0] and Cin in HALO["channels"] and stride == 1 and residual is None \
+    halo_ok = HALO["enabled"] and Cin == 64 and weight.shape[0] == 64 and stride == 1 and residual is None \
         and weight.shape[2] == 3
     name = ("halo" if halo_ok else "tile") if (DETERMINISTIC["enabled"] and Cin % 32 == 0) else _CHOICE.get(key)
     if name is None:      # shipped choice (dispatch_gfx950.json): no measurement, the same kernel on every box
@@ -165,7 +158,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
         else:
             from .linear import graph_time_us
             times = {}
-            for cand, fn in (("tile", conv_nhwc), ("library", _library)) + ((("halo", conv3x3_c64 if Cin == 64 else conv3x3_c128),) if halo_ok else ()):
+            for cand, fn in (("tile", conv_nhwc), ("library", _library)) + ((("halo", conv3x3_c64),) if halo_ok else ()):
                 for _ in range(2):
                     fn(x, weight, bias, relu, residual, stride)
                 torch.cuda.synchronize()
@@ -173,8 +166,7 @@ def conv3x3_auto(x, weight, bias=None, relu=False, residual=None, stride=1):
                 times[cand] = round(graph_time_us(lambda: fn(x, weight, bias, relu, residual, stride), 4, 3), 1)
             CONV_LOG.append((key, times))
             name = _CHOICE[key] = min(times, key=times.get)
-    fn = {"tile": conv_nhwc, "halo": conv3x3_c64 if Cin == 64 else conv3x3_c128, "library": _library}[name]
-    return fn(x, weight, bias, relu, residual, stride)
+    return {"tile": conv_nhwc, "halo": conv3x3_c64, "library": _library}[name](x, weight, bias, relu, residual, stride)
 
 
 _STEM_PACKED = _TensorCache()   # stem weight -> (bias stamp, packed matrix-core operand image)

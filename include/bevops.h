@@ -444,13 +444,6 @@ int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bia
  * NOT_SUPPORTED unless Cin == Cout == 64. */
 int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H, int W,
                            int Cin, int Cout, int relu, void *stream);
-/* The same layer shape for 128 -> 128 channels (conv2 of the ResNet stage-2 bottlenecks): the weight matrix does not
- * fit LDS, so each of twelve waves keeps the weights of one (kernel row, block of 32 outputs) in registers and the
- * image goes through LDS in 8 x 8-pixel tiles (double-buffered LDS-DMA); the three kernel-row partials of an output are
- * added in fp32 ((row 0 + row 1) + row 2, then the bias) -- another summation order than bevops_conv_tile_f16, same
- * products.  Same operands as bevops_conv3x3_c64_f16.  NOT_SUPPORTED unless Cin == Cout == 128. */
-int bevops_conv3x3_c128_f16(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H, int W,
-                            int Cin, int Cout, int relu, void *stream);
 /* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
  * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
  * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */

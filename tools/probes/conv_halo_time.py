@@ -19,12 +19,3 @@ for B, H, W, what in ((6, 232, 400, "base"), (6, 184, 320, "small"), (6, 120, 20
             row.setdefault(name, []).append(round(graph_time_us(lambda: fn(x, w, b, True, None, 1), 4, 3), 1))
     print(json.dumps(row), flush=True)
 
-for B, H, W, what in ((6, 116, 200, "base stage 2"), (6, 92, 160, "small stage 2"), (6, 60, 100, "tiny stage 2"), (1, 116, 200, "base stage 2, one camera")):
-    x = torch.randn(B, 128, H, W, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(128, 128, 3, 3, generator=g) / 34).half().cuda().contiguous(memory_format=torch.channels_last)
-    b = torch.randn(128, generator=g).half().cuda()
-    row = {"shape": [B, 128, H, W], "what": what}
-    for _ in range(2):
-        for name, fn in (("tile", CV.conv_nhwc), ("rowsplit", CV.conv3x3_c128), ("library", CV._library)):
-            row.setdefault(name, []).append(round(graph_time_us(lambda: fn(x, w, b, True, None, 1), 4, 3), 1))
-    print(json.dumps(row), flush=True)
