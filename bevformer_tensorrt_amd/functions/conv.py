@@ -84,35 +84,6 @@ def conv3x3_c64(x, weight, bias=None, relu=False, residual=None, stride=1):
     return out
 
 
-def bottleneck_c256_64(x, w1, b1, w2, b2, w3, b3):
-    """relu(conv1x1(relu(conv3x3(relu(conv1x1(x, w1) + b1), w2, pad 1) + b2), w3) + b3 + x) for a ResNet stage-1 bottleneck
-    with an identity shortcut as ONE kernel (bevops_bottleneck_c256_64_f16, csrc/bottleneck.hip): x [B, 256, H, W]
-    channels-last fp16, w1 [64, 256, 1, 1], w2 [64, 64, 3, 3], w3 [256, 64, 1, 1], biases [64] / [64] / [256] or None.
-    Bit-identical to the three hand-written kernels in sequence.  Raises BevopsError(NOT_SUPPORTED) for other shapes."""
-    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4
-    assert x.is_contiguous(memory_format=torch.channels_last)
-    B, Cin, H, W = x.shape
-    planes = w1.shape[0]
-    if tuple(w1.shape[1:]) not in ((Cin, 1, 1), (Cin,)) or tuple(w2.shape) != (planes, planes, 3, 3) or w3.shape[0] != Cin \
-            or w3.shape[1] != planes:
-        raise _lib.BevopsError("bevops_bottleneck_c256_64_f16: not a 256 -> 64 -> 64 -> 256 bottleneck", _lib.NOT_SUPPORTED)
-    w1m = w1.reshape(planes, Cin).contiguous()
-    w3m = w3.reshape(Cin, planes).contiguous()
-    wt = pack_taps(w2)
-    out = torch.empty_like(x, memory_format=torch.channels_last)
-    bs = [None if b is None else b.to(torch.float16).contiguous() for b in (b1, b2, b3)]
-    if B == 0:
-        return out
-    handle = _lib.load_library()
-    with torch.cuda.device(x.device):
-        st = handle.bevops_bottleneck_c256_64_f16(x.data_ptr(), w1m.data_ptr(), bs[0].data_ptr() if bs[0] is not None else None,
-                                                  wt.data_ptr(), bs[1].data_ptr() if bs[1] is not None else None,
-                                                  w3m.data_ptr(), bs[2].data_ptr() if bs[2] is not None else None,
-                                                  out.data_ptr(), B, H, W, Cin, planes, _lib.current_stream_ptr(x.device))
-    _lib.check(st, "bevops_bottleneck_c256_64_f16")
-    return out
-
-
 def conv_int8_nhwc(x, scale_a, w_q_taps, scale_w, bias=None, relu=False, residual=None, stride=1):
     """The INT8 flavour (bevops_conv_tile_int8_fused): x [B, Cin, H, W] channels-last fp16, quantised with scale_a
     inside the kernel; w_q_taps [Cout, k, k, Cin] int8 (taps-major), scale_w a float or an fp32 [Cout] tensor; bias

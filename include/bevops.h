@@ -444,16 +444,6 @@ int bevops_conv_tile_f16(const void *x, const void *weight_taps, const void *bia
  * NOT_SUPPORTED unless Cin == Cout == 64. */
 int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, const void *bias, void *out, int B, int H, int W,
                            int Cin, int Cout, int relu, void *stream);
-/* A whole ResNet stage-1 bottleneck with an identity shortcut (det2trt/models/backbones/resnet.py:106-260, BatchNorms
- * folded: 256 -> 64 -> 64 -> 256 channels, stride 1) as one kernel on channels-last fp16 activations:
- *   out = relu(conv1x1(relu(conv3x3(relu(conv1x1(x, w1) + b1), w2_taps, pad 1) + b2), w3) + b3 + x)
- * x, out [B, H, W, 256] (out must not alias x); w1 [64][256], w2_taps [64][3][3][64] (as bevops_conv_tile_f16 takes it),
- * w3 [256][64]; biases fp16 or NULL.  The intermediate images never leave the CU (8 x 8-pixel tiles, x read once per
- * tile with its one-pixel border); every stage rounds to binary16 exactly as the separate kernels do: bit-identical
- * to bevops_tile_gemm_f16 -> bevops_conv_tile_f16 -> bevops_tile_gemm_f16.  NOT_SUPPORTED unless Cin == 256, planes == 64. */
-int bevops_bottleneck_c256_64_f16(const void *x, const void *w1, const void *b1, const void *w2_taps, const void *b2,
-                                  const void *w3, const void *b3, void *out, int B, int H, int W, int Cin, int planes,
-                                  void *stream);
 /* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
  * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
  * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */
