@@ -29,7 +29,6 @@ namespace bevops {
 thread_local int g_mdconv_variant = 0;
 thread_local bool g_mdconv_no_tail = false;
 thread_local bool g_mdconv_wide = false;  // variant 5: 1024-thread blocks, 128-pixel tiles whatever the tile count
-thread_local bool g_mdconv_pc = false;   // variant 14: producer / consumer wave roles for the main tiles (dcn_glds_f16_pc_kernel)
 thread_local int g_mdconv_rotate = 0;   // fp16 LDS-DMA kernel: 0 = round 6's wave order; variant 7 -> 1: halves rotated by half an iteration
                                         // (round 2); variant 13 -> 2: one order for all waves (rounds 2-5, the A/B partner)
 namespace {
@@ -917,224 +916,6 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 1) void dcn_glds_f16_kernel
 }
 
 
-// ---- 5d. the same kernel with the waves in TWO ROLES (round 6, late; WN = 4, main tiles only) --------------------------
-// In the loop above every wave gathers, blends, issues weight DMA AND multiplies; a wave that sits in its load-issue
-// segment (the CU's load path accepts ~0.4 lines per clock: ~2 k cycles for a step's 96 KB) issues no matrix
-// instructions, and the step costs ~3.2 k cycles although its 8 matrix instructions per wave are 1 k per SIMD.  Here
-//   waves 0-7  PRODUCE: each thread owns two (pixel, 16-byte channel piece) slots of the 128 x 64 pixel tile -- 8 corner
-//              gathers two steps ahead, blend, ds_write -- and the eight waves issue the step's 32 weight DMA pieces;
-//   waves 8-15 MULTIPLY: wave tile 64 output channels x 64 pixels (2 x 2 accumulator blocks), nothing in front of their
-//              matrix segment but the barrier.
-// Same buffers, same barrier per step, same arithmetic and summation order as dcn_glds_f16_kernel<4, *>: bit-identical.
-// Tail tiles (the K-split blocks) keep the kernel above -- launched separately, their partial layout is per thread.
-__global__ __launch_bounds__(1024, 1) void dcn_glds_f16_pc_kernel(
-    const __half *__restrict__ xt, const __half *__restrict__ offset, const __half *__restrict__ mask,
-    const __half *__restrict__ wt, const __half *__restrict__ bias, __half *__restrict__ out, ConvDims d, int g, TailPlan tp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][B0][B1]
-  constexpr int kN = Glds<4>::kN, kGB = Glds<4>::kB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int KK = d.Kh * d.Kw, cin_g = d.Cin / d.G, cout_g = d.Cout / d.G;
-  const int HoWo = d.Ho * d.Wo;
-  const int N = d.B * HoWo;
-  const int ntile = (int)xcd_remap(blockIdx.x, tp.main_tiles);
-  const int n0 = ntile * kN, m0 = blockIdx.y * kFM;
-  const int Kg = KK * cin_g;
-  const __half *A = wt + (size_t)g * cout_g * Kg;
-  const int dg = (g * cin_g) / (d.Cin / d.DG);
-  const int chunks = cin_g / kFK;
-  const bool stagger = (size_t)cout_g * Kg * 2 <= (size_t)(2 << 20);
-  const int tap_begin = stagger ? ntile % KK : 0;
-  const int n_steps = KK * chunks;
-  const bool producer = __builtin_amdgcn_readfirstlane(wave) < 8;
-  if (producer) {
-    // ================= waves 0-7
-    const int cq = tid & 7;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__half *>(xt), 0, (unsigned)((size_t)d.B * d.H * d.W * d.Cin * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__half *>(A), 0, (unsigned)((size_t)cout_g * Kg * 2), 0x00020000);
-    bool pvalid[2];
-    int pho[2], pwo[2];
-    unsigned ximg_off[2], b_dst[2];
-    size_t omb[2], ob[2], mb[2];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const int pp = (tid >> 3) + 64 * sl;
-      const int pn = n0 + pp;
-      pvalid[sl] = pn < N;
-      const int pb = pvalid[sl] ? pn / HoWo : 0;
-      const int ppix = pvalid[sl] ? pn - pb * HoWo : 0;
-      pho[sl] = ppix / d.Wo;
-      pwo[sl] = ppix - pho[sl] * d.Wo;
-      ximg_off[sl] = (unsigned)(((size_t)pb * d.H * d.W * d.Cin + g * cin_g + cq * 8) * 2);
-      b_dst[sl] = (unsigned)(pp * 128 + ((cq ^ swz8(pp)) << 4));
-      ob[sl] = (((size_t)pb * d.DG + dg) * 2 * KK) * HoWo + ppix;
-      mb[sl] = (((size_t)pb * d.DG + dg) * KK) * HoWo + ppix;
-      omb[sl] = ((size_t)pb * HoWo + ppix) * (size_t)tp.om_channels + (size_t)dg * 3 * KK;
-    }
-    unsigned a_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned row = (unsigned)((wave * 4 + j) * 8 + (lane >> 3));
-      const unsigned chunk = (lane & 7u) ^ swz8(row);
-      a_off[j] = (m0 + (int)row) < cout_g ? (unsigned)(((size_t)(m0 + row) * Kg) * 2 + chunk * 16) : 0xFFFFFFF0u;
-    }
-    __half n_oh[2], n_ow[2], n_mm[2];
-    auto load_om = [&](int sl, int tap) {
-      if (tp.om_channels) {
-        const unsigned o2 = *reinterpret_cast<const unsigned *>(offset + omb[sl] + 2 * tap);
-        n_oh[sl] = __ushort_as_half((unsigned short)(o2 & 0xffffu));
-        n_ow[sl] = __ushort_as_half((unsigned short)(o2 >> 16));
-        n_mm[sl] = offset[omb[sl] + 2 * KK + tap];
-      } else {
-        n_oh[sl] = offset[ob[sl] + (size_t)(2 * tap) * HoWo];
-        n_ow[sl] = offset[ob[sl] + (size_t)(2 * tap + 1) * HoWo];
-        n_mm[sl] = mask[mb[sl] + (size_t)tap * HoWo];
-      }
-    };
-    load_om(0, tap_begin);
-    load_om(1, tap_begin);
-    int fidx[2][4];
-    unsigned fw[2][4], c_fw[2][4];
-    uint4 rb[2][4];
-    auto footprint = [&](int sl, int tap) {
-      const float off_h = __half2float(n_oh[sl]), off_w = __half2float(n_ow[sl]);
-      const float m = tp.om_channels ? __half2float(__float2half_rn(1.f / (1.f + __expf(-__half2float(n_mm[sl])))))
-                                     : __half2float(n_mm[sl]);
-      load_om(sl, tap + 1 < KK ? tap + 1 : 0);
-      const int i = tap / d.Kw, j = tap - i * d.Kw;
-      const float h_im = (float)(pho[sl] * d.sh - d.ph + i * d.dh) + off_h;
-      const float w_im = (float)(pwo[sl] * d.sw - d.pw + j * d.dw) + off_w;
-      const bool in = pvalid[sl] && h_im > -1.f && w_im > -1.f && h_im < (float)d.H && w_im < (float)d.W;
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h0 = (int)hf, w0 = (int)wf;
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const float wq[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-      const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = in && hs[q] >= 0 && hs[q] <= d.H - 1 && ws[q] >= 0 && ws[q] <= d.W - 1;
-        fidx[sl][q] = (int)(ximg_off[sl] + (unsigned)(ok ? hs[q] * d.W + ws[q] : 0) * (unsigned)(d.Cin * 2));
-        const float w = ok ? wq[q] * m : 0.f;
-        fw[sl][q] = pack_h2(w, w);
-      }
-    };
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(3))) char lds_char;
-    int g_tap = tap_begin, g_chunk = 0, w_tap = tap_begin, w_chunk = 0;
-    auto gather_next = [&]() {
-      if (g_chunk == 0) {
-        footprint(0, g_tap);
-        footprint(1, g_tap);
-      }
-      const int c0 = g_chunk * kFK;
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          rb[sl][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, fidx[sl][q], c0 * 2, 0));
-          c_fw[sl][q] = fw[sl][q];
-        }
-      if (++g_chunk == chunks) { g_chunk = 0; g_tap = g_tap + 1 < KK ? g_tap + 1 : 0; }
-    };
-    auto weights_next = [&](int buf) {
-      const int a_s = (w_tap * cin_g + w_chunk * kFK) * 2;
-      char *adst = smem + buf * kGA + wave * 4096;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(adst + j * 1024), 16, (int)a_off[j], a_s, 0, 0);
-      if (++w_chunk == chunks) { w_chunk = 0; w_tap = w_tap + 1 < KK ? w_tap + 1 : 0; }
-    };
-    const unsigned b_lds = (unsigned)(size_t)((lds_char *)smem) + (unsigned)(2 * kGA);
-    auto blend_store = [&](int buf) {
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl) {
-        u32x4_t bl;
-        bl.x = pk_mul(rb[sl][0].x, c_fw[sl][0]); bl.y = pk_mul(rb[sl][0].y, c_fw[sl][0]);
-        bl.z = pk_mul(rb[sl][0].z, c_fw[sl][0]); bl.w = pk_mul(rb[sl][0].w, c_fw[sl][0]);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-          bl.x = pk_fma(rb[sl][q].x, c_fw[sl][q], bl.x); bl.y = pk_fma(rb[sl][q].y, c_fw[sl][q], bl.y);
-          bl.z = pk_fma(rb[sl][q].z, c_fw[sl][q], bl.z); bl.w = pk_fma(rb[sl][q].w, c_fw[sl][q], bl.w);
-        }
-        asm volatile("ds_write_b128 %0, %1" ::"v"(b_lds + b_dst[sl] + (unsigned)(buf * kGB)), "v"(bl) : "memory");
-      }
-    };
-    // prologue: step 0 -> buffer 0, corners of step 1 in flight
-    gather_next();
-    blend_store(0);
-    __builtin_amdgcn_sched_barrier(0);
-    weights_next(0);
-    if (n_steps > 1) gather_next();
-    if (n_steps > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int step = 0; step < n_steps; ++step) {
-      const bool more1 = step + 1 < n_steps, more2 = step + 2 < n_steps;
-      if (more1) blend_store((step + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more1) weights_next((step + 1) & 1);
-      if (more2) gather_next();
-      __builtin_amdgcn_sched_barrier(0);
-      if (more2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    return;
-  }
-  // ================= waves 8-15: 64 output channels x 64 pixels each
-  const int cw = wave - 8, wm = cw & 3, wn2 = cw >> 2;
-  const unsigned hi = lane >> 5;
-  unsigned fa[2], fb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) fa[i] = (unsigned)(wm * 64 + i * 32 + (lane & 31));
-#pragma unroll
-  for (int j = 0; j < 2; ++j) fb[j] = (unsigned)(wn2 * 64 + j * 32 + (lane & 31));
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  __builtin_amdgcn_s_barrier();     // (the producers' prologue)
-  for (int step = 0; step < n_steps; ++step) {
-    const char *Ab = smem + (step & 1) * kGA;
-    const char *Bb = smem + 2 * kGA + (step & 1) * kGB;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const unsigned c = 2u * ks + hi;
-      f16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f16x8 *>(Ab + fa[i] * 128 + ((c ^ swz8(fa[i])) << 4));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8 *>(Bb + fb[j] * 128 + ((c ^ swz8(fb[j])) << 4));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn2 * 64 + j * 32 + (lane & 31);
-    if (n < N) {
-      const int b = n / HoWo, pix = n - b * HoWo;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int m = m0 + wm * 64 + i * 32 + 8 * rq + 4 * (lane >> 5);
-          const float v[4] = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
-          dcn_store4(out, bias, v, b, pix, m, g, cout_g, d.Cout, HoWo, tp);
-        }
-    }
-  }
-}
-
-
 // grid (tail tiles, Cout tiles, 8): block z sums accumulator quad z = i*4 + r of every thread
 template <int WN>
 __global__ __launch_bounds__(256 * WN) void dcn_tail_finish_kernel(const __half *__restrict__ bias,
@@ -1219,29 +1000,6 @@ int launch_glds(const __half *xt, const void *offset, const void *mask, const __
                               Glds<WN>::kLds) != hipSuccess)
         return BEVOPS_FAILURE;
       lds_set[WN == 4] = dev + 1;
-    }
-  }
-  if constexpr (WN == 4) {
-    if (g_mdconv_pc && tp.rotate == 0) {
-      // two roles per block (dcn_glds_f16_pc_kernel) for the main tiles; the K-split tail blocks keep the kernel above
-      static thread_local int pc_set = 0;
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (pc_set != dev + 1) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_glds_f16_pc_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, Glds<4>::kLds) != hipSuccess)
-          return BEVOPS_FAILURE;
-        pc_set = dev + 1;
-      }
-      if (tp.tail_tiles)
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tp.tail_tiles * tp.split), grid.y), dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st,
-                           xt, (const __half *)offset, (const __half *)mask, wt, (const __half *)bias, (__half *)output, d, g, tp);
-      hipLaunchKernelGGL(dcn_glds_f16_pc_kernel, dim3((unsigned)tp.main_tiles, grid.y), dim3(1024), Glds<4>::kLds, st, xt,
-                         (const __half *)offset, (const __half *)mask, wt, (const __half *)bias, (__half *)output, d, g, tp);
-      if (tp.tail_tiles)
-        hipLaunchKernelGGL(dcn_tail_finish_kernel<WN>, dim3((unsigned)tp.tail_tiles, grid.y, 8),
-                           dim3(Glds<WN>::kThreads), 0, st, (const __half *)bias, (__half *)output, d, g, tp);
-      return launch_status();
     }
   }
   hipLaunchKernelGGL(kern, grid2, dim3(Glds<WN>::kThreads), Glds<WN>::kLds, st, xt,
@@ -1370,8 +1128,7 @@ extern "C" int bevops_mdconv_set_variant(int variant) {
   g_mdconv_wide = variant == 5;
   g_mdconv_rotate = variant == 7 ? 1 : (variant == 13 ? 2 : 0);
   g_mdconv_old_copy = variant == 12;
-  g_mdconv_pc = variant == 14;
-  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 12 || variant == 13 || variant == 14) ? 0 : variant;
+  g_mdconv_variant = (variant == 4 || variant == 5 || variant == 7 || variant == 12 || variant == 13) ? 0 : variant;
   return prev;
 }
 
