@@ -1,0 +1,29 @@
+"""Decoder reference-point refinement (det2trt/models/modules/decoder.py:93-103) as one bit-exact launch
+(bevops_refine_reference_points, csrc/refine.hip).  Not a reference plugin: the reference's engine evaluates these
+element-wise layers itself."""
+import torch
+
+from ..utils import lib as _lib
+
+
+def refine_reference_points(tmp, reference_points):
+    """tmp [1, n, >= 5] (regression branch output), reference_points [1, n, 3], both fp16 on the device ->
+    (new_reference_points [1, n, 3], reference_xy [1, n, 1, 2] contiguous): sigmoid(tmp[..., (0, 1, 4)] +
+    inverse_sigmoid(reference_points)) with the framework's rounding after every step."""
+    assert tmp.is_cuda and tmp.dtype == torch.float16 and reference_points.dtype == torch.float16
+    n = reference_points.shape[-2]
+    assert reference_points.shape[-1] == 3 and tmp.shape[-2] == n and tmp.shape[-1] >= 5
+    t2 = tmp.reshape(n, tmp.shape[-1])
+    if not t2.is_contiguous():
+        t2 = t2.contiguous()
+    r2 = reference_points.reshape(n, 3)
+    if not r2.is_contiguous():
+        r2 = r2.contiguous()
+    new = torch.empty((1, n, 3), dtype=torch.float16, device=tmp.device)
+    xy = torch.empty((1, n, 1, 2), dtype=torch.float16, device=tmp.device)
+    handle = _lib.load_library()
+    with torch.cuda.device(tmp.device):
+        st = handle.bevops_refine_reference_points(_lib.F16, t2.data_ptr(), r2.data_ptr(), new.data_ptr(), xy.data_ptr(), n,
+                                                   t2.shape[-1], _lib.current_stream_ptr(tmp.device))
+    _lib.check(st, "bevops_refine_reference_points")
+    return new, xy

@@ -1,0 +1,56 @@
+"""bevops_refine_reference_points (csrc/refine.hip) against the framework's op sequence of the decoder's reference-point
+refinement (geometry.refine_reference_points = det2trt/models/modules/decoder.py:24-40, 93-103): BIT-EXACT -- the refined
+points are the next layer's sampling locations."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _all_half(lo, hi):
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16)
+    v = bits.view(torch.float16)
+    keep = torch.isfinite(v.float()) & (v.float() >= lo) & (v.float() <= hi)
+    return v[keep]
+
+
+def _check(tmp3, ref):
+    """tmp3 [n, 3] (the three regression values that are used), ref [n, 3]"""
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd import geometry as G
+    n = ref.shape[0]
+    tmp = torch.zeros(1, n, 10, dtype=torch.float16, device="cuda")
+    tmp[0, :, 0], tmp[0, :, 1], tmp[0, :, 4] = tmp3[:, 0], tmp3[:, 1], tmp3[:, 2]
+    tmp[0, :, 2] = 7.0      # (columns the refinement must not read)
+    r = ref.cuda().view(1, n, 3)
+    want = G.refine_reference_points(tmp, r)
+    new, xy = bev.refine_reference_points(tmp, r)
+    assert new.shape == (1, n, 3) and xy.shape == (1, n, 1, 2) and xy.is_contiguous()
+    same = (new.view(torch.int16) == want.view(torch.int16)) | (torch.isnan(new) & torch.isnan(want))
+    assert bool(same.all()), "differs at %d of %d" % (int((~same).sum()), same.numel())
+    assert torch.equal(xy.view(n, 2).view(torch.int16), new[0, :, :2].contiguous().view(torch.int16))
+
+
+def test_every_reference_point_value_and_every_regression_value():
+    """(a) every binary16 reference point in [0, 1] (15 361 values: the inverse sigmoid incl. both clamps) with a few
+    regression values; (b) every finite binary16 regression value against reference points that make the inverse sigmoid
+    0 (0.5) and +- large: the sum and the sigmoid on every input they can see."""
+    refs = _all_half(0.0, 1.0)
+    n = refs.numel()
+    for t in (0.0, 0.37, -2.5, 11.0):
+        _check(torch.full((n, 3), t, dtype=torch.float16).cuda(), torch.stack([refs, refs.flip(0), refs], 1))
+    ts = _all_half(-65504.0, 65504.0)
+    m = ts.numel()
+    for rv in (0.5, 0.25, 0.999, 1e-4):
+        _check(torch.stack([ts, ts.flip(0), ts], 1).cuda(), torch.full((m, 3), rv, dtype=torch.float16))
+
+
+def test_random_points_beyond_the_unit_interval_and_the_model_shapes():
+    """Reference points outside [0, 1] (clamped), NaN / inf regression values, the decoder's 900 queries."""
+    g = torch.Generator().manual_seed(0)
+    ref = (torch.rand(900, 3, generator=g) * 1.4 - 0.2).half()
+    tmp3 = (torch.randn(900, 3, generator=g) * 3).half()
+    tmp3[5, 0], tmp3[6, 1], tmp3[7, 2] = float("inf"), float("-inf"), float("nan")
+    _check(tmp3.cuda(), ref)
+    ref[11, 0] = float("nan")
+    _check(tmp3.cuda(), ref)
