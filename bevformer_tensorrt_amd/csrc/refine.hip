@@ -4,11 +4,14 @@
 // add, sigmoid, + the contiguous copy of the (x, y) columns the next layer's sampler takes): 42 launches of 4-5 us per
 // frame.  The refined points are SAMPLING LOCATIONS of the next layer (index generation bit-exact),
 // so every step is the framework's: operands widened to fp32, ONE operation, rounded back to binary16 -- clamp against
-// the fp32 images of the Python scalars 1e-5 and 1 - 1e-5, 1 - x, IEEE division, the device library's log, the sum,
-// 1 / (1 + exp(-x)) with the device library's exp and an IEEE division -- with floating-point contraction off.
+// the fp32 images of the Python scalars 1e-5 and 1 - 1e-5, 1 - x, IEEE division, log, the sum, sigmoid.  The two
+// transcendental steps are binary16 -> binary16 functions of ONE argument, and this compiler's logf is not the
+// framework binary's (its log of 0.0895385742 lands on the other side of a binary16 tie: one reference point in 15 361
+// came out three ulps off; round 4's one-launch refinement was removed for the same reason), so they are TABLES: 65 536
+// entries each, filled once per process by the framework's own torch.log / torch.sigmoid on every binary16 value
+// (functions/refine.py) -- bit-exact by construction, whatever device library either side was built with.
 // tests/test_refine_gpu.py compares with the framework's op sequence on EVERY binary16 reference point in [0, 1] and on
-// every finite binary16 regression value.  (Round 4 had a one-launch refinement that missed single ulps and was
-// removed; it had used the fast exp / log intrinsics.)
+// every finite binary16 regression value.
 #include "common.h"
 
 namespace bevops {
@@ -16,7 +19,12 @@ namespace {
 
 __device__ __forceinline__ float r16(float v) { return __half2float(__float2half_rn(v)); }   // one binary16 rounding
 
-__device__ __forceinline__ float refine_one(float t, float ref) {
+__device__ __forceinline__ float table16(const __half *__restrict__ tab, float v) {
+  return __half2float(tab[__half_as_ushort(__float2half_rn(v))]);
+}
+
+__device__ __forceinline__ float refine_one(float t, float ref, const __half *__restrict__ log_tab,
+                                            const __half *__restrict__ sig_tab) {
 #pragma clang fp contract(off) reciprocal(off)
   const float lo = 1e-5f, hi = (float)(1.0 - 1e-5);
   const float x = r16(fminf(fmaxf(ref, lo), hi));       // torch.clamp(min=eps, max=1 - eps) on a half tensor
@@ -24,21 +32,23 @@ __device__ __forceinline__ float refine_one(float t, float ref) {
   const float xc = ref != ref ? ref : x;
   const float om = r16(1.0f - xc);                        // 1 - x
   const float q = r16(__fdiv_rn(xc, om));                 // x / (1 - x)
-  const float l = r16(logf(q));                           // torch.log
+  const float l = table16(log_tab, q);                    // torch.log (q is a binary16 value)
   const float s = r16(t + l);                             // tmp + inverse_sigmoid(ref)
-  return r16(__fdiv_rn(1.0f, 1.0f + expf(-s)));          // torch.sigmoid
+  return table16(sig_tab, s);                             // torch.sigmoid
 }
 
 __global__ __launch_bounds__(256) void refine_reference_points_kernel(const __half *__restrict__ tmp,
                                                                       const __half *__restrict__ ref,
                                                                       __half *__restrict__ new_ref,
-                                                                      __half *__restrict__ ref_xy, int n, int tmp_stride) {
+                                                                      __half *__restrict__ ref_xy, int n, int tmp_stride,
+                                                                      const __half *__restrict__ log_tab,
+                                                                      const __half *__restrict__ sig_tab) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= n) return;
   const __half *t = tmp + (size_t)q * tmp_stride;
-  const float v0 = refine_one(__half2float(t[0]), __half2float(ref[3 * q]));
-  const float v1 = refine_one(__half2float(t[1]), __half2float(ref[3 * q + 1]));
-  const float v2 = refine_one(__half2float(t[4]), __half2float(ref[3 * q + 2]));
+  const float v0 = refine_one(__half2float(t[0]), __half2float(ref[3 * q]), log_tab, sig_tab);
+  const float v1 = refine_one(__half2float(t[1]), __half2float(ref[3 * q + 1]), log_tab, sig_tab);
+  const float v2 = refine_one(__half2float(t[4]), __half2float(ref[3 * q + 2]), log_tab, sig_tab);
   new_ref[3 * q] = __float2half_rn(v0);
   new_ref[3 * q + 1] = __float2half_rn(v1);
   new_ref[3 * q + 2] = __float2half_rn(v2);
@@ -54,15 +64,18 @@ __global__ __launch_bounds__(256) void refine_reference_points_kernel(const __ha
 using namespace bevops;
 
 // tmp [n, tmp_stride >= 5] (the regression branch's output: columns 0, 1 and 4 are used), reference_points [n, 3],
-// new_reference_points [n, 3], reference_xy [n, 2] (may be null): all fp16.
+// new_reference_points [n, 3], reference_xy [n, 2] (may be null): all fp16.  log_table / sigmoid_table: fp16 [65 536],
+// entry i = the function of the binary16 value with bit pattern i (the caller's definition of log and sigmoid).
 extern "C" int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points,
                                               void *new_reference_points, void *reference_xy, int num_query, int tmp_stride,
-                                              void *stream) {
+                                              const void *log_table, const void *sigmoid_table, void *stream) {
   if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
-  if (!tmp || !reference_points || !new_reference_points || num_query <= 0 || tmp_stride < 5) return BEVOPS_BAD_PARAM;
+  if (!tmp || !reference_points || !new_reference_points || !log_table || !sigmoid_table || num_query <= 0 || tmp_stride < 5)
+    return BEVOPS_BAD_PARAM;
   hipLaunchKernelGGL(refine_reference_points_kernel, dim3((unsigned)((num_query + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const __half *>(tmp),
                      static_cast<const __half *>(reference_points), static_cast<__half *>(new_reference_points),
-                     static_cast<__half *>(reference_xy), num_query, tmp_stride);
+                     static_cast<__half *>(reference_xy), num_query, tmp_stride, static_cast<const __half *>(log_table),
+                     static_cast<const __half *>(sigmoid_table));
   return launch_status();
 }

@@ -5,6 +5,21 @@ import torch
 
 from ..utils import lib as _lib
 
+_TABLES = {}      # device -> (log table, sigmoid table): fp16 [65536], entry i = f(binary16 value with bit pattern i)
+
+
+def _tables(device):
+    """log and sigmoid of EVERY binary16 value, evaluated once per process by the framework's own element-wise kernels:
+    inside the fused launch the two transcendental steps are then the framework's results bit for bit (this library's
+    compiler does not produce the framework binary's logf: csrc/refine.hip)."""
+    key = str(device)
+    hit = _TABLES.get(key)
+    if hit is None:
+        assert not torch.cuda.is_current_stream_capturing(), "refine tables must be built before stream capture"
+        v = torch.arange(0, 1 << 16, dtype=torch.int32, device=device).to(torch.int16).view(torch.float16)
+        hit = _TABLES[key] = (torch.log(v).contiguous(), torch.sigmoid(v).contiguous())
+    return hit
+
 
 def refine_reference_points(tmp, reference_points):
     """tmp [1, n, >= 5] (regression branch output), reference_points [1, n, 3], both fp16 on the device ->
@@ -21,9 +36,11 @@ def refine_reference_points(tmp, reference_points):
         r2 = r2.contiguous()
     new = torch.empty((1, n, 3), dtype=torch.float16, device=tmp.device)
     xy = torch.empty((1, n, 1, 2), dtype=torch.float16, device=tmp.device)
+    log_t, sig_t = _tables(tmp.device)
     handle = _lib.load_library()
     with torch.cuda.device(tmp.device):
         st = handle.bevops_refine_reference_points(_lib.F16, t2.data_ptr(), r2.data_ptr(), new.data_ptr(), xy.data_ptr(), n,
-                                                   t2.shape[-1], _lib.current_stream_ptr(tmp.device))
+                                                   t2.shape[-1], log_t.data_ptr(), sig_t.data_ptr(),
+                                                   _lib.current_stream_ptr(tmp.device))
     _lib.check(st, "bevops_refine_reference_points")
     return new, xy

@@ -447,10 +447,13 @@ int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, const void *b
 /* Decoder reference-point refinement (det2trt/models/modules/decoder.py:24-40, 93-103) as one launch:
  *   new_reference_points[q] = sigmoid((tmp[q][0], tmp[q][1], tmp[q][4]) + inverse_sigmoid(reference_points[q]))
  * on fp16 tensors, every step rounded to binary16 as the framework's op sequence rounds it (the refined points are the
- * next layer's sampling locations: bit-exact, tests/test_refine_gpu.py); reference_xy [n, 2] (optional) receives the
- * (x, y) columns contiguously.  tmp [n, tmp_stride], tmp_stride >= 5. */
+ * next layer's sampling locations: bit-exact, tests/test_refine_gpu.py).  log and sigmoid are binary16 -> binary16
+ * functions of one argument: the caller hands them in as tables of 65 536 fp16 entries (entry i = f(value with bit
+ * pattern i)), filled by whatever defines its reference -- the host layer fills them with the framework's own ops.
+ * reference_xy [n, 2] (optional) receives the (x, y) columns contiguously.  tmp [n, tmp_stride], tmp_stride >= 5. */
 int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points, void *new_reference_points,
-                                   void *reference_xy, int num_query, int tmp_stride, void *stream);
+                                   void *reference_xy, int num_query, int tmp_stride, const void *log_table,
+                                   const void *sigmoid_table, void *stream);
 /* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
  * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
  * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */
