@@ -175,6 +175,7 @@ def _layer_norm(ops, norm, x):
     return fn(x, norm.weight, norm.bias, norm.eps)
 
 
+_FUSED_REFINE = {"enabled": os.environ.get("BEVOPS_FUSED_REFINE", "1") == "1"}   # A/B: decoder refinement as one launch
 _OWN_ATTN = {"enabled": os.environ.get("BEVOPS_OWN_ATTN", "1") == "1"}   # A/B: decoder self-attention on csrc/attention.hip
 _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
 # The dense layers behind the backbone (the GEMMs that wrap the samplers, SURVEY.md 8a-5, the decoder, the heads) on the
@@ -1009,15 +1010,21 @@ class BEVFormer(nn.Module):
         init_reference = reference_points
         inter, inter_refs, regs = [], [], []
         out = query
-        # (a one-launch fused refinement was built in round 4 and REMOVED: index generation must stay bit-exact, and the
-        # device's exp / log inside a hand-written kernel did not reproduce the framework's op sequence on every element
-        # -- 1 binary16 ulp on a handful of 19 000; the seven small launches per layer stay)
+        # The refinement is ONE launch (round 6, functions/refine.py): the framework's eight element-wise launches per
+        # layer with its rounding after every step, log and sigmoid taken from tables the framework's own kernels
+        # filled -- bit-exact on every binary16 input (round 4's one-launch build evaluated exp / log itself, missed
+        # single ulps -- the refined points are sampling locations -- and was removed).
+        fused_refine = getattr(self.ops, "refine_reference_points", None) if _FUSED_REFINE["enabled"] and _R3["enabled"] \
+            and dtype == torch.float16 and dev.type == "cuda" else None
         ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
         for lid, layer in enumerate(self.decoder):
             out = layer(out, bev_embed, query_pos, ref_xy, bev_shapes)
             tmp = _mlp(self.ops, self.reg_branches[lid], out).view(1, -1, 10)
-            reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
-            ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
+            if fused_refine is not None:
+                reference_points, ref_xy = fused_refine(tmp, reference_points)
+            else:
+                reference_points = G.refine_reference_points(tmp, reference_points)      # decoder.py:93-103
+                ref_xy = reference_points[..., :2].unsqueeze(2).contiguous()
             inter.append(out)
             inter_refs.append(reference_points)
             regs.append(tmp)

@@ -484,6 +484,32 @@ def test_dense_layers_behind_the_backbone_run_on_the_hand_written_kernels():
     assert calls["backbone"].get("blaslt", 0) > 0     # ... while the backbone's 1x1 convolutions keep the table's choice
 
 
+def test_fused_decoder_refinement_leaves_the_frame_bit_identical():
+    """The one-launch reference-point refinement (bevops_refine_reference_points, default) against the framework's
+    eight launches per decoder layer: the whole base frame -- BEV features, class logits, boxes -- bit for bit, over two
+    frames (the second with history), eager and under graph replay."""
+    from bevformer_tensorrt_amd import bevformer as B, geometry as G
+    dev, dtype = torch.device("cuda"), torch.float16
+    model = B.BEVFormer("base", seed=0).to(dev, dtype)
+    H, W = B.CONFIGS["base"]["image"]
+    l2i = G.synthetic_lidar2img((H, W)).to(dev)
+    outs = {}
+    try:
+        for fused, graph in ((True, False), (False, False), (True, True)):
+            B._FUSED_REFINE["enabled"] = fused
+            r = B.FrameRunner(model, dev, dtype, graph=graph)
+            got = []
+            for img, can, scene in frames((H, W), 3, dev, dtype):
+                cls, crd = r.step(img, can, l2i, scene)
+                got.append((r.prev_bev.clone(), cls.clone(), crd.clone()))
+            outs[(fused, graph)] = got
+    finally:
+        B._FUSED_REFINE["enabled"] = True
+    for key in ((False, False), (True, True)):
+        for (ba, ca, da), (bb, cb, db) in zip(outs[(True, False)], outs[key]):
+            assert torch.equal(ba, bb) and torch.equal(ca, cb) and torch.equal(da, db), key
+
+
 def _frame_metrics(got, want):
     """(bev_embed mean |err| / std of the reference, class-logit MAE, box MAE, top-1 class agreement of the last decoder
     layer) of one frame's (prev_bev, classes, boxes) against the reference evaluation's."""
