@@ -1048,13 +1048,17 @@ class BEVFormer(nn.Module):
                 coords.append(crd)
             return bev_embed, torch.stack(classes), torch.stack(coords)
         crd = torch.stack(regs)                                                        # [6, 1, 900, 10]
+        decode = getattr(self.ops, "decode_boxes", None) if fused_refine is not None else None
+        hs = torch.stack(inter).view(6, NUM_QUERY, EMBED)
+        if decode is not None:      # the ~20 element-wise launches below as ONE, bit-exact (functions/refine.py)
+            crd = decode(crd, torch.stack([init_reference] + inter_refs[:-1]), PC_RANGE)
+            return bev_embed, self._cls_batched(hs).view(6, 1, NUM_QUERY, -1), crd
         reference = inverse_sigmoid(torch.stack([init_reference] + inter_refs[:-1]))   # [6, 1, 900, 3]
         crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
         crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
         crd[..., 0:1] = crd[..., 0:1] * (PC_RANGE[3] - PC_RANGE[0]) + PC_RANGE[0]
         crd[..., 1:2] = crd[..., 1:2] * (PC_RANGE[4] - PC_RANGE[1]) + PC_RANGE[1]
         crd[..., 4:5] = crd[..., 4:5] * (PC_RANGE[5] - PC_RANGE[2]) + PC_RANGE[2]
-        hs = torch.stack(inter).view(6, NUM_QUERY, EMBED)
         return bev_embed, self._cls_batched(hs).view(6, 1, NUM_QUERY, -1), crd
 
     def _cls_batched(self, hs):

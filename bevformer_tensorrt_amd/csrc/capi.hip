@@ -89,6 +89,7 @@ const Entry kTable[] = {
     {"bevops_conv_tile_f16", (void *)&bevops_conv_tile_f16},
     {"bevops_conv3x3_c64_f16", (void *)&bevops_conv3x3_c64_f16},
     {"bevops_refine_reference_points", (void *)&bevops_refine_reference_points},
+    {"bevops_decode_boxes", (void *)&bevops_decode_boxes},
     {"bevops_conv_tile_int8_fused", (void *)&bevops_conv_tile_int8_fused},
     {"bevops_linear_int8_chain", (void *)&bevops_linear_int8_chain},
     {"bevops_conv_tile_int8", (void *)&bevops_conv_tile_int8},

@@ -58,10 +58,62 @@ __global__ __launch_bounds__(256) void refine_reference_points_kernel(const __ha
   }
 }
 
+// The head's box decoding (bevformer_head.py:247-282 with mmdet's inverse_sigmoid, :6,254: clamp to [0, 1], then each
+// factor to >= eps) on the stacked decoder levels, same construction: per element
+//   ref' = log(max(clamp(ref, 0, 1), eps) / max(1 - clamp(ref, 0, 1), eps))
+//   x = sigmoid(reg[0] + ref'[0]) * sx + ox,  y = sigmoid(reg[1] + ref'[1]) * sy + oy,  z = sigmoid(reg[4] + ref'[2]) * sz + oz
+// every step rounded to binary16 as the framework's ~20 launches round it; the other seven columns are copied.
+__device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) {
+  return v != v ? v : fminf(fmaxf(v, lo), hi);
+}
+__device__ __forceinline__ float max_keep_nan(float v, float lo) { return v != v ? v : fmaxf(v, lo); }
+
+__device__ __forceinline__ float decode_one(float reg, float ref, float scale, float off, const __half *__restrict__ log_tab,
+                                            const __half *__restrict__ sig_tab) {
+#pragma clang fp contract(off) reciprocal(off)
+  const float c = r16(clamp_keep_nan(ref, 0.f, 1.f));
+  const float x1 = r16(max_keep_nan(c, 1e-5f));
+  const float x2 = r16(max_keep_nan(r16(1.0f - c), 1e-5f));
+  const float l = table16(log_tab, r16(__fdiv_rn(x1, x2)));
+  const float sg = table16(sig_tab, r16(reg + l));
+  return r16(r16(sg * scale) + off);
+}
+
+__global__ __launch_bounds__(256) void decode_boxes_kernel(const __half *__restrict__ regs, const __half *__restrict__ refs,
+                                                           __half *__restrict__ out, int n, float sx, float ox, float sy,
+                                                           float oy, float sz, float oz, const __half *__restrict__ log_tab,
+                                                           const __half *__restrict__ sig_tab) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  const __half *r = regs + (size_t)q * 10;
+  __half o[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) o[k] = r[k];
+  o[0] = __float2half_rn(decode_one(__half2float(r[0]), __half2float(refs[3 * q]), sx, ox, log_tab, sig_tab));
+  o[1] = __float2half_rn(decode_one(__half2float(r[1]), __half2float(refs[3 * q + 1]), sy, oy, log_tab, sig_tab));
+  o[4] = __float2half_rn(decode_one(__half2float(r[4]), __half2float(refs[3 * q + 2]), sz, oz, log_tab, sig_tab));
+#pragma unroll
+  for (int k = 0; k < 10; ++k) out[(size_t)q * 10 + k] = o[k];
+}
+
 }  // namespace
 }  // namespace bevops
 
 using namespace bevops;
+
+// regs [count, 10], refs [count, 3] -> out [count, 10] (fp16; out may alias regs): the head's decoded boxes of all stacked
+// levels.  (scale, offset) per axis = (pc_range[3 + a] - pc_range[a], pc_range[a]) as fp32.  Tables as below.
+extern "C" int bevops_decode_boxes(int dtype, const void *regs, const void *refs, void *out, int count, float scale_x,
+                                   float offset_x, float scale_y, float offset_y, float scale_z, float offset_z,
+                                   const void *log_table, const void *sigmoid_table, void *stream) {
+  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
+  if (!regs || !refs || !out || !log_table || !sigmoid_table || count <= 0) return BEVOPS_BAD_PARAM;
+  hipLaunchKernelGGL(decode_boxes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const __half *>(regs), static_cast<const __half *>(refs), static_cast<__half *>(out), count,
+                     scale_x, offset_x, scale_y, offset_y, scale_z, offset_z, static_cast<const __half *>(log_table),
+                     static_cast<const __half *>(sigmoid_table));
+  return launch_status();
+}
 
 // tmp [n, tmp_stride >= 5] (the regression branch's output: columns 0, 1 and 4 are used), reference_points [n, 3],
 // new_reference_points [n, 3], reference_xy [n, 2] (may be null): all fp16.  log_table / sigmoid_table: fp16 [65 536],

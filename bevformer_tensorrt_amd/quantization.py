@@ -180,7 +180,7 @@ class Int8PluginOps:
     # for LinearQ, and -- `fused_sca=True` -- the fused fp16 SCA sampler.  Like a TensorRT INT8 engine the
     # build is then mixed: INT8 where an INT8 implementation exists and pays, fp16 elsewhere.
     _PASS = ("bias_act_nhwc_", "conv_offset_nhwc", "modulated_deformable_conv2d_nhwc", "layer_norm",
-             "linear_bias_act", "dense_auto", "tsgemm_ln", "self_attention_qkv", "refine_reference_points", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "stem_conv_pool",
+             "linear_bias_act", "dense_auto", "tsgemm_ln", "self_attention_qkv", "refine_reference_points", "decode_boxes", "conv3x3_auto", "conv_nhwc", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "stem_conv_pool",
              "image_normalize_pad", "upsample_add_nhwc_", "feat_embed_nhwc", "tsa_split", "queue_mean2")
     # `engine=True` (the build bench.py times, build_int8_engine below) additionally passes the entries whose fp16
     # form is FASTER than any int8 form on MI355X: the channels-last nearest-neighbour rotate of prev_bev (pure data

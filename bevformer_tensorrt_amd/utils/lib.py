@@ -105,6 +105,7 @@ SIGNATURES = {
     "bevops_conv_tile_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "bevops_conv3x3_c64_f16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "bevops_refine_reference_points": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 2 + [c_void_p] * 3),
+    "bevops_decode_boxes": (c_int, [c_int] + [c_void_p] * 3 + [c_int] + [c_float] * 6 + [c_void_p] * 3),
     "bevops_bias_relu_maxpool_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bevops_stem_packed_size": (c_size_t, []),
     "bevops_stem_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

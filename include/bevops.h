@@ -454,6 +454,13 @@ int bevops_conv3x3_c64_f16(const void *x, const void *weight_taps, const void *b
 int bevops_refine_reference_points(int dtype, const void *tmp, const void *reference_points, void *new_reference_points,
                                    void *reference_xy, int num_query, int tmp_stride, const void *log_table,
                                    const void *sigmoid_table, void *stream);
+/* The head's box decoding on the stacked decoder levels (det2trt/models/dense_heads/bevformer_head.py:247-282 with
+ * mmdet's inverse_sigmoid): x / y / z columns (0, 1, 4) = sigmoid(reg + inverse_sigmoid(ref)) * scale + offset, the
+ * other seven columns copied; every step rounded to binary16 as the framework's op sequence rounds it, log / sigmoid
+ * from the caller's tables (see bevops_refine_reference_points).  regs, out [count, 10]; refs [count, 3]. */
+int bevops_decode_boxes(int dtype, const void *regs, const void *refs, void *out, int count, float scale_x, float offset_x,
+                        float scale_y, float offset_y, float scale_z, float offset_z, const void *log_table,
+                        const void *sigmoid_table, void *stream);
 /* The same convolution as an INT8 layer (`Conv2dQ`, det2trt/models/utils/register.py:79): fp16 activation
  * quantised with scale_a inside the operand load (as bevops_linear_int8_fused), int8 weights in the taps-major
  * layout, int32 sums, de-quantising epilogue with fp32 bias / fp16 identity / ReLU, fp16 out.  Cin % 64 == 0. */

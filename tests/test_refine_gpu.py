@@ -54,3 +54,47 @@ def test_random_points_beyond_the_unit_interval_and_the_model_shapes():
     _check(tmp3.cuda(), ref)
     ref[11, 0] = float("nan")
     _check(tmp3.cuda(), ref)
+
+
+def _decode_reference(regs, refs):
+    """the framework's op sequence (bevformer.py, the per-level loop of the reference head, batched)"""
+    from bevformer_tensorrt_amd import bevformer as B
+    crd = regs.clone()
+    reference = B.inverse_sigmoid(refs)
+    crd[..., 0:2] = (crd[..., 0:2] + reference[..., 0:2]).sigmoid()
+    crd[..., 4:5] = (crd[..., 4:5] + reference[..., 2:3]).sigmoid()
+    P = B.PC_RANGE
+    crd[..., 0:1] = crd[..., 0:1] * (P[3] - P[0]) + P[0]
+    crd[..., 1:2] = crd[..., 1:2] * (P[4] - P[1]) + P[1]
+    crd[..., 4:5] = crd[..., 4:5] * (P[5] - P[2]) + P[2]
+    return crd
+
+
+def test_decode_boxes_is_bit_exact_on_every_reference_value_and_every_regression_value():
+    import bevformer_tensorrt_amd as bev
+    from bevformer_tensorrt_amd import bevformer as B
+
+    def check(regs, refs):
+        want = _decode_reference(regs, refs)
+        got = bev.decode_boxes(regs, refs, B.PC_RANGE)
+        same = (got.view(torch.int16) == want.view(torch.int16)) | (torch.isnan(got) & torch.isnan(want))
+        assert bool(same.all()), "differs at %d of %d" % (int((~same).sum()), same.numel())
+
+    g = torch.Generator().manual_seed(3)
+    refs_all = _all_half(-0.25, 1.25)                 # incl. values the first clamp cuts
+    n = refs_all.numel()
+    for t in (0.0, -1.3, 4.0):
+        regs = (torch.randn(n, 10, generator=g) * 2).half()
+        regs[:, 0], regs[:, 1], regs[:, 4] = t, t, t
+        check(regs.cuda(), torch.stack([refs_all, refs_all.flip(0), refs_all], 1).cuda())
+    ts = _all_half(-65504.0, 65504.0)
+    m = ts.numel()
+    for rv in (0.5, 0.031, 0.97):
+        regs = torch.zeros(m, 10, dtype=torch.float16)
+        regs[:, 0], regs[:, 1], regs[:, 4] = ts, ts.flip(0), ts
+        check(regs.cuda(), torch.full((m, 3), rv, dtype=torch.float16).cuda())
+    regs = (torch.randn(6, 1, 900, 10, generator=g) * 3).half().cuda()     # the model's stacked shape, NaN / inf inside
+    regs[0, 0, 3, 0], regs[1, 0, 4, 4] = float("nan"), float("inf")
+    refs = torch.rand(6, 1, 900, 3, generator=g).half().cuda()
+    refs[2, 0, 5, 1] = float("nan")
+    check(regs, refs)
