@@ -175,7 +175,6 @@ def _layer_norm(ops, norm, x):
     return fn(x, norm.weight, norm.bias, norm.eps)
 
 
-_TSA_MEAN2 = {"enabled": os.environ.get("BEVOPS_TSA_MEAN2", "1") == "1"}   # A/B: TSA sampling + queue mean in one launch
 _FUSED_REFINE = {"enabled": os.environ.get("BEVOPS_FUSED_REFINE", "1") == "1"}   # A/B: decoder refinement as one launch
 _OWN_ATTN = {"enabled": os.environ.get("BEVOPS_OWN_ATTN", "1") == "1"}   # A/B: decoder self-attention on csrc/attention.hip
 _LN_FUSED = {"enabled": os.environ.get("BEVOPS_LN_FUSED", "1") == "1"}   # A/B: LayerNorm in the epilogue of the GEMM in front of it
@@ -539,21 +538,6 @@ class TemporalSelfAttention(nn.Module):
         # layout-preserving entry skips the head-major re-layout the default dispatch needs for random points
         msda = (getattr(self.ops, "multi_scale_deformable_attn_local", None) if _TSA_LOCAL["enabled"] else None) \
             or self.ops.multi_scale_deformable_attn
-        # round 6: sampling of both queue entries AND their mean in one launch (same bits as the two launches below)
-        fused_mean = getattr(self.ops, "multi_scale_deformable_attn_mean2", None) \
-            if (_TSA_MEAN2["enabled"] and _TSA_LOCAL["enabled"] and _TSA_GLUE["enabled"] and _R3["enabled"]) else None
-        out = None
-        if fused_mean is not None and value.is_cuda and value.dtype == torch.float16 and value.shape[0] == 2 \
-                and self.points == 4 and spatial_shapes.shape[0] == 1:
-            try:
-                out = fused_mean(value, spatial_shapes, ref_2d, off, w)
-            except _lib.BevopsError as exc:
-                if exc.status != _lib.NOT_SUPPORTED:
-                    raise
-        if out is not None:
-            if norm is not None:
-                return _dense_norm(self.ops, self.output_proj, out, identity, norm)
-            return _dense(self.ops, self.output_proj, out, identity, False)
         out = msda(value, spatial_shapes, ref_2d, off, w).flatten(2)
         mean2 = getattr(self.ops, "queue_mean2", None) if _TSA_GLUE["enabled"] else None
         if mean2 is not None and out.is_cuda and out.dtype == torch.float16 and out.numel() % 16 == 0 and _R3["enabled"]:

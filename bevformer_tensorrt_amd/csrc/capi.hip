@@ -25,7 +25,6 @@ struct Entry {
 };
 const Entry kTable[] = {
     {"bevops_msda_forward", (void *)&bevops_msda_forward},
-    {"bevops_msda_forward_mean2", (void *)&bevops_msda_forward_mean2},
     {"bevops_msda_forward_ws", (void *)&bevops_msda_forward_ws},
     {"bevops_msda_workspace_size", (void *)&bevops_msda_workspace_size},
     {"MultiScaleDeformableAttnTRT", (void *)&bevops_msda_forward},

@@ -27,20 +27,12 @@
 namespace bevops {
 namespace {
 
-template <typename T> __device__ __forceinline__ float round_to(float v);
-template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half_rn(v)); }
-
 // ---------------------------------------------------------------------------
 // quad kernel: C == 32, (L*P) % 4 == 0.  PPL = points owned per lane = L*P/4.
 // CH = how many of its own points a lane prepares per pass (register pressure
 // knob: state is 8 VGPR per prepared point).
 // ---------------------------------------------------------------------------
-// MEAN2 (round 6, temporal self-attention: bs == 2 = the two BEV-queue entries, temporal_self_attention.py:350-457):
-// a quad computes the SAME (query, head) of both batch entries and stores their mean -- each entry rounded to T as the
-// separate launch stores it, (x0 + x1) / 2 in fp32, one rounding: the bits of this kernel + bevops_queue_mean2, without
-// the second launch and without writing / re-reading the 2 x [nq, 256] intermediate.  n_item counts ONE entry's items.
-template <typename T, int PPL, int CH, bool MEAN2 = false>
+template <typename T, int PPL, int CH>
 __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
     const T *__restrict__ value, unsigned value_bytes, const int32_t *__restrict__ shapes,
     const T *__restrict__ ref, const T *__restrict__ off, const T *__restrict__ logit,
@@ -59,12 +51,9 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
   __syncthreads();
 
   const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned item0 = vb * (kBlock / 4) + (threadIdx.x >> 2);
-  if (item0 >= n_item) return;  // whole quads leave together
+  const unsigned item = vb * (kBlock / 4) + (threadIdx.x >> 2);
+  if (item >= n_item) return;  // whole quads leave together
   const unsigned sub = threadIdx.x & 3u;
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value), 0, value_bytes, 0x00020000);
-  auto compute = [&](const unsigned item, float (&acc)[V]) __attribute__((always_inline)) {
   const unsigned bq = item / (unsigned)d.heads;
   const unsigned h = item - bq * (unsigned)d.heads;
   const unsigned b = bq / (unsigned)d.nq;
@@ -72,6 +61,9 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
   const unsigned row_bytes = (unsigned)d.heads * 32u * (unsigned)sizeof(T);  // one pixel, all heads
   const unsigned lane_base =
       ((b * (unsigned)d.nk * (unsigned)d.heads + h) * 32u + sub * V) * (unsigned)sizeof(T);
+
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value), 0, value_bytes, 0x00020000);
 
   // ---- own logits -> softmax numerators ----
   // row of this item in sampling_offsets / attention_weights (camera-shared when d.shared)
@@ -100,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
   int p = j0 - l * d.P;
   int g = p % d.ppg;
 
+  float acc[V];
 #pragma unroll
   for (int c = 0; c < V; ++c) acc[c] = 0.f;
 
@@ -167,16 +160,7 @@ __global__ __launch_bounds__(kBlock) void msda_quad_kernel(
   const float inv = 1.0f / s;
 #pragma unroll
   for (int c = 0; c < V; ++c) acc[c] *= inv;
-  };   // compute
-  float acc[V];
-  compute(item0, acc);
-  if constexpr (MEAN2) {
-    float acc1[V];
-    compute(item0 + n_item, acc1);      // the same (query, head) of the second batch entry
-#pragma unroll
-    for (int c = 0; c < V; ++c) acc[c] = (round_to<T>(acc[c]) + round_to<T>(acc1[c])) * 0.5f;
-  }
-  store8(out + (size_t)item0 * 32u + sub * V, acc);
+  store8(out + (size_t)item * 32u + sub * V, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,20 +518,6 @@ int launch_quad(const T *value, const int32_t *shapes, const T *ref, const T *of
   return launch_status();
 }
 
-// temporal self-attention's call with the mean over its two batch entries in the kernel (fp16, bs == 2, L * P == 4)
-int msda_quad_mean2(const __half *value, const int32_t *shapes, const __half *ref, const __half *off, const __half *logit,
-                    __half *out, const MsdaDims &d, hipStream_t st) {
-  const size_t n_item = (size_t)d.nq * d.heads;
-  const size_t vbytes = (size_t)d.bs * d.nk * d.heads * d.C * sizeof(__half);
-  if (d.bs != 2 || d.C != 32 || d.L * d.P != 4 || d.L > kMaxLevels || vbytes >= 0xFFFFFF00ull || 2 * n_item >= 0x7FFFFFFFull ||
-      !aligned16(value) || !aligned16(off) || !aligned16(logit) || !aligned16(out) || !aligned16(ref))
-    return BEVOPS_NOT_SUPPORTED;
-  const unsigned grid = (unsigned)((n_item + kBlock / 4 - 1) / (kBlock / 4));
-  hipLaunchKernelGGL((msda_quad_kernel<__half, 1, 1, true>), dim3(grid), dim3(kBlock), 0, st, value, (unsigned)vbytes, shapes,
-                     ref, off, logit, out, d, (unsigned)n_item);
-  return launch_status();
-}
-
 template <typename T>
 int msda_float(const T *value, const int32_t *shapes, const T *ref, const T *off, const T *logit,
                T *out, const MsdaDims &d, hipStream_t st) {
@@ -882,25 +852,6 @@ extern "C" int bevops_msda_forward(int dtype, const void *value, const int32_t *
                                 output, bs, nk, heads, channels, num_levels, num_query, num_point,
                                 points_per_group, scale_value, scale_offset, scale_weight,
                                 scale_out, 0, nullptr, 0, stream);
-}
-
-// Temporal self-attention's sampling with the mean over its two BEV-queue entries inside the kernel
-// (temporal_self_attention.py:350-457: value [2, nk, heads, 32], one level, four points): out [1, nq, heads, 32] =
-// mean over bs of bevops_msda_forward -- each entry rounded to fp16, (x0 + x1) / 2 in fp32, one rounding: the bits of
-// bevops_msda_forward (layout-preserving kernel) followed by bevops_queue_mean2.
-extern "C" int bevops_msda_forward_mean2(int dtype, const void *value, const int32_t *spatial_shapes,
-                                         const void *reference_points, const void *sampling_offsets,
-                                         const void *attention_weights, void *output, int nk, int heads, int channels,
-                                         int num_levels, int num_query, int num_point, int points_per_group, void *stream) {
-  if (!value || !spatial_shapes || !reference_points || !sampling_offsets || !attention_weights || !output)
-    return BEVOPS_BAD_PARAM;
-  if (nk <= 0 || heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 || num_point <= 0 || points_per_group <= 0)
-    return BEVOPS_BAD_PARAM;
-  if (dtype != BEVOPS_F16) return BEVOPS_NOT_SUPPORTED;
-  const MsdaDims d{2, nk, heads, channels, num_levels, num_query, num_point, points_per_group, 0};
-  return msda_quad_mean2((const __half *)value, spatial_shapes, (const __half *)reference_points,
-                         (const __half *)sampling_offsets, (const __half *)attention_weights, (__half *)output, d,
-                         static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bevops_msda_forward_ws(int dtype, const void *value, const int32_t *spatial_shapes,

@@ -5,7 +5,6 @@ from .multi_scale_deformable_attn import (
     multi_scale_deformable_attn2,
     multi_scale_deformable_attn_int8,
     multi_scale_deformable_attn_local,
-    multi_scale_deformable_attn_mean2,
     msda_pack_value,
     multi_scale_deformable_attn_prepacked,
 )
@@ -45,5 +44,5 @@ __all__ = [
     "bev_pool_v2", "bev_pool_v2_2", "bev_pool_v2_int8",
     "modulated_deformable_conv2d", "modulated_deformable_conv2d2", "modulated_deformable_conv2d_int8",
     "spatial_cross_attention_sample", "spatial_cross_attention_projected", "spatial_cross_attention_plan", "modulated_deformable_conv2d_nhwc", "bias_act_nhwc_", "linear_bias_act", "layer_norm", "rotate_hwc", "conv_offset_nhwc", "upsample_add_nhwc_", "feat_embed_nhwc",
-    "msda_pack_value", "multi_scale_deformable_attn_prepacked", "multi_scale_deformable_attn_local", "multi_scale_deformable_attn_mean2", "image_normalize_pad", "padded_size", "quantize_rows", "dequantize_rows", "linear_int8", "tsgemm", "tsgemm_ln", "tile_gemm", "small_gemm", "dense_auto", "tsa_split", "queue_mean2", "conv_nhwc", "conv3x3_nhwc", "conv3x3_auto", "conv3x3_c64", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "stem_conv_pool", "point_sampling", "self_attention_qkv", "refine_reference_points", "decode_boxes",
+    "msda_pack_value", "multi_scale_deformable_attn_prepacked", "multi_scale_deformable_attn_local", "image_normalize_pad", "padded_size", "quantize_rows", "dequantize_rows", "linear_int8", "tsgemm", "tsgemm_ln", "tile_gemm", "small_gemm", "dense_auto", "tsa_split", "queue_mean2", "conv_nhwc", "conv3x3_nhwc", "conv3x3_auto", "conv3x3_c64", "conv_int8_nhwc", "bias_relu_maxpool_nhwc", "stem_conv_pool", "point_sampling", "self_attention_qkv", "refine_reference_points", "decode_boxes",
 ]

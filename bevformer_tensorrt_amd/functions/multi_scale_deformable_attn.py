@@ -172,35 +172,6 @@ def multi_scale_deformable_attn_local(value, value_spatial_shapes, reference_poi
         handle.bevops_msda_set_variant(prev)
 
 
-def multi_scale_deformable_attn_mean2(value, value_spatial_shapes, reference_points, sampling_offsets, attention_weights):
-    """Temporal self-attention's call -- value [2, nk, heads, 32] = the two BEV-queue entries, one level, four points --
-    with torch.mean(dim=0) of the result INSIDE the kernel (bevops_msda_forward_mean2): returns [1, nq, heads * 32], the
-    bits of multi_scale_deformable_attn_local(...).flatten(2) followed by queue_mean2.  Raises BevopsError
-    (NOT_SUPPORTED) for other shapes.  Not a reference name."""
-    assert value.is_cuda and value.dtype == torch.float16 and value.dim() == 4
-    bs, nk, heads, ch = value.shape
-    L = value_spatial_shapes.shape[0]
-    nq = sampling_offsets.shape[1]
-    ppg = reference_points.shape[-1] // 2
-    if bs != 2 or reference_points.dtype != torch.float16 or sampling_offsets.dtype != torch.float16 \
-            or attention_weights.dtype != torch.float16 or nq == 0:
-        raise _lib.BevopsError("bevops_msda_forward_mean2: two fp16 batch entries only", _lib.NOT_SUPPORTED)
-    P = attention_weights.numel() // (bs * nq * heads * L)
-    if sampling_offsets.numel() != bs * nq * heads * L * P * 2 or reference_points.numel() != bs * nq * ppg * 2:
-        raise ValueError("sampling_offsets / attention_weights / reference_points shapes disagree")
-    value, reference_points, sampling_offsets, attention_weights = (
-        t.contiguous() for t in (value, reference_points, sampling_offsets, attention_weights))
-    shapes_dev, _ = _shapes_i32(value_spatial_shapes, value.device)
-    out = torch.empty((1, nq, heads * ch), dtype=value.dtype, device=value.device)
-    handle = _lib.load_library()
-    with torch.cuda.device(value.device):
-        st = handle.bevops_msda_forward_mean2(_lib.F16, value.data_ptr(), shapes_dev.data_ptr(), reference_points.data_ptr(),
-                                              sampling_offsets.data_ptr(), attention_weights.data_ptr(), out.data_ptr(),
-                                              nk, heads, ch, L, nq, P, ppg, _lib.current_stream_ptr(value.device))
-    _lib.check(st, "bevops_msda_forward_mean2")
-    return out
-
-
 def multi_scale_deformable_attn2(value, value_spatial_shapes, reference_points, sampling_offsets,
                                  attention_weights):
     """Same op under the reference's `half2` plugin name (MultiScaleDeformableAttnTRT2,

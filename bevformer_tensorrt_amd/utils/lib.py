@@ -24,7 +24,6 @@ SIGNATURES = {
                             [c_float] * 4 + [c_void_p]),
     "bevops_msda_workspace_size": (c_size_t, [c_int] * 8),
     "bevops_msda_workspace_size_shapes": (c_size_t, [c_int, c_void_p] + [c_int] * 7),
-    "bevops_msda_forward_mean2": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "bevops_msda_forward_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                                [c_float] * 4 + [c_int, c_void_p, c_size_t, c_void_p]),

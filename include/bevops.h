@@ -113,14 +113,6 @@ int bevops_msda_forward(int dtype, const void *value, const int32_t *spatial_sha
  * to passing them repeated bs times, without the 6x redundant HBM reads. */
 size_t bevops_msda_workspace_size(int dtype, int bs, int nk, int heads, int channels,
                                   int num_levels, int num_query, int num_point);
-/* Temporal self-attention's sampling (det2trt/models/modules/temporal_self_attention.py:350-457: the two BEV-queue
- * entries are batch entries of one MSDA call, then averaged) with the mean INSIDE the kernel: value [2, nk, heads, 32],
- * reference_points [2, nq, 1, 2 ppg], sampling_offsets [2, nq, heads, L P 2], attention_weights [2, nq, heads, L P] (fp16,
- * L * P == 4) -> output [1, nq, heads, 32] = the bits of bevops_msda_forward followed by bevops_queue_mean2 (each entry
- * rounded to fp16, (x0 + x1) / 2 in fp32, one rounding).  spatial_shapes: DEVICE int32 [L][2].  NOT_SUPPORTED otherwise. */
-int bevops_msda_forward_mean2(int dtype, const void *value, const int32_t *spatial_shapes, const void *reference_points,
-                              const void *sampling_offsets, const void *attention_weights, void *output, int nk, int heads,
-                              int channels, int num_levels, int num_query, int num_point, int points_per_group, void *stream);
 /* Same, for a caller that knows the level shapes on the host ([num_levels][2] = (H, W)):
  * also covers the zero-padded re-layout with LDS-resident small levels (msda_hm3.hip), whose
  * size depends on the level shapes.  >= bevops_msda_workspace_size. */

@@ -66,29 +66,3 @@ def test_tsa_split_and_queue_mean_equal_the_framework_ops(nq):
     x[0, 0, :4] = torch.tensor([65504.0, -65504.0, 6.1e-5, 5.96e-8]).half()      # extremes: the sum is formed in fp32
     x[1, 0, :4] = torch.tensor([65504.0, 65504.0, 6.1e-5, 5.96e-8]).half()
     assert torch.equal(bev.queue_mean2(x), torch.mean(x, dim=0, keepdim=True))
-
-
-@pytest.mark.parametrize("bev,heads", [((200, 200), 8), ((50, 50), 8), ((13, 7), 8), ((1, 1), 8), ((30, 20), 4)])
-def test_tsa_sampling_with_the_queue_mean_in_the_kernel_is_bit_identical(bev, heads):
-    """bevops_msda_forward_mean2 (round 6): temporal self-attention's MSDA call on both BEV-queue entries with their mean
-    inside the kernel == the layout-preserving kernel followed by bevops_queue_mean2, bit for bit; other shapes are
-    NOT_SUPPORTED through the wrapper."""
-    import bevformer_tensorrt_amd as bevops
-    from bevformer_tensorrt_amd.utils import lib as _lib
-    H, W = bev
-    nq = H * W
-    g = torch.Generator().manual_seed(H + W + heads)
-    value = torch.randn(2, nq, heads, 32, generator=g).half().cuda()
-    ref = torch.rand(2, nq, 1, 2, generator=g).half().cuda()
-    off = (torch.randn(2, nq, heads, 8, generator=g) * 2).half().cuda()
-    w = torch.randn(2, nq, heads, 4, generator=g).half().cuda()
-    shapes = torch.tensor([[H, W]], dtype=torch.int32)
-    want = bevops.queue_mean2(bevops.multi_scale_deformable_attn_local(value, shapes, ref, off, w).flatten(2))
-    got = bevops.multi_scale_deformable_attn_mean2(value, shapes, ref, off, w)
-    assert got.shape == (1, nq, heads * 32) and torch.equal(got, want.view(1, nq, -1))
-    assert torch.equal(got, bevops.multi_scale_deformable_attn_mean2(value, shapes, ref, off, w))
-    with pytest.raises(_lib.BevopsError) as e:
-        bevops.multi_scale_deformable_attn_mean2(value[:1], shapes, ref[:1], off[:1], w[:1])
-    assert e.value.status == _lib.NOT_SUPPORTED
-    with pytest.raises(_lib.BevopsError):          # eight points: outside the kernel's L * P == 4 domain
-        bevops.multi_scale_deformable_attn_mean2(value, shapes, ref, torch.cat([off, off], -1), torch.cat([w, w], -1))
